@@ -1,0 +1,1177 @@
+// oracle/ecne_oracle.cpp — TEST INFRASTRUCTURE ONLY. Not part of the shipped product.
+//
+// Sequential CPU restatement of Ecne's solver path, statement by statement:
+//   readR1CS                    /root/reference/src/ParseR1CS.jl:50-124
+//   nonzeroKeys, getVariables   /root/reference/src/R1CSConstraintSolver.jl:26-56
+//   VariableState + make_*      :135-201
+//   checkNonZeroValues          :205-226      hash_r1cs_equation :228-235
+//   abstraction                 :237-395
+//   solveWithTrustedFunctions   :502-581
+//   SolveConstraintsSymbolic    :583-1646
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+// the product (ecneproject_amd/) never does.
+//
+// PARITY STATUS: Julia is not installed in the build container, so the reference itself cannot
+// be run. This restatement is pinned by: the 9 booleans of test/runtests.jl, the asserted
+// examples, the README.md:95-107 transcript for target/division.r1cs, the known/output lists in
+// Circom_Functions/benchmarks/*.txt:1-4, and the term order of those dumps (Julia Set order).
+// The per-variable known-signal set is NOT pinned by any reference artefact ("parity unpinned"
+// at that level) — see DESIGN.md.
+//
+// Every quirk of the reference is kept on purpose (insert-on-read DefaultDict, in-place row
+// flip in checkBinary, key_1 written twice in checkpropagateBounds, slow_det summing only the
+// odd permutations, make_values/make_bounds resetting abz, ...). Do not "fix" them here.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <deque>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "jldict.hpp"
+#include "u256.hpp"
+
+using namespace orc;
+
+namespace {
+
+enum Status {
+    ST_OK = 0,
+    ST_EFORMAT = -1,     // @assert failures ParseR1CS.jl:58,62,69 / truncated file
+    ST_EBOUNDS = -2,     // BoundsError (variable_states[-1] :916; special inputs :762,:785)
+    ST_EDIVZERO = -3,    // DivideError from divexact by 0 (:919-920, :961, :1467)
+    ST_EUNDEF_DSU = -4,  // UndefVarError dsu at :762 when secp_solve == false
+    ST_EKEY = -5,        // KeyError in abstraction's variable map (:381-382)
+    ST_EDETSIZE = -6,    // slow_det on k > 10 unknowns: the reference would need k!*k steps
+    ST_EIO = -7,
+};
+struct OracleError {
+    int code;
+};
+
+static const U256 ONE(1);
+static const U256 ZERO(0);
+static U256 PM1() {
+    U256 r;
+    sub_b(r, P, ONE);
+    return r;
+}
+
+typedef JlDict<U256> LinMap;  // DefaultDict{Int64,GFElem}(F(0)) — reads through rd() insert
+
+// DefaultDict getindex: get!(d.d, key, d.default)  (DataStructures default_dict.jl) — inserts.
+static inline U256& rd(LinMap& m, int64_t key) { return m.get_or_insert(key, ZERO); }
+
+struct Eq {  // R1CSEquation, ParseR1CS.jl:13-25
+    LinMap a, b, c;
+};
+
+struct VarState {  // :135-160
+    int64_t index = 0;
+    bool is_known = false;
+    bool unique = false;
+    std::vector<U256> values;
+    U256 lb, ub;
+    bool bounds_negative = false;
+    int64_t abz = -1;
+};
+static VarState new_state(int64_t i) {  // VariableState(a) :144-146
+    VarState s;
+    s.index = i;
+    s.lb = ZERO;
+    s.ub = PM1();
+    return s;
+}
+// the 8-argument constructor ignores its abz argument (:158)
+static VarState make_values(const VarState& a, const std::vector<U256>& nv) {  // :176-190
+    VarState s;
+    s.index = a.index; s.is_known = true; s.unique = a.unique; s.values = nv;
+    s.lb = a.lb; s.ub = a.ub; s.bounds_negative = a.bounds_negative; s.abz = -1;
+    return s;
+}
+static VarState make_bounds(const VarState& a, const U256& lb, const U256& ub) {  // :192-200
+    VarState s;
+    s.index = a.index; s.is_known = true; s.unique = a.unique; s.values = a.values;
+    s.lb = lb; s.ub = ub; s.bounds_negative = false; s.abz = -1;
+    return s;
+}
+
+struct Parsed {
+    std::vector<Eq> eqs;
+    std::vector<int64_t> knowns, outputs;
+    int64_t nvars = 0;
+    // header fields (for tests)
+    uint32_t field_size = 0, n_wires = 0, n_pub_out = 0, n_pub_in = 0, n_prv_in = 0, n_cons = 0;
+    uint64_t n_labels = 0;
+};
+
+// ---------------------------------------------------------------- readR1CS ParseR1CS.jl:50-124
+static bool read_file(const char* path, std::vector<uint8_t>& out) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    size_t got = n ? std::fread(out.data(), 1, (size_t)n, f) : 0;
+    std::fclose(f);
+    return got == (size_t)n;
+}
+struct Bytes {
+    const std::vector<uint8_t>& v;
+    uint32_t u32(size_t off) const {
+        if (off + 4 > v.size()) throw OracleError{ST_EFORMAT};
+        return (uint32_t)v[off] | ((uint32_t)v[off + 1] << 8) | ((uint32_t)v[off + 2] << 16) |
+               ((uint32_t)v[off + 3] << 24);
+    }
+    uint64_t u64(size_t off) const { return (uint64_t)u32(off) | ((uint64_t)u32(off + 4) << 32); }
+};
+static void parse_r1cs(const char* path, Parsed& out) {
+    std::vector<uint8_t> arr;
+    if (!read_file(path, arr)) throw OracleError{ST_EIO};
+    Bytes B{arr};
+    // bytes 0-3 (magic) are never checked (:57)
+    if (B.u32(4) != 1) throw OracleError{ST_EFORMAT};   // :58
+    uint32_t sections = B.u32(8);                       // :60
+    if (sections != 3) throw OracleError{ST_EFORMAT};   // :62
+    size_t cur = 12;
+    size_t starts[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < sections; ++i) {           // :66-75
+        uint32_t t = B.u32(cur);
+        if (t < 1 || t > 3) throw OracleError{ST_EFORMAT};  // :69
+        starts[t] = cur;
+        uint64_t sz = B.u64(cur + 4);
+        cur += 12 + (size_t)sz;
+    }
+    size_t s1 = starts[1] + 12;                          // :80-96
+    out.field_size = B.u32(s1); s1 += 4;
+    s1 += out.field_size;                                // prime is read, never compared (:84)
+    out.n_wires = B.u32(s1); s1 += 4;
+    out.n_pub_out = B.u32(s1); s1 += 4;
+    out.n_pub_in = B.u32(s1); s1 += 4;
+    out.n_prv_in = B.u32(s1); s1 += 4;
+    out.n_labels = B.u64(s1); s1 += 8;
+    out.n_cons = B.u32(s1);
+    size_t s2 = starts[2] + 12;                          // :97-98
+    out.eqs.resize(out.n_cons);
+    for (uint32_t ci = 0; ci < out.n_cons; ++ci) {       // :100-122
+        LinMap* parts[3] = {&out.eqs[ci].a, &out.eqs[ci].b, &out.eqs[ci].c};
+        for (int part = 0; part < 3; ++part) {
+            uint32_t n = B.u32(s2); s2 += 4;
+            for (uint32_t k = 0; k < n; ++k) {
+                uint32_t idx = B.u32(s2); s2 += 4;
+                if (s2 + 32 > arr.size()) throw OracleError{ST_EFORMAT};
+                U256 c;
+                for (int w = 0; w < 4; ++w) c.w[w] = B.u64(s2 + 8 * w);  // width hard-coded 32 (:109)
+                s2 += 32;
+                parts[part]->set((int64_t)idx + 1, fp_reduce(c));       // :111, duplicates: last wins
+            }
+            if (n == 0) parts[part]->set(1, ZERO);                      // :113-115
+        }
+    }
+    out.knowns.push_back(1);                             // :123
+    for (int64_t i = 2 + out.n_pub_out; i <= 1 + (int64_t)out.n_pub_out + out.n_pub_in + out.n_prv_in; ++i)
+        out.knowns.push_back(i);
+    for (int64_t i = 2; i <= 1 + (int64_t)out.n_pub_out; ++i) out.outputs.push_back(i);
+    out.nvars = (int64_t)out.n_wires + 1;
+}
+
+// ---------------------------------------------------------------- nonzeroKeys / getVariables :26-56
+static JlSet nonzeroKeys(const LinMap& m, OrderCtx* ctx) {
+    JlSet s;
+    for (int64_t slot : m.order(ctx))
+        if (!m.vals[slot].is_zero()) s.set(m.keys[slot], Nothing());
+    return s;
+}
+static JlSet getVariables(const Eq& e, OrderCtx* ctx) {
+    JlSet s;
+    const LinMap* parts[3] = {&e.a, &e.b, &e.c};
+    for (int p = 0; p < 3; ++p)
+        for (int64_t slot : parts[p]->order(ctx))
+            if (!parts[p]->vals[slot].is_zero()) s.set(parts[p]->keys[slot], Nothing());
+    return s;
+}
+static std::vector<U256> sorted_values(const LinMap& m) {  // sort([x.d for x in values(m)])
+    std::vector<U256> v;
+    v.reserve((size_t)m.count);
+    for (int64_t i = 0; i < (int64_t)m.slots.size(); ++i)
+        if (m.slots[i]) v.push_back(m.vals[i]);
+    std::sort(v.begin(), v.end());
+    return v;
+}
+static bool maps_equal(const LinMap& x, const LinMap& y) {  // AbstractDict == (:1512)
+    if (x.count != y.count) return false;
+    for (int64_t i = 0; i < (int64_t)x.slots.size(); ++i)
+        if (x.slots[i]) {
+            const U256* v = y.get(x.keys[i]);
+            if (!v || *v != x.vals[i]) return false;
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------- abstraction :205-395
+struct Special {
+    std::string name;
+    std::vector<int64_t> inputs, outputs;
+};
+// hash_r1cs_equation (:228-235): hash of vcat(sort(a), sort(b), sort(c)) with zeros dropped.
+// Only hash *equality* is observable, so the flat list itself is the restated "hash".
+static std::vector<U256> eq_signature(const Eq& e) {
+    std::vector<U256> l;
+    const LinMap* parts[3] = {&e.a, &e.b, &e.c};
+    for (int p = 0; p < 3; ++p) {
+        std::vector<U256> v = sorted_values(*parts[p]);
+        for (auto& x : v)
+            if (!x.is_zero()) l.push_back(x);
+    }
+    return l;
+}
+static bool checkNonZeroValues(const LinMap& m1, const LinMap& m2) {  // :205-226
+    std::vector<U256> a, b;
+    for (auto& x : sorted_values(m1)) if (!x.is_zero()) a.push_back(x);
+    for (auto& x : sorted_values(m2)) if (!x.is_zero()) b.push_back(x);
+    return a == b;  // multisets of non-zero values agree
+}
+typedef std::vector<std::pair<int64_t, U256>> AppList;
+static bool applist_less(const AppList& x, const AppList& y) {  // isless on Vector{Tuple{Int,BigInt}}
+    size_t n = std::min(x.size(), y.size());
+    for (size_t i = 0; i < n; ++i) {
+        if (x[i].first != y[i].first) return x[i].first < y[i].first;
+        int c = cmp(x[i].second, y[i].second);
+        if (c) return c < 0;
+    }
+    return x.size() < y.size();
+}
+static bool applist_eq(const AppList& x, const AppList& y) {
+    if (x.size() != y.size()) return false;
+    for (size_t i = 0; i < x.size(); ++i)
+        if (x[i].first != y[i].first || x[i].second != y[i].second) return false;
+    return true;
+}
+static void abstraction(const std::string& fname, std::vector<Eq>& constraints,
+                        const std::vector<int64_t>& known_inputs, std::vector<Eq>& sub,
+                        const std::vector<int64_t>& known_outputs, std::vector<Special>& specials_out,
+                        OrderCtx* ctx) {
+    int64_t nC = (int64_t)constraints.size(), nS = (int64_t)sub.size();
+    std::vector<std::vector<U256>> hc(nC), hs(nS);                      // :252-253
+    for (int64_t i = 0; i < nC; ++i) hc[i] = eq_signature(constraints[i]);
+    for (int64_t i = 0; i < nS; ++i) hs[i] = eq_signature(sub[i]);
+    std::vector<int64_t> candidates;                                    // :258-270
+    for (int64_t i = 1; i <= nC - nS + 1; ++i) {
+        bool matches = true;
+        for (int64_t j = 1; j <= nS - 1; ++j)                           // only the first len-1 rows
+            if (hc[i + j - 2] != hs[j - 1]) { matches = false; break; }
+        if (matches) candidates.push_back(i);
+    }
+    JlDict<AppList> app_orig;                                           // :276-292
+    int64_t sub_eq_counter = 1;
+    for (int64_t j = 0; j < nS; ++j) {
+        LinMap* parts[3] = {&sub[j].a, &sub[j].b, &sub[j].c};
+        for (int p = 0; p < 3; ++p) {
+            for (int64_t slot : parts[p]->order(ctx))
+                if (!parts[p]->vals[slot].is_zero())
+                    app_orig.get_or_insert(parts[p]->keys[slot], AppList())
+                        .push_back({sub_eq_counter, parts[p]->vals[slot]});
+            sub_eq_counter += 1;
+        }
+    }
+    struct Match { int64_t i; std::map<int64_t, int64_t> m; };
+    std::vector<Match> matches;
+    auto sorted_entries = [&](const JlDict<AppList>& d) {               // sort(collect(d), by=...) stable
+        std::vector<int64_t> slots = d.order(ctx);
+        std::stable_sort(slots.begin(), slots.end(), [&](int64_t x, int64_t y) {
+            return applist_less(d.vals[x], d.vals[y]);
+        });
+        return slots;
+    };
+    std::vector<int64_t> l2 = sorted_entries(app_orig);
+    for (int64_t i : candidates) {                                      // :293-352
+        bool works = true;
+        JlDict<AppList> app_cur;
+        int64_t app_counter = 0;
+        auto addEquation = [&](LinMap& e1, LinMap& e2) {                // :301-312
+            if (!checkNonZeroValues(e1, e2)) return false;
+            for (int64_t slot : e1.order(ctx))
+                if (!e1.vals[slot].is_zero())
+                    app_cur.get_or_insert(e1.keys[slot], AppList()).push_back({app_counter, e1.vals[slot]});
+            return true;
+        };
+        for (int64_t j = 1; j <= nS; ++j) {
+            Eq& big = constraints[i + j - 2];
+            Eq& sm = sub[j - 1];
+            app_counter += 1;
+            if (!addEquation(big.a, sm.a)) { works = false; break; }
+            app_counter += 1;
+            if (!addEquation(big.b, sm.b)) { works = false; break; }
+            app_counter += 1;
+            if (!addEquation(big.c, sm.c)) { works = false; break; }
+        }
+        if (!works) continue;
+        std::vector<int64_t> l1 = sorted_entries(app_cur);              // :334
+        if (l1.size() != l2.size()) continue;                           // :336
+        for (size_t x = 0; x < l1.size(); ++x)
+            if (!applist_eq(app_cur.vals[l1[x]], app_orig.vals[l2[x]])) { works = false; break; }
+        if (!works) continue;
+        Match m;
+        m.i = i;
+        for (size_t x = 0; x < l1.size(); ++x) m.m[app_orig.keys[l2[x]]] = app_cur.keys[l1[x]];  // :351
+        matches.push_back(std::move(m));
+    }
+    std::vector<Eq> red;                                                // :357-388
+    size_t cur_idx = 0;  // 0-based
+    int64_t i = 1;
+    while (i <= nC) {
+        if (cur_idx >= matches.size() || i != matches[cur_idx].i) {
+            red.push_back(std::move(constraints[i - 1]));
+            i += 1;
+        } else {
+            Special sp;
+            sp.name = fname;
+            for (int64_t x : known_inputs)
+                if (x != 1) {
+                    auto it = matches[cur_idx].m.find(x);
+                    if (it == matches[cur_idx].m.end()) throw OracleError{ST_EKEY};
+                    sp.inputs.push_back(it->second);
+                }
+            for (int64_t x : known_outputs) {
+                auto it = matches[cur_idx].m.find(x);
+                if (it == matches[cur_idx].m.end()) throw OracleError{ST_EKEY};
+                sp.outputs.push_back(it->second);
+            }
+            specials_out.push_back(std::move(sp));
+            i += nS;
+            cur_idx += 1;
+        }
+    }
+    constraints.swap(red);
+}
+
+// ---------------------------------------------------------------- IntDisjointSet (secp_solve, :634-678)
+struct DSU {
+    std::vector<int64_t> parent, rank;
+    explicit DSU(int64_t n) : parent(n), rank(n, 0) { for (int64_t i = 0; i < n; ++i) parent[i] = i; }
+    int64_t push() { parent.push_back((int64_t)parent.size()); rank.push_back(0); return (int64_t)parent.size(); }
+    int64_t root(int64_t x) {  // 1-based
+        if (x < 1 || x > (int64_t)parent.size()) throw OracleError{ST_EBOUNDS};
+        int64_t r = x - 1;
+        while (parent[r] != r) r = parent[r];
+        while (parent[x - 1] != r) { int64_t n = parent[x - 1]; parent[x - 1] = r; x = n + 1; }
+        return r + 1;
+    }
+    void unite(int64_t x, int64_t y) {
+        int64_t a = root(x) - 1, b = root(y) - 1;
+        if (a == b) return;
+        if (rank[a] < rank[b]) std::swap(a, b);
+        parent[b] = a;
+        if (rank[a] == rank[b]) rank[a]++;
+    }
+};
+
+// ---------------------------------------------------------------- result object
+struct Result {
+    int32_t status = 0;
+    int32_t verdict = 0;
+    int64_t n_vars = 0, n_rows_main = 0, n_rows_reduced = 0, n_specials = 0;
+    int64_t unique_nontrivial = 0, n_nontrivial = 0, unique_targets = 0, n_targets = 0;
+    int64_t successful_steps = 0, outer_iterations = 0, pops = 0, num_unique = 0;
+    int64_t rule_hits[16] = {0};   // 0..7 = R1..R8, 8..12 = P1..P5
+    int64_t alg_bytes_pops = 0;    // sum over pops of 20 + 40*nnz(row)          
+    int64_t alg_bytes_sweep = 0;   // sum over rows of 12 + 40*nnz(row)  (one full-system sweep)
+    int64_t nnz_reduced = 0;
+    double t_read = 0, t_abstract = 0, t_solve = 0;
+    std::vector<VarState> states;
+    std::vector<int64_t> bad_rows;      // 1-based rows that still hold a non-unique variable (:1609-1618)
+    std::vector<Special> specials;
+    std::vector<int64_t> knowns, targets;
+};
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------- SolveConstraintsSymbolic :583-1646
+static void solve(std::vector<Eq>& constraints, const std::vector<Special>& special_constraints,
+                  const std::vector<int64_t>& known_variables, const std::vector<int64_t>& target_variables,
+                  int64_t num_variables, bool secp_solve, OrderCtx* ctx, bool shuffle_queue, Result& R) {
+    const int64_t nC = (int64_t)constraints.size();
+    const U256 pm1 = PM1();
+    // static nnz per row for the algorithmic-byte tally
+    std::vector<int64_t> row_nnz(nC, 0);
+    // --- setup :593-704
+    JlSet known_set;
+    for (int64_t k : known_variables) known_set.set(k, Nothing());
+    std::vector<int64_t> num_unknowns(nC);
+    for (int64_t i = 0; i < nC; ++i) {                                   // :595-596
+        JlSet gv = getVariables(constraints[i], ctx);
+        int64_t n = 0;
+        for (int64_t v : gv.ordered_keys()) if (!known_set.contains(v)) n++;
+        num_unknowns[i] = n;
+    }
+    std::vector<char> in_queue(nC, 0), equation_solved(nC, 0);
+    std::vector<char> special_solved(special_constraints.size(), 0);
+    JlSet all_nontrivial;                                                // :600-618
+    for (int64_t i = 0; i < nC; ++i)
+        for (int64_t v : getVariables(constraints[i], ctx).ordered_keys()) all_nontrivial.set(v, Nothing());
+    for (auto& sp : special_constraints) {
+        for (int64_t v : sp.inputs) all_nontrivial.set(v, Nothing());
+        for (int64_t v : sp.outputs) all_nontrivial.set(v, Nothing());
+    }
+    for (int64_t v : target_variables) all_nontrivial.set(v, Nothing());
+
+    std::deque<int64_t> q;                                               // :621-627 (1-based rows)
+    for (int64_t i = 1; i <= nC; ++i)
+        if (num_unknowns[i - 1] <= 1) { q.push_back(i); in_queue[i - 1] = 1; }
+    if (shuffle_queue && ctx) {  // invariance-test only
+        std::vector<int64_t> tmp(q.begin(), q.end());
+        std::shuffle(tmp.begin(), tmp.end(), ctx->rng);
+        q.assign(tmp.begin(), tmp.end());
+    }
+    std::vector<std::vector<int64_t>> variable_to_indices(num_variables + 2);   // :628-633
+    auto v2i = [&](int64_t v) -> std::vector<int64_t>& {
+        if (v < 1) throw OracleError{ST_EBOUNDS};
+        if (v >= (int64_t)variable_to_indices.size()) variable_to_indices.resize(v + 1);
+        return variable_to_indices[v];
+    };
+    for (int64_t i = 1; i <= nC; ++i)
+        for (int64_t v : getVariables(constraints[i - 1], ctx).ordered_keys()) v2i(v).push_back(i);
+
+    std::vector<JlSet> nzk_a(nC), nzk_b(nC), nzk_c(nC);                  // :698-700
+    for (int64_t i = 0; i < nC; ++i) {
+        nzk_a[i] = nonzeroKeys(constraints[i].a, ctx);
+        nzk_b[i] = nonzeroKeys(constraints[i].b, ctx);
+        nzk_c[i] = nonzeroKeys(constraints[i].c, ctx);
+        row_nnz[i] = nzk_a[i].count + nzk_b[i].count + nzk_c[i].count;
+        R.alg_bytes_sweep += 12 + 40 * row_nnz[i];
+        R.nnz_reduced += row_nnz[i];
+    }
+
+    std::unique_ptr<DSU> dsu;                                            // :634-678
+    if (secp_solve) {
+        dsu.reset(new DSU(num_variables));
+        std::map<std::vector<uint64_t>, int64_t> const_vals;
+        std::vector<U256> tv = {ONE, pm1};
+        for (int64_t e = 0; e < nC; ++e) {
+            Eq& eq = constraints[e];
+            if (nzk_a[e].count == 0 && nzk_b[e].count == 0) {
+                if (eq.c.count == 2) {
+                    if (sorted_values(eq.c) == tv) {
+                        std::vector<int64_t> l = nonzeroKeys(eq.c, ctx).ordered_keys(ctx);
+                        dsu->unite(l.at(0), l.at(1));
+                    } else {
+                        std::vector<int64_t> l;
+                        bool constant_val = false;
+                        for (int64_t k : nonzeroKeys(eq.c, ctx).ordered_keys(ctx)) {
+                            l.push_back(k);
+                            if (k == 1) constant_val = true;
+                        }
+                        if (l.empty()) throw OracleError{ST_EBOUNDS};
+                        int64_t non_one = l[0];
+                        if (l[0] == 1) {
+                            if (l.size() < 2) throw OracleError{ST_EBOUNDS};
+                            non_one = l[1];
+                        }
+                        if (!constant_val) continue;
+                        U256 value;
+                        try { value = fp_div(rd(eq.c, 1), fp_neg(rd(eq.c, non_one))); }
+                        catch (DivideError&) { throw OracleError{ST_EDIVZERO}; }
+                        std::vector<uint64_t> key(value.w, value.w + 4);
+                        if (!const_vals.count(key)) const_vals[key] = dsu->push();
+                        dsu->unite(non_one, const_vals[key]);
+                    }
+                }
+            }
+        }
+    }
+
+    std::vector<VarState>& vs = R.states;                                // :680-693 (1-based; slot 0 unused)
+    vs.resize(num_variables + 1);
+    for (int64_t i = 1; i <= num_variables; ++i) vs[i] = new_state(i);
+    auto st = [&](int64_t v) -> VarState& {
+        if (v < 1 || v > num_variables) throw OracleError{ST_EBOUNDS};
+        return vs[v];
+    };
+    for (int64_t k : known_variables) {
+        if (k == 1) { st(k).values = {ONE}; }
+        st(k).unique = true;
+        st(k).is_known = true;
+    }
+    int64_t successful_steps = 0, prev_successful_steps = -1, num_unique = 0;
+
+    auto requeue = [&](int64_t v) {   // the verbatim idiom at :739-744 etc.
+        for (int64_t cons : v2i(v))
+            if (!in_queue[cons - 1]) { q.push_back(cons); in_queue[cons - 1] = 1; }
+    };
+
+    // --- outer loop :706-1556
+    for (;;) {
+        if (prev_successful_steps == successful_steps) break;            // :708-711
+        prev_successful_steps = successful_steps;
+        R.outer_iterations += 1;
+
+        // P1 :718-747
+        for (size_t i = 0; i < special_constraints.size(); ++i) {
+            if (special_solved[i]) continue;
+            bool solved = true;
+            for (int64_t j : special_constraints[i].inputs)
+                if (!st(j).unique) { solved = false; break; }
+            if (!solved) continue;
+            special_solved[i] = 1;
+            successful_steps += 1;
+            R.rule_hits[8] += 1;
+            for (int64_t j : special_constraints[i].outputs) {
+                if (st(j).unique) continue;
+                st(j).unique = true;
+                st(j).is_known = true;
+                requeue(j);
+            }
+        }
+        // P2 :750-800
+        for (size_t i = 0; i < special_constraints.size(); ++i) {
+            if (special_constraints[i].name != "BigMultModP") continue;
+            for (size_t j = 0; j < special_constraints.size(); ++j) {
+                if (special_constraints[j].name != "BigLessThan") continue;
+                const Special& ci = special_constraints[i];
+                const Special& cj = special_constraints[j];
+                bool same_set = true;
+                for (int k = 1; k <= 6; ++k) {                           // :761-765
+                    if (!dsu) throw OracleError{ST_EUNDEF_DSU};
+                    if ((size_t)(k + 3) > ci.inputs.size() || (size_t)k > cj.inputs.size())
+                        throw OracleError{ST_EBOUNDS};
+                    if (dsu->root(ci.inputs[k + 2]) != dsu->root(cj.inputs[k - 1])) same_set = false;
+                }
+                // :766-784 — the guarded block only `continue`s its own inner loops: no state
+                // effect; it can only raise BoundsError through its indexing.
+                if (same_set) {
+                    if (cj.outputs.empty()) throw OracleError{ST_EBOUNDS};      // constraint_j[3][1]
+                    const VarState& o = st(cj.outputs[0]);
+                    if (o.values.size() == 1 && o.values[0].is_one()) {
+                        for (int64_t v : ci.outputs) (void)st(v);
+                        for (int idx : {1, 2, 3, 7, 8, 9}) (void)st(ci.inputs.at(idx - 1));
+                    }
+                }
+                if (cj.inputs.size() < 3) throw OracleError{ST_EBOUNDS}; // constraint_j[2][1:3]
+                R.rule_hits[9] += 1;
+                for (int t = 0; t < 3; ++t) {                            // :785-798
+                    int64_t v = cj.inputs[t];
+                    if (st(v).unique) continue;
+                    st(v).unique = true;
+                    st(v).is_known = true;
+                    requeue(v);
+                }
+            }
+        }
+
+        // QUEUE :805-1349
+        while (!q.empty()) {
+            int64_t lead = q.front();                                    // :817
+            q.pop_front();
+            in_queue[lead - 1] = 0;
+            R.pops += 1;
+            R.alg_bytes_pops += 20 + 40 * row_nnz[lead - 1];
+            if (equation_solved[lead - 1]) continue;                     // :820-822
+            Eq* te = &constraints[lead - 1];
+            JlSet& NA = nzk_a[lead - 1];
+            JlSet& NB = nzk_b[lead - 1];
+            JlSet& NC = nzk_c[lead - 1];
+
+            // R1 check_unique :827-873
+            [&]() {
+                for (int64_t i : NB.ordered_keys(ctx)) if (!st(i).unique) return;
+                for (int64_t i : NA.ordered_keys(ctx)) if (!st(i).unique) return;
+                int64_t non_unique = -1;
+                for (int64_t i : NC.ordered_keys(ctx))
+                    if (!st(i).unique) {
+                        if (non_unique == -1) non_unique = i; else return;
+                    }
+                if (non_unique == -1) return;
+                st(non_unique).unique = true;
+                num_unique += 1;
+                st(non_unique).is_known = true;
+                successful_steps += 1;
+                R.rule_hits[0] += 1;
+                requeue(non_unique);
+            }();
+            // R2 check_quadratic :875-942
+            [&]() {
+                if (NC.count >= 1) return;
+                int64_t unknown_var = -1;
+                for (int64_t i : getVariables(*te, ctx).ordered_keys(ctx))
+                    if (!st(i).is_known) {
+                        if (unknown_var == -1) unknown_var = i; else return;
+                    }
+                U256 slope_a, intercept_a, slope_b, intercept_b;
+                for (int64_t i : NA.ordered_keys(ctx)) {
+                    if (i == unknown_var) slope_a = rd(te->a, i);
+                    else if (i == 1) intercept_a = rd(te->a, i);
+                    else return;
+                }
+                for (int64_t i : NB.ordered_keys(ctx)) {
+                    if (i == unknown_var) slope_b = rd(te->b, i);
+                    else if (i == 1) intercept_b = rd(te->b, i);
+                    else return;
+                }
+                if (unknown_var == -1) throw OracleError{ST_EBOUNDS};    // variable_states[-1] :916
+                std::vector<U256> nv;
+                try {
+                    nv.push_back(fp_div(fp_neg(intercept_a), slope_a));  // :919
+                    nv.push_back(fp_div(fp_neg(intercept_b), slope_b));  // :920
+                } catch (DivideError&) { throw OracleError{ST_EDIVZERO}; }
+                st(unknown_var) = make_values(st(unknown_var), nv);
+                const std::vector<U256>& vv = st(unknown_var).values;
+                if ((vv[0].is_zero() && vv[1].is_one()) || (vv[0].is_one() && vv[1].is_zero()))
+                    st(unknown_var) = make_bounds(st(unknown_var), ZERO, ONE);   // :923-927
+                requeue(unknown_var);
+                equation_solved[lead - 1] = 1;
+                successful_steps += 1;
+                R.rule_hits[1] += 1;
+            }();
+            if (NA.count >= 1 || NB.count >= 1) continue;                // :944-946
+
+            // R3 check_linear :949-988
+            [&]() {
+                std::vector<int64_t> non_one_keys;
+                for (int64_t i : NC.ordered_keys(ctx)) if (i != 1) non_one_keys.push_back(i);
+                if (non_one_keys.size() != 1) return;
+                int64_t x = non_one_keys[0];
+                U256 true_value;
+                {
+                    U256 c1 = rd(te->c, 1);   // inserts 1=>0 if absent (insert-on-read)
+                    U256 cx = rd(te->c, x);
+                    try { true_value = fp_div(fp_neg(c1), cx); }
+                    catch (DivideError&) { throw OracleError{ST_EDIVZERO}; }
+                }
+                bool new_info = false;
+                VarState& s = st(x);
+                if (!(s.values.size() == 1 && s.values[0] == true_value)) {
+                    s.values = {true_value};
+                    successful_steps += 1;
+                    R.rule_hits[2] += 1;
+                    new_info = true;
+                }
+                s.lb = true_value;
+                s.ub = true_value;
+                if (!s.unique) { s.unique = true; num_unique += 1; new_info = true; }
+                s.is_known = true;
+                if (new_info) requeue(x);
+            }();
+            // R4 checkBinary :991-1076
+            [&]() {
+                int64_t l = NC.count;
+                if (l == 0) return;
+                std::vector<U256> target, target2;                       // :999-1000
+                target.push_back(ONE);
+                target2.push_back(pm1);
+                U256 pw = ONE;                                           // F(2)^i mod p
+                for (int64_t i = 0; i <= l - 2; ++i) {
+                    target.push_back(fp_neg(pw));
+                    target2.push_back(pw);
+                    pw = fp_add(pw, pw);
+                }
+                std::sort(target.begin(), target.end());
+                std::sort(target2.begin(), target2.end());
+                if (sorted_values(te->c) == target2) {                   // :1001-1011 persistent flip
+                    LinMap flipped;
+                    for (int64_t slot : te->c.order(ctx)) flipped.set(te->c.keys[slot], fp_neg(te->c.vals[slot]));
+                    constraints[lead - 1].c = flipped;
+                    te = &constraints[lead - 1];
+                }
+                if (sorted_values(te->c) != target) return;              // :1013
+                int64_t new_key = -1;
+                for (int64_t i : NC.ordered_keys(ctx)) {                 // :1020-1029
+                    if (rd(te->c, i).is_one()) new_key = i;
+                    else if (!st(i).lb.is_zero() || !st(i).ub.is_one()) return;
+                }
+                // F(2)^(l-1) - F(1), field arithmetic                   :1033
+                U256 pow_l1 = ONE;
+                for (int64_t i = 0; i < l - 1; ++i) pow_l1 = fp_add(pow_l1, pow_l1);
+                U256 fub = fp_sub(pow_l1, ONE);
+                VarState& n = st(new_key);
+                if (!(n.lb.is_zero() && n.ub == fub)) {                  // :1031-1048
+                    // integer compare ub.d > BigInt(2)^(l-1) - 1        :1035
+                    bool gt;
+                    if (l - 1 >= 256) gt = false;
+                    else {
+                        U256 ipow;  // 2^(l-1) as an integer
+                        ipow.w[(l - 1) >> 6] = (uint64_t)1 << ((l - 1) & 63);
+                        U256 im1;
+                        sub_b(im1, ipow, ONE);
+                        gt = cmp(n.ub, im1) > 0;
+                    }
+                    if (gt) {
+                        n.lb = ZERO;
+                        n.ub = fub;
+                        n.is_known = true;
+                        successful_steps += 1;
+                        R.rule_hits[3] += 1;
+                        requeue(new_key);
+                    }
+                }
+                if (st(new_key).unique) {                                // :1049-1067
+                    for (int64_t i : NC.ordered_keys(ctx)) {
+                        if (i == new_key) continue;
+                        if (!st(i).unique) {
+                            st(i).unique = true;
+                            num_unique += 1;
+                            st(i).is_known = true;
+                            successful_steps += 1;
+                            R.rule_hits[3] += 1;
+                            requeue(i);
+                        }
+                    }
+                }
+            }();
+            // R5 checkpropagateBounds :1078-1146
+            [&]() {
+                if (NC.count >= 3) return;
+                std::vector<U256> tv = {ONE, pm1};
+                if (sorted_values(te->c) != tv) return;
+                std::vector<int64_t> x = te->c.ordered_keys(ctx);        // keys(true_equation.c)
+                int64_t key_1 = x.at(0), key_2 = x.at(1);
+                VarState& s1 = st(key_1);
+                VarState& s2 = st(key_2);
+                std::vector<int64_t> changed;
+                if (s2.ub != s1.ub || s2.lb != s1.lb || s2.unique != s1.unique) {
+                    if (s2.unique != s1.unique) {
+                        // `!=` on a mutable struct vs a fresh copy is identity: both branches taken
+                        s1.is_known = true; s1.unique = true; changed.push_back(key_1); num_unique += 1;
+                        s1.is_known = true; s1.unique = true; num_unique += 1; changed.push_back(key_2);  // sic :1107-1108
+                    }
+                    U256 mnub = std::min(s1.ub, s2.ub);
+                    U256 mxlb = std::max(s1.lb, s2.lb);
+                    if (s1.ub > mnub || s1.lb < mxlb) {
+                        s1.is_known = true; s1.lb = mxlb; s1.ub = mnub; changed.push_back(key_1);
+                    }
+                    if (s2.ub > mnub || s2.lb < mxlb) {
+                        s2.is_known = true; s2.lb = mxlb; s2.ub = mnub; changed.push_back(key_2);
+                    }
+                    JlSet cs;                                            // Set(changed_vars)
+                    for (int64_t v : changed) cs.set(v, Nothing());
+                    successful_steps += cs.count;
+                    if (cs.count) R.rule_hits[4] += 1;
+                    for (int64_t v : cs.ordered_keys(ctx)) requeue(v);
+                }
+            }();
+            // R6 checkOnePropagateBounds :1148-1232
+            [&]() {
+                if (NC.count >= 4) return;
+                std::vector<U256> tv = {ONE, pm1, pm1};
+                if (sorted_values(te->c) != tv) return;
+                std::vector<int64_t> ord = te->c.order(ctx);
+                for (int64_t slot : ord)                                 // :1158-1162
+                    if (te->c.vals[slot].is_one() && te->c.keys[slot] != 1) return;
+                int64_t key_1 = -1, key_2 = -1;
+                for (int64_t slot : ord)
+                    if (te->c.vals[slot] == pm1) {
+                        if (key_1 == -1) key_1 = te->c.keys[slot]; else key_2 = te->c.keys[slot];
+                    }
+                VarState& s1 = st(key_1);
+                VarState& s2 = st(key_2);
+                std::vector<int64_t> changed;
+                if (s2.ub != s1.ub || s2.lb != s1.lb || s2.unique != s1.unique) {
+                    if (s2.unique != s1.unique) {
+                        s1.is_known = true; s1.unique = true; changed.push_back(key_1); num_unique += 1;
+                        s2.is_known = true; s2.unique = true; num_unique += 1; changed.push_back(key_2);
+                    }
+                    U256 mnub = std::min(s1.ub, s2.ub);
+                    U256 mxlb = std::max(s1.lb, s2.lb);
+                    if (!mnub.is_one() || !mxlb.is_zero()) return;       // :1196-1199
+                    if (s1.ub > mnub || s1.lb < mxlb) {
+                        s1.is_known = true; s1.lb = mxlb; s1.ub = mnub; s1.values = {mnub, mxlb};
+                        changed.push_back(key_1);
+                    }
+                    if (s2.ub > mnub || s2.lb < mxlb) {
+                        s2.is_known = true; s2.lb = mxlb; s2.ub = mnub; s2.values = {mnub, mxlb};
+                        changed.push_back(key_2);
+                    }
+                    JlSet cs;
+                    for (int64_t v : changed) cs.set(v, Nothing());
+                    successful_steps += cs.count;
+                    if (cs.count) R.rule_hits[5] += 1;
+                    for (int64_t v : cs.ordered_keys(ctx)) requeue(v);
+                }
+            }();
+            // R7 checkModularArithmetic :1235-1298
+            [&]() {
+                std::vector<int64_t> keys;
+                for (int64_t a : NC.ordered_keys(ctx)) if (!st(a).unique) keys.push_back(a);
+                if (keys.empty()) return;
+                static const U256 THRESH(0x43e1f593f0000000ULL, 0x9c41be16bb2a8891ULL,
+                                         0x045fcd3eea44076aULL, 0x2e2e53955f6f1dfeULL);  // literal at :1247
+                std::vector<U256> coeffs;   // abs(flip_coeffs(c.d))
+                for (int64_t k : keys) {
+                    U256 x = rd(te->c, k);
+                    if (cmp(x, THRESH) > 0) { U256 t; sub_b(t, P, x); x = t; }  // |x - p| = p - x
+                    coeffs.push_back(x);
+                }
+                for (int64_t k : keys) if (!st(k).is_known) return;
+                std::vector<size_t> r(keys.size());                      // sortperm (ties by index)
+                for (size_t i = 0; i < r.size(); ++i) r[i] = i;
+                std::stable_sort(r.begin(), r.end(), [&](size_t a, size_t b) { return coeffs[a] < coeffs[b]; });
+                for (size_t i = 0; i + 1 < r.size(); ++i) {
+                    const U256& cn = coeffs[r[i + 1]];
+                    const U256& cc = coeffs[r[i]];
+                    if (cc.is_zero()) throw OracleError{ST_EDIVZERO};
+                    U256 qq, rem;
+                    divmod(cn, cc, qq, rem);
+                    if (!rem.is_zero()) return;
+                    // quotient <= ub.d - lb.d  (signed integer difference)
+                    const VarState& s = st(keys[r[i]]);
+                    if (cmp(s.ub, s.lb) >= 0) {
+                        U256 diff;
+                        sub_b(diff, s.ub, s.lb);
+                        if (cmp(qq, diff) <= 0) return;
+                    }  // negative difference: a positive quotient is never <= it
+                }
+                {
+                    const VarState& s = st(keys[r.back()]);
+                    U256 ub1;
+                    uint64_t carry = add_c(ub1, s.ub, ONE);
+                    (void)carry;  // ub < p < 2^254: no carry
+                    U512 prod = mul_wide(coeffs[r.back()], ub1);
+                    if (cmp512_256(prod, P) > 0) return;                 // :1274
+                }
+                successful_steps += (int64_t)keys.size();
+                R.rule_hits[6] += 1;
+                for (int64_t j : keys) {
+                    st(j).unique = true;
+                    num_unique += 1;
+                    st(j).is_known = true;
+                    requeue(j);
+                }
+            }();
+            // R8 checkAllButOneZeroGroup :1304-1348
+            [&]() {
+                int64_t ABZ_index = -1;
+                std::vector<int64_t> abzs;
+                for (int64_t i : NC.ordered_keys(ctx)) {
+                    if (st(i).unique) continue;
+                    if (st(i).abz != -1) {
+                        if (ABZ_index == -1) { ABZ_index = st(i).abz; abzs.push_back(i); }
+                        else if (st(i).abz != ABZ_index) return;
+                        else abzs.push_back(i);
+                    } else return;
+                }
+                if (abzs.empty()) return;
+                R.rule_hits[7] += 1;
+                for (int64_t i : abzs) {
+                    if (st(i).unique) continue;
+                    st(i).unique = true;
+                    num_unique += 1;
+                    successful_steps += 1;
+                    st(i).is_known = true;
+                    requeue(i);
+                }
+            }();
+        }
+
+        // P3 linear systems :1357-1417
+        {
+            std::map<std::vector<int64_t>, std::vector<std::vector<U256>>> lin_freq;
+            for (int64_t i = 1; i <= nC; ++i) {
+                Eq& E = constraints[i - 1];
+                std::vector<int64_t> all_vars = getVariables(E, ctx).ordered_keys(ctx);
+                std::vector<int64_t> unk;
+                bool linear_eq = true, c_linear_eq = true;
+                for (int64_t j : all_vars)
+                    if (!st(j).unique) {
+                        if (nzk_a[i - 1].contains(j) && nzk_b[i - 1].contains(j)) { linear_eq = false; break; }
+                        unk.push_back(j);
+                    }
+                if (!linear_eq) continue;
+                for (int64_t j : all_vars)
+                    if (!st(j).unique)
+                        if (nzk_a[i - 1].contains(j) || nzk_b[i - 1].contains(j) || !nzk_c[i - 1].contains(j))
+                            c_linear_eq = false;
+                if (!c_linear_eq) continue;
+                std::sort(unk.begin(), unk.end());
+                std::vector<U256> rowv;
+                for (int64_t k : unk) rowv.push_back(rd(E.c, k));
+                auto& grp = lin_freq[unk];
+                grp.push_back(rowv);
+                if (grp.size() == unk.size()) {                          // :1388 (never again)
+                    size_t k = unk.size();
+                    if (k > 10) throw OracleError{ST_EDETSIZE};
+                    // slow_det :1389-1400: res += F(parity(perm)) * prod, and Combinatorics.parity
+                    // is 0 for even / 1 for odd permutations: only ODD permutations contribute.
+                    U256 res = ZERO;
+                    std::vector<int> perm(k);
+                    for (size_t t = 0; t < k; ++t) perm[t] = (int)t;
+                    do {
+                        int inv = 0;
+                        for (size_t a = 0; a < k; ++a)
+                            for (size_t b = a + 1; b < k; ++b) if (perm[a] > perm[b]) inv++;
+                        if (inv & 1) {
+                            U256 term = ONE;
+                            for (size_t j = 0; j < k; ++j) term = fp_mul(term, grp[j][perm[j]]);
+                            res = fp_add(res, term);
+                        }
+                    } while (std::next_permutation(perm.begin(), perm.end()));
+                    if (!res.is_zero() || (k == 1 && !grp[0][0].is_zero())) {   // :1402
+                        successful_steps += (int64_t)k;
+                        R.rule_hits[10] += 1;
+                        for (int64_t nv : unk) {
+                            st(nv).unique = true;
+                            st(nv).is_known = true;
+                            requeue(nv);
+                        }
+                    }
+                }
+            }
+        }
+        // P4 ABZ tagging :1425-1483
+        for (int64_t i = 1; i <= nC; ++i) {
+            if (nzk_c[i - 1].count != 0) continue;
+            if (nzk_b[i - 1].count > 1) continue;
+            int64_t b_val = 0;
+            bool unique_b = true;
+            for (int64_t j : nzk_b[i - 1].ordered_keys(ctx))
+                if (!st(j).unique) { unique_b = false; b_val = j; }
+            if (unique_b) continue;
+            if (nzk_a[i - 1].count > 2) continue;
+            U256 slope = ZERO, intercept = ZERO;
+            int64_t slope_index = 0;
+            for (int64_t j : nzk_a[i - 1].ordered_keys(ctx)) {
+                if (j == 1) intercept = rd(constraints[i - 1].a, j);
+                else { slope = rd(constraints[i - 1].a, j); slope_index = j; }
+            }
+            try { (void)fp_div(fp_neg(intercept), slope); }              // root, :1467 (then unused)
+            catch (DivideError&) { throw OracleError{ST_EDIVZERO}; }
+            if (st(b_val).abz == -1) successful_steps += 1; else continue;
+            R.rule_hits[11] += 1;
+            st(b_val).abz = slope_index;
+            st(b_val).is_known = true;
+            requeue(b_val);
+        }
+        // P5 isZero pairs :1492-1550
+        for (int64_t i = 1; i <= nC - 1; ++i) {
+            if (nzk_c[i].count != 0) continue;          // nzk_c[i+1]
+            if (nzk_b[i].count != 1) continue;          // nzk_b[i+1]
+            if (nzk_c[i - 1].count != 2) continue;      // nzk_c[i]
+            bool a_unique = true;
+            for (int64_t j : nzk_a[i - 1].ordered_keys(ctx)) if (!st(j).unique) { a_unique = false; break; }
+            if (!a_unique) continue;
+            if (!maps_equal(constraints[i - 1].a, constraints[i].a)) continue;
+            bool is_not_one = false;
+            int64_t var_key = 0;
+            for (int64_t j : nzk_b[i].ordered_keys(ctx)) if (j != 1) { is_not_one = true; var_key = j; }
+            if (!is_not_one) continue;
+            bool bad_key = false;
+            for (int64_t j : nzk_c[i - 1].ordered_keys(ctx)) if (j != 1 && j != var_key) bad_key = true;
+            if (bad_key) continue;
+            if (!st(var_key).unique) {
+                st(var_key).is_known = true;
+                st(var_key).unique = true;
+                successful_steps += 1;
+                R.rule_hits[12] += 1;
+                equation_solved[i - 1] = 1;
+                equation_solved[i] = 1;
+                requeue(var_key);
+            }
+        }
+    }
+
+    // verdict :1558-1597
+    int64_t unique_variables = 0;
+    for (int64_t i = 1; i <= num_variables; ++i)
+        if (vs[i].unique && all_nontrivial.contains(i)) unique_variables += 1;
+    R.unique_nontrivial = unique_variables;
+    R.n_nontrivial = all_nontrivial.count;
+    int64_t target_unique = 0;
+    for (int64_t t : target_variables) if (st(t).unique) target_unique += 1;
+    R.unique_targets = target_unique;
+    R.n_targets = (int64_t)target_variables.size();
+    R.verdict = (target_unique == (int64_t)target_variables.size()) ? 1 : 0;
+    R.successful_steps = successful_steps;
+    R.num_unique = num_unique;
+    // "Bad Constraints" :1609-1618
+    for (int64_t i = 1; i <= nC; ++i) {
+        bool all_unique = true;
+        for (int64_t v : getVariables(constraints[i - 1], ctx).ordered_keys(ctx))
+            if (!st(v).unique) all_unique = false;
+        if (!all_unique) R.bad_rows.push_back(i);
+    }
+}
+
+// solveWithTrustedFunctions :502-581 (without the text output)
+static Result* run(const char* main_path, int ntrusted, const char** tpaths, const char** tnames,
+                   int secp_solve, int policy, uint64_t seed, int shuffle_queue) {
+    Result* R = new Result();
+    OrderCtx ctx;
+    ctx.policy = policy;
+    ctx.rng.seed(seed);
+    try {
+        double t0 = now_s();
+        Parsed main;
+        parse_r1cs(main_path, main);
+        struct Fn { std::string name; Parsed p; };
+        std::vector<Fn> fl(ntrusted);
+        for (int i = 0; i < ntrusted; ++i) {
+            fl[i].name = tnames[i];
+            parse_r1cs(tpaths[i], fl[i].p);
+        }
+        double t1 = now_s();
+        R->t_read = t1 - t0;
+        R->n_rows_main = (int64_t)main.eqs.size();
+        // sort(function_list, by = x -> -length(x[2]))  — stable (:527)
+        std::stable_sort(fl.begin(), fl.end(),
+                         [](const Fn& x, const Fn& y) { return x.p.eqs.size() > y.p.eqs.size(); });
+        std::vector<Special> specials;
+        for (auto& f : fl) abstraction(f.name, main.eqs, f.p.knowns, f.p.eqs, f.p.outputs, specials, &ctx);
+        double t2 = now_s();
+        R->t_abstract = t2 - t1;
+        R->n_rows_reduced = (int64_t)main.eqs.size();
+        R->n_specials = (int64_t)specials.size();
+        R->n_vars = main.nvars;
+        R->specials = specials;
+        R->knowns = main.knowns;
+        R->targets = main.outputs;
+        solve(main.eqs, specials, main.knowns, main.outputs, main.nvars, secp_solve != 0, &ctx,
+              shuffle_queue != 0, *R);
+        R->t_solve = now_s() - t2;
+    } catch (OracleError& e) {
+        R->status = e.code;
+    } catch (std::out_of_range&) {
+        R->status = ST_EBOUNDS;
+    }
+    return R;
+}
+
+}  // namespace
+
+// ============================================================== C API (ctypes, tests only)
+extern "C" {
+
+struct orc_summary {
+    int32_t status, verdict;
+    int64_t n_vars, n_rows_main, n_rows_reduced, n_specials;
+    int64_t unique_nontrivial, n_nontrivial, unique_targets, n_targets;
+    int64_t successful_steps, outer_iterations, pops, num_unique;
+    int64_t rule_hits[16];
+    int64_t alg_bytes_pops, alg_bytes_sweep, nnz_reduced, n_bad_rows;
+    double t_read, t_abstract, t_solve;
+};
+
+void* orc_run(const char* main_path, int ntrusted, const char** tpaths, const char** tnames,
+              int secp_solve, int policy, uint64_t seed, int shuffle_queue) {
+    return run(main_path, ntrusted, tpaths, tnames, secp_solve, policy, seed, shuffle_queue);
+}
+void orc_get_summary(void* h, orc_summary* s) {
+    Result* R = (Result*)h;
+    s->status = R->status; s->verdict = R->verdict;
+    s->n_vars = R->n_vars; s->n_rows_main = R->n_rows_main; s->n_rows_reduced = R->n_rows_reduced;
+    s->n_specials = R->n_specials;
+    s->unique_nontrivial = R->unique_nontrivial; s->n_nontrivial = R->n_nontrivial;
+    s->unique_targets = R->unique_targets; s->n_targets = R->n_targets;
+    s->successful_steps = R->successful_steps; s->outer_iterations = R->outer_iterations;
+    s->pops = R->pops; s->num_unique = R->num_unique;
+    for (int i = 0; i < 16; ++i) s->rule_hits[i] = R->rule_hits[i];
+    s->alg_bytes_pops = R->alg_bytes_pops; s->alg_bytes_sweep = R->alg_bytes_sweep;
+    s->nnz_reduced = R->nnz_reduced; s->n_bad_rows = (int64_t)R->bad_rows.size();
+    s->t_read = R->t_read; s->t_abstract = R->t_abstract; s->t_solve = R->t_solve;
+}
+// per-variable state, 1-based variable v stored at index v-1.
+// flags bit0 = unique, bit1 = is_known; lb/ub/values as 4 little-endian u64 limbs.
+void orc_get_states(void* h, uint8_t* flags, uint64_t* lb, uint64_t* ub, int64_t* abz,
+                    uint8_t* nvalues, uint64_t* values /* 2*4 per var */) {
+    Result* R = (Result*)h;
+    for (int64_t v = 1; v <= R->n_vars && v < (int64_t)R->states.size(); ++v) {
+        const VarState& s = R->states[v];
+        if (flags) flags[v - 1] = (s.unique ? 1 : 0) | (s.is_known ? 2 : 0);
+        if (lb) std::memcpy(lb + 4 * (v - 1), s.lb.w, 32);
+        if (ub) std::memcpy(ub + 4 * (v - 1), s.ub.w, 32);
+        if (abz) abz[v - 1] = s.abz;
+        if (nvalues) nvalues[v - 1] = (uint8_t)std::min<size_t>(s.values.size(), 2);
+        if (values) {
+            std::memset(values + 8 * (v - 1), 0, 64);
+            for (size_t k = 0; k < s.values.size() && k < 2; ++k)
+                std::memcpy(values + 8 * (v - 1) + 4 * k, s.values[k].w, 32);
+        }
+    }
+}
+void orc_get_bad_rows(void* h, int64_t* out) {
+    Result* R = (Result*)h;
+    for (size_t i = 0; i < R->bad_rows.size(); ++i) out[i] = R->bad_rows[i];
+}
+int64_t orc_special_count(void* h) { return (int64_t)((Result*)h)->specials.size(); }
+int64_t orc_special_get(void* h, int64_t idx, char* name, int64_t name_cap, int64_t* inputs, int64_t in_cap,
+                        int64_t* outputs, int64_t out_cap, int64_t* n_out) {
+    Result* R = (Result*)h;
+    const Special& s = R->specials[(size_t)idx];
+    std::snprintf(name, (size_t)name_cap, "%s", s.name.c_str());
+    for (size_t i = 0; i < s.inputs.size() && (int64_t)i < in_cap; ++i) inputs[i] = s.inputs[i];
+    for (size_t i = 0; i < s.outputs.size() && (int64_t)i < out_cap; ++i) outputs[i] = s.outputs[i];
+    *n_out = (int64_t)s.outputs.size();
+    return (int64_t)s.inputs.size();
+}
+void orc_free(void* h) { delete (Result*)h; }
+
+// readR1CS header/IO lists for the reader tests. Returns status.
+int orc_read_info(const char* path, int64_t* info /* nWires,nOut,nPubIn,nPrvIn,nLabels,nC,nVars,fieldSize */,
+                  int64_t* knowns, int64_t knowns_cap, int64_t* n_knowns, int64_t* outputs, int64_t out_cap,
+                  int64_t* n_outputs, int64_t* nnz /*3*/) {
+    try {
+        Parsed p;
+        parse_r1cs(path, p);
+        info[0] = p.n_wires; info[1] = p.n_pub_out; info[2] = p.n_pub_in; info[3] = p.n_prv_in;
+        info[4] = (int64_t)p.n_labels; info[5] = p.n_cons; info[6] = p.nvars; info[7] = p.field_size;
+        *n_knowns = (int64_t)p.knowns.size();
+        *n_outputs = (int64_t)p.outputs.size();
+        for (size_t i = 0; i < p.knowns.size() && (int64_t)i < knowns_cap; ++i) knowns[i] = p.knowns[i];
+        for (size_t i = 0; i < p.outputs.size() && (int64_t)i < out_cap; ++i) outputs[i] = p.outputs[i];
+        nnz[0] = nnz[1] = nnz[2] = 0;
+        for (auto& e : p.eqs) {
+            nnz[0] += nonzeroKeys(e.a, nullptr).count;
+            nnz[1] += nonzeroKeys(e.b, nullptr).count;
+            nnz[2] += nonzeroKeys(e.c, nullptr).count;
+        }
+        return 0;
+    } catch (OracleError& e) {
+        return e.code;
+    }
+}
+
+// Julia iteration-order known-answer hooks (tests/test_julia_order.py):
+//  mode 0: Set order after push!-ing `keys` in the given order
+//  mode 1: "file order -> row map (Dict) -> nonzeroKeys Set" order (all coefficients non-zero)
+//  mode 2: Dict order after inserting `keys` in the given order
+void orc_julia_order(const int64_t* keys, int64_t n, int mode, int64_t* out) {
+    if (mode == 0) {
+        JlSet s;
+        for (int64_t i = 0; i < n; ++i) s.set(keys[i], Nothing());
+        std::vector<int64_t> o = s.ordered_keys();
+        for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+    } else {
+        LinMap m;
+        for (int64_t i = 0; i < n; ++i) m.set(keys[i], ONE);
+        if (mode == 2) {
+            std::vector<int64_t> o = m.ordered_keys();
+            for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+        } else {
+            std::vector<int64_t> o = nonzeroKeys(m, nullptr).ordered_keys();
+            for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+        }
+    }
+}
+
+// field KAT hooks (tests/test_field.py): op 0 add, 1 sub, 2 mul, 3 inv(a), 4 div a/b, 5 neg(a)
+int orc_fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    U256 x(a[0], a[1], a[2], a[3]), y(b[0], b[1], b[2], b[3]), r;
+    try {
+        switch (op) {
+            case 0: r = fp_add(x, y); break;
+            case 1: r = fp_sub(x, y); break;
+            case 2: r = fp_mul(x, y); break;
+            case 3: r = fp_inv(x); break;
+            case 4: r = fp_div(x, y); break;
+            case 5: r = fp_neg(x); break;
+            default: return -1;
+        }
+    } catch (DivideError&) { return ST_EDIVZERO; }
+    std::memcpy(out, r.w, 32);
+    return 0;
+}
+}
