@@ -1,0 +1,303 @@
+"""ecneproject_amd — host-side mirror of Ecne's solver interface over libecne_hip (MI355X / gfx950).
+
+The reference (franklynwang/EcneProject) is Julia; its seam for the hot path is three functions
+(src/ParseR1CS.jl:50, src/R1CSConstraintSolver.jl:502 and :583).  Julia is not available in the
+build image, so this Python module plays the role the Julia shim `julia/EcneHIP.jl` plays for a
+Julia user: the same function names, argument meaning and error behaviour, on top of the C ABI of
+include/ecne.h.  All propagation work happens in the HIP kernels; nothing here evaluates a rule.
+
+    readR1CS(filename)                         -> (equations, known_vars, output_vars, nVars)
+    SolveConstraintsSymbolic(constraints, special_constraints, known_variables, debug=False,
+                             target_variables=[], num_variables=-1, input_sym="default.sym",
+                             secp_solve=False) -> bool
+    solveWithTrustedFunctions(input_r1cs, input_r1cs_name, trusted_r1cs=[], trusted_r1cs_names=[],
+                              debug=False, printRes=True, abstractionOnly=False, input_sym="",
+                              secp_solve=False) -> bool
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import Info, Opts, Summary, SystemInfo
+
+__all__ = ["readR1CS", "SolveConstraintsSymbolic", "solveWithTrustedFunctions", "solve_batch",
+           "R1CS", "System", "SolveResult", "EcneError", "BoundsError", "DivideError", "UndefVarError",
+           "device_count", "classify"]
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+# ---- the reference's exception types, as raised through the status codes of the C ABI
+class EcneError(Exception):
+    status = 0
+
+
+class BoundsError(EcneError, IndexError):        # Julia BoundsError (:916, :762, :785)
+    status = -2
+
+
+class DivideError(EcneError, ZeroDivisionError):  # Julia DivideError (:919-920, :1467)
+    status = -3
+
+
+class UndefVarError(EcneError, NameError):       # Julia UndefVarError: dsu (:762), msg (:556-559)
+    status = -4
+
+
+class FormatError(EcneError, AssertionError):    # @assert in readR1CS (ParseR1CS.jl:58,62,69)
+    status = -1
+
+
+class AbstractionKeyError(EcneError, KeyError):  # KeyError (:381-382)
+    status = -5
+
+
+class DetSizeError(EcneError):
+    status = -6
+
+
+class NoDeviceError(EcneError, RuntimeError):
+    status = -8
+
+
+_EXC = {-1: FormatError, -2: BoundsError, -3: DivideError, -4: UndefVarError, -5: AbstractionKeyError,
+        -6: DetSizeError, -7: OSError, -8: NoDeviceError, -9: ValueError, -10: EcneError}
+
+
+def _check(st, what=""):
+    if st == 0:
+        return
+    msg = _lib.lib().ecne_strerror(st).decode()
+    raise _EXC.get(st, EcneError)("%s%s (ecne_status %d)" % (what + ": " if what else "", msg, st))
+
+
+def device_count():
+    return _lib.lib().ecne_device_count()
+
+
+class R1CS:
+    """A parsed .r1cs file (the `equations` object of readR1CS)."""
+
+    def __init__(self, path):
+        self.path = os.fspath(path)
+        self._h = C.c_void_p()
+        _check(_lib.lib().ecne_r1cs_load(os.fsencode(self.path), C.byref(self._h)), self.path)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().ecne_r1cs_free(h)
+            self._h = None
+
+    @property
+    def info(self):
+        i = Info()
+        _check(_lib.lib().ecne_r1cs_info(self._h, C.byref(i)))
+        return i
+
+    def __len__(self):
+        return int(self.info.n_constraints)
+
+    def io(self):
+        kn, tg = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+        nk, nt = C.c_size_t(), C.c_size_t()
+        _check(_lib.lib().ecne_r1cs_io(self._h, C.byref(kn), C.byref(nk), C.byref(tg), C.byref(nt)))
+        return [kn[i] for i in range(nk.value)], [tg[i] for i in range(nt.value)]
+
+    def csr(self, part):
+        """(rowptr, col, coeff[nnz,4]) of part 0/1/2 in file order; copies."""
+        rp, col, cf = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)()
+        _check(_lib.lib().ecne_r1cs_csr(self._h, part, C.byref(rp), C.byref(col), C.byref(cf)))
+        n = len(self)
+        rowptr = np.ctypeslib.as_array(rp, (n + 1,)).copy()
+        nnz = int(rowptr[-1])
+        c = np.ctypeslib.as_array(col, (max(nnz, 1),))[:nnz].copy()
+        v = np.ctypeslib.as_array(cf, (max(nnz, 1) * 4,))[:nnz * 4].reshape(nnz, 4).copy()
+        return rowptr, c, v
+
+
+class System:
+    """Rows + special constraints + I/O lists: what SolveConstraintsSymbolic is called with."""
+
+    def __init__(self, r1cs):
+        self._h = C.c_void_p()
+        self.main = r1cs
+        _check(_lib.lib().ecne_system_from_r1cs(r1cs._h, C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().ecne_system_free(h)
+            self._h = None
+
+    def abstract(self, trusted, name):
+        """abstraction(name, rows, knowns_t, eqs_t, outs_t) (:237-395) applied in place."""
+        _check(_lib.lib().ecne_abstract(self._h, trusted._h, name.encode()), "abstraction(%s)" % name)
+
+    @property
+    def info(self):
+        i = SystemInfo()
+        _check(_lib.lib().ecne_system_info_get(self._h, C.byref(i)))
+        return i
+
+    def specials(self):
+        out = []
+        for k in range(int(self.info.n_specials)):
+            name = C.c_char_p()
+            ins, outs = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+            ni, no = C.c_size_t(), C.c_size_t()
+            _check(_lib.lib().ecne_system_special(self._h, k, C.byref(name), C.byref(ins), C.byref(ni),
+                                                  C.byref(outs), C.byref(no)))
+            out.append((name.value.decode(), [ins[i] for i in range(ni.value)], [outs[i] for i in range(no.value)]))
+        return out
+
+    def __len__(self):
+        return int(self.info.n_rows)
+
+
+class SolveResult:
+    def __init__(self, handle):
+        L = _lib.lib()
+        s = Summary()
+        _check(L.ecne_result_summary(handle, C.byref(s)))
+        self.summary = s
+        self.status = int(s.status)
+        self.function_good = bool(s.function_good)
+        nv = int(s.n_vars)
+        fl, lb, ub = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        abz, nvs, vals = C.POINTER(C.c_int32)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
+        _check(L.ecne_result_states(handle, C.byref(fl), C.byref(lb), C.byref(ub), C.byref(abz), C.byref(nvs),
+                                    C.byref(vals)))
+
+        def arr(p, shape):
+            if nv == 0:
+                return np.zeros(shape, dtype=np.ctypeslib.as_array(p, (1,)).dtype if p else np.uint8)
+            return np.ctypeslib.as_array(p, shape).copy()
+        self.flags = arr(fl, (nv,))
+        self.lb = arr(lb, (nv, 4))
+        self.ub = arr(ub, (nv, 4))
+        self.abz = arr(abz, (nv,))
+        self.nvalues = arr(nvs, (nv,))
+        self.values = arr(vals, (nv, 2, 4))
+        rows, n = C.POINTER(C.c_int64)(), C.c_size_t()
+        _check(L.ecne_result_bad_rows(handle, C.byref(rows), C.byref(n)))
+        self.bad_rows = np.array([rows[i] for i in range(n.value)], dtype=np.int64)
+        L.ecne_result_free(handle)
+
+    @property
+    def unique(self):
+        return (self.flags & 1).astype(bool)
+
+    @property
+    def is_known(self):
+        return ((self.flags >> 1) & 1).astype(bool)
+
+    def counts(self):
+        s = self.summary
+        return (s.unique_nontrivial, s.n_nontrivial, s.unique_targets, s.n_targets)
+
+    def raise_for_status(self):
+        _check(self.status, "SolveConstraintsSymbolic")
+
+
+def _opts(device=0, secp_solve=False, queue_mode=0, stream=None):
+    o = Opts()
+    o.device = int(device)
+    o.secp_solve = int(bool(secp_solve))
+    o.debug = 0
+    o.queue_mode = int(queue_mode)
+    o.stream = stream
+    return o
+
+
+def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None):
+    """Run n independent systems in one launch (one workgroup each). Returns SolveResult list."""
+    L = _lib.lib()
+    n = len(systems)
+    hs = (C.c_void_p * n)(*[s._h for s in systems])
+    outs = (C.c_void_p * n)()
+    o = _opts(device, secp_solve, queue_mode, stream)
+    _check(L.ecne_solve_batch(hs, n, C.byref(o), outs), "ecne_solve_batch")
+    return [SolveResult(C.c_void_p(outs[i])) for i in range(n)]
+
+
+def classify(system, device=0):
+    """k_classify_rows on one system: (shape words, kernel ms, bytes streamed)."""
+    L = _lib.lib()
+    n = len(system)
+    shape = np.zeros(max(n, 1), np.uint32)
+    ms, by = C.c_double(), C.c_uint64()
+    o = _opts(device)
+    _check(L.ecne_classify(system._h, C.byref(o), shape.ctypes.data, C.byref(ms), C.byref(by)), "ecne_classify")
+    return shape[:n], ms.value, int(by.value)
+
+
+# ------------------------------------------------------------------ the reference's interface
+def readR1CS(filename):
+    """ParseR1CS.jl:50-124 -> (equations, known_vars, output_vars, nVars)."""
+    f = R1CS(filename)
+    kn, out = f.io()
+    return f, kn, out, int(f.info.n_vars)
+
+
+# state of the last solve, for callers that want more than the Bool
+last_result = None
+
+
+def SolveConstraintsSymbolic(constraints, special_constraints, known_variables, debug=False,
+                             target_variables=(), num_variables=-1, input_sym="default.sym",
+                             secp_solve=False, device=0):
+    """R1CSConstraintSolver.jl:583-1646.  `constraints` is a System (rows after abstraction; its
+    special constraints and I/O lists travel inside the handle) or an R1CS (no special constraints)."""
+    global last_result
+    system = constraints if isinstance(constraints, System) else System(constraints)
+    res = solve_batch([system], secp_solve=secp_solve, device=device)[0]
+    last_result = res
+    res.raise_for_status()
+    s = res.summary
+    # the three lines the reference always prints (:1565-1571, :1586-1592, :1599)
+    print("Solved for %d variables out of %d total variables" % (s.unique_nontrivial, s.n_nontrivial))
+    print("Solved for %d target variables out of %d total target variables" % (s.unique_targets, s.n_targets))
+    print("------ Bad Constraints ------")
+    print()
+    return res.function_good
+
+
+def solveWithTrustedFunctions(input_r1cs, input_r1cs_name, trusted_r1cs=(), trusted_r1cs_names=(),
+                              debug=False, printRes=True, abstractionOnly=False, input_sym="",
+                              secp_solve=False, device=0):
+    """R1CSConstraintSolver.jl:502-581."""
+    a = time.time()
+    assert len(trusted_r1cs) == len(trusted_r1cs_names)                      # :514
+    main, _knowns, _outs, _nv = readR1CS(input_r1cs)                           # :515
+    function_list = []
+    for path, name in zip(trusted_r1cs, trusted_r1cs_names):                   # :517-523
+        function_list.append((name, R1CS(path)))
+    if debug:
+        print("file read")
+    function_list.sort(key=lambda x: -len(x[1]))                               # :527 (stable)
+    system = System(main)
+    for name, f in function_list:                                              # :531-544
+        if printRes:
+            print("called abstraction")
+        system.abstract(f, name)
+    if abstractionOnly:                                                        # :546-549
+        print(system.specials())
+        return True
+    print("time to prep inputs %d milliseconds" % int((time.time() - a) * 1000))   # :551
+    result = SolveConstraintsSymbolic(system, None, None, debug, (), -1, input_sym, secp_solve, device=device)
+    if result:
+        if function_list:
+            if printRes:
+                # :556-559 is a tuple assignment that reads `msg` before binding it: UndefVarError
+                raise UndefVarError("msg not defined (reference :556-559)")
+            return True
+        if printRes:
+            print("R1CS function " + input_r1cs_name + " has sound constraints (No trusted functions needed!)")
+        return True
+    if printRes:
+        print("R1CS function " + input_r1cs_name + " has potentially unsound constraints")
+    return False

@@ -1,0 +1,713 @@
+// ecne_engine.hip — libecne_hip: C ABI (include/ecne.h) + host orchestration of the gfx950 kernels.
+//
+// What runs where
+//   host (this file, host_model.hpp): .r1cs parsing, trusted-function abstraction, and the one-time
+//        layout of a constraint system into flat HBM arrays (row entries stored in the order the
+//        reference would visit them, variable->rows fan-out, static candidate lists).
+//   device (kernels.hip.hpp): k_classify_rows (row shapes + field constants) and k_solve, the
+//        whole SolveConstraintsSymbolic fixed point (reference src/R1CSConstraintSolver.jl:583-1646).
+// There is no CPU implementation of the propagation rules in this library: without a HIP device
+// every solve entry point returns ECNE_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ecne.h"
+#include "engine_types.hpp"
+#include "fp256.hpp"
+#include "host_model.hpp"
+#include "jlorder.hpp"
+#include "kernels.hip.hpp"
+
+using namespace ecne;
+
+struct ecne_r1cs {
+    R1CSFile f;
+};
+
+// Host image of the flat arrays (built once per system, uploaded once per device)
+struct Layout {
+    uint32_t nC = 0, nV = 0;
+    std::vector<uint32_t> rp[3], col[3];
+    std::vector<uint64_t> coef[3];
+    std::vector<RowInfo> rinfo;
+    uint32_t n_vals = 0;
+    std::vector<uint32_t> fo_ptr, fo_rows;
+    std::vector<uint32_t> sp_in_ptr, sp_in, sp_out_ptr, sp_out;
+    std::vector<uint8_t> sp_kind;
+    std::vector<uint32_t> knowns, targets;
+    std::vector<uint8_t> nontrivial;
+    std::vector<uint32_t> p4_list, p5_rows, p5_y;
+    uint64_t nnz[3] = {0, 0, 0};
+    uint64_t stream_bytes = 0;   // bytes k_classify_rows reads + writes (roofline numerator)
+};
+
+struct DeviceImage {
+    int device = -1;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    Job job;          // host copy with device pointers
+    bool classified = false;
+    double classify_ms = 0;
+};
+
+struct ecne_system {
+    Rows rows;                    // dictionary order, current (possibly reduced) rows
+    std::vector<Special> specials;
+    std::vector<int64_t> knowns, targets;
+    int64_t n_vars = 0, n_rows_main = 0;
+    bool laid_out = false;
+    Layout L;
+    DeviceImage dev;
+    ~ecne_system() {
+        if (dev.arena) {
+            (void)hipSetDevice(dev.device);
+            (void)hipFree(dev.arena);
+        }
+    }
+};
+
+struct ecne_result {
+    ecne_summary sum;
+    std::vector<uint8_t> flags, nvalues;
+    std::vector<uint64_t> lb, ub, values;
+    std::vector<int32_t> abz;
+    std::vector<int64_t> bad_rows;
+};
+
+// ------------------------------------------------------------------------------------ layout
+static void build_layout(ecne_system& S) {
+    Layout& L = S.L;
+    const Rows& R = S.rows;
+    const size_t nC = R.n();
+    L = Layout();
+    L.nC = (uint32_t)nC;
+    L.nV = (uint32_t)S.n_vars;
+    // a special or a row may mention a variable above nWires+1 only in malformed input; size state
+    // arrays for the largest id seen so that indexing stays in bounds
+    uint32_t maxv = L.nV;
+    for (int p = 0; p < 3; ++p)
+        for (uint32_t v : R.var[p]) maxv = std::max(maxv, v);
+    for (auto& sp : S.specials) {
+        for (int64_t v : sp.inputs) maxv = std::max<uint32_t>(maxv, (uint32_t)v);
+        for (int64_t v : sp.outputs) maxv = std::max<uint32_t>(maxv, (uint32_t)v);
+    }
+    const uint32_t nVall = maxv;   // arrays hold ids 0..nVall
+    L.nV = nVall;
+    for (int p = 0; p < 3; ++p) { L.rp[p].assign(1, 0); L.col[p].clear(); L.coef[p].clear(); }
+    L.rinfo.assign(nC, RowInfo());
+    L.nontrivial.assign((size_t)nVall + 1, 0);
+    std::vector<uint32_t> deg((size_t)nVall + 2, 0);
+
+    const fp::u256 ONE = fp::make(1), PM1 = fp::pminus1();
+    jl::SlotTable set;
+    struct E { uint32_t v; fp::u256 c; };
+    std::vector<E> nz[3];
+    std::vector<uint32_t> zeros_c;   // unused beyond counting
+    std::vector<uint8_t> a_equal_next(nC, 0);
+    std::vector<uint32_t> seen_stamp((size_t)nVall + 1, 0xFFFFFFFFu);
+
+    for (size_t i = 0; i < nC; ++i) {
+        RowInfo ri;
+        std::memset(&ri, 0, sizeof ri);
+        ri.validx = 0xFFFFFFFFu;
+        uint32_t zc[3] = {0, 0, 0};
+        bool c_has_key1 = false;
+        for (int p = 0; p < 3; ++p) {
+            // nonzeroKeys(part): a Set filled in dictionary order, iterated in slot order (:26-34)
+            nz[p].clear();
+            set.reset();
+            std::vector<E> tmp;
+            for (uint64_t k = R.ptr[p][i]; k < R.ptr[p][i + 1]; ++k) {
+                if (p == 2 && R.var[p][k] == 1) c_has_key1 = true;
+                if (fp::is_zero(R.coef[p][k])) { zc[p]++; continue; }
+                bool ins;
+                set.upsert((int64_t)R.var[p][k], (int64_t)tmp.size(), ins);
+                tmp.push_back({R.var[p][k], R.coef[p][k]});
+            }
+            set.for_each([&](int64_t, int64_t pay) { nz[p].push_back(tmp[(size_t)pay]); });
+            for (auto& e : nz[p]) {
+                L.col[p].push_back(e.v);
+                for (int w = 0; w < 4; ++w) L.coef[p].push_back(e.c.w[w]);
+                L.nontrivial[e.v] = 1;
+                if (seen_stamp[e.v] != (uint32_t)i) { seen_stamp[e.v] = (uint32_t)i; deg[e.v]++; }
+            }
+            L.rp[p].push_back((uint32_t)L.col[p].size());
+            L.nnz[p] += nz[p].size();
+        }
+        const size_t nA = nz[0].size(), nB = nz[1].size(), nCc = nz[2].size();
+        ri.lenC = (uint32_t)nCc;
+        if (nA || nB) ri.shape |= SH_HAS_AB;
+        if (nCc == 0) {
+            ri.shape |= SH_C_EMPTY;
+            // S = (nzA u nzB) \ {1}
+            uint32_t x = 0, distinct = 0;
+            for (int p = 0; p < 2; ++p)
+                for (auto& e : nz[p])
+                    if (e.v != 1) {
+                        if (distinct == 0) { x = e.v; distinct = 1; }
+                        else if (e.v != x) distinct = 2;
+                    }
+            if (distinct == 0) ri.shape |= SH_R2_BOUNDSERR;
+            else if (distinct == 1) {
+                ri.shape |= SH_R2;
+                ri.x = x;
+                bool inA = false, inB = false;
+                for (auto& e : nz[0]) inA |= e.v == x;
+                for (auto& e : nz[1]) inB |= e.v == x;
+                if (!inA || !inB) ri.shape |= SH_R2_DIV0;
+            }
+            // P4 static test (:1427-1466)
+            if (nB == 1 && nA <= 2) {
+                ri.shape |= SH_P4;
+                ri.kpos = nz[1][0].v;
+                uint32_t slope_index = 0;
+                bool have = false;
+                for (auto& e : nz[0])
+                    if (e.v != 1) { slope_index = e.v; have = true; }   // last one wins (:1462-1465)
+                ri.kneg = slope_index;
+                if (!have) ri.shape |= SH_P4_DIV0;
+                L.p4_list.push_back((uint32_t)i);
+            }
+        }
+        if (!(ri.shape & SH_HAS_AB) && nCc > 0) {
+            // R3 (:949-960)
+            uint32_t nonone = 0, x = 0;
+            for (auto& e : nz[2]) if (e.v != 1) { nonone++; x = e.v; }
+            if (nonone == 1) { ri.shape |= SH_R3; ri.x = x; }
+            uint32_t czero_eff = zc[2] + (((ri.shape & SH_R3) && !c_has_key1) ? 1u : 0u);
+            if (czero_eff) ri.shape |= SH_CZERO;
+            // R5 / R6 in dictionary order (:1082-1092, :1154-1173)
+            const uint64_t d0 = R.ptr[2][i], d1 = R.ptr[2][i + 1];
+            if (!czero_eff && d1 - d0 == 2) {
+                const fp::u256 &u = R.coef[2][d0], &v = R.coef[2][d0 + 1];
+                if ((fp::eq(u, ONE) && fp::eq(v, PM1)) || (fp::eq(u, PM1) && fp::eq(v, ONE))) {
+                    ri.shape |= SH_R5;
+                    ri.k1 = R.var[2][d0];
+                    ri.k2 = R.var[2][d0 + 1];
+                }
+            }
+            if (!czero_eff && d1 - d0 == 3) {
+                int ones = 0, mones = 0;
+                bool one_on_const = true;
+                uint32_t k1 = 0, k2 = 0;
+                for (uint64_t k = d0; k < d1; ++k) {
+                    if (fp::eq(R.coef[2][k], ONE)) { ones++; if (R.var[2][k] != 1) one_on_const = false; }
+                    else if (fp::eq(R.coef[2][k], PM1)) { if (mones == 0) k1 = R.var[2][k]; else k2 = R.var[2][k]; mones++; }
+                }
+                if (ones == 1 && mones == 2 && one_on_const) { ri.shape |= SH_R6; ri.k1 = k1; ri.k2 = k2; }
+            }
+            if (ri.shape & (SH_R5 | SH_R6)) {   // order of `for j in Set([k1, k2])`
+                set.reset();
+                bool ins;
+                set.upsert(ri.k1, 0, ins);
+                set.upsert(ri.k2, 1, ins);
+                int64_t first = -1;
+                set.for_each([&](int64_t key, int64_t) { if (first < 0) first = key; });
+                if ((uint32_t)first == ri.k2 && ri.k1 != ri.k2) ri.shape |= SH_R56_SWAP;
+            }
+        }
+        if ((ri.shape & SH_R2) || (!(ri.shape & SH_HAS_AB) && nCc > 0)) {
+            ri.validx = L.n_vals;
+            L.n_vals += 2;
+        }
+        L.rinfo[i] = ri;
+        // A-map equality with the next row, zeros included (:1512)
+        if (i + 1 < nC) {
+            const uint64_t x0 = R.ptr[0][i], x1 = R.ptr[0][i + 1], y0 = R.ptr[0][i + 1], y1 = R.ptr[0][i + 2];
+            bool eq = (x1 - x0) == (y1 - y0);
+            for (uint64_t k = x0; eq && k < x1; ++k) {
+                bool found = false;
+                for (uint64_t m = y0; m < y1; ++m)
+                    if (R.var[0][m] == R.var[0][k]) { found = fp::eq(R.coef[0][m], R.coef[0][k]); break; }
+                eq = found;
+            }
+            a_equal_next[i] = eq;
+        }
+    }
+    // P5 static candidates (:1492-1536)
+    for (size_t i = 0; i + 1 < nC; ++i) {
+        const uint32_t nc_next = L.rp[2][i + 2] - L.rp[2][i + 1];
+        const uint32_t nb_next = L.rp[1][i + 2] - L.rp[1][i + 1];
+        const uint32_t nc_this = L.rp[2][i + 1] - L.rp[2][i];
+        if (nc_next != 0 || nb_next != 1 || nc_this != 2 || !a_equal_next[i]) continue;
+        const uint32_t y = L.col[1][L.rp[1][i + 1]];
+        if (y == 1) continue;
+        bool bad = false;
+        for (uint32_t k = L.rp[2][i]; k < L.rp[2][i + 1]; ++k)
+            if (L.col[2][k] != 1 && L.col[2][k] != y) bad = true;
+        if (bad) continue;
+        L.p5_rows.push_back((uint32_t)i);
+        L.p5_y.push_back(y);
+    }
+    // variable_to_indices (:628-633): ascending rows per variable
+    L.fo_ptr.assign((size_t)nVall + 2, 0);
+    for (uint32_t v = 0; v <= nVall; ++v) L.fo_ptr[v + 1] = L.fo_ptr[v] + deg[v];
+    L.fo_rows.assign(L.fo_ptr[nVall + 1], 0);
+    {
+        std::vector<uint32_t> fill(L.fo_ptr.begin(), L.fo_ptr.end() - 1);
+        std::fill(seen_stamp.begin(), seen_stamp.end(), 0xFFFFFFFFu);
+        for (size_t i = 0; i < nC; ++i)
+            for (int p = 0; p < 3; ++p)
+                for (uint32_t k = L.rp[p][i]; k < L.rp[p][i + 1]; ++k) {
+                    uint32_t v = L.col[p][k];
+                    if (seen_stamp[v] != (uint32_t)i) { seen_stamp[v] = (uint32_t)i; L.fo_rows[fill[v]++] = (uint32_t)i; }
+                }
+    }
+    // specials, I/O lists, nontrivial set (:600-618)
+    L.sp_in_ptr.assign(1, 0);
+    L.sp_out_ptr.assign(1, 0);
+    for (auto& sp : S.specials) {
+        for (int64_t v : sp.inputs) { L.sp_in.push_back((uint32_t)v); L.nontrivial[(size_t)v] = 1; }
+        for (int64_t v : sp.outputs) { L.sp_out.push_back((uint32_t)v); L.nontrivial[(size_t)v] = 1; }
+        L.sp_in_ptr.push_back((uint32_t)L.sp_in.size());
+        L.sp_out_ptr.push_back((uint32_t)L.sp_out.size());
+        L.sp_kind.push_back(sp.name == "BigMultModP" ? 1 : sp.name == "BigLessThan" ? 2 : 0);
+    }
+    for (int64_t v : S.knowns) if (v >= 1 && (uint64_t)v <= nVall) L.knowns.push_back((uint32_t)v);
+    for (int64_t v : S.targets) if (v >= 1 && (uint64_t)v <= nVall) { L.targets.push_back((uint32_t)v); L.nontrivial[(size_t)v] = 1; }
+    uint64_t nnz = L.nnz[0] + L.nnz[1] + L.nnz[2];
+    L.stream_bytes = (uint64_t)nC * (12 + 32 + 32) + nnz * 36 + L.nnz[2] * 4 + (uint64_t)L.n_vals * 32;
+    S.laid_out = true;
+}
+
+// ------------------------------------------------------------------------------------ device image
+#define HIP_TRY(x)                                   \
+    do {                                             \
+        hipError_t e_ = (x);                         \
+        if (e_ != hipSuccess) return K_ENODEVICE;      \
+    } while (0)
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+static uint32_t pow2_at_least(uint64_t x) {
+    uint64_t p = 16;
+    while (p < x) p <<= 1;
+    return (uint32_t)p;
+}
+
+static int upload_system(ecne_system& S, int device) {
+    if (S.dev.arena && S.dev.device == device) return K_OK;
+    if (S.dev.arena) { (void)hipSetDevice(S.dev.device); (void)hipFree(S.dev.arena); S.dev = DeviceImage(); }
+    if (!S.laid_out) build_layout(S);
+    const Layout& L = S.L;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t nC = L.nC, nV = L.nV, nSp = (uint32_t)L.sp_kind.size();
+    const uint32_t qcap = pow2_at_least((uint64_t)nC + 2);
+    const uint32_t htcap = pow2_at_least((uint64_t)nC * 2 + 16);
+    const uint32_t hotcap = 4096;
+    const uint32_t nev = std::max<uint32_t>((uint32_t)L.p4_list.size(), 64);
+    Carver c;
+    size_t o_rp[3], o_col[3], o_coef[3];
+    for (int p = 0; p < 3; ++p) {
+        o_rp[p] = c.take(4ull * (nC + 1));
+        o_col[p] = c.take(4ull * std::max<size_t>(L.col[p].size(), 1));
+        o_coef[p] = c.take(8ull * std::max<size_t>(L.coef[p].size(), 4));
+    }
+    size_t o_csort = c.take(4ull * std::max<size_t>(L.col[2].size(), 1));
+    size_t o_rinfo = c.take(sizeof(RowInfo) * std::max<size_t>(nC, 1));
+    size_t o_vals = c.take(32ull * std::max<uint32_t>(L.n_vals, 1));
+    size_t o_foptr = c.take(4ull * L.fo_ptr.size());
+    size_t o_forows = c.take(4ull * std::max<size_t>(L.fo_rows.size(), 1));
+    size_t o_spinptr = c.take(4ull * L.sp_in_ptr.size()), o_spin = c.take(4ull * std::max<size_t>(L.sp_in.size(), 1));
+    size_t o_spoutptr = c.take(4ull * L.sp_out_ptr.size()), o_spout = c.take(4ull * std::max<size_t>(L.sp_out.size(), 1));
+    size_t o_spkind = c.take(std::max<size_t>(nSp, 1));
+    size_t o_knowns = c.take(4ull * std::max<size_t>(L.knowns.size(), 1)), o_targets = c.take(4ull * std::max<size_t>(L.targets.size(), 1));
+    size_t o_nontriv = c.take((size_t)nV + 1);
+    size_t o_p4 = c.take(4ull * std::max<size_t>(L.p4_list.size(), 1));
+    size_t o_p5r = c.take(4ull * std::max<size_t>(L.p5_rows.size(), 1)), o_p5y = c.take(4ull * std::max<size_t>(L.p5_y.size(), 1));
+    const size_t static_end = c.off;
+    size_t o_flags = c.take((size_t)nV + 1), o_abz = c.take(4ull * (nV + 1));
+    size_t o_lb = c.take(32ull * (nV + 1)), o_ub = c.take(32ull * (nV + 1));
+    size_t o_nvalues = c.take((size_t)nV + 1), o_values = c.take(64ull * (nV + 1));
+    size_t o_inq = c.take(std::max<size_t>(nC, 1)), o_solved = c.take((size_t)nC + 1), o_flip3 = c.take(std::max<size_t>(nC, 1));
+    size_t o_queue = c.take(4ull * qcap);
+    size_t o_varmin = c.take(4ull * (nV + 1));
+    size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
+    size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
+    size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
+    size_t o_ctr = c.take(sizeof(Counters));
+    (void)static_end;
+    char* base = nullptr;
+    HIP_TRY(hipMalloc((void**)&base, c.off));
+    S.dev.arena = base;
+    S.dev.arena_bytes = c.off;
+    S.dev.device = device;
+    auto up = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        return hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
+    };
+    for (int p = 0; p < 3; ++p) {
+        HIP_TRY(up(o_rp[p], L.rp[p].data(), 4ull * L.rp[p].size()));
+        HIP_TRY(up(o_col[p], L.col[p].data(), 4ull * L.col[p].size()));
+        HIP_TRY(up(o_coef[p], L.coef[p].data(), 8ull * L.coef[p].size()));
+    }
+    HIP_TRY(up(o_rinfo, L.rinfo.data(), sizeof(RowInfo) * L.rinfo.size()));
+    HIP_TRY(up(o_foptr, L.fo_ptr.data(), 4ull * L.fo_ptr.size()));
+    HIP_TRY(up(o_forows, L.fo_rows.data(), 4ull * L.fo_rows.size()));
+    HIP_TRY(up(o_spinptr, L.sp_in_ptr.data(), 4ull * L.sp_in_ptr.size()));
+    HIP_TRY(up(o_spin, L.sp_in.data(), 4ull * L.sp_in.size()));
+    HIP_TRY(up(o_spoutptr, L.sp_out_ptr.data(), 4ull * L.sp_out_ptr.size()));
+    HIP_TRY(up(o_spout, L.sp_out.data(), 4ull * L.sp_out.size()));
+    HIP_TRY(up(o_spkind, L.sp_kind.data(), L.sp_kind.size()));
+    HIP_TRY(up(o_knowns, L.knowns.data(), 4ull * L.knowns.size()));
+    HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
+    HIP_TRY(up(o_nontriv, L.nontrivial.data(), L.nontrivial.size()));
+    HIP_TRY(up(o_p4, L.p4_list.data(), 4ull * L.p4_list.size()));
+    HIP_TRY(up(o_p5r, L.p5_rows.data(), 4ull * L.p5_rows.size()));
+    HIP_TRY(up(o_p5y, L.p5_y.data(), 4ull * L.p5_y.size()));
+    Job& J = S.dev.job;
+    std::memset(&J, 0, sizeof J);
+    J.nC = nC; J.nV = nV; J.nSp = nSp;
+    J.nKnown = (uint32_t)L.knowns.size(); J.nTarget = (uint32_t)L.targets.size();
+    J.nP4 = (uint32_t)L.p4_list.size(); J.nP5 = (uint32_t)L.p5_rows.size();
+    J.qmask = qcap - 1; J.htmask = htcap - 1; J.hotcap = hotcap;
+    J.rpA = (const uint32_t*)(base + o_rp[0]); J.rpB = (const uint32_t*)(base + o_rp[1]); J.rpC = (const uint32_t*)(base + o_rp[2]);
+    J.colA = (const uint32_t*)(base + o_col[0]); J.colB = (const uint32_t*)(base + o_col[1]); J.colC = (const uint32_t*)(base + o_col[2]);
+    J.coefA = (const uint64_t*)(base + o_coef[0]); J.coefB = (const uint64_t*)(base + o_coef[1]); J.coefC = (const uint64_t*)(base + o_coef[2]);
+    J.csort = (uint32_t*)(base + o_csort);
+    J.rinfo = (RowInfo*)(base + o_rinfo);
+    J.vals = (uint64_t*)(base + o_vals);
+    J.fo_ptr = (const uint32_t*)(base + o_foptr); J.fo_rows = (const uint32_t*)(base + o_forows);
+    J.sp_in_ptr = (const uint32_t*)(base + o_spinptr); J.sp_in = (const uint32_t*)(base + o_spin);
+    J.sp_out_ptr = (const uint32_t*)(base + o_spoutptr); J.sp_out = (const uint32_t*)(base + o_spout);
+    J.sp_kind = (const uint8_t*)(base + o_spkind);
+    J.knowns = (const uint32_t*)(base + o_knowns); J.targets = (const uint32_t*)(base + o_targets);
+    J.nontrivial = (const uint8_t*)(base + o_nontriv);
+    J.p4_list = (const uint32_t*)(base + o_p4);
+    J.p5_rows = (const uint32_t*)(base + o_p5r); J.p5_y = (const uint32_t*)(base + o_p5y);
+    J.flags = (uint8_t*)(base + o_flags); J.abz = (int32_t*)(base + o_abz);
+    J.lb = (uint64_t*)(base + o_lb); J.ub = (uint64_t*)(base + o_ub);
+    J.nvalues = (uint8_t*)(base + o_nvalues); J.values = (uint64_t*)(base + o_values);
+    J.inq = (uint8_t*)(base + o_inq); J.solved = (uint8_t*)(base + o_solved); J.flip3 = (uint8_t*)(base + o_flip3);
+    J.queue = (uint32_t*)(base + o_queue);
+    J.varmin = (uint32_t*)(base + o_varmin);
+    J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
+    J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
+    J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
+    J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
+    J.ctr = (Counters*)(base + o_ctr);
+    S.dev.classified = false;
+    return K_OK;
+}
+
+// k_classify_rows on one system (idempotent); records the HIP-event time
+static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) {
+    if (S.dev.classified) return K_OK;
+    HIP_TRY(hipMemcpyAsync(d_job_slot, &S.dev.job, sizeof(Job), hipMemcpyHostToDevice, stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    uint32_t nblk = (S.L.nC + 3) / 4;
+    if (nblk > 256 * 32) nblk = 256 * 32;   // >> 256 workgroups: fills all 8 XCDs, grid-strides the rest
+    if (nblk == 0) nblk = 1;
+    HIP_TRY(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_classify_rows, dim3(nblk), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    S.dev.classify_ms = ms;
+    S.dev.classified = true;
+    return K_OK;
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int ecne_r1cs_load(const char* path, ecne_r1cs** out) {
+    if (!path || !out) return ECNE_EINVAL;
+    ecne_r1cs* r = new ecne_r1cs();
+    int st = load_r1cs(path, r->f);
+    if (st != K_OK) { delete r; *out = nullptr; return st; }
+    *out = r;
+    return ECNE_OK;
+}
+int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* o) {
+    if (!f || !o) return ECNE_EINVAL;
+    o->field_size = f->f.field_size; o->n_wires = f->f.n_wires; o->n_pub_out = f->f.n_pub_out;
+    o->n_pub_in = f->f.n_pub_in; o->n_prv_in = f->f.n_prv_in; o->n_constraints = f->f.n_cons;
+    o->n_labels = f->f.n_labels;
+    for (int p = 0; p < 3; ++p) o->nnz[p] = f->f.nnz[p];
+    o->n_vars = f->f.n_vars;
+    return ECNE_OK;
+}
+int ecne_r1cs_csr(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
+    if (!f || part < 0 || part > 2) return ECNE_EINVAL;
+    if (rowptr) *rowptr = f->f.csr_ptr[part].data();
+    if (col) *col = f->f.csr_col[part].data();
+    if (coeff) *coeff = f->f.csr_coef[part].data();
+    return ECNE_OK;
+}
+int ecne_r1cs_io(const ecne_r1cs* f, const int64_t** known, size_t* nk, const int64_t** targets, size_t* nt) {
+    if (!f) return ECNE_EINVAL;
+    if (known) *known = f->f.knowns.data();
+    if (nk) *nk = f->f.knowns.size();
+    if (targets) *targets = f->f.outputs.data();
+    if (nt) *nt = f->f.outputs.size();
+    return ECNE_OK;
+}
+void ecne_r1cs_free(ecne_r1cs* f) { delete f; }
+
+int ecne_system_from_r1cs(const ecne_r1cs* m, ecne_system** out) {
+    if (!m || !out) return ECNE_EINVAL;
+    ecne_system* s = new ecne_system();
+    s->rows = m->f.rows;
+    s->knowns = m->f.knowns;
+    s->targets = m->f.outputs;
+    s->n_vars = m->f.n_vars;
+    s->n_rows_main = (int64_t)m->f.rows.n();
+    *out = s;
+    return ECNE_OK;
+}
+int ecne_abstract(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
+    if (!sys || !trusted || !name) return ECNE_EINVAL;
+    sys->laid_out = false;
+    return abstract_one(name, sys->rows, trusted->f, sys->specials);
+}
+int ecne_system_info_get(const ecne_system* sys, ecne_system_info* o) {
+    if (!sys || !o) return ECNE_EINVAL;
+    ecne_system* s = const_cast<ecne_system*>(sys);
+    if (!s->laid_out) build_layout(*s);
+    o->n_rows = (int64_t)sys->rows.n();
+    o->n_rows_main = sys->n_rows_main;
+    o->n_vars = sys->n_vars;
+    o->n_specials = (int64_t)sys->specials.size();
+    o->n_known = (int64_t)sys->knowns.size();
+    o->n_targets = (int64_t)sys->targets.size();
+    for (int p = 0; p < 3; ++p) o->nnz[p] = s->L.nnz[p];
+    return ECNE_OK;
+}
+int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, const int64_t** in, size_t* nin,
+                        const int64_t** outv, size_t* nout) {
+    if (!sys || idx < 0 || (size_t)idx >= sys->specials.size()) return ECNE_EINVAL;
+    const Special& sp = sys->specials[(size_t)idx];
+    if (name) *name = sp.name.c_str();
+    if (in) *in = sp.inputs.data();
+    if (nin) *nin = sp.inputs.size();
+    if (outv) *outv = sp.outputs.data();
+    if (nout) *nout = sp.outputs.size();
+    return ECNE_OK;
+}
+void ecne_system_free(ecne_system* sys) { delete sys; }
+
+int ecne_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out) {
+    if (!sys || !out || n == 0) return ECNE_EINVAL;
+    for (size_t i = 0; i < n; ++i) out[i] = nullptr;
+    ecne_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    if (ecne_device_count() <= o.device) return ECNE_ENODEVICE;   // never falls back to a CPU path
+    HIP_TRY(hipSetDevice(o.device));
+    hipStream_t stream = (hipStream_t)o.stream;
+    for (size_t i = 0; i < n; ++i) {
+        if (!sys[i]) return ECNE_EINVAL;
+        int st = upload_system(*sys[i], o.device);
+        if (st != K_OK) return st;
+    }
+    Job* d_jobs = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_jobs, sizeof(Job) * n));
+    std::vector<Job> hj(n);
+    int rc = ECNE_OK;
+    do {
+        for (size_t i = 0; i < n; ++i) {
+            int st = classify_system(*sys[i], stream, d_jobs);
+            if (st != K_OK) { rc = st; break; }
+            hj[i] = sys[i]->dev.job;
+            hj[i].secp_solve = o.secp_solve ? 1u : 0u;
+            hj[i].queue_mode = (uint32_t)o.queue_mode;
+            if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        }
+        if (rc != ECNE_OK) break;
+        if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        (void)hipEventRecord(e0, stream);
+        hipLaunchKernelGGL(k_solve, dim3((unsigned)n), dim3(ECNE_WG), 0, stream, (const Job*)d_jobs);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        for (size_t i = 0; i < n; ++i) {
+            ecne_system& S = *sys[i];
+            const Layout& L = S.L;
+            ecne_result* r = new ecne_result();
+            Counters c;
+            if (hipMemcpy(&c, hj[i].ctr, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { delete r; rc = ECNE_ENODEVICE; break; }
+            const size_t nv = (size_t)S.n_vars;
+            std::vector<uint8_t> flags(L.nV + 1), nvals(L.nV + 1);
+            std::vector<uint64_t> lb(4ull * (L.nV + 1)), ub(4ull * (L.nV + 1)), vals(8ull * (L.nV + 1));
+            std::vector<int32_t> abz(L.nV + 1);
+            bool ok = hipMemcpy(flags.data(), hj[i].flags, flags.size(), hipMemcpyDeviceToHost) == hipSuccess &&
+                      hipMemcpy(nvals.data(), hj[i].nvalues, nvals.size(), hipMemcpyDeviceToHost) == hipSuccess &&
+                      hipMemcpy(lb.data(), hj[i].lb, lb.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                      hipMemcpy(ub.data(), hj[i].ub, ub.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                      hipMemcpy(vals.data(), hj[i].values, vals.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                      hipMemcpy(abz.data(), hj[i].abz, abz.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) { delete r; rc = ECNE_ENODEVICE; break; }
+            // re-base to "variable v at index v-1", n_vars entries
+            r->flags.assign(nv, 0); r->nvalues.assign(nv, 0); r->abz.assign(nv, -1);
+            r->lb.assign(4 * nv, 0); r->ub.assign(4 * nv, 0); r->values.assign(8 * nv, 0);
+            for (size_t v = 1; v <= nv && v <= L.nV; ++v) {
+                r->flags[v - 1] = flags[v] & 3;
+                r->nvalues[v - 1] = nvals[v];
+                r->abz[v - 1] = abz[v];
+                std::memcpy(&r->lb[4 * (v - 1)], &lb[4 * v], 32);
+                std::memcpy(&r->ub[4 * (v - 1)], &ub[4 * v], 32);
+                if (nvals[v] >= 1) std::memcpy(&r->values[8 * (v - 1)], &vals[8 * v], 32);
+                if (nvals[v] >= 2) std::memcpy(&r->values[8 * (v - 1) + 4], &vals[8 * v + 4], 32);
+            }
+            // "Bad Constraints": rows with a variable that is not uniquely determined (:1609-1618)
+            for (uint32_t row = 0; row < L.nC; ++row) {
+                bool bad = false;
+                for (int p = 0; p < 3 && !bad; ++p)
+                    for (uint32_t k = L.rp[p][row]; k < L.rp[p][row + 1]; ++k)
+                        if (!(flags[L.col[p][k]] & 1)) { bad = true; break; }
+                if (bad) r->bad_rows.push_back((int64_t)row + 1);
+            }
+            ecne_summary& s = r->sum;
+            std::memset(&s, 0, sizeof s);
+            s.status = c.error;
+            s.unique_nontrivial = (int64_t)c.unique_nontrivial;
+            s.n_nontrivial = (int64_t)c.n_nontrivial;
+            s.unique_targets = (int64_t)c.unique_targets;
+            s.n_targets = (int64_t)S.targets.size();
+            s.function_good = (c.error == 0 && s.unique_targets == s.n_targets) ? 1 : 0;
+            s.successful_steps = (int64_t)c.successful_steps;
+            s.outer_iterations = (int64_t)c.outer_iterations;
+            s.pops = (int64_t)c.pops;
+            s.num_unique = (int64_t)c.num_unique;
+            for (int k = 0; k < 16; ++k) s.rule_hits[k] = (int64_t)c.rule_hits[k];
+            s.n_rows = (int64_t)L.nC;
+            s.n_vars = S.n_vars;
+            s.device_ms = ms;
+            s.classify_ms = S.dev.classify_ms;
+            out[i] = r;
+        }
+    } while (0);
+    (void)hipFree(d_jobs);
+    if (rc != ECNE_OK)
+        for (size_t i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
+    return rc;
+}
+
+int ecne_solve(ecne_system* sys, const ecne_opts* opts, ecne_result** out) {
+    return ecne_solve_batch(&sys, 1, opts, out);
+}
+
+int ecne_result_summary(const ecne_result* r, ecne_summary* out) {
+    if (!r || !out) return ECNE_EINVAL;
+    *out = r->sum;
+    return ECNE_OK;
+}
+int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
+                       const int32_t** abz, const uint8_t** nvalues, const uint64_t** values) {
+    if (!r) return ECNE_EINVAL;
+    if (flags) *flags = r->flags.data();
+    if (lb) *lb = r->lb.data();
+    if (ub) *ub = r->ub.data();
+    if (abz) *abz = r->abz.data();
+    if (nvalues) *nvalues = r->nvalues.data();
+    if (values) *values = r->values.data();
+    return ECNE_OK;
+}
+int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n) {
+    if (!r) return ECNE_EINVAL;
+    if (rows) *rows = r->bad_rows.data();
+    if (n) *n = r->bad_rows.size();
+    return ECNE_OK;
+}
+void ecne_result_free(ecne_result* r) { delete r; }
+
+int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, double* kernel_ms, uint64_t* bytes) {
+    if (!sys) return ECNE_EINVAL;
+    ecne_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    if (ecne_device_count() <= o.device) return ECNE_ENODEVICE;
+    HIP_TRY(hipSetDevice(o.device));
+    int st = upload_system(*sys, o.device);
+    if (st != K_OK) return st;
+    Job* d_job = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_job, sizeof(Job)));
+    sys->dev.classified = false;
+    // restore the host-computed structural words so that repeated calls time the same work
+    (void)hipMemcpy(sys->dev.job.rinfo, sys->L.rinfo.data(), sizeof(RowInfo) * sys->L.rinfo.size(), hipMemcpyHostToDevice);
+    st = classify_system(*sys, (hipStream_t)o.stream, d_job);
+    (void)hipFree(d_job);
+    if (st != K_OK) return st;
+    if (shape_out && sys->L.nC) {
+        std::vector<RowInfo> ri(sys->L.nC);
+        HIP_TRY(hipMemcpy(ri.data(), sys->dev.job.rinfo, sizeof(RowInfo) * ri.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ri.size(); ++i) shape_out[i] = ri[i].shape;
+    }
+    if (kernel_ms) *kernel_ms = sys->dev.classify_ms;
+    if (bytes) *bytes = sys->L.stream_bytes;
+    return ECNE_OK;
+}
+
+int ecne_fp_selftest(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    if (ecne_device_count() <= device) return ECNE_ENODEVICE;
+    HIP_TRY(hipSetDevice(device));
+    uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&da, 32 * n + 32));
+    HIP_TRY(hipMalloc((void**)&db, 32 * n + 32));
+    HIP_TRY(hipMalloc((void**)&dout, 32 * n + 32));
+    HIP_TRY(hipMemcpy(da, a, 32 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, 32 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fp_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, da, db, dout);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, 32 * n, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return ECNE_OK;
+}
+
+int ecne_fp_sqrt(const uint64_t* a, uint64_t* root) {
+    fp::u256 x = fp::make(a[0], a[1], a[2], a[3]), r;
+    if (!fp::sqrt(fp::reduce(x), r)) return 0;
+    for (int i = 0; i < 4; ++i) root[i] = r.w[i];
+    return 1;
+}
+
+const char* ecne_strerror(int st) {
+    switch (st) {
+        case ECNE_OK: return "ok";
+        case ECNE_EFORMAT: return "malformed .r1cs (reference: AssertionError in readR1CS)";
+        case ECNE_EBOUNDS: return "BoundsError (reference: variable_states[-1] or special-constraint indexing)";
+        case ECNE_EDIVZERO: return "DivideError (reference: divexact by zero)";
+        case ECNE_EUNDEF_DSU: return "UndefVarError: dsu (BigMultModP x BigLessThan needs secp_solve=true)";
+        case ECNE_EKEY: return "KeyError in abstraction's variable map";
+        case ECNE_EDETSIZE: return "linear-system group with more than 10 unknowns";
+        case ECNE_EIO: return "cannot read file";
+        case ECNE_ENODEVICE: return "no usable HIP device (the engine has no CPU fallback)";
+        case ECNE_EINVAL: return "invalid argument";
+        case ECNE_ECAPACITY: return "internal device table overflow";
+        default: return "unknown status";
+    }
+}
+const char* ecne_version(void) { return "ecne-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// engine_types.hpp — data layout shared by the host layout step and the gfx950 kernels.
+//
+// HBM layout of one constraint system ("job"), all arrays flat, 1-based variable ids:
+//   rp{A,B,C}[nC+1] u32      row pointers per part
+//   col{A,B,C}[nnz] u32      variable ids; within a row part the entries are stored in the order
+//                            the reference would iterate nonzeroKeys(part) (a Julia Set), so that
+//                            every ordered walk of the reference is a left-to-right walk here
+//   coef{A,B,C}[nnz][4] u64  canonical residues
+//   csort[nnzC] u32          per row: entry positions sorted by |signed coefficient| (rule R7)
+//   rinfo[nC] RowInfo        static shape of the row = which propagation rules it can ever feed
+//   vals[...][4] u64         per-row constants: R2's two candidate values / R3's value, R4's bound
+//   fo_ptr[nV+2], fo_rows    variable -> ascending rows containing it (variable_to_indices, :628-633)
+// and the mutable solver state (SoA): flags u8 (bit0 unique, bit1 is_known, bit2 bounds==[0,1]),
+// abz i32, lb/ub 4xu64, nvalues u8 + values 2x4xu64, per-row inq/solved/flip bytes, FIFO ring.
+#pragma once
+#include <stdint.h>
+
+namespace ecne {
+
+// RowInfo.shape bits. "static" = depends only on coefficients/structure, computed once.
+enum : uint32_t {
+    SH_HAS_AB = 1u << 0,        // nzA or nzB non-empty: rules R3..R8 never run (:944-946)
+    SH_C_EMPTY = 1u << 1,       // nzC empty
+    SH_R2 = 1u << 2,            // C empty and (nzA u nzB) \ {1} is a single variable x (:875-942)
+    SH_R2_BOUNDSERR = 1u << 3,  // C empty and no variable besides the constant: variable_states[-1] (:916)
+    SH_R2_DIV0 = 1u << 4,       // x missing from A or from B: divexact by zero (:919-920)
+    SH_R2_IS01 = 1u << 5,       // the two roots are {0,1}: bounds become [0,1] (:923-927)
+    SH_R3 = 1u << 6,            // linear row with exactly one non-constant variable (:949-988)
+    SH_R4_T = 1u << 7,          // C's values = {1,-2^0..-2^(l-2)} (:999, :1013)
+    SH_R4_T2 = 1u << 8,         // C's values = {-1, 2^0..2^(l-2)}: flipped on first visit (:1000-1011)
+    SH_R5 = 1u << 9,            // x == y (:1078-1146)
+    SH_R6 = 1u << 10,           // 1 = x + y (:1148-1232)
+    SH_R56_SWAP = 1u << 11,     // Set([k1,k2]) iterates k2 first (:1130, :1216)
+    SH_P4 = 1u << 12,           // static part of the ABZ tagging test (:1427-1453)
+    SH_P4_DIV0 = 1u << 13,      // A has no non-constant variable: divexact by zero (:1467)
+    SH_CZERO = 1u << 14,        // C's map holds an explicit zero (incl. the one R3 inserts, :962)
+    SH_R7_SORTED = 1u << 15,    // csort valid for this row
+};
+
+struct RowInfo {   // 32 bytes
+    uint32_t shape;
+    uint32_t x;      // R2 / R3 variable
+    uint32_t kpos;   // linear rows: variable whose coefficient is  1 ; P4 rows: the B variable
+    uint32_t kneg;   // linear rows: variable whose coefficient is -1 ; P4 rows: slope variable of A
+    uint32_t k1, k2; // R5 / R6: the two variables in the reference's Dict order
+    uint32_t validx; // first of two u256 slots in vals[], or 0xFFFFFFFF
+    uint32_t lenC;   // l = |nzC|
+};
+
+struct Counters {   // one per job, device memory
+    unsigned long long successful_steps, num_unique, pops, outer_iterations;
+    unsigned long long rule_hits[16];
+    unsigned long long unique_nontrivial, n_nontrivial, unique_targets;
+    int error;          // first ecne_status raised on the device (0 = none)
+    unsigned int q_head, q_tail;
+    unsigned int pad;
+};
+
+struct Job {
+    // sizes
+    uint32_t nC, nV, nSp, nKnown, nTarget, nP4, nP5, qmask, htmask, secp_solve, queue_mode, hotcap;
+    // static system
+    const uint32_t *rpA, *rpB, *rpC;
+    const uint32_t *colA, *colB, *colC;
+    const uint64_t *coefA, *coefB, *coefC;
+    uint32_t* csort;
+    RowInfo* rinfo;
+    uint64_t* vals;
+    const uint32_t *fo_ptr, *fo_rows;
+    const uint32_t *sp_in_ptr, *sp_in, *sp_out_ptr, *sp_out;
+    const uint8_t* sp_kind;   // 1 = "BigMultModP", 2 = "BigLessThan", 0 = anything else (:751, :755)
+    const uint32_t *knowns, *targets;
+    const uint8_t* nontrivial;
+    const uint32_t* p4_list;
+    const uint32_t *p5_rows, *p5_y;
+    // mutable state
+    uint8_t* flags;
+    int32_t* abz;
+    uint64_t *lb, *ub;
+    uint8_t* nvalues;
+    uint64_t* values;
+    uint8_t *inq, *solved, *flip3;
+    uint32_t* queue;
+    // scratch
+    uint32_t* varmin;
+    uint8_t* p3k;
+    uint64_t *p3h, *p3h2;
+    uint64_t *ht_key, *ht_key2;
+    uint32_t *ht_new, *ht_frozen;
+    uint32_t* hot;
+    uint8_t* fired;
+    uint32_t* events;
+    Counters* ctr;
+};
+
+}  // namespace ecne

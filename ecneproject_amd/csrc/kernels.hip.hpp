@@ -1,0 +1,1124 @@
+// kernels.hip.hpp — gfx950 device code of the Ecne propagation engine (included by ecne_engine.hip).
+//
+// Kernels
+//   k_classify_rows   one wavefront per row: streams the row's (col, coeff) pairs once, decides the
+//                     static shape of the row (which of the reference's rules R2..R8 it can ever
+//                     feed), computes the rule constants that need field arithmetic (the two roots
+//                     of a bit-check row, the value of a single-variable linear row, the power-of-two
+//                     bound of a binary-decomposition row) and the |coefficient| order rule R7 walks.
+//                     HBM-bound streaming pass: ~36 B per non-zero in, 32 B per row + 4 B per C
+//                     non-zero out.  Reference: the pattern tests re-done on every queue visit at
+//                     src/R1CSConstraintSolver.jl:875-927, :949-964, :999-1013, :1245-1265.
+//   k_solve           one 1024-thread workgroup per constraint system, persistent for the whole
+//                     fixed point (outer loop :706-1556): FIFO worklist in HBM/L2, rules R1-R8,
+//                     batch phases P1-P5, verdict counts.  All ordering-sensitive steps follow the
+//                     reference's sequential order exactly (see DESIGN.md "Schedule").
+//   k_fp_selftest     field-arithmetic known-answer vectors on the device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "engine_types.hpp"
+#include "fp256.hpp"
+
+namespace ecne {
+
+#define ECNE_WG 1024
+#define ECNE_NWAVES (ECNE_WG / 64)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__device__ __forceinline__ fp::u256 ld256(const uint64_t* p) { return fp::make(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ void st256(uint64_t* p, const fp::u256& v) {
+    p[0] = v.w[0]; p[1] = v.w[1]; p[2] = v.w[2]; p[3] = v.w[3];
+}
+__device__ __forceinline__ fp::u256 shfl256(const fp::u256& v, int src) {
+    fp::u256 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned lo = __shfl((unsigned)(v.w[i] & 0xffffffffu), src, 64);
+        unsigned hi = __shfl((unsigned)(v.w[i] >> 32), src, 64);
+        r.w[i] = ((uint64_t)hi << 32) | lo;
+    }
+    return r;
+}
+
+// abs(flip_coeffs(x)) of rule R7 (:1245-1259): values above the literal threshold are taken as
+// negative numbers. The literal is NOT p-1 (it is ~1e75 below it) and is kept exactly.
+__device__ __forceinline__ fp::u256 r7_abs(const fp::u256& c) {
+    const fp::u256 thr = fp::make(0x43e1f593f0000000ULL, 0x9c41be16bb2a8891ULL, 0x045fcd3eea44076aULL,
+                                  0x2e2e53955f6f1dfeULL);
+    if (fp::cmp(c, thr) > 0) {
+        fp::u256 t;
+        fp::sub_raw(t, fp::modulus(), c);
+        return t;
+    }
+    return c;
+}
+
+// ====================================================================================== classify
+// popcount / ctz of a 256-bit value
+__device__ __forceinline__ int popc256(const fp::u256& a) {
+    return __popcll(a.w[0]) + __popcll(a.w[1]) + __popcll(a.w[2]) + __popcll(a.w[3]);
+}
+__device__ __forceinline__ int ctz256(const fp::u256& a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (a.w[i]) return 64 * i + (__ffsll((long long)a.w[i]) - 1);
+    return 256;
+}
+
+// One wavefront classifies one row. wave_scratch: 8 u32 of LDS per wave (256-bit exponent bitmap).
+__device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch) {
+    const int lane = lane_id();
+    RowInfo ri = J.rinfo[row];   // structural bits and keys were laid down by the host
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t l = c1 - c0;
+    uint32_t shape = ri.shape;
+    // ---- R2 constants: values = [-a1/ax, -b1/bx]  (:916-927)
+    if ((shape & SH_R2) && !(shape & SH_R2_DIV0)) {
+        // lanes 0 and 1 each handle one part
+        fp::u256 val = fp::make(0);
+        if (lane < 2) {
+            const uint32_t* rp = lane == 0 ? J.rpA : J.rpB;
+            const uint32_t* col = lane == 0 ? J.colA : J.colB;
+            const uint64_t* cf = lane == 0 ? J.coefA : J.coefB;
+            fp::u256 slope = fp::make(0), icpt = fp::make(0);
+            for (uint32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                uint32_t v = col[k];
+                fp::u256 c = ld256(cf + 4ull * k);
+                if (v == ri.x) slope = c;
+                else if (v == 1) icpt = c;
+            }
+            val = fp::mul(fp::neg(icpt), fp::inv(slope));
+            st256(J.vals + 4ull * (ri.validx + lane), val);
+        }
+        fp::u256 v0 = shfl256(val, 0), v1 = shfl256(val, 1);
+        if ((fp::is_zero(v0) && fp::is_one(v1)) || (fp::is_one(v0) && fp::is_zero(v1))) shape |= SH_R2_IS01;
+    }
+    if (!(shape & SH_HAS_AB) && l > 0) {
+        // ---- R3 constant: -c[1]/c[x]  (:961-964)
+        if ((shape & SH_R3) && lane == 0) {
+            fp::u256 c1v = fp::make(0), cx = fp::make(0);
+            for (uint32_t k = c0; k < c1; ++k) {
+                uint32_t v = J.colC[k];
+                if (v == 1) c1v = ld256(J.coefC + 4ull * k);
+                else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
+            }
+            st256(J.vals + 4ull * ri.validx, fp::mul(fp::neg(c1v), fp::inv(cx)));
+        }
+        // ---- R4 pattern: multiset {1, -2^0..-2^(l-2)} (T) or its negation (T2)  (:999-1013)
+        if (!(shape & SH_CZERO)) {
+            bool isT = false, isT2 = false;
+            uint32_t kpos = 0, kneg = 0;
+            if (l <= 255) {
+                if (lane < 8) wave_scratch[lane] = 0;       // T bitmap
+                if (lane < 8) wave_scratch[8 + lane] = 0;   // T2 bitmap
+                wg_fence();
+                int n_one = 0, n_mone = 0, okT = 1, okT2 = 1;
+                for (uint32_t base = c0; base < c1; base += 64) {
+                    uint32_t k = base + lane;
+                    bool act = k < c1;
+                    fp::u256 c = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
+                    uint32_t v = act ? J.colC[k] : 0;
+                    bool one = act && fp::is_one(c);
+                    fp::u256 nc = fp::neg(c);
+                    bool mone = act && fp::is_one(nc);
+                    uint64_t m1 = __ballot(one), m2 = __ballot(mone);
+                    n_one += __popcll(m1);
+                    n_mone += __popcll(m2);
+                    if (m1) kpos = __shfl(v, __ffsll((long long)m1) - 1, 64);
+                    if (m2) kneg = __shfl(v, __ffsll((long long)m2) - 1, 64);
+                    // exponent of -c (T) / of c (T2); the "1" / "-1" entries are the pivots
+                    bool badT = false, badT2 = false;
+                    if (act && !one) {           // T: every non-1 entry must be -2^k, k <= l-2, distinct
+                        int e = (popc256(nc) == 1) ? ctz256(nc) : 999;
+                        if (e > (int)l - 2) badT = true;
+                        else if (atomicOr(&wave_scratch[e >> 5], 1u << (e & 31)) & (1u << (e & 31))) badT = true;
+                    }
+                    if (act && !mone) {          // T2: every non-(-1) entry must be 2^k
+                        int e = (popc256(c) == 1) ? ctz256(c) : 999;
+                        if (e > (int)l - 2) badT2 = true;
+                        else if (atomicOr(&wave_scratch[8 + (e >> 5)], 1u << (e & 31)) & (1u << (e & 31))) badT2 = true;
+                    }
+                    if (__ballot(badT)) okT = 0;
+                    if (__ballot(badT2)) okT2 = 0;
+                }
+                // l == 1: T = [1], T2 = [p-1]
+                isT = okT && n_one == 1;
+                isT2 = okT2 && n_mone == 1;
+            } else {
+                // l > 255: powers 2^k wrap modulo p for k >= 254. Quick reject (exactly one 1 / one -1),
+                // then the literal multiset comparison, lanes striding over targets.
+                int n_one = 0, n_mone = 0;
+                for (uint32_t base = c0; base < c1; base += 64) {
+                    uint32_t k = base + lane;
+                    bool act = k < c1;
+                    fp::u256 c = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
+                    uint32_t v = act ? J.colC[k] : 0;
+                    uint64_t m1 = __ballot(act && fp::is_one(c)), m2 = __ballot(act && fp::is_one(fp::neg(c)));
+                    n_one += __popcll(m1);
+                    n_mone += __popcll(m2);
+                    if (m1) kpos = __shfl(v, __ffsll((long long)m1) - 1, 64);
+                    if (m2) kneg = __shfl(v, __ffsll((long long)m2) - 1, 64);
+                }
+                if (n_one == 1 && n_mone == 1) {
+                    // T  <=> one "1"  and every 2^k mod p (k = 0..l-2) occurs exactly once among the -c
+                    // T2 <=> one "-1" and every 2^k mod p occurs exactly once among the c
+                    int okT = 1, okT2 = 1;
+                    for (uint32_t tb = 0; tb < l - 1; tb += 64) {
+                        uint32_t t = tb + lane;
+                        bool act = t < l - 1;
+                        fp::u256 pw = fp::make(1);
+                        for (uint32_t s = 0; act && s < t; ++s) pw = fp::add(pw, pw);
+                        int cntT = 0, cntT2 = 0;
+                        if (act)
+                            for (uint32_t k = c0; k < c1; ++k) {
+                                fp::u256 c = ld256(J.coefC + 4ull * k);
+                                if (fp::eq(c, pw)) cntT2++;
+                                if (fp::eq(fp::neg(c), pw)) cntT++;
+                            }
+                        if (__ballot(act && cntT != 1)) okT = 0;
+                        if (__ballot(act && cntT2 != 1)) okT2 = 0;
+                    }
+                    isT = okT;
+                    isT2 = okT2;
+                }
+            }
+            if (isT) shape |= SH_R4_T;
+            if (isT2) shape |= SH_R4_T2;
+            if (isT || isT2) {
+                ri.kpos = kpos;
+                ri.kneg = kneg;
+                if (lane == 0) {   // F(2)^(l-1) - F(1), field arithmetic (:1033)
+                    fp::u256 pw = fp::make(1);
+                    for (uint32_t s = 0; s + 1 < l; ++s) pw = fp::add(pw, pw);
+                    st256(J.vals + 4ull * (ri.validx + 1), fp::sub(pw, fp::make(1)));
+                }
+            }
+        }
+        // ---- R7 order: stable rank of |coefficient| in the orientation R7 will see (:1256-1265).
+        // A T2-only row has been negated by R4 before R7 first looks at it.
+        {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            for (uint32_t base = c0; base < c1; base += 64) {
+                uint32_t k = base + lane;
+                bool act = k < c1;
+                fp::u256 mine = fp::make(0);
+                if (act) {
+                    mine = ld256(J.coefC + 4ull * k);
+                    if (negated) mine = fp::neg(mine);
+                    mine = r7_abs(mine);
+                }
+                uint32_t rank = 0;
+                for (uint32_t ob = c0; ob < c1; ob += 64) {
+                    uint32_t ok_ = ob + lane;
+                    fp::u256 oth = fp::make(0);
+                    bool oact = ok_ < c1;
+                    if (oact) {
+                        oth = ld256(J.coefC + 4ull * ok_);
+                        if (negated) oth = fp::neg(oth);
+                        oth = r7_abs(oth);
+                    }
+                    uint32_t cnt = (c1 - ob) < 64 ? (c1 - ob) : 64;
+                    for (uint32_t s = 0; s < cnt; ++s) {
+                        fp::u256 o = shfl256(oth, (int)s);
+                        uint32_t oidx = ob + s;
+                        int cm = fp::cmp(o, mine);
+                        if (act && (cm < 0 || (cm == 0 && oidx < k))) rank++;
+                    }
+                }
+                if (act) J.csort[c0 + rank] = k - c0;
+            }
+            shape |= SH_R7_SORTED;
+        }
+    }
+    if (lane == 0) {
+        ri.shape = shape;
+        J.rinfo[row] = ri;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index) {
+    __shared__ uint32_t scratch[4][16];
+    __shared__ Job sJ;
+    if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t nw = gridDim.x * 4;
+    for (uint32_t row = blockIdx.x * 4 + wave; row < sJ.nC; row += nw) classify_row(sJ, row, scratch[wave]);
+}
+
+// ====================================================================================== solver
+struct QState {   // FIFO cursors, wave-uniform registers of the wave that drives the queue
+    uint32_t head, tail;
+};
+
+__device__ __forceinline__ void raise(const Job& J, int code) { atomicCAS(&J.ctr->error, 0, code); }
+
+__device__ __forceinline__ void set_bounds(const Job& J, uint32_t v, const fp::u256& lb, const fp::u256& ub) {
+    st256(J.lb + 4ull * v, lb);
+    st256(J.ub + 4ull * v, ub);
+    uint8_t f = J.flags[v];
+    f = (uint8_t)((f & ~4u) | ((fp::is_zero(lb) && fp::is_one(ub)) ? 4u : 0u));
+    J.flags[v] = f;
+}
+
+// REQUEUE(v): for each row r of variable_to_indices[v], ascending: push r unless already queued.
+// Wave-cooperative; exactly the sequential order because the rows of one list are distinct.
+__device__ void requeue(const Job& J, QState& q, uint32_t v) {
+    const int lane = lane_id();
+    const uint32_t beg = J.fo_ptr[v], end = J.fo_ptr[v + 1];
+    for (uint32_t base = beg; base < end; base += 64) {
+        uint32_t k = base + lane;
+        bool act = k < end;
+        uint32_t r = act ? J.fo_rows[k] : 0;
+        bool push = act && J.inq[r] == 0;
+        uint64_t m = __ballot(push);
+        if (push) {
+            uint32_t pos = q.tail + (uint32_t)__popcll(m & lanes_below());
+            J.queue[pos & J.qmask] = r;
+            J.inq[r] = 1;
+        }
+        q.tail += (uint32_t)__popcll(m);
+    }
+    wg_fence();
+}
+
+// make `v` unique + known (lane 0 writes), wave-uniform
+__device__ __forceinline__ void mark_unique(const Job& J, uint32_t v) {
+    if (lane_id() == 0) J.flags[v] |= 3;
+    wg_fence();
+}
+
+// walk C entries [c0,c1) in stored (= reference Set) order; every non-unique variable other than
+// `skip` becomes unique and is re-queued, in order. Returns how many.
+__device__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0, uint32_t c1, uint32_t skip) {
+    const int lane = lane_id();
+    uint32_t n = 0;
+    for (uint32_t base = c0; base < c1; base += 64) {
+        uint32_t k = base + lane;
+        bool act = k < c1;
+        uint32_t v = act ? J.colC[k] : 0;
+        bool todo = act && v != skip && !(J.flags[v] & 1);
+        uint64_t m = __ballot(todo);
+        while (m) {
+            int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            uint32_t vv = __shfl(v, src, 64);
+            mark_unique(J, vv);
+            requeue(J, q, vv);
+            ++n;
+        }
+    }
+    return n;
+}
+
+// ---- one queue pop: rules R1..R8 on row `row`, in the reference's order (:824-1348)
+__device__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
+                         unsigned long long& steps, unsigned long long& nuniq) {
+    const int lane = lane_id();
+    const RowInfo ri = J.rinfo[row];
+    const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1];
+    const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t shape = ri.shape;
+
+    // R1 check_unique (:827-873)
+    {
+        bool nu = false;
+        for (uint32_t k = a0 + lane; k < a1; k += 64) nu |= !(J.flags[J.colA[k]] & 1);
+        for (uint32_t k = b0 + lane; k < b1; k += 64) nu |= !(J.flags[J.colB[k]] & 1);
+        if (!__ballot(nu)) {
+            uint32_t cnt = 0, u = 0;
+            for (uint32_t base = c0; base < c1; base += 64) {
+                uint32_t k = base + lane;
+                bool act = k < c1;
+                uint32_t v = act ? J.colC[k] : 0;
+                bool x = act && !(J.flags[v] & 1);
+                uint64_t m = __ballot(x);
+                if (m && cnt == 0) u = __shfl(v, __ffsll((long long)m) - 1, 64);
+                cnt += (uint32_t)__popcll(m);
+            }
+            if (cnt == 1) {
+                mark_unique(J, u);
+                nuniq++; steps++; hits[0]++;
+                requeue(J, q, u);
+            }
+        }
+    }
+    // R2 check_quadratic (:875-942)
+    if (shape & SH_C_EMPTY) {
+        if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
+        if (shape & SH_R2) {
+            const uint32_t x = ri.x;
+            if (!(J.flags[x] & 2)) {
+                if (shape & SH_R2_DIV0) { raise(J, K_EDIVZERO); return; }
+                if (lane == 0) {
+                    // make_values: is_known, values; abz reset by the constructor (:158)
+                    st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));
+                    st256(J.values + 8ull * x + 4, ld256(J.vals + 4ull * (ri.validx + 1)));
+                    J.nvalues[x] = 2;
+                    J.flags[x] |= 2;
+                    J.abz[x] = -1;
+                    if (shape & SH_R2_IS01) set_bounds(J, x, fp::make(0), fp::make(1));   // make_bounds (:923-927)
+                    J.solved[row] = 1;
+                }
+                wg_fence();
+                requeue(J, q, x);
+                steps++; hits[1]++;
+            }
+        }
+    }
+    if (shape & SH_HAS_AB) return;   // (:944-946)
+    const uint32_t l = c1 - c0;
+
+    // R3 check_linear (:949-988)
+    if (shape & SH_R3) {
+        const uint32_t x = ri.x;
+        const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
+        bool new_info = false;
+        bool same = J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv);
+        uint8_t f = J.flags[x];
+        if (!same) { steps++; hits[2]++; new_info = true; }
+        if (!(f & 1)) { nuniq++; new_info = true; }
+        if (lane == 0) {
+            if (!same) { st256(J.values + 8ull * x, tv); J.nvalues[x] = 1; }
+            J.flags[x] = (uint8_t)(f | 3);
+            set_bounds(J, x, tv, tv);
+        }
+        wg_fence();
+        if (new_info) requeue(J, q, x);
+    }
+    // R4 checkBinary (:991-1076)
+    if ((shape & (SH_R4_T | SH_R4_T2)) && l > 0) {
+        uint32_t new_key;
+        if ((shape & SH_R4_T) && (shape & SH_R4_T2)) {   // l == 2: the row is negated on every visit
+            uint8_t o = (uint8_t)(J.flip3[row] ^ 1);
+            if (lane == 0) J.flip3[row] = o;
+            new_key = o ? ri.kneg : ri.kpos;
+        } else if (shape & SH_R4_T2) {
+            new_key = ri.kneg;   // negated once; the -1 entry is the 1 entry from then on
+        } else {
+            new_key = ri.kpos;
+        }
+        bool bad = false;   // every other variable needs bounds exactly [0,1] (:1020-1029)
+        for (uint32_t k = c0 + lane; k < c1; k += 64) {
+            uint32_t v = J.colC[k];
+            if (v != new_key && !(J.flags[v] & 4)) bad = true;
+        }
+        if (!__ballot(bad)) {
+            const fp::u256 fub = ld256(J.vals + 4ull * (ri.validx + 1));
+            const fp::u256 nlb = ld256(J.lb + 4ull * new_key), nub = ld256(J.ub + 4ull * new_key);
+            if (!(fp::is_zero(nlb) && fp::eq(nub, fub))) {
+                bool gt = false;   // integer compare ub.d > 2^(l-1) - 1 (:1035)
+                if (l - 1 < 254) {
+                    fp::u256 ip = fp::make(0);
+                    ip.w[(l - 1) >> 6] = 1ull << ((l - 1) & 63);
+                    fp::u256 im1;
+                    fp::sub_raw(im1, ip, fp::make(1));
+                    gt = fp::cmp(nub, im1) > 0;
+                }
+                if (gt) {
+                    if (lane == 0) { set_bounds(J, new_key, fp::make(0), fub); J.flags[new_key] |= 2; }
+                    wg_fence();
+                    steps++; hits[3]++;
+                    requeue(J, q, new_key);
+                }
+            }
+            if (J.flags[new_key] & 1) {   // (:1049-1067)
+                uint32_t n = uniq_range_and_requeue(J, q, c0, c1, new_key);
+                nuniq += n; steps += n; hits[3] += n;
+            }
+        }
+    }
+    // R5 checkpropagateBounds (:1078-1146) and R6 checkOnePropagateBounds (:1148-1232)
+    if (shape & (SH_R5 | SH_R6)) {
+        const bool is6 = (shape & SH_R6) != 0;
+        const uint32_t k1 = ri.k1, k2 = ri.k2;
+        fp::u256 lb1 = ld256(J.lb + 4ull * k1), ub1 = ld256(J.ub + 4ull * k1);
+        fp::u256 lb2 = ld256(J.lb + 4ull * k2), ub2 = ld256(J.ub + 4ull * k2);
+        uint8_t f1 = J.flags[k1], f2 = J.flags[k2];
+        bool ch1 = false, ch2 = false;
+        if (!fp::eq(ub2, ub1) || !fp::eq(lb2, lb1) || ((f1 ^ f2) & 1)) {
+            bool proceed = true;
+            if ((f1 ^ f2) & 1) {
+                // `!=` between a mutable struct and a fresh copy is identity, so both branches run.
+                // R5 writes key_1 twice (:1107-1108, sic); R6 writes key_2 (:1188-1189).
+                f1 |= 3;
+                if (is6) f2 |= 3;
+                nuniq += 2;
+                ch1 = ch2 = true;
+            }
+            fp::u256 mn = fp::cmp(ub1, ub2) <= 0 ? ub1 : ub2;
+            fp::u256 mx = fp::cmp(lb1, lb2) >= 0 ? lb1 : lb2;
+            if (is6 && (!fp::is_one(mn) || !fp::is_zero(mx))) proceed = false;   // (:1196-1199) returns before counting
+            bool w1 = false, w2 = false;
+            if (proceed) {
+                w1 = fp::cmp(ub1, mn) > 0 || fp::cmp(lb1, mx) < 0;
+                w2 = fp::cmp(ub2, mn) > 0 || fp::cmp(lb2, mx) < 0;
+            }
+            if (lane == 0) {
+                J.flags[k1] = f1;
+                J.flags[k2] = f2;
+                if (w1) {
+                    J.flags[k1] |= 2;
+                    set_bounds(J, k1, mx, mn);
+                    if (is6) { st256(J.values + 8ull * k1, mn); st256(J.values + 8ull * k1 + 4, mx); J.nvalues[k1] = 2; }
+                }
+                if (w2) {
+                    J.flags[k2] |= 2;
+                    set_bounds(J, k2, mx, mn);
+                    if (is6) { st256(J.values + 8ull * k2, mn); st256(J.values + 8ull * k2 + 4, mx); J.nvalues[k2] = 2; }
+                }
+            }
+            wg_fence();
+            if (proceed) {
+                ch1 |= w1; ch2 |= w2;
+                uint32_t nset = (k1 == k2) ? ((ch1 || ch2) ? 1u : 0u) : ((ch1 ? 1u : 0u) + (ch2 ? 1u : 0u));
+                steps += nset;
+                if (nset) hits[is6 ? 5 : 4]++;
+                // for j in Set(changed_vars): hash order of the (at most two) keys
+                uint32_t first = (shape & SH_R56_SWAP) ? k2 : k1, second = (shape & SH_R56_SWAP) ? k1 : k2;
+                bool cf = (shape & SH_R56_SWAP) ? ch2 : ch1, cs = (shape & SH_R56_SWAP) ? ch1 : ch2;
+                if (cf) requeue(J, q, first);
+                if (cs && second != first) requeue(J, q, second);
+            }
+        }
+    }
+    // R7 checkModularArithmetic (:1235-1298)
+    if (l > 0) {
+        uint32_t nunk = 0;
+        bool notknown = false;
+        for (uint32_t base = c0; base < c1; base += 64) {
+            uint32_t k = base + lane;
+            bool act = k < c1;
+            uint8_t f = act ? J.flags[J.colC[k]] : 1;
+            uint64_t m = __ballot(act && !(f & 1));
+            nunk += (uint32_t)__popcll(m);
+            if (act && !(f & 1) && !(f & 2)) notknown = true;
+        }
+        if (nunk > 0 && !__ballot(notknown)) {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            bool fail = false;
+            // previous non-unique entry in sorted order, carried across chunks (wave-uniform)
+            uint32_t carry_k = 0xFFFFFFFFu;
+            for (uint32_t sb = 0; sb < l; sb += 64) {
+                uint32_t s = sb + lane;
+                bool act = s < l;
+                uint32_t k = act ? c0 + J.csort[c0 + s] : 0;
+                uint32_t v = act ? J.colC[k] : 0;
+                bool nu = act && !(J.flags[v] & 1);
+                uint64_t m = __ballot(nu);
+                uint64_t below = m & lanes_below();
+                // every lane executes the shuffle (uniform control flow); lanes without an in-chunk
+                // predecessor fall back to the carried one
+                const int psrc = below ? 63 - __clzll((long long)below) : 0;
+                const uint32_t pk = __shfl(k, psrc, 64);
+                const uint32_t prev_k = below ? pk : carry_k;
+                if (nu && prev_k != 0xFFFFFFFFu) {
+                    fp::u256 cn = ld256(J.coefC + 4ull * k), cc = ld256(J.coefC + 4ull * prev_k);
+                    if (negated) { cn = fp::neg(cn); cc = fp::neg(cc); }
+                    cn = r7_abs(cn); cc = r7_abs(cc);
+                    fp::u256 qq, rem;
+                    fp::divmod(cn, cc, qq, rem);
+                    if (!fp::is_zero(rem)) fail = true;
+                    else {
+                        uint32_t pv = J.colC[prev_k];
+                        fp::u256 ub = ld256(J.ub + 4ull * pv), lb = ld256(J.lb + 4ull * pv);
+                        if (fp::cmp(ub, lb) >= 0) {
+                            fp::u256 diff;
+                            fp::sub_raw(diff, ub, lb);
+                            if (fp::cmp(qq, diff) <= 0) fail = true;
+                        }
+                    }
+                }
+                if (m) carry_k = __shfl(k, 63 - __clzll((long long)m), 64);
+            }
+            if (!__ballot(fail)) {
+                // coeffs[last] * (ub(last) + 1) <= p  (:1274)
+                uint32_t lv = J.colC[carry_k];
+                fp::u256 cl = ld256(J.coefC + 4ull * carry_k);
+                if (negated) cl = fp::neg(cl);
+                cl = r7_abs(cl);
+                fp::u256 ub1;
+                fp::add_raw(ub1, ld256(J.ub + 4ull * lv), fp::make(1));
+                if (!fp::mul_gt_p(cl, ub1)) {
+                    steps += nunk; hits[6]++;
+                    uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
+                    nuniq += n;
+                }
+            }
+        }
+    }
+    // R8 checkAllButOneZeroGroup (:1304-1348)
+    if (l > 0) {
+        int group = -1;
+        bool bad = false;
+        uint32_t cnt = 0;
+        for (uint32_t base = c0; base < c1; base += 64) {
+            uint32_t k = base + lane;
+            bool act = k < c1;
+            uint32_t v = act ? J.colC[k] : 0;
+            bool nu = act && !(J.flags[v] & 1);
+            int a = nu ? J.abz[v] : -1;
+            uint64_t m = __ballot(nu);
+            if (m) {
+                if (group == -1) group = __shfl(a, __ffsll((long long)m) - 1, 64);
+                if (nu && (a == -1 || a != group)) bad = true;
+                cnt += (uint32_t)__popcll(m);
+            }
+        }
+        // a first non-unique variable with abz == -1 leaves group == -1 and bad == true
+        if (cnt > 0 && !__ballot(bad)) {
+            hits[7]++;
+            uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
+            nuniq += n; steps += n;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------- workgroup tools
+// exclusive prefix sum of one value per thread over the 1024-thread workgroup; returns the
+// thread's offset, *total receives the sum. lds: ECNE_NWAVES + 1 words.
+__device__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* lds, uint32_t* total) {
+    const int lane = lane_id(), w = wave_id();
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t v = lane < ECNE_NWAVES ? lds[lane] : 0, inc = v;
+#pragma unroll
+        for (int d = 1; d < ECNE_NWAVES; d <<= 1) {
+            uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane < ECNE_NWAVES) lds[lane] = inc - v;
+        if (lane == ECNE_NWAVES - 1) lds[ECNE_NWAVES] = inc;
+    }
+    __syncthreads();
+    uint32_t off = lds[w] + incl - x;
+    *total = lds[ECNE_NWAVES];
+    __syncthreads();
+    return off;
+}
+
+// Ordered multi-source REQUEUE: events[0..n) are variables in the reference's order; equivalent to
+// calling requeue() for each in turn. Driven by one wavefront (the caller passes the queue cursor).
+__device__ void requeue_events(const Job& J, QState& q, const uint32_t* events, uint32_t n) {
+    for (uint32_t e = 0; e < n; ++e) requeue(J, q, events[e]);
+}
+
+// 128-bit commutative hash of a set of variable ids (P3 group key: the sorted unknown tuple, :1386-1387)
+__device__ __forceinline__ uint64_t mixA(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint64_t mixB(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL; x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+// P3 eligibility of one row (one lane per row): no non-unique variable in A or B; k = number of
+// non-unique variables of C; h/h2 = commutative hash of that set (:1360-1386).
+__device__ void p3_eval(const Job& J, uint32_t row, uint32_t& k, uint64_t& h, uint64_t& h2) {
+    k = 0; h = 0; h2 = 0;
+    for (uint32_t e = J.rpA[row]; e < J.rpA[row + 1]; ++e)
+        if (!(J.flags[J.colA[e]] & 1)) { k = 0xFFFFFFFFu; return; }
+    for (uint32_t e = J.rpB[row]; e < J.rpB[row + 1]; ++e)
+        if (!(J.flags[J.colB[e]] & 1)) { k = 0xFFFFFFFFu; return; }
+    for (uint32_t e = J.rpC[row]; e < J.rpC[row + 1]; ++e) {
+        uint32_t v = J.colC[e];
+        if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
+    }
+    h = mixA(h + k);   // never 0-sensitive: empty sets are not inserted
+}
+// Open-addressing table keyed by the 64-bit half of the group hash; the other half is recorded with
+// a second CAS by every visitor, so two different keys that agree on 64 bits are DETECTED (the solve
+// stops with ECNE_ECAPACITY) instead of being merged. No lane ever spins on another lane.
+__device__ __forceinline__ uint32_t ht_slot(const Job& J, uint64_t h, uint64_t h2, bool insert) {
+    const unsigned long long key = (unsigned long long)(h | 1ull), key2 = (unsigned long long)(h2 | 1ull);
+    uint32_t s = (uint32_t)((h >> 1) & J.htmask);
+    for (uint32_t probe = 0; probe <= J.htmask; ++probe) {
+        unsigned long long cur = atomicAdd((unsigned long long*)&J.ht_key[s], 0ull);
+        if (cur == 0ull) {
+            if (!insert) return 0xFFFFFFFFu;
+            cur = atomicCAS((unsigned long long*)&J.ht_key[s], 0ull, key);
+            if (cur == 0ull) cur = key;
+        }
+        if (cur == key) {
+            unsigned long long o2 = atomicCAS((unsigned long long*)&J.ht_key2[s], 0ull, key2);
+            if (o2 != 0ull && o2 != key2) { raise(J, K_ECAPACITY); return 0xFFFFFFFFu; }
+            return s;
+        }
+        s = (s + 1) & J.htmask;
+    }
+    raise(J, K_ECAPACITY);
+    return 0xFFFFFFFFu;
+}
+
+// coefficient of variable v in row's C part (0 if absent)
+__device__ fp::u256 c_coef(const Job& J, uint32_t row, uint32_t v) {
+    for (uint32_t e = J.rpC[row]; e < J.rpC[row + 1]; ++e)
+        if (J.colC[e] == v) return ld256(J.coefC + 4ull * e);
+    return fp::make(0);
+}
+
+// slow_det (:1389-1400): sum over ODD permutations only (Combinatorics.parity is 0 for even and
+// 1 for odd permutations and is used as a factor). Wave-parallel over permutation indices.
+// rows[0..k) in arrival order, vars[0..k) ascending. Returns non-zero?
+__device__ bool p3_odd_perm_sum_nonzero(const Job& J, const uint32_t* rows, const uint32_t* vars, uint32_t k) {
+    const int lane = lane_id();
+    uint64_t nperm = 1;
+    for (uint32_t i = 2; i <= k; ++i) nperm *= i;
+    fp::u256 acc = fp::make(0);
+    for (uint64_t pi = lane; pi < nperm; pi += 64) {
+        // decode permutation number pi (factoradic) into perm[], count inversions
+        uint32_t perm[10], avail[10];
+        for (uint32_t i = 0; i < k; ++i) avail[i] = i;
+        uint64_t rem = pi;
+        uint64_t f = nperm;
+        uint32_t inv = 0;
+        for (uint32_t i = 0; i < k; ++i) {
+            f /= (k - i);
+            uint32_t d = (uint32_t)(rem / f);
+            rem -= (uint64_t)d * f;
+            perm[i] = avail[d];
+            inv += d;
+            for (uint32_t j = d; j + 1 < k - i; ++j) avail[j] = avail[j + 1];
+        }
+        if (inv & 1) {
+            fp::u256 term = fp::make(1);
+            for (uint32_t j = 0; j < k; ++j) term = fp::mul(term, c_coef(J, rows[j], vars[perm[j]]));
+            acc = fp::add(acc, term);
+        }
+    }
+    // wave reduction (field addition)
+    for (int d = 32; d >= 1; d >>= 1) {
+        fp::u256 o = shfl256(acc, (lane + d) & 63);
+        if (lane < d) acc = fp::add(acc, o);
+    }
+    acc = shfl256(acc, 0);
+    return !fp::is_zero(acc);
+}
+
+// ---------------------------------------------------------------------------------------- k_solve
+// workgroup-uniform view of the device error word (every thread takes the same branch)
+__device__ __forceinline__ int wg_error(const Job& J, int* s_err) {
+    __syncthreads();
+    if (threadIdx.x == 0) *s_err = atomicAdd(&J.ctr->error, 0);
+    __syncthreads();
+    return *s_err;
+}
+
+__global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
+    __shared__ Job J;
+    __shared__ uint32_t s_scan[ECNE_NWAVES + 2];
+    __shared__ uint32_t s_u32[8];
+    __shared__ unsigned long long s_steps;
+    __shared__ uint32_t m_rows[10], m_vars[10];
+    __shared__ int s_err;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if (tid < (int)(sizeof(Job) / 4)) ((uint32_t*)&J)[tid] = ((const uint32_t*)&jobs[blockIdx.x])[tid];
+    __syncthreads();
+    const uint32_t nC = J.nC, nV = J.nV;
+
+    // ---------------- setup (:593-704)
+    for (uint32_t v = tid; v <= nV; v += ECNE_WG) {
+        J.flags[v] = 0;
+        J.abz[v] = -1;
+        J.nvalues[v] = 0;
+        st256(J.lb + 4ull * v, fp::make(0));
+        st256(J.ub + 4ull * v, fp::pminus1());
+        J.varmin[v] = 0xFFFFFFFFu;
+    }
+    for (uint32_t r = tid; r < nC; r += ECNE_WG) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; }
+    for (uint32_t r = tid; r < nC + J.nSp; r += ECNE_WG) J.fired[r] = 0;   // [nC..) = special_solved
+    for (uint32_t s = tid; s <= J.htmask; s += ECNE_WG) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < J.nKnown; i += ECNE_WG) {
+        uint32_t v = J.knowns[i];
+        J.flags[v] = 3;
+        if (v == 1) { J.nvalues[1] = 1; st256(J.values + 8ull, fp::make(1)); }
+    }
+    __syncthreads();
+    // initial queue: rows with at most one variable outside known_variables, ascending (:621-627)
+    QState q;
+    q.head = 0; q.tail = 0;
+    for (uint32_t base = 0; base < nC; base += ECNE_WG) {
+        uint32_t r = base + tid;
+        uint32_t push = 0;
+        if (r < nC) {
+            uint32_t first = 0, cnt = 0;
+            const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
+            const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
+            for (int p = 0; p < 3 && cnt < 2; ++p)
+                for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
+                    uint32_t v = cl[p][e];
+                    if (!(J.flags[v] & 1)) {
+                        if (cnt == 0) { first = v; cnt = 1; }
+                        else if (v != first) { cnt = 2; break; }
+                    }
+                }
+            push = cnt <= 1;
+        }
+        uint32_t total, off = wg_exclusive_scan(push, s_scan, &total);
+        if (push) { J.queue[(q.tail + off) & J.qmask] = r; J.inq[r] = 1; }
+        q.tail += total;
+    }
+    __syncthreads();
+
+    unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0;
+    unsigned long long hits[16];
+    for (int i = 0; i < 16; ++i) hits[i] = 0;
+    // `steps` is kept consistent across the workgroup through s_steps at phase boundaries
+
+    for (;;) {
+        if (wg_error(J, &s_err)) break;
+        if (prev_steps == steps) break;   // (:708-711)
+        prev_steps = steps;
+        outer++;
+        // ================= P1, P2 and the queue are driven by wave 0, in the reference's order
+        if (w == 0) {
+            // P1 (:718-747)
+            for (uint32_t i = 0; i < J.nSp; ++i) {
+                if (J.fired[nC + i]) continue;   // special_solved
+                bool ok = true;
+                for (uint32_t e = J.sp_in_ptr[i] + lane; e < J.sp_in_ptr[i + 1]; e += 64)
+                    if (!(J.flags[J.sp_in[e]] & 1)) ok = false;
+                if (__ballot(!ok)) continue;
+                if (lane == 0) J.fired[nC + i] = 1;
+                steps++; hits[8]++;
+                for (uint32_t e = J.sp_out_ptr[i]; e < J.sp_out_ptr[i + 1]; ++e) {
+                    uint32_t v = J.sp_out[e];
+                    if (J.flags[v] & 1) continue;
+                    mark_unique(J, v);
+                    requeue(J, q, v);
+                }
+            }
+            // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair
+            for (uint32_t i = 0; i < J.nSp; ++i) {
+                if (J.sp_kind[i] != 1) continue;
+                for (uint32_t j = 0; j < J.nSp; ++j) {
+                    if (J.sp_kind[j] != 2) continue;
+                    if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
+                    uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
+                    if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
+                    hits[9]++;
+                    for (uint32_t t = 0; t < 3; ++t) {                                   // constraint_j[2][1:3]
+                        uint32_t v = J.sp_in[J.sp_in_ptr[j] + t];
+                        if (J.flags[v] & 1) continue;
+                        mark_unique(J, v);
+                        requeue(J, q, v);
+                    }
+                }
+                if (J.ctr->error) break;
+            }
+            // QUEUE (:805-1349)
+            // watchdog: every pop is caused by a state change of one of the row's variables and each
+            // variable changes a bounded number of times, so pops <= c * nnz in any terminating run
+            const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
+            while (q.head != q.tail && !J.ctr->error) {
+                if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+                uint32_t row = J.queue[q.head & J.qmask];
+                q.head++;
+                if (lane == 0) J.inq[row] = 0;
+                wg_fence();
+                pops++;
+                if (J.solved[row]) continue;
+                exec_row(J, q, row, hits, steps, nuniq);
+            }
+            if (lane == 0) s_steps = steps;
+        }
+        __syncthreads();
+        steps = s_steps;
+        if (wg_error(J, &s_err)) break;
+
+        // ================= P3 linear systems (:1357-1417)
+        {
+            uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
+            bool any_group = false;
+            for (;;) {
+                if (tid == 0) { s_u32[0] = 0xFFFFFFFFu; s_u32[1] = 0; s_u32[2] = 0xFFFFFFFFu; s_u32[3] = 0; }
+                __syncthreads();
+                // phase 1: evaluate rows >= f against the current state
+                for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                    uint32_t k; uint64_t h, h2;
+                    p3_eval(J, r, k, h, h2);
+                    if (k == 0xFFFFFFFFu) k = 0;
+                    J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+                    J.p3h[r] = h; J.p3h2[r] = h2;
+                    if (k == 1) atomicMin(&s_u32[0], r);
+                    else if (k >= 2) {
+                        uint32_t s = ht_slot(J, h, h2, true);
+                        if (s == 0xFFFFFFFFu) raise(J, K_ECAPACITY);
+                        else atomicAdd(&J.ht_new[s], 1u);
+                        s_u32[3] = 1;
+                    }
+                }
+                if (wg_error(J, &s_err)) break;
+                any_group = any_group || s_u32[3];
+                // phase 2: rows whose group could reach its size in this pass
+                if (s_u32[3]) {
+                    for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                        uint32_t k = J.p3k[r];
+                        if (k < 2) continue;
+                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        uint32_t fr = J.ht_frozen[s];
+                        if (fr < k && fr + J.ht_new[s] >= k) {
+                            uint32_t pos = atomicAdd(&s_u32[1], 1u);
+                            if (pos < J.hotcap) J.hot[pos] = r;
+                        }
+                    }
+                    __syncthreads();
+                    if (s_u32[1] > J.hotcap) raise(J, K_ECAPACITY);
+                }
+                if (wg_error(J, &s_err)) break;
+                // phase 3 (wave 0): find the earliest trigger row that passes the test
+                if (w == 0) {
+                    uint32_t nhot = s_u32[1];
+                    uint32_t best = s_u32[0];   // k == 1: first arrival of a one-variable group always fires
+                    // ascending selection over the hot list; groups are tiny, the list is short
+                    for (uint32_t a = 0; a < nhot; ++a) {
+                        uint32_t t = J.hot[a];
+                        if (t >= best) continue;
+                        uint32_t k = J.p3k[t];
+                        if (k > 10) { if (k == J.p3k[t]) { /* trigger only if arrival == k, checked below */ } }
+                        uint64_t h = J.p3h[t], h2 = J.p3h2[t];
+                        uint32_t s = ht_slot(J, h, h2, false);
+                        uint32_t fr = J.ht_frozen[s];
+                        // arrival number of t = frozen + fresh members with index <= t
+                        uint32_t arr = fr;
+                        for (uint32_t b = lane; b < nhot; b += 64) {
+                            uint32_t o = J.hot[b];
+                            if (o <= t && J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k) arr++;
+                        }
+                        // lanes hold partial counts: reduce
+                        uint32_t part = arr - fr;
+                        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                        arr = fr + part;
+                        if (arr != k) continue;
+                        if (k > 10) { raise(J, K_EDETSIZE); break; }
+                        // collect the k member rows in arrival (index) order and the k variables ascending
+                        if (lane == 0) {
+                            uint32_t n = 0;
+                            if (fr) {   // frozen members: rows < f with the same key at their time
+                                for (uint32_t r = 0; r < f && n < k; ++r)
+                                    if (J.p3k[r] == k && J.p3h[r] == h && J.p3h2[r] == h2) m_rows[n++] = r;
+                            }
+                            // fresh members ascending (selection sort over the short hot list)
+                            uint32_t last = 0; bool have = false;
+                            while (n < k) {
+                                uint32_t mn = 0xFFFFFFFFu;
+                                for (uint32_t b = 0; b < nhot; ++b) {
+                                    uint32_t o = J.hot[b];
+                                    if (J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k && (!have || o > last) && o < mn) mn = o;
+                                }
+                                if (mn == 0xFFFFFFFFu) break;
+                                m_rows[n++] = mn; last = mn; have = true;
+                            }
+                            uint32_t nv = 0;
+                            for (uint32_t e = J.rpC[t]; e < J.rpC[t + 1]; ++e) {
+                                uint32_t v = J.colC[e];
+                                if (!(J.flags[v] & 1)) {
+                                    uint32_t pos = nv++;
+                                    while (pos > 0 && m_vars[pos - 1] > v) { m_vars[pos] = m_vars[pos - 1]; --pos; }
+                                    m_vars[pos] = v;
+                                }
+                            }
+                        }
+                        wg_fence();
+                        if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
+                    }
+                    if (lane == 0) s_u32[2] = best;
+                }
+                if (wg_error(J, &s_err)) break;
+                const uint32_t fire = s_u32[2];
+                const uint32_t upto = fire == 0xFFFFFFFFu ? nC : fire + 1;
+                // phase 4: freeze rows [f, upto): their arrivals are now history; forget fresh counts
+                if (s_u32[3]) {
+                    for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                        uint32_t k = J.p3k[r];
+                        if (k < 2) continue;
+                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        if (r < upto) atomicAdd(&J.ht_frozen[s], 1u);
+                    }
+                    __syncthreads();
+                    for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                        uint32_t k = J.p3k[r];
+                        if (k < 2) continue;
+                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        J.ht_new[s] = 0;
+                    }
+                    __syncthreads();
+                }
+                if (fire == 0xFFFFFFFFu) break;
+                // apply the firing: the group's variables, ascending, become unique (:1403-1414)
+                if (w == 0) {
+                    uint32_t k = J.p3k[fire];
+                    steps += k; hits[10]++;
+                    // ascending variable order: repeatedly take the smallest not yet handled
+                    uint32_t lastv = 0;
+                    for (uint32_t n = 0; n < k; ++n) {
+                        uint32_t mn = 0xFFFFFFFFu;
+                        for (uint32_t e = J.rpC[fire] + lane; e < J.rpC[fire + 1]; e += 64) {
+                            uint32_t v = J.colC[e];
+                            if (!(J.flags[v] & 1) && v > lastv && v < mn) mn = v;
+                        }
+                        for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
+                        if (mn == 0xFFFFFFFFu) break;
+                        lastv = mn;
+                        // defer the flag write until all k are collected? No: the reference marks them one by
+                        // one, and later variables of the same group are selected by the saved list `unk`.
+                        J.events[n] = mn;
+                    }
+                    wg_fence();
+                    for (uint32_t n = 0; n < k; ++n) {
+                        uint32_t v = J.events[n];
+                        mark_unique(J, v);
+                        requeue(J, q, v);
+                    }
+                    if (lane == 0) s_steps = steps;
+                }
+                __syncthreads();
+                steps = s_steps;
+                f = fire + 1;
+            }
+            // leave the table clean for the next outer iteration
+            if (any_group) {
+                __syncthreads();
+                for (uint32_t s = tid; s <= J.htmask; s += ECNE_WG) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
+            }
+            if (wg_error(J, &s_err)) break;
+        }
+
+        // ================= P4 ABZ tagging (:1425-1483)
+        {
+            if (tid == 0) s_u32[4] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
+                const RowInfo ri = J.rinfo[J.p4_list[i]];
+                const uint32_t b = ri.kpos;
+                if (J.flags[b] & 1) continue;
+                if (ri.shape & SH_P4_DIV0) { raise(J, K_EDIVZERO); continue; }
+                atomicMin(&J.varmin[b], i);
+            }
+            __syncthreads();
+            uint32_t nfired_local = 0;
+            for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
+                const RowInfo ri = J.rinfo[J.p4_list[i]];
+                const uint32_t b = ri.kpos;
+                J.fired[J.p4_list[i]] = 0;
+                if (J.flags[b] & 1) continue;
+                if (J.varmin[b] != i) continue;
+                if (J.abz[b] != -1) continue;
+                J.abz[b] = (int32_t)ri.kneg;
+                J.flags[b] |= 2;
+                J.fired[J.p4_list[i]] = 1;
+                nfired_local++;
+            }
+            __syncthreads();
+            // ordered event list = fired rows ascending -> their b variable
+            uint32_t nev = 0;
+            for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
+                uint32_t i = base + tid;
+                uint32_t fl = (i < J.nP4) ? J.fired[J.p4_list[i]] : 0;
+                uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
+                if (fl) J.events[nev + off] = J.rinfo[J.p4_list[i]].kpos;
+                nev += total;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
+                const uint32_t b = J.rinfo[J.p4_list[i]].kpos;
+                J.varmin[b] = 0xFFFFFFFFu;
+                J.fired[J.p4_list[i]] = 0;
+            }
+            __syncthreads();
+            if (w == 0) {
+                steps += nev; hits[11] += nev;
+                requeue_events(J, q, J.events, nev);
+                if (lane == 0) s_steps = steps;
+            }
+            __syncthreads();
+            steps = s_steps;
+            if (wg_error(J, &s_err)) break;
+        }
+
+        // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates
+        if (w == 0) {
+            for (uint32_t i = 0; i < J.nP5; ++i) {
+                const uint32_t r = J.p5_rows[i], y = J.p5_y[i];
+                bool nu = false;
+                for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nu |= !(J.flags[J.colA[e]] & 1);
+                if (__ballot(nu)) continue;
+                if (J.flags[y] & 1) continue;
+                mark_unique(J, y);
+                if (lane == 0) { J.solved[r] = 1; J.solved[r + 1] = 1; }
+                wg_fence();
+                steps++; hits[12]++;
+                requeue(J, q, y);
+            }
+            if (lane == 0) s_steps = steps;
+        }
+        __syncthreads();
+        steps = s_steps;
+    }
+
+    // ---------------- verdict counts (:1558-1597)
+    __syncthreads();
+    uint32_t un = 0, nn = 0, ut = 0;
+    for (uint32_t v = 1 + tid; v <= nV; v += ECNE_WG) {
+        if (J.nontrivial[v]) { nn++; if (J.flags[v] & 1) un++; }
+    }
+    for (uint32_t i = tid; i < J.nTarget; i += ECNE_WG)
+        if (J.flags[J.targets[i]] & 1) ut++;
+    {
+        uint32_t t0, t1, t2;
+        wg_exclusive_scan(un, s_scan, &t0);
+        wg_exclusive_scan(nn, s_scan, &t1);
+        wg_exclusive_scan(ut, s_scan, &t2);
+        if (tid == 0) {
+            Counters* c = J.ctr;
+            c->successful_steps = steps;
+            c->num_unique = nuniq;
+            c->pops = pops;
+            c->outer_iterations = outer;
+            for (int i = 0; i < 16; ++i) c->rule_hits[i] = hits[i];
+            c->unique_nontrivial = t0;
+            c->n_nontrivial = t1;
+            c->unique_targets = t2;
+            c->q_head = q.head;
+            c->q_tail = q.tail;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- fp self-test
+__global__ void k_fp_selftest(int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp::u256 x = ld256(a + 4 * i), y = ld256(b + 4 * i), r = fp::make(0);
+    switch (op) {
+        case 0: r = fp::add(x, y); break;
+        case 1: r = fp::sub(x, y); break;
+        case 2: r = fp::mul(x, y); break;
+        case 3: r = fp::is_zero(x) ? fp::make(0) : fp::inv(x); break;
+        case 4: r = fp::neg(x); break;
+        case 5: r = fp::is_zero(y) ? fp::make(0) : fp::mul(x, fp::inv(y)); break;
+        case 6: { fp::u256 q, rem; if (!fp::is_zero(y)) { fp::divmod(x, y, q, rem); r = q; } } break;
+        case 7: r = fp::make(fp::mul_gt_p(x, y) ? 1 : 0); break;
+    }
+    st256(out + 4 * i, r);
+}
+
+}  // namespace ecne

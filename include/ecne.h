@@ -1,0 +1,137 @@
+/* ecne.h — C ABI of libecne_hip, the MI355X-native replacement for the hot path of Ecne
+ * (franklynwang/EcneProject): the fixed-point constraint-propagation loop SolveConstraintsSymbolic
+ * and the two steps that feed it (readR1CS, abstraction).
+ *
+ * The reference has no FFI/plugin interface; its seam is three Julia functions. Each entry point
+ * below names the reference interface it stands in for (paths relative to the reference tree):
+ *
+ *   ecne_r1cs_load / _info / _csr / _io      readR1CS(filename)          src/ParseR1CS.jl:50-124
+ *   ecne_system_from_r1cs + ecne_abstract    the trusted-function loop   src/R1CSConstraintSolver.jl:513-544
+ *                                            abstraction(...)            src/R1CSConstraintSolver.jl:237-395
+ *   ecne_solve / ecne_solve_batch            SolveConstraintsSymbolic    src/R1CSConstraintSolver.jl:583-1646
+ *   ecne_result_*                            its Bool result + the counts it prints (:1565-1592) and
+ *                                            the per-variable VariableState (:135-160) it reports (:1609-1643)
+ *
+ * The Julia shim julia/EcneHIP.jl binds these with ccall and re-exports the reference's own
+ * readR1CS / SolveConstraintsSymbolic / solveWithTrustedFunctions signatures.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 or a negative ecne_status;
+ * nothing throws across the ABI; no global mutable state; a handle is used by one thread at a
+ * time, different handles may be used concurrently. Variable ids are 1-based (wire id + 1, variable
+ * 1 = the constant-one wire) exactly as in the reference. Field elements are 4 little-endian
+ * uint64 limbs holding the canonical residue < p (BN254 scalar field).
+ */
+#ifndef ECNE_H
+#define ECNE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ecne_status {
+    ECNE_OK = 0,
+    ECNE_EFORMAT = -1,    /* @assert failures ParseR1CS.jl:58,62,69; truncated file                  */
+    ECNE_EBOUNDS = -2,    /* BoundsError: variable_states[-1] (:916); special indexing (:762,:785)  */
+    ECNE_EDIVZERO = -3,   /* DivideError from divexact by zero (:919-920, :1467)                    */
+    ECNE_EUNDEF_DSU = -4, /* UndefVarError `dsu` (:762): BigMultModP x BigLessThan without secp_solve */
+    ECNE_EKEY = -5,       /* KeyError in abstraction's variable map (:381-382)                      */
+    ECNE_EDETSIZE = -6,   /* linear-system group with > 10 unknowns (reference would run k!*k steps) */
+    ECNE_EIO = -7,
+    ECNE_ENODEVICE = -8,  /* no usable HIP device: the engine never falls back to the CPU           */
+    ECNE_EINVAL = -9,
+    ECNE_ECAPACITY = -10  /* internal device table overflow (reported, never silently truncated)    */
+} ecne_status;
+
+typedef struct ecne_r1cs ecne_r1cs;     /* a parsed .r1cs file                                   */
+typedef struct ecne_system ecne_system; /* rows + special constraints + I/O lists fed to a solve  */
+typedef struct ecne_result ecne_result; /* outcome of one solve                                  */
+
+typedef struct ecne_info {
+    uint32_t field_size, n_wires, n_pub_out, n_pub_in, n_prv_in, n_constraints;
+    uint64_t n_labels;
+    uint64_t nnz[3];   /* non-zero terms in A, B, C */
+    int64_t n_vars;    /* nWires + 1 (ParseR1CS.jl:123) */
+} ecne_info;
+
+/* readR1CS — ParseR1CS.jl:50-124 */
+int ecne_r1cs_load(const char* path, ecne_r1cs** out);
+int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* out);
+/* CSR view of one part (0 = A, 1 = B, 2 = C) in file order, non-zero terms only; borrowed pointers,
+ * valid until ecne_r1cs_free. coeff holds 4 limbs per term. */
+int ecne_r1cs_csr(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col,
+                  const uint64_t** coeff);
+/* known_variables = [1] ++ inputs, target_variables = outputs (ParseR1CS.jl:123) */
+int ecne_r1cs_io(const ecne_r1cs* f, const int64_t** known, size_t* n_known, const int64_t** targets,
+                 size_t* n_targets);
+void ecne_r1cs_free(ecne_r1cs* f);
+
+/* solveWithTrustedFunctions :515-544: start from the main file, then abstract trusted functions away.
+ * The caller passes trusted functions in the reference's order (already sorted long -> short, :527). */
+int ecne_system_from_r1cs(const ecne_r1cs* main_file, ecne_system** out);
+int ecne_abstract(ecne_system* sys, const ecne_r1cs* trusted, const char* name);
+typedef struct ecne_system_info {
+    int64_t n_rows;      /* rows handed to the solver (after abstraction) */
+    int64_t n_rows_main; /* rows of the main file as read                 */
+    int64_t n_vars, n_specials, n_known, n_targets;
+    uint64_t nnz[3];
+} ecne_system_info;
+int ecne_system_info_get(const ecne_system* sys, ecne_system_info* out);
+/* special constraint idx: name and mapped input / output variable lists (borrowed) */
+int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, const int64_t** inputs,
+                        size_t* n_inputs, const int64_t** outputs, size_t* n_outputs);
+void ecne_system_free(ecne_system* sys);
+
+typedef struct ecne_opts {
+    int32_t device;      /* HIP device ordinal                                                       */
+    int32_t secp_solve;  /* kwarg secp_solve (:511): defines `dsu`, required when P2 has work (:762)  */
+    int32_t debug;       /* reserved                                                                 */
+    int32_t queue_mode;  /* 0 = default schedule; 1 = force strictly sequential pops (debug/parity)  */
+    void* stream;        /* hipStream_t to launch on, or NULL for the device's default stream         */
+} ecne_opts;
+
+typedef struct ecne_summary {
+    int32_t status;          /* ecne_status of the solve itself                                  */
+    int32_t function_good;   /* the Bool SolveConstraintsSymbolic returns (:1594-1597, :1645)   */
+    int64_t unique_nontrivial, n_nontrivial;   /* "Solved for U variables out of N" (:1565-1571) */
+    int64_t unique_targets, n_targets;         /* "Solved for T target variables out of M" (:1586-1592) */
+    int64_t successful_steps, outer_iterations, pops, num_unique;
+    int64_t rule_hits[16];   /* 0..7 = R1..R8 (:827-1348), 8..12 = P1..P5 (:718-800, :1357-1550) */
+    int64_t n_rows, n_vars;
+    double device_ms;        /* HIP-event time of the solve kernels on their stream              */
+    double classify_ms;      /* HIP-event time of k_classify_rows                                */
+} ecne_summary;
+
+/* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is
+ * usable. ecne_solve_batch runs n independent systems in one launch (one workgroup per system). */
+int ecne_solve(ecne_system* sys, const ecne_opts* opts, ecne_result** out);
+int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out);
+int ecne_result_summary(const ecne_result* r, ecne_summary* out);
+/* per-variable VariableState (:135-160), variable v at index v-1; borrowed, valid until free.
+ * flags bit0 = unique, bit1 = is_known; lb/ub: 4 limbs; nvalues in {0,1,2}; values: 2 x 4 limbs. */
+int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
+                       const int32_t** abz, const uint8_t** nvalues, const uint64_t** values);
+/* rows that still contain a non-uniquely-determined variable ("Bad Constraints", :1609-1618), 1-based */
+int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n);
+void ecne_result_free(ecne_result* r);
+
+/* k_classify_rows output for tests/profiling: per-row shape word (see ecne_engine.hip SH_*) */
+int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out /* n_rows */, double* kernel_ms,
+                  uint64_t* bytes_streamed);
+
+/* device self-tests of the field arithmetic: runs `n` vectors op(a,b) on the GPU.
+ * op: 0 add, 1 sub, 2 mul, 3 inv(a), 4 neg(a), 5 a/b. a, b, out: n x 4 limbs. */
+int ecne_fp_selftest(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+/* host-side utilities named by the north star (src/Math.jl:14-90 is dead code in the reference;
+ * provided with self-consistency tests only): sqrt returns 1 and a root when one exists, else 0. */
+int ecne_fp_sqrt(const uint64_t* a, uint64_t* root);
+
+int ecne_device_count(void);
+const char* ecne_strerror(int status);
+const char* ecne_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECNE_H */
