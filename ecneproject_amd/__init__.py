@@ -159,13 +159,21 @@ class System:
 
 
 class SolveResult:
-    def __init__(self, handle):
+    """Outcome of one solve. With fetch_states=False only the summary (verdict + counts) is read
+    back; the per-variable arrays stay in HBM and the attributes below are None."""
+
+    flags = lb = ub = abz = nvalues = values = bad_rows = None
+
+    def __init__(self, handle, fetch_states=True):
         L = _lib.lib()
         s = Summary()
         _check(L.ecne_result_summary(handle, C.byref(s)))
         self.summary = s
         self.status = int(s.status)
         self.function_good = bool(s.function_good)
+        if not fetch_states:
+            L.ecne_result_free(handle)
+            return
         nv = int(s.n_vars)
         fl, lb, ub = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
         abz, nvs, vals = C.POINTER(C.c_int32)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
@@ -213,7 +221,7 @@ def _opts(device=0, secp_solve=False, queue_mode=0, stream=None):
     return o
 
 
-def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None):
+def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None, fetch_states=True):
     """Run n independent systems in one launch (one workgroup each). Returns SolveResult list."""
     L = _lib.lib()
     n = len(systems)
@@ -221,7 +229,7 @@ def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None):
     outs = (C.c_void_p * n)()
     o = _opts(device, secp_solve, queue_mode, stream)
     _check(L.ecne_solve_batch(hs, n, C.byref(o), outs), "ecne_solve_batch")
-    return [SolveResult(C.c_void_p(outs[i])) for i in range(n)]
+    return [SolveResult(C.c_void_p(outs[i]), fetch_states) for i in range(n)]
 
 
 def classify(system, device=0):

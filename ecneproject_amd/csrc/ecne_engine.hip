@@ -62,6 +62,7 @@ struct ecne_system {
     std::vector<int64_t> knowns, targets;
     int64_t n_vars = 0, n_rows_main = 0;
     bool laid_out = false;
+    uint64_t generation = 0;   // bumped by every solve
     Layout L;
     DeviceImage dev;
     ~ecne_system() {
@@ -74,6 +75,11 @@ struct ecne_system {
 
 struct ecne_result {
     ecne_summary sum;
+    // per-variable state is downloaded from HBM on first request (ecne_result_states /
+    // ecne_result_bad_rows), and only while `sys` has not been solved again (generation check)
+    ecne_system* sys = nullptr;
+    uint64_t generation = 0;
+    bool have_states = false;
     std::vector<uint8_t> flags, nvalues;
     std::vector<uint64_t> lb, ub, values;
     std::vector<int32_t> abz;
@@ -427,6 +433,48 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     return K_OK;
 }
 
+// download the per-variable state of a finished solve (lazy; see ecne_result)
+static int fetch_states(ecne_result* r) {
+    if (r->have_states) return K_OK;
+    if (!r->sys || r->sys->generation != r->generation || !r->sys->dev.arena) return K_EINVAL;
+    ecne_system& S = *r->sys;
+    const Layout& L = S.L;
+    const Job& J = S.dev.job;
+    HIP_TRY(hipSetDevice(S.dev.device));
+    const size_t nv = (size_t)S.n_vars;
+    std::vector<uint8_t> flags(L.nV + 1), nvals(L.nV + 1);
+    std::vector<uint64_t> lb(4ull * (L.nV + 1)), ub(4ull * (L.nV + 1)), vals(8ull * (L.nV + 1));
+    std::vector<int32_t> abz(L.nV + 1);
+    HIP_TRY(hipMemcpy(flags.data(), J.flags, flags.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nvals.data(), J.nvalues, nvals.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lb.data(), J.lb, lb.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ub.data(), J.ub, ub.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vals.data(), J.values, vals.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(abz.data(), J.abz, abz.size() * 4, hipMemcpyDeviceToHost));
+    // re-base to "variable v at index v-1", n_vars entries
+    r->flags.assign(nv, 0); r->nvalues.assign(nv, 0); r->abz.assign(nv, -1);
+    r->lb.assign(4 * nv, 0); r->ub.assign(4 * nv, 0); r->values.assign(8 * nv, 0);
+    for (size_t v = 1; v <= nv && v <= L.nV; ++v) {
+        r->flags[v - 1] = flags[v] & 3;
+        r->nvalues[v - 1] = nvals[v];
+        r->abz[v - 1] = abz[v];
+        std::memcpy(&r->lb[4 * (v - 1)], &lb[4 * v], 32);
+        std::memcpy(&r->ub[4 * (v - 1)], &ub[4 * v], 32);
+        if (nvals[v] >= 1) std::memcpy(&r->values[8 * (v - 1)], &vals[8 * v], 32);
+        if (nvals[v] >= 2) std::memcpy(&r->values[8 * (v - 1) + 4], &vals[8 * v + 4], 32);
+    }
+    // "Bad Constraints": rows with a variable that is not uniquely determined (:1609-1618)
+    for (uint32_t row = 0; row < L.nC; ++row) {
+        bool bad = false;
+        for (int p = 0; p < 3 && !bad; ++p)
+            for (uint32_t k = L.rp[p][row]; k < L.rp[p][row + 1]; ++k)
+                if (!(flags[L.col[p][k]] & 1)) { bad = true; break; }
+        if (bad) r->bad_rows.push_back((int64_t)row + 1);
+    }
+    r->have_states = true;
+    return K_OK;
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -557,37 +605,9 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             ecne_result* r = new ecne_result();
             Counters c;
             if (hipMemcpy(&c, hj[i].ctr, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { delete r; rc = ECNE_ENODEVICE; break; }
-            const size_t nv = (size_t)S.n_vars;
-            std::vector<uint8_t> flags(L.nV + 1), nvals(L.nV + 1);
-            std::vector<uint64_t> lb(4ull * (L.nV + 1)), ub(4ull * (L.nV + 1)), vals(8ull * (L.nV + 1));
-            std::vector<int32_t> abz(L.nV + 1);
-            bool ok = hipMemcpy(flags.data(), hj[i].flags, flags.size(), hipMemcpyDeviceToHost) == hipSuccess &&
-                      hipMemcpy(nvals.data(), hj[i].nvalues, nvals.size(), hipMemcpyDeviceToHost) == hipSuccess &&
-                      hipMemcpy(lb.data(), hj[i].lb, lb.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-                      hipMemcpy(ub.data(), hj[i].ub, ub.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-                      hipMemcpy(vals.data(), hj[i].values, vals.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-                      hipMemcpy(abz.data(), hj[i].abz, abz.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
-            if (!ok) { delete r; rc = ECNE_ENODEVICE; break; }
-            // re-base to "variable v at index v-1", n_vars entries
-            r->flags.assign(nv, 0); r->nvalues.assign(nv, 0); r->abz.assign(nv, -1);
-            r->lb.assign(4 * nv, 0); r->ub.assign(4 * nv, 0); r->values.assign(8 * nv, 0);
-            for (size_t v = 1; v <= nv && v <= L.nV; ++v) {
-                r->flags[v - 1] = flags[v] & 3;
-                r->nvalues[v - 1] = nvals[v];
-                r->abz[v - 1] = abz[v];
-                std::memcpy(&r->lb[4 * (v - 1)], &lb[4 * v], 32);
-                std::memcpy(&r->ub[4 * (v - 1)], &ub[4 * v], 32);
-                if (nvals[v] >= 1) std::memcpy(&r->values[8 * (v - 1)], &vals[8 * v], 32);
-                if (nvals[v] >= 2) std::memcpy(&r->values[8 * (v - 1) + 4], &vals[8 * v + 4], 32);
-            }
-            // "Bad Constraints": rows with a variable that is not uniquely determined (:1609-1618)
-            for (uint32_t row = 0; row < L.nC; ++row) {
-                bool bad = false;
-                for (int p = 0; p < 3 && !bad; ++p)
-                    for (uint32_t k = L.rp[p][row]; k < L.rp[p][row + 1]; ++k)
-                        if (!(flags[L.col[p][k]] & 1)) { bad = true; break; }
-                if (bad) r->bad_rows.push_back((int64_t)row + 1);
-            }
+            S.generation++;
+            r->sys = &S;
+            r->generation = S.generation;
             ecne_summary& s = r->sum;
             std::memset(&s, 0, sizeof s);
             s.status = c.error;
@@ -603,6 +623,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             for (int k = 0; k < 16; ++k) s.rule_hits[k] = (int64_t)c.rule_hits[k];
             s.n_rows = (int64_t)L.nC;
             s.n_vars = S.n_vars;
+            s.pop_nnz = (int64_t)c.pop_nnz;
             s.device_ms = ms;
             s.classify_ms = S.dev.classify_ms;
             out[i] = r;
@@ -626,6 +647,8 @@ int ecne_result_summary(const ecne_result* r, ecne_summary* out) {
 int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
                        const int32_t** abz, const uint8_t** nvalues, const uint64_t** values) {
     if (!r) return ECNE_EINVAL;
+    int st = fetch_states(const_cast<ecne_result*>(r));
+    if (st != K_OK) return st;
     if (flags) *flags = r->flags.data();
     if (lb) *lb = r->lb.data();
     if (ub) *ub = r->ub.data();
@@ -636,6 +659,8 @@ int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64
 }
 int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n) {
     if (!r) return ECNE_EINVAL;
+    int st = fetch_states(const_cast<ecne_result*>(r));
+    if (st != K_OK) return st;
     if (rows) *rows = r->bad_rows.data();
     if (n) *n = r->bad_rows.size();
     return ECNE_OK;

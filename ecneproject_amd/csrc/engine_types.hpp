@@ -50,7 +50,7 @@ struct RowInfo {   // 32 bytes
 struct Counters {   // one per job, device memory
     unsigned long long successful_steps, num_unique, pops, outer_iterations;
     unsigned long long rule_hits[16];
-    unsigned long long unique_nontrivial, n_nontrivial, unique_targets;
+    unsigned long long unique_nontrivial, n_nontrivial, unique_targets, pop_nnz;
     int error;          // first ecne_status raised on the device (0 = none)
     unsigned int q_head, q_tail;
     unsigned int pad;

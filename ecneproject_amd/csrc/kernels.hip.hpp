@@ -778,7 +778,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
     }
     __syncthreads();
 
-    unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0;
+    unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
     unsigned long long hits[16];
     for (int i = 0; i < 16; ++i) hits[i] = 0;
     // `steps` is kept consistent across the workgroup through s_steps at phase boundaries
@@ -835,6 +835,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
                 if (lane == 0) J.inq[row] = 0;
                 wg_fence();
                 pops++;
+                pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
                 if (J.solved[row]) continue;
                 exec_row(J, q, row, hits, steps, nuniq);
             }
@@ -1092,6 +1093,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
             c->successful_steps = steps;
             c->num_unique = nuniq;
             c->pops = pops;
+            c->pop_nnz = pop_nnz;
             c->outer_iterations = outer;
             for (int i = 0; i < 16; ++i) c->rule_hits[i] = hits[i];
             c->unique_nontrivial = t0;

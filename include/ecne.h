@@ -99,6 +99,7 @@ typedef struct ecne_summary {
     int64_t successful_steps, outer_iterations, pops, num_unique;
     int64_t rule_hits[16];   /* 0..7 = R1..R8 (:827-1348), 8..12 = P1..P5 (:718-800, :1357-1550) */
     int64_t n_rows, n_vars;
+    int64_t pop_nnz;         /* sum over queue pops of the popped row's non-zero count (roofline numerator) */
     double device_ms;        /* HIP-event time of the solve kernels on their stream              */
     double classify_ms;      /* HIP-event time of k_classify_rows                                */
 } ecne_summary;

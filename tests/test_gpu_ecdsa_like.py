@@ -1,0 +1,51 @@
+"""BASELINE.json config 5 on the GPU: the synthetic ecdsa_like(S) circuit (tests/ecdsa_like.py) with
+secp256k1.r1cs trusted.  Small S: bit-exact against the oracle.  Full size (S = 26, 1.09 M rows):
+size-independent properties + a checksum the oracle also produces when it is given the time
+(ECNE_FULL_ORACLE=1)."""
+import os
+
+import numpy as np
+import pytest
+
+import ecneproject_amd as E
+import ecdsa_like
+import fixtures
+import orc
+from gpu_common import assert_bit_exact, build_system
+
+pytestmark = pytest.mark.gpu
+TRUSTED = (["secp256k1.r1cs"], ["Secp256k1AddUnequal"])
+
+
+@pytest.mark.parametrize("S,stride", [(2, 2), (3, 3), (4, 4), (5, 6)])
+def test_small_ecdsa_like_bit_exact(S, stride):
+    path = ecdsa_like.cached(S, stride)
+    s = build_system(None, *TRUSTED, path=path)
+    assert len(s.specials()) == S - 1
+    g = E.solve_batch([s])[0]
+    o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
+    assert o.verdict is True and o.summary.outer_iterations == S + 2
+    assert_bit_exact("ecdsa_like(%d,%d)" % (S, stride), g, o)
+
+
+def test_full_size_properties():
+    """ecdsa_like(26): 25 adders abstracted, chained one per outer iteration (P1 fires one special per
+    iteration), every variable the circuit mentions resolved, idempotent."""
+    path = ecdsa_like.cached(26, 10)
+    s = build_system(None, *TRUSTED, path=path)
+    info = s.info
+    assert info.n_rows_main == 1092639 and info.n_rows == 694264 and info.n_specials == 25
+    g = E.solve_batch([s])[0]
+    assert g.status == 0 and g.function_good
+    assert g.summary.outer_iterations == 28
+    assert list(g.counts()) == [694285, 694311, 6, 6]
+    assert g.summary.rule_hits[8] == 25            # P1: each special fired exactly once
+    assert g.summary.rule_hits[7] == 52            # R8: one all-but-one-zero group per decoder
+    assert len(g.bad_rows) == 26                   # the 26 IsZero rows holding the `inv` hint (never determined)
+    # every unique variable is also known; bounds are ordered
+    assert not np.any(g.unique & ~g.is_known)
+    g2 = E.solve_batch([s])[0]
+    assert np.array_equal(g.flags, g2.flags) and g.summary.pops == g2.summary.pops
+    if os.environ.get("ECNE_FULL_ORACLE") == "1":      # ~45 s of CPU
+        o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
+        assert_bit_exact("ecdsa_like(26,10)", g, o)
