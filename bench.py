@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--S", type=int, default=26, help="strides of ecdsa_like (26 = ECDSAPrivToPub(86,3))")
     ap.add_argument("--stride", type=int, default=10)
-    ap.add_argument("--cpu-sample-S", type=int, default=4, help="strides of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample-S", type=int, default=13, help="strides of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queue-mode", type=int, default=0)
     return ap.parse_args()
@@ -136,6 +136,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "alg_bytes_per_launch": b_alg, "kernel_ms": k_ms,
+                         "phase_ms": {k: round(v, 3) for k, v in zip(["setup", "queue", "P3", "P4", "P5", "verdict", "P3_rounds"], list(s.phase_ms)[:7])},
                          "note": "fixed point is dependency-depth bound; see DESIGN.md"},
         }
         if not args.no_cpu_baseline:

@@ -148,6 +148,8 @@ static void build_layout(ecne_system& S) {
         }
         const size_t nA = nz[0].size(), nB = nz[1].size(), nCc = nz[2].size();
         ri.lenC = (uint32_t)nCc;
+        for (auto& e : nz[2]) if (e.v == 1) ri.shape |= SH_C_HAS1;
+        if (nA + nB + nCc > ECNE_SMALL_ROW) ri.shape |= SH_BIG;
         if (nA || nB) ri.shape |= SH_HAS_AB;
         if (nCc == 0) {
             ri.shape |= SH_C_EMPTY;
@@ -338,12 +340,14 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_flags = c.take((size_t)nV + 1), o_abz = c.take(4ull * (nV + 1));
     size_t o_lb = c.take(32ull * (nV + 1)), o_ub = c.take(32ull * (nV + 1));
     size_t o_nvalues = c.take((size_t)nV + 1), o_values = c.take(64ull * (nV + 1));
-    size_t o_inq = c.take(std::max<size_t>(nC, 1)), o_solved = c.take((size_t)nC + 1), o_flip3 = c.take(std::max<size_t>(nC, 1));
+    size_t o_inq = c.take(2 * std::max<size_t>(nC, 1)), o_solved = c.take((size_t)nC + 1), o_flip3 = c.take(std::max<size_t>(nC, 1));
     size_t o_queue = c.take(4ull * qcap);
     size_t o_varmin = c.take(4ull * (nV + 1));
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
+    size_t o_wmark = c.take(4ull * (nV + 1)), o_rmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_rmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1));
+    size_t o_evbuf = c.take(4ull * ECNE_WG * ECNE_EVCAP), o_evcnt = c.take(4ull * ECNE_WG), o_cand = c.take(4ull * ECNE_CANDCAP);
     size_t o_ctr = c.take(sizeof(Counters));
     (void)static_end;
     char* base = nullptr;
@@ -397,13 +401,15 @@ static int upload_system(ecne_system& S, int device) {
     J.flags = (uint8_t*)(base + o_flags); J.abz = (int32_t*)(base + o_abz);
     J.lb = (uint64_t*)(base + o_lb); J.ub = (uint64_t*)(base + o_ub);
     J.nvalues = (uint8_t*)(base + o_nvalues); J.values = (uint64_t*)(base + o_values);
-    J.inq = (uint8_t*)(base + o_inq); J.solved = (uint8_t*)(base + o_solved); J.flip3 = (uint8_t*)(base + o_flip3);
+    J.inq = (uint16_t*)(base + o_inq); J.solved = (uint8_t*)(base + o_solved); J.flip3 = (uint8_t*)(base + o_flip3);
     J.queue = (uint32_t*)(base + o_queue);
     J.varmin = (uint32_t*)(base + o_varmin);
     J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
+    J.wmarkU = (uint32_t*)(base + o_wmark); J.rmarkU = (uint32_t*)(base + o_rmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.rmarkB = (uint32_t*)(base + o_rmarkB); J.best = (uint32_t*)(base + o_best);
+    J.evbuf = (uint32_t*)(base + o_evbuf); J.evcnt = (uint32_t*)(base + o_evcnt); J.cand = (uint32_t*)(base + o_cand);
     J.ctr = (Counters*)(base + o_ctr);
     S.dev.classified = false;
     return K_OK;
@@ -626,6 +632,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             s.pop_nnz = (int64_t)c.pop_nnz;
             s.device_ms = ms;
             s.classify_ms = S.dev.classify_ms;
+            for (int k = 0; k < 8; ++k) s.phase_ms[k] = (k == 6) ? (double)c.phase_ticks[k] : (double)c.phase_ticks[k] * 1e-5;
             out[i] = r;
         }
     } while (0);

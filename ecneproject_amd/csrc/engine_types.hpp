@@ -17,6 +17,10 @@
 
 namespace ecne {
 
+#define ECNE_SMALL_ROW 64   // rows with more entries than this are popped alone (wave-cooperative path)
+#define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
+#define ECNE_CANDCAP 65536  // push candidates resolved in parallel per round; beyond: sequential fallback
+
 // RowInfo.shape bits. "static" = depends only on coefficients/structure, computed once.
 enum : uint32_t {
     SH_HAS_AB = 1u << 0,        // nzA or nzB non-empty: rules R3..R8 never run (:944-946)
@@ -35,6 +39,9 @@ enum : uint32_t {
     SH_P4_DIV0 = 1u << 13,      // A has no non-constant variable: divexact by zero (:1467)
     SH_CZERO = 1u << 14,        // C's map holds an explicit zero (incl. the one R3 inserts, :962)
     SH_R7_SORTED = 1u << 15,    // csort valid for this row
+    SH_C_HAS1 = 1u << 16,       // the constant wire occurs in C with a non-zero coefficient
+    SH_TOUCH1 = 1u << 17,       // the row can read/write the constant wire's bounds (R4/R5 shapes holding it)
+    SH_BIG = 1u << 18,          // more than ECNE_SMALL_ROW entries: popped alone, wave-cooperatively
 };
 
 struct RowInfo {   // 32 bytes
@@ -54,6 +61,7 @@ struct Counters {   // one per job, device memory
     int error;          // first ecne_status raised on the device (0 = none)
     unsigned int q_head, q_tail;
     unsigned int pad;
+    unsigned long long phase_ticks[8];   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 
 struct Job {
@@ -79,7 +87,8 @@ struct Job {
     uint64_t *lb, *ub;
     uint8_t* nvalues;
     uint64_t* values;
-    uint8_t *inq, *solved, *flip3;
+    uint16_t* inq;   // 0 = not queued, 1 = queued, r+2 = being popped at rank r of the current chunk
+    uint8_t *solved, *flip3;
     uint32_t* queue;
     // scratch
     uint32_t* varmin;
@@ -90,6 +99,12 @@ struct Job {
     uint32_t* hot;
     uint8_t* fired;
     uint32_t* events;
+    // per variable: lowest chunk rank that may write / read its U-class state (unique, is_known bits:
+    // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
+    uint32_t *wmarkU, *rmarkU, *wmarkB, *rmarkB;
+    uint32_t* best;            // per row: lowest candidate index that wants to push it
+    uint32_t *evbuf, *evcnt;   // per chunk rank: REQUEUE events emitted by the row popped there
+    uint32_t* cand;            // per push candidate: target row | eligibility bit
     Counters* ctr;
 };
 

@@ -236,6 +236,7 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
             shape |= SH_R7_SORTED;
         }
     }
+    if ((shape & SH_C_HAS1) && (shape & (SH_R4_T | SH_R4_T2 | SH_R5))) shape |= SH_TOUCH1;
     if (lane == 0) {
         ri.shape = shape;
         J.rinfo[row] = ri;
@@ -721,6 +722,592 @@ __device__ __forceinline__ int wg_error(const Job& J, int* s_err) {
     return *s_err;
 }
 
+// ================================================================== chunk-parallel queue schedule
+// The reference pops one row at a time. Here the first n <= 1024 queue entries ("chunk", ranks
+// 0..n-1) are examined together and the longest prefix of pairwise independent rows is executed in
+// parallel, one lane per row, directly on the shared state. Two rows are independent when neither
+// can write a variable the other reads or writes; the read/write sets are static supersets derived
+// from the row shape:
+//     non-linear row, C non-empty : reads A u B u C, may write C            (R1)
+//     C empty, bit-check shaped   : reads/writes x                          (R2)
+//     C empty, anything else      : touches nothing (no rule can fire)
+//     linear row                  : reads/writes C                          (R1, R3..R8)
+// (the constant wire's `unique`/`is_known` never change, so it only counts for rows flagged
+// SH_TOUCH1). Independent rows commute, so executing the prefix in parallel gives exactly the state
+// the sequential pops give; the queue itself is then rebuilt in sequential order by resolving all
+// REQUEUE events of the prefix in (rank, emission order, fan-out position) order with the reference's
+// in_queue semantics. Rows with more than ECNE_SMALL_ROW entries are popped alone through the
+// wave-cooperative exec_row().  DESIGN.md "Schedule" has the equivalence argument.
+
+struct LaneCtr {   // per-lane counter deltas of one queue phase (reduced at the end)
+    uint32_t steps, nuniq, hits[8];
+};
+
+__device__ __forceinline__ uint32_t lane_uniq_range(const Job& J, uint32_t c0, uint32_t c1, uint32_t skip,
+                                                    uint32_t* ev, uint32_t& nev) {
+    uint32_t n = 0;
+    for (uint32_t k = c0; k < c1; ++k) {
+        uint32_t v = J.colC[k];
+        if (v != skip && !(J.flags[v] & 1)) {
+            J.flags[v] |= 3;
+            ev[nev++] = v;
+            ++n;
+        }
+    }
+    return n;
+}
+
+// One queue pop executed by ONE lane (rows with at most ECNE_SMALL_ROW entries). Statement-for-
+// statement the same rules as exec_row(); REQUEUE(v) becomes an event appended to ev[].
+__device__ void exec_row_lane(const Job& J, uint32_t row, uint32_t* ev, uint32_t& nev, LaneCtr& C) {
+    const RowInfo ri = J.rinfo[row];
+    const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1];
+    const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t shape = ri.shape;
+    // R1 (:827-873)
+    {
+        bool nu = false;
+        for (uint32_t k = a0; k < a1 && !nu; ++k) nu = !(J.flags[J.colA[k]] & 1);
+        for (uint32_t k = b0; k < b1 && !nu; ++k) nu = !(J.flags[J.colB[k]] & 1);
+        if (!nu) {
+            uint32_t cnt = 0, u = 0;
+            for (uint32_t k = c0; k < c1 && cnt < 2; ++k) {
+                uint32_t v = J.colC[k];
+                if (!(J.flags[v] & 1)) { if (cnt == 0) u = v; ++cnt; }
+            }
+            if (cnt == 1) {
+                J.flags[u] |= 3;
+                C.nuniq++; C.steps++; C.hits[0]++;
+                ev[nev++] = u;
+            }
+        }
+    }
+    // R2 (:875-942)
+    if (shape & SH_C_EMPTY) {
+        if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
+        if (shape & SH_R2) {
+            const uint32_t x = ri.x;
+            if (!(J.flags[x] & 2)) {
+                if (shape & SH_R2_DIV0) { raise(J, K_EDIVZERO); return; }
+                st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));
+                st256(J.values + 8ull * x + 4, ld256(J.vals + 4ull * (ri.validx + 1)));
+                J.nvalues[x] = 2;
+                J.flags[x] |= 2;
+                J.abz[x] = -1;
+                if (shape & SH_R2_IS01) set_bounds(J, x, fp::make(0), fp::make(1));
+                J.solved[row] = 1;
+                ev[nev++] = x;
+                C.steps++; C.hits[1]++;
+            }
+        }
+    }
+    if (shape & SH_HAS_AB) return;
+    const uint32_t l = c1 - c0;
+    // R3 (:949-988)
+    if (shape & SH_R3) {
+        const uint32_t x = ri.x;
+        const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
+        bool new_info = false;
+        const bool same = J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv);
+        const uint8_t f = J.flags[x];
+        if (!same) { st256(J.values + 8ull * x, tv); J.nvalues[x] = 1; C.steps++; C.hits[2]++; new_info = true; }
+        if (!(f & 1)) { C.nuniq++; new_info = true; }
+        J.flags[x] = (uint8_t)(f | 3);
+        set_bounds(J, x, tv, tv);
+        if (new_info) ev[nev++] = x;
+    }
+    // R4 (:991-1076)
+    if ((shape & (SH_R4_T | SH_R4_T2)) && l > 0) {
+        uint32_t new_key;
+        if ((shape & SH_R4_T) && (shape & SH_R4_T2)) {
+            uint8_t o = (uint8_t)(J.flip3[row] ^ 1);
+            J.flip3[row] = o;
+            new_key = o ? ri.kneg : ri.kpos;
+        } else if (shape & SH_R4_T2) new_key = ri.kneg;
+        else new_key = ri.kpos;
+        bool bad = false;
+        for (uint32_t k = c0; k < c1 && !bad; ++k) {
+            uint32_t v = J.colC[k];
+            if (v != new_key && !(J.flags[v] & 4)) bad = true;
+        }
+        if (!bad) {
+            const fp::u256 fub = ld256(J.vals + 4ull * (ri.validx + 1));
+            const fp::u256 nlb = ld256(J.lb + 4ull * new_key), nub = ld256(J.ub + 4ull * new_key);
+            if (!(fp::is_zero(nlb) && fp::eq(nub, fub))) {
+                bool gt = false;
+                if (l - 1 < 254) {
+                    fp::u256 ip = fp::make(0);
+                    ip.w[(l - 1) >> 6] = 1ull << ((l - 1) & 63);
+                    fp::u256 im1;
+                    fp::sub_raw(im1, ip, fp::make(1));
+                    gt = fp::cmp(nub, im1) > 0;
+                }
+                if (gt) {
+                    set_bounds(J, new_key, fp::make(0), fub);
+                    J.flags[new_key] |= 2;
+                    C.steps++; C.hits[3]++;
+                    ev[nev++] = new_key;
+                }
+            }
+            if (J.flags[new_key] & 1) {
+                uint32_t n = lane_uniq_range(J, c0, c1, new_key, ev, nev);
+                C.nuniq += n; C.steps += n; C.hits[3] += n;
+            }
+        }
+    }
+    // R5 / R6 (:1078-1232)
+    if (shape & (SH_R5 | SH_R6)) {
+        const bool is6 = (shape & SH_R6) != 0;
+        const uint32_t k1 = ri.k1, k2 = ri.k2;
+        fp::u256 lb1 = ld256(J.lb + 4ull * k1), ub1 = ld256(J.ub + 4ull * k1);
+        fp::u256 lb2 = ld256(J.lb + 4ull * k2), ub2 = ld256(J.ub + 4ull * k2);
+        uint8_t f1 = J.flags[k1], f2 = J.flags[k2];
+        bool ch1 = false, ch2 = false;
+        if (!fp::eq(ub2, ub1) || !fp::eq(lb2, lb1) || ((f1 ^ f2) & 1)) {
+            bool proceed = true;
+            if ((f1 ^ f2) & 1) {
+                f1 |= 3;
+                if (is6) f2 |= 3;
+                C.nuniq += 2;
+                ch1 = ch2 = true;
+            }
+            fp::u256 mn = fp::cmp(ub1, ub2) <= 0 ? ub1 : ub2;
+            fp::u256 mx = fp::cmp(lb1, lb2) >= 0 ? lb1 : lb2;
+            if (is6 && (!fp::is_one(mn) || !fp::is_zero(mx))) proceed = false;
+            bool w1 = false, w2 = false;
+            if (proceed) {
+                w1 = fp::cmp(ub1, mn) > 0 || fp::cmp(lb1, mx) < 0;
+                w2 = fp::cmp(ub2, mn) > 0 || fp::cmp(lb2, mx) < 0;
+            }
+            J.flags[k1] = f1;
+            J.flags[k2] = f2;
+            if (w1) {
+                J.flags[k1] |= 2;
+                set_bounds(J, k1, mx, mn);
+                if (is6) { st256(J.values + 8ull * k1, mn); st256(J.values + 8ull * k1 + 4, mx); J.nvalues[k1] = 2; }
+            }
+            if (w2) {
+                J.flags[k2] |= 2;
+                set_bounds(J, k2, mx, mn);
+                if (is6) { st256(J.values + 8ull * k2, mn); st256(J.values + 8ull * k2 + 4, mx); J.nvalues[k2] = 2; }
+            }
+            if (proceed) {
+                ch1 |= w1; ch2 |= w2;
+                uint32_t nset = (ch1 ? 1u : 0u) + (ch2 ? 1u : 0u);
+                C.steps += nset;
+                if (nset) C.hits[is6 ? 5 : 4]++;
+                const bool sw = (shape & SH_R56_SWAP) != 0;
+                uint32_t first = sw ? k2 : k1, second = sw ? k1 : k2;
+                bool cf = sw ? ch2 : ch1, cs = sw ? ch1 : ch2;
+                if (cf) ev[nev++] = first;
+                if (cs) ev[nev++] = second;
+            }
+        }
+    }
+    // R7 (:1235-1298)
+    if (l > 0) {
+        uint32_t nunk = 0;
+        bool notknown = false;
+        for (uint32_t k = c0; k < c1; ++k) {
+            uint8_t f = J.flags[J.colC[k]];
+            if (!(f & 1)) { ++nunk; if (!(f & 2)) notknown = true; }
+        }
+        if (nunk > 0 && !notknown) {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            bool fail = false;
+            uint32_t prev_k = 0xFFFFFFFFu;
+            for (uint32_t s = 0; s < l && !fail; ++s) {
+                uint32_t k = c0 + J.csort[c0 + s];
+                uint32_t v = J.colC[k];
+                if (J.flags[v] & 1) continue;
+                if (prev_k != 0xFFFFFFFFu) {
+                    fp::u256 cn = ld256(J.coefC + 4ull * k), cc = ld256(J.coefC + 4ull * prev_k);
+                    if (negated) { cn = fp::neg(cn); cc = fp::neg(cc); }
+                    cn = r7_abs(cn); cc = r7_abs(cc);
+                    fp::u256 qq, rem;
+                    fp::divmod(cn, cc, qq, rem);
+                    if (!fp::is_zero(rem)) fail = true;
+                    else {
+                        uint32_t pv = J.colC[prev_k];
+                        fp::u256 ub = ld256(J.ub + 4ull * pv), lb = ld256(J.lb + 4ull * pv);
+                        if (fp::cmp(ub, lb) >= 0) {
+                            fp::u256 diff;
+                            fp::sub_raw(diff, ub, lb);
+                            if (fp::cmp(qq, diff) <= 0) fail = true;
+                        }
+                    }
+                }
+                prev_k = k;
+            }
+            if (!fail) {
+                uint32_t lv = J.colC[prev_k];
+                fp::u256 cl = ld256(J.coefC + 4ull * prev_k);
+                if (negated) cl = fp::neg(cl);
+                cl = r7_abs(cl);
+                fp::u256 ub1;
+                fp::add_raw(ub1, ld256(J.ub + 4ull * lv), fp::make(1));
+                if (!fp::mul_gt_p(cl, ub1)) {
+                    C.steps += nunk; C.hits[6]++;
+                    C.nuniq += lane_uniq_range(J, c0, c1, 0xFFFFFFFFu, ev, nev);
+                }
+            }
+        }
+    }
+    // R8 (:1304-1348)
+    if (l > 0) {
+        int group = -1;
+        bool bad = false;
+        uint32_t cnt = 0;
+        for (uint32_t k = c0; k < c1 && !bad; ++k) {
+            uint32_t v = J.colC[k];
+            if (J.flags[v] & 1) continue;
+            int a = J.abz[v];
+            if (a == -1) bad = true;
+            else if (group == -1) group = a;
+            else if (a != group) bad = true;
+            ++cnt;
+        }
+        if (cnt > 0 && !bad) {
+            C.hits[7]++;
+            uint32_t n = lane_uniq_range(J, c0, c1, 0xFFFFFFFFu, ev, nev);
+            C.nuniq += n; C.steps += n;
+        }
+    }
+}
+
+// Access sets of a small row for the conflict test, f(v, read_mask, write_mask) with bit0 = U-class
+// (unique / is_known bits) and bit1 = B-class (lb, ub, bounds01 bit, values, abz):
+//     non-linear row, C non-empty : reads U of A u B u C, may write U of C                  (R1)
+//     C empty, bit-check shaped   : reads U(x), may write U(x) and B(x)                      (R2)
+//     C empty, anything else      : touches nothing
+//     linear row                  : reads and may write U and B of C                          (R1, R3..R8)
+// U-class state of a variable is FINAL once both bits are set (they are only ever set), so U-class
+// accesses to such variables are dropped: no row can change them and every reader sees the same value.
+template <class F>
+__device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_t shape, uint32_t x, F f) {
+    if (shape & SH_C_EMPTY) {
+        if (shape & SH_R2) {
+            const bool fin = (J.flags[x] & 3) == 3;
+            f(x, fin ? 0u : 1u, fin ? 2u : 3u);
+        }
+        return;
+    }
+    const bool lin = !(shape & SH_HAS_AB);
+    if (!lin) {
+        for (uint32_t k = J.rpA[row]; k < J.rpA[row + 1]; ++k) { uint32_t v = J.colA[k]; if ((J.flags[v] & 3) != 3) f(v, 1u, 0u); }
+        for (uint32_t k = J.rpB[row]; k < J.rpB[row + 1]; ++k) { uint32_t v = J.colB[k]; if ((J.flags[v] & 3) != 3) f(v, 1u, 0u); }
+        for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) { uint32_t v = J.colC[k]; if ((J.flags[v] & 3) != 3) f(v, 1u, 1u); }
+        return;
+    }
+    // linear row. B-class state is only ever WRITTEN by: R3 on x, R4 on its pivot(s), R5/R6 on k1, k2.
+    // Where the current state shows that such a write would store what is already there (R3) or
+    // would not happen (equal bounds on an x == y / 1 = x + y row), it is not counted as a write;
+    // the row still READS that state, so an earlier writer in the chunk blocks it and the
+    // observation cannot go stale.
+    const bool touch1 = (shape & SH_TOUCH1) != 0;
+    uint32_t wb0 = 0xFFFFFFFFu, wb1 = 0xFFFFFFFFu, wb2 = 0xFFFFFFFFu;   // variables whose B-state may be written
+    if (shape & SH_R3) {
+        const RowInfo ri = J.rinfo[row];
+        const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
+        const bool same = J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv) &&
+                          fp::eq(ld256(J.lb + 4ull * x), tv) && fp::eq(ld256(J.ub + 4ull * x), tv);
+        if (!same) wb0 = x;
+    }
+    if (shape & (SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6)) {
+        const RowInfo ri = J.rinfo[row];
+        if (shape & (SH_R5 | SH_R6)) {
+            const bool eqb = fp::eq(ld256(J.lb + 4ull * ri.k1), ld256(J.lb + 4ull * ri.k2)) &&
+                             fp::eq(ld256(J.ub + 4ull * ri.k1), ld256(J.ub + 4ull * ri.k2));
+            if (!eqb || wb0 != 0xFFFFFFFFu) { wb1 = ri.k1; wb2 = ri.k2; }   // R3 may first move x's bounds
+        } else {
+            // binary-decomposition row: only the pivot's bounds can be written
+            if ((shape & SH_R4_T) && (shape & SH_R4_T2)) { wb1 = ri.kpos; wb2 = ri.kneg; }
+            else if (shape & SH_R4_T2) wb1 = ri.kneg;
+            else wb1 = ri.kpos;
+        }
+    }
+    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) {
+        uint32_t v = J.colC[k];
+        if (v == 1 && !touch1) continue;
+        const uint32_t u = ((J.flags[v] & 3) == 3) ? 0u : 1u;
+        const uint32_t wb = (v == wb0 || v == wb1 || v == wb2) ? 2u : 0u;
+        f(v, u | 2u, u | wb);
+    }
+}
+
+// Exact "this pop changes no variable" test against the current state, for rows all of whose
+// variables are final. Such a pop only toggles the row's own R4 orientation byte (x == y rows).
+// reads_b tells whether the verdict depended on B-class state (then earlier B-writers still block it).
+__device__ bool row_is_noop(const Job& J, uint32_t row, const RowInfo& ri, bool& reads_b) {
+    const uint32_t shape = ri.shape;
+    reads_b = false;
+    if (shape & SH_R2_BOUNDSERR) return false;
+    for (uint32_t k = J.rpA[row]; k < J.rpA[row + 1]; ++k) if ((J.flags[J.colA[k]] & 3) != 3) return false;
+    for (uint32_t k = J.rpB[row]; k < J.rpB[row + 1]; ++k) if ((J.flags[J.colB[k]] & 3) != 3) return false;
+    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) if ((J.flags[J.colC[k]] & 3) != 3) return false;
+    if (shape & SH_HAS_AB) return true;            // R1 needs a non-unique variable; R2 needs !is_known(x)
+    if (shape & SH_C_EMPTY) return true;
+    // linear row, every variable unique and known: R1, R7, R8 cannot fire. R3 / R4 / R5 / R6 may still
+    // move bounds or values.
+    const bool r4 = (shape & (SH_R4_T | SH_R4_T2)) != 0;
+    const bool r56 = (shape & (SH_R5 | SH_R6)) != 0;
+    if (r4 && !(shape & SH_R5)) return false;       // binary-decomposition rows are always executed
+    if (shape & SH_R3) {
+        reads_b = true;
+        const uint32_t x = ri.x;
+        const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
+        if (!(J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv))) return false;
+        if (!fp::eq(ld256(J.lb + 4ull * x), tv) || !fp::eq(ld256(J.ub + 4ull * x), tv)) return false;
+    }
+    if (r56) {
+        reads_b = true;   // equal bounds (and equal unique bits, given above): R5/R6 return at their first test,
+        // and R4 on an x == y row finds either a non-[0,1] partner or already-equal [0,1] bounds
+        if (!fp::eq(ld256(J.lb + 4ull * ri.k1), ld256(J.lb + 4ull * ri.k2))) return false;
+        if (!fp::eq(ld256(J.ub + 4ull * ri.k1), ld256(J.ub + 4ull * ri.k2))) return false;
+    }
+    return true;
+}
+
+struct ChunkShared {   // LDS of the chunked queue phase
+    uint32_t cut;
+    uint32_t bases[ECNE_WG + 1];
+    uint32_t scan[ECNE_NWAVES + 2];
+    unsigned long long acc[12];   // steps, nuniq, hits[0..7], pops, pop_nnz
+    uint32_t head, tail, fallback;
+};
+
+// candidate j of the current round -> (rank, target row); bases[] holds the exclusive scan of the
+// per-rank candidate counts
+__device__ __forceinline__ uint32_t cand_target(const Job& J, const ChunkShared& S, uint32_t j, uint32_t n, uint32_t& rank) {
+    uint32_t lo = 0, hi = n;   // largest r with bases[r] <= j
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (S.bases[mid] <= j) lo = mid; else hi = mid;
+    }
+    rank = lo;
+    uint32_t off = j - S.bases[lo];
+    const uint32_t* ev = J.evbuf + (size_t)lo * ECNE_EVCAP;
+    const uint32_t ne = J.evcnt[lo];
+    for (uint32_t e = 0; e < ne; ++e) {
+        uint32_t v = ev[e];
+        uint32_t d = J.fo_ptr[v + 1] - J.fo_ptr[v];
+        if (off < d) return J.fo_rows[J.fo_ptr[v] + off];
+        off -= d;
+    }
+    return 0xFFFFFFFFu;   // unreachable
+}
+
+// The whole QUEUE phase (:805-1349), executed by all 1024 threads. q is kept identical in every thread.
+__device__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
+                                    unsigned long long& steps, unsigned long long& nuniq,
+                                    unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
+    if (tid < 12) S.acc[tid] = 0;
+    LaneCtr C;
+    C.steps = C.nuniq = 0;
+    for (int i = 0; i < 8; ++i) C.hits[i] = 0;
+    uint32_t my_pops = 0, my_nnz = 0;
+    unsigned long long pops_total = pops;
+    __syncthreads();
+    while (q.head != q.tail) {
+        if (wg_error(J, s_err)) break;
+        if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
+        const uint32_t n = (q.tail - q.head) < ECNE_WG ? (q.tail - q.head) : ECNE_WG;
+        uint32_t row = 0, shape = 0, x = 0;
+        bool live = false;
+        if ((uint32_t)tid < n) {
+            row = J.queue[(q.head + tid) & J.qmask];
+            const RowInfo ri = J.rinfo[row];
+            shape = ri.shape;
+            x = ri.x;
+            live = !J.solved[row];
+        }
+        if (tid == 0) { S.cut = n; S.fallback = (shape & SH_BIG) ? 1u : 0u; }
+        __syncthreads();
+        if (S.fallback) {
+            // a big row at the queue head: one sequential, wave-cooperative pop (wave 0)
+            if (w == 0) {
+                const uint32_t r0 = __shfl(row, 0, 64);
+                QState qq = q;
+                qq.head++;
+                if (lane == 0) J.inq[r0] = 0;
+                wg_fence();
+                unsigned long long st = 0, nu = 0, ht[16];
+                for (int i = 0; i < 16; ++i) ht[i] = 0;
+                if (!J.solved[r0]) exec_row(J, qq, r0, ht, st, nu);
+                if (lane == 0) {
+                    S.acc[0] += st; S.acc[1] += nu;
+                    for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
+                    S.acc[10] += 1;
+                    S.acc[11] += (J.rpA[r0 + 1] - J.rpA[r0]) + (J.rpB[r0 + 1] - J.rpB[r0]) + (J.rpC[r0 + 1] - J.rpC[r0]);
+                    S.head = qq.head; S.tail = qq.tail;
+                }
+            }
+            __syncthreads();
+            q.head = S.head; q.tail = S.tail;
+            pops_total++;
+            hits[14]++;
+            __syncthreads();
+            continue;
+        }
+        // ---- mark
+        bool noop = false, noop_b = false;
+        RowInfo myri;
+        if ((uint32_t)tid < n) {
+            if (shape & SH_BIG) atomicMin(&S.cut, (uint32_t)tid);
+            else if (live) {
+                myri = J.rinfo[row];
+                noop = row_is_noop(J, row, myri, noop_b);
+                if (!noop)
+                    for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                        if (rd & 1) atomicMin(&J.rmarkU[v], (uint32_t)tid);
+                        if (wr & 1) atomicMin(&J.wmarkU[v], (uint32_t)tid);
+                        if (rd & 2) atomicMin(&J.rmarkB[v], (uint32_t)tid);
+                        if (wr & 2) atomicMin(&J.wmarkB[v], (uint32_t)tid);
+                    });
+            }
+        }
+        __syncthreads();
+        // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write
+        if ((uint32_t)tid < n && live && !(shape & SH_BIG)) {
+            bool blocked = false;
+            if (noop) {
+                // all U-class state is final; the verdict may have read B-class state of C's variables
+                if (noop_b)
+                    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k)
+                        if (J.wmarkB[J.colC[k]] < (uint32_t)tid) blocked = true;
+            } else {
+                for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if (((rd | wr) & 1) && J.wmarkU[v] < (uint32_t)tid) blocked = true;
+                    if ((wr & 1) && J.rmarkU[v] < (uint32_t)tid) blocked = true;
+                    if (((rd | wr) & 2) && J.wmarkB[v] < (uint32_t)tid) blocked = true;
+                    if ((wr & 2) && J.rmarkB[v] < (uint32_t)tid) blocked = true;
+                });
+            }
+            if (blocked) atomicMin(&S.cut, (uint32_t)tid);
+        }
+        __syncthreads();
+        const uint32_t c = S.cut;   // >= 1: rank 0 is never blocked and not big
+        // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see below)
+        if ((uint32_t)tid < n && live && !(shape & SH_BIG) && !noop)
+            for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if (rd & 1) J.rmarkU[v] = 0xFFFFFFFFu;
+                if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+                if (rd & 2) J.rmarkB[v] = 0xFFFFFFFFu;
+                if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+            });
+        if ((uint32_t)tid < c) J.inq[row] = (uint16_t)(tid + 2);
+        __syncthreads();
+        // ---- execute the independent prefix, one lane per row
+        uint32_t nev = 0;
+        if ((uint32_t)tid < c) {
+            my_pops++;
+            my_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+            if (live) {
+                if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }   // the pop's only effect
+                else exec_row_lane(J, row, J.evbuf + (size_t)tid * ECNE_EVCAP, nev, C);
+            }
+            J.evcnt[tid] = nev;
+        }
+        // ---- REQUEUE resolution in sequential order
+        uint32_t mycand = 0;
+        if ((uint32_t)tid < c) {
+            const uint32_t* ev = J.evbuf + (size_t)tid * ECNE_EVCAP;
+            for (uint32_t e = 0; e < nev; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+        }
+        uint32_t M;
+        uint32_t base = wg_exclusive_scan(mycand, S.scan, &M);   // (contains the barriers that publish evbuf)
+        if ((uint32_t)tid < c) S.bases[tid] = base;
+        if (tid == 0) S.bases[c] = M;
+        __syncthreads();
+        uint32_t new_tail = q.tail;
+        if (M > ECNE_CANDCAP) {
+            // rare (a variable with a huge fan-out): replay the events sequentially on wave 0
+            if (w == 0) {
+                QState qq = q;
+                for (uint32_t r = 0; r < c; ++r) {
+                    const uint32_t rr = J.queue[(q.head + r) & J.qmask];
+                    if (lane == 0) J.inq[rr] = 0;      // popped
+                    wg_fence();
+                    for (uint32_t e = 0; e < J.evcnt[r]; ++e) requeue(J, qq, J.evbuf[(size_t)r * ECNE_EVCAP + e]);
+                }
+                // rows of the prefix not re-pushed are left with inq == 0; later ranks still hold their tag
+                for (uint32_t r = lane; r < c; r += 64) {
+                    const uint32_t rr = J.queue[(q.head + r) & J.qmask];
+                    if (J.inq[rr] >= 2) J.inq[rr] = 0;
+                }
+                if (lane == 0) S.tail = qq.tail;
+            }
+            __syncthreads();
+            new_tail = S.tail;
+        } else if (M > 0) {
+            // a candidate (rank a, target t) may push iff t is not queued "as of rank a":
+            //   inq[t] == 0, or t is itself being popped in this prefix at a rank <= a
+            for (uint32_t j = tid; j < M; j += ECNE_WG) {
+                uint32_t a;
+                const uint32_t t = cand_target(J, S, j, c, a);
+                const uint32_t st = J.inq[t];
+                const bool elig = st == 0 || (st >= 2 && st - 2 <= a);
+                J.cand[j] = t | (elig ? 0x80000000u : 0u);
+                if (elig) atomicMin(&J.best[t], j);
+            }
+            __syncthreads();
+            // the earliest eligible candidate of each target wins; winners keep candidate order
+            for (uint32_t jb = 0; jb < M; jb += ECNE_WG) {
+                const uint32_t j = jb + tid;
+                uint32_t t = 0;
+                uint32_t win = 0;
+                if (j < M) {
+                    const uint32_t cw = J.cand[j];
+                    t = cw & 0x7FFFFFFFu;
+                    win = (cw & 0x80000000u) && J.best[t] == j;
+                }
+                uint32_t tot;
+                const uint32_t off = wg_exclusive_scan(win, S.scan, &tot);
+                if (win) J.queue[(new_tail + off) & J.qmask] = t;
+                new_tail += tot;
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j < M; j += ECNE_WG) {
+                const uint32_t cw = J.cand[j];
+                const uint32_t t = cw & 0x7FFFFFFFu;
+                if ((cw & 0x80000000u) && J.best[t] == j) { J.inq[t] = 1; }
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j < M; j += ECNE_WG) {
+                const uint32_t cw = J.cand[j];
+                if (cw & 0x80000000u) J.best[cw & 0x7FFFFFFFu] = 0xFFFFFFFFu;
+            }
+            if ((uint32_t)tid < c && J.inq[row] >= 2) J.inq[row] = 0;
+        } else {
+            if ((uint32_t)tid < c) J.inq[row] = 0;
+        }
+        __syncthreads();
+        q.head += c;
+        q.tail = new_tail;
+        pops_total += c;
+        hits[13]++;
+        if (M > ECNE_CANDCAP) hits[15]++;
+    }
+    // ---- reduce the per-lane counters
+    __syncthreads();
+    if (C.steps) atomicAdd(&S.acc[0], (unsigned long long)C.steps);
+    if (C.nuniq) atomicAdd(&S.acc[1], (unsigned long long)C.nuniq);
+    for (int i = 0; i < 8; ++i)
+        if (C.hits[i]) atomicAdd(&S.acc[2 + i], (unsigned long long)C.hits[i]);
+    if (my_pops) atomicAdd(&S.acc[10], (unsigned long long)my_pops);
+    if (my_nnz) atomicAdd(&S.acc[11], (unsigned long long)my_nnz);
+    __syncthreads();
+    steps += S.acc[0];
+    nuniq += S.acc[1];
+    for (int i = 0; i < 8; ++i) hits[i] += S.acc[2 + i];
+    pops += S.acc[10];
+    pop_nnz += S.acc[11];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
     __shared__ Job J;
     __shared__ uint32_t s_scan[ECNE_NWAVES + 2];
@@ -728,10 +1315,15 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
     __shared__ unsigned long long s_steps;
     __shared__ uint32_t m_rows[10], m_vars[10];
     __shared__ int s_err;
+    __shared__ QState s_q;
+    __shared__ ChunkShared s_chunk;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     if (tid < (int)(sizeof(Job) / 4)) ((uint32_t*)&J)[tid] = ((const uint32_t*)&jobs[blockIdx.x])[tid];
     __syncthreads();
     const uint32_t nC = J.nC, nV = J.nV;
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = wall_clock64();
+#define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
 
     // ---------------- setup (:593-704)
     for (uint32_t v = tid; v <= nV; v += ECNE_WG) {
@@ -741,8 +1333,12 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
         st256(J.lb + 4ull * v, fp::make(0));
         st256(J.ub + 4ull * v, fp::pminus1());
         J.varmin[v] = 0xFFFFFFFFu;
+        J.wmarkU[v] = 0xFFFFFFFFu;
+        J.rmarkU[v] = 0xFFFFFFFFu;
+        J.wmarkB[v] = 0xFFFFFFFFu;
+        J.rmarkB[v] = 0xFFFFFFFFu;
     }
-    for (uint32_t r = tid; r < nC; r += ECNE_WG) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; }
+    for (uint32_t r = tid; r < nC; r += ECNE_WG) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; }
     for (uint32_t r = tid; r < nC + J.nSp; r += ECNE_WG) J.fired[r] = 0;   // [nC..) = special_solved
     for (uint32_t s = tid; s <= J.htmask; s += ECNE_WG) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
     __syncthreads();
@@ -778,6 +1374,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
     }
     __syncthreads();
 
+    ECNE_TICK(0);
     unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
     unsigned long long hits[16];
     for (int i = 0; i < 16; ++i) hits[i] = 0;
@@ -824,32 +1421,47 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
                 }
                 if (J.ctr->error) break;
             }
-            // QUEUE (:805-1349)
-            // watchdog: every pop is caused by a state change of one of the row's variables and each
-            // variable changes a bounded number of times, so pops <= c * nnz in any terminating run
-            const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
-            while (q.head != q.tail && !J.ctr->error) {
-                if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
-                uint32_t row = J.queue[q.head & J.qmask];
-                q.head++;
-                if (lane == 0) J.inq[row] = 0;
-                wg_fence();
-                pops++;
-                pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
-                if (J.solved[row]) continue;
-                exec_row(J, q, row, hits, steps, nuniq);
+            if (J.queue_mode == 1) {
+                // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
+                // watchdog: every pop is caused by a state change of one of the row's variables and each
+                // variable changes a bounded number of times, so pops <= c * nnz in any terminating run
+                const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
+                while (q.head != q.tail && !J.ctr->error) {
+                    if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+                    uint32_t row = J.queue[q.head & J.qmask];
+                    q.head++;
+                    if (lane == 0) J.inq[row] = 0;
+                    wg_fence();
+                    pops++;
+                    pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+                    if (J.solved[row]) continue;
+                    exec_row(J, q, row, hits, steps, nuniq);
+                }
             }
+            if (lane == 0) { s_q = q; }
             if (lane == 0) s_steps = steps;
         }
         __syncthreads();
         steps = s_steps;
+        q = s_q;
         if (wg_error(J, &s_err)) break;
+        if (J.queue_mode != 1) {
+            // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
+            unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
+            for (int i = 0; i < 16; ++i) ht2[i] = 0;
+            queue_phase_chunked(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
+            steps = st2;
+            if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
+            if (wg_error(J, &s_err)) break;
+        }
+        ECNE_TICK(1);
 
         // ================= P3 linear systems (:1357-1417)
         {
             uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
             bool any_group = false;
             for (;;) {
+                tk[6]++;
                 if (tid == 0) { s_u32[0] = 0xFFFFFFFFu; s_u32[1] = 0; s_u32[2] = 0xFFFFFFFFu; s_u32[3] = 0; }
                 __syncthreads();
                 // phase 1: evaluate rows >= f against the current state
@@ -1002,6 +1614,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
             }
             if (wg_error(J, &s_err)) break;
         }
+        ECNE_TICK(2);
 
         // ================= P4 ABZ tagging (:1425-1483)
         {
@@ -1054,6 +1667,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
             steps = s_steps;
             if (wg_error(J, &s_err)) break;
         }
+        ECNE_TICK(3);
 
         // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates
         if (w == 0) {
@@ -1073,6 +1687,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
         }
         __syncthreads();
         steps = s_steps;
+        ECNE_TICK(4);
     }
 
     // ---------------- verdict counts (:1558-1597)
@@ -1101,6 +1716,8 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
             c->unique_targets = t2;
             c->q_head = q.head;
             c->q_tail = q.tail;
+            ECNE_TICK(5);
+            for (int i = 0; i < 8; ++i) c->phase_ticks[i] = tk[i];
         }
     }
 }
