@@ -211,23 +211,23 @@ class SolveResult:
         _check(self.status, "SolveConstraintsSymbolic")
 
 
-def _opts(device=0, secp_solve=False, queue_mode=0, stream=None):
+def _opts(device=0, secp_solve=False, queue_mode=0, stream=None, force_nwg=0):
     o = Opts()
     o.device = int(device)
     o.secp_solve = int(bool(secp_solve))
-    o.debug = 0
+    o.debug = int(force_nwg)
     o.queue_mode = int(queue_mode)
     o.stream = stream
     return o
 
 
-def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None, fetch_states=True):
+def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None, fetch_states=True, force_nwg=0):
     """Run n independent systems in one launch (one workgroup each). Returns SolveResult list."""
     L = _lib.lib()
     n = len(systems)
     hs = (C.c_void_p * n)(*[s._h for s in systems])
     outs = (C.c_void_p * n)()
-    o = _opts(device, secp_solve, queue_mode, stream)
+    o = _opts(device, secp_solve, queue_mode, stream, force_nwg)
     _check(L.ecne_solve_batch(hs, n, C.byref(o), outs), "ecne_solve_batch")
     return [SolveResult(C.c_void_p(outs[i]), fetch_states) for i in range(n)]
 

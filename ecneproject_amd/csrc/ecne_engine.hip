@@ -347,7 +347,12 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
     size_t o_wmark = c.take(4ull * (nV + 1)), o_rmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_rmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1));
-    size_t o_evbuf = c.take(4ull * ECNE_WG * ECNE_EVCAP), o_evcnt = c.take(4ull * ECNE_WG), o_cand = c.take(4ull * ECNE_CANDCAP);
+    size_t o_evbuf = c.take(4ull * ECNE_WG * ECNE_EVCAP), o_cand = c.take(4ull * ECNE_CANDCAP);
+    uint32_t maxrowC = 0;
+    for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
+    const size_t flatcap = std::max<size_t>((size_t)ECNE_WG * ECNE_EVCAP, 16384);
+    size_t o_fvar = c.take(4ull * flatcap), o_frank = c.take(4ull * flatcap), o_fbase = c.take(4ull * (flatcap + 1));
+    size_t o_bigev = c.take(4ull * ((size_t)maxrowC * 3 + 64));
     size_t o_ctr = c.take(sizeof(Counters));
     (void)static_end;
     char* base = nullptr;
@@ -409,7 +414,9 @@ static int upload_system(ecne_system& S, int device) {
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
     J.wmarkU = (uint32_t*)(base + o_wmark); J.rmarkU = (uint32_t*)(base + o_rmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.rmarkB = (uint32_t*)(base + o_rmarkB); J.best = (uint32_t*)(base + o_best);
-    J.evbuf = (uint32_t*)(base + o_evbuf); J.evcnt = (uint32_t*)(base + o_evcnt); J.cand = (uint32_t*)(base + o_cand);
+    J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
+    J.fvar = (uint32_t*)(base + o_fvar); J.frank = (uint32_t*)(base + o_frank); J.fbase = (uint32_t*)(base + o_fbase);
+    J.bigev = (uint32_t*)(base + o_bigev);
     J.ctr = (Counters*)(base + o_ctr);
     S.dev.classified = false;
     return K_OK;
@@ -594,13 +601,42 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
         if (rc != ECNE_OK) break;
+        // Workgroups per job: large systems get helpers for the row-parallel sweep passes. All
+        // workgroups of one launch must be co-resident (they meet at a hand-rolled barrier), and
+        // k_solve occupies a whole CU per workgroup (1024 threads x 128 VGPRs), so a launch never
+        // holds more workgroups than the device has CUs; a batch that needs more is split.
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) != hipSuccess || n_cu < 1) { rc = ECNE_ENODEVICE; break; }
+        const uint32_t cap = (uint32_t)std::max(1, n_cu - 8);   // margin: never rely on the last CU being free
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t want = (hj[i].nC + 8191u) / 8192u;
+            if (o.debug > 0) want = (uint32_t)o.debug;          // test hook: force the helper count
+            hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, 96u)));
+        }
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         hipEvent_t e0, e1;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         (void)hipEventRecord(e0, stream);
-        hipLaunchKernelGGL(k_solve, dim3((unsigned)n), dim3(ECNE_WG), 0, stream, (const Job*)d_jobs);
-        (void)hipEventRecord(e1, stream);
-        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        {
+            std::vector<WgDesc> descs;
+            WgDesc* d_descs = nullptr;
+            size_t i = 0;
+            bool fail = false;
+            if (hipMalloc((void**)&d_descs, sizeof(WgDesc) * (size_t)cap) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+            while (i < n && !fail) {
+                descs.clear();
+                while (i < n && descs.size() + hj[i].nwg <= cap) {
+                    for (uint32_t r = 0; r < hj[i].nwg; ++r) descs.push_back({(uint32_t)i, r});
+                    ++i;
+                }
+                if (hipMemcpyAsync(d_descs, descs.data(), sizeof(WgDesc) * descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) { fail = true; break; }
+                hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), 0, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
+            }
+            (void)hipEventRecord(e1, stream);
+            if (fail || hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(d_descs); rc = ECNE_ENODEVICE; break; }
+            (void)hipFree(d_descs);
+        }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         (void)hipEventDestroy(e0);

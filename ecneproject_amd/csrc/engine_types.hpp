@@ -61,12 +61,18 @@ struct Counters {   // one per job, device memory
     int error;          // first ecne_status raised on the device (0 = none)
     unsigned int q_head, q_tail;
     unsigned int pad;
-    unsigned long long phase_ticks[8];   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
+    unsigned long long phase_ticks[8];
+    // job-wide synchronisation words (zeroed before every launch)
+    unsigned long long sync_steps;
+    unsigned int bar_count, bar_gen;
+    int error_snap;
+    unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 
 struct Job {
     // sizes
     uint32_t nC, nV, nSp, nKnown, nTarget, nP4, nP5, qmask, htmask, secp_solve, queue_mode, hotcap;
+    uint32_t nwg, pad_;   // workgroups cooperating on this job (1 = the master alone)
     // static system
     const uint32_t *rpA, *rpB, *rpC;
     const uint32_t *colA, *colB, *colC;
@@ -103,7 +109,9 @@ struct Job {
     // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
     uint32_t *wmarkU, *rmarkU, *wmarkB, *rmarkB;
     uint32_t* best;            // per row: lowest candidate index that wants to push it
-    uint32_t *evbuf, *evcnt;   // per chunk rank: REQUEUE events emitted by the row popped there
+    uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there
+    uint32_t *fvar, *frank, *fbase;   // flat event list of one resolution round: variable, rank, candidate base
+    uint32_t* bigev;           // events of a big row popped alone
     uint32_t* cand;            // per push candidate: target row | eligibility bit
     Counters* ctr;
 };

@@ -256,6 +256,11 @@ __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t
 // ====================================================================================== solver
 struct QState {   // FIFO cursors, wave-uniform registers of the wave that drives the queue
     uint32_t head, tail;
+    // "emit" mode: REQUEUE(v) appends v to evout[] instead of pushing; the pushes are resolved later,
+    // in the same order, by the whole workgroup (resolve_pushes)
+    uint32_t* evout;
+    uint32_t nev;
+    uint32_t emit;
 };
 
 __device__ __forceinline__ void raise(const Job& J, int code) { atomicCAS(&J.ctr->error, 0, code); }
@@ -272,6 +277,11 @@ __device__ __forceinline__ void set_bounds(const Job& J, uint32_t v, const fp::u
 // Wave-cooperative; exactly the sequential order because the rows of one list are distinct.
 __device__ void requeue(const Job& J, QState& q, uint32_t v) {
     const int lane = lane_id();
+    if (q.emit) {
+        if (lane == 0) q.evout[q.nev] = v;
+        q.nev++;
+        return;
+    }
     const uint32_t beg = J.fo_ptr[v], end = J.fo_ptr[v + 1];
     for (uint32_t base = beg; base < end; base += 64) {
         uint32_t k = base + lane;
@@ -306,13 +316,21 @@ __device__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0,
         uint32_t v = act ? J.colC[k] : 0;
         bool todo = act && v != skip && !(J.flags[v] & 1);
         uint64_t m = __ballot(todo);
-        while (m) {
-            int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            uint32_t vv = __shfl(v, src, 64);
-            mark_unique(J, vv);
-            requeue(J, q, vv);
-            ++n;
+        if (!m) continue;
+        // REQUEUE never reads flags, so marking this chunk's variables first and re-queueing them
+        // afterwards, in order, is the reference's mark-one/requeue-one sequence
+        if (todo) J.flags[v] |= 3;
+        wg_fence();
+        n += (uint32_t)__popcll(m);
+        if (q.emit) {
+            if (todo) q.evout[q.nev + (uint32_t)__popcll(m & lanes_below())] = v;
+            q.nev += (uint32_t)__popcll(m);
+        } else {
+            while (m) {
+                int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                requeue(J, q, __shfl(v, src, 64));
+            }
         }
     }
     return n;
@@ -1074,28 +1092,100 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t bases[ECNE_WG + 1];
     uint32_t scan[ECNE_NWAVES + 2];
     unsigned long long acc[12];   // steps, nuniq, hits[0..7], pops, pop_nnz
-    uint32_t head, tail, fallback;
+    uint32_t head, tail, fallback, nbig;
 };
 
-// candidate j of the current round -> (rank, target row); bases[] holds the exclusive scan of the
-// per-rank candidate counts
-__device__ __forceinline__ uint32_t cand_target(const Job& J, const ChunkShared& S, uint32_t j, uint32_t n, uint32_t& rank) {
-    uint32_t lo = 0, hi = n;   // largest r with bases[r] <= j
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (S.bases[mid] <= j) lo = mid; else hi = mid;
+// Ordered multi-source REQUEUE by the whole workgroup. Input: a flat list of N events (variables) in
+// the order the reference would issue REQUEUE(v), each tagged with the rank of the queue entry that
+// emitted it (rank_of: J.frank[e] when `ranks` is true, else 0). The result is exactly what calling
+// REQUEUE for every event in order leaves in the queue and in inq[]. head >= 0 means ranks are the
+// queue entries head.. being popped right now (their inq[] holds rank + 2: a push may re-queue a row
+// popped at the same or a lower rank, never one still waiting at a higher rank); head < 0: nothing is
+// being popped (sweep phases). Returns the new tail. All threads of the workgroup must call it.
+__device__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, const uint32_t* fvar, bool ranks, uint32_t N,
+                                   long long head, uint32_t nranks, uint32_t tail, unsigned long long* n_fallback) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    // candidate base of every event = exclusive scan of the fan-out sizes
+    uint32_t M = 0;
+    for (uint32_t eb = 0; eb < N; eb += ECNE_WG) {
+        const uint32_t e = eb + tid;
+        uint32_t d = 0;
+        if (e < N) { const uint32_t v = fvar[e]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+        uint32_t tot;
+        const uint32_t off = wg_exclusive_scan(d, S.scan, &tot);
+        if (e < N) J.fbase[e] = M + off;
+        M += tot;
+        if (M > ECNE_CANDCAP) break;   // uniform: M and tot are workgroup-wide values
     }
-    rank = lo;
-    uint32_t off = j - S.bases[lo];
-    const uint32_t* ev = J.evbuf + (size_t)lo * ECNE_EVCAP;
-    const uint32_t ne = J.evcnt[lo];
-    for (uint32_t e = 0; e < ne; ++e) {
-        uint32_t v = ev[e];
-        uint32_t d = J.fo_ptr[v + 1] - J.fo_ptr[v];
-        if (off < d) return J.fo_rows[J.fo_ptr[v] + off];
-        off -= d;
+    __syncthreads();
+    uint32_t new_tail = tail;
+    if (M > ECNE_CANDCAP) {
+        // rare (a variable with a huge fan-out): replay the events sequentially on wave 0
+        if (n_fallback) (*n_fallback)++;
+        if (w == 0) {
+            QState qq;
+            qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+            uint32_t popped = 0;   // ranks < popped have been popped
+            for (uint32_t e = 0; e < N; ++e) {
+                const uint32_t a = ranks ? J.frank[e] : 0;
+                if (head >= 0)
+                    for (; popped <= a && popped < nranks; ++popped) {
+                        const uint32_t rr = J.queue[((uint32_t)head + popped) & J.qmask];
+                        if (lane == 0) J.inq[rr] = 0;
+                        wg_fence();
+                    }
+                requeue(J, qq, fvar[e]);
+            }
+            if (head >= 0)
+                for (; popped < nranks; ++popped) {
+                    const uint32_t rr = J.queue[((uint32_t)head + popped) & J.qmask];
+                    if (lane == 0 && J.inq[rr] >= 2) J.inq[rr] = 0;
+                }
+            if (lane == 0) S.tail = qq.tail;
+        }
+        __syncthreads();
+        new_tail = S.tail;
+    } else if (M > 0) {
+        // event-parallel expansion. A candidate (rank a, target t) may push iff t is not queued
+        // "as of rank a": inq[t] == 0, or t is itself being popped at a rank <= a
+        for (uint32_t e = tid; e < N; e += ECNE_WG) {
+            const uint32_t v = fvar[e], a = ranks ? J.frank[e] : 0, b0 = J.fbase[e];
+            const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+            for (uint32_t k = f0; k < f1; ++k) {
+                const uint32_t t = J.fo_rows[k], j = b0 + (k - f0);
+                const uint32_t st = J.inq[t];
+                const bool elig = st == 0 || (st >= 2 && st - 2 <= a);
+                J.cand[j] = t | (elig ? 0x80000000u : 0u);
+                if (elig) atomicMin(&J.best[t], j);
+            }
+        }
+        __syncthreads();
+        // the earliest eligible candidate of each target wins; winners keep candidate order
+        for (uint32_t jb = 0; jb < M; jb += ECNE_WG) {
+            const uint32_t j = jb + tid;
+            uint32_t t = 0, win = 0;
+            if (j < M) {
+                const uint32_t cw = J.cand[j];
+                t = cw & 0x7FFFFFFFu;
+                win = (cw & 0x80000000u) && J.best[t] == j;
+            }
+            uint32_t tot;
+            const uint32_t off = wg_exclusive_scan(win, S.scan, &tot);
+            if (win) J.queue[(new_tail + off) & J.qmask] = t;
+            if (j < M) J.cand[j] = t | (win ? 0x80000000u : 0u);
+            new_tail += tot;
+        }
+        __syncthreads();
+        // winners are queued again; forget the per-target minima
+        for (uint32_t j = tid; j < M; j += ECNE_WG) {
+            const uint32_t cw = J.cand[j];
+            const uint32_t t = cw & 0x7FFFFFFFu;
+            if (cw & 0x80000000u) J.inq[t] = 1;
+            J.best[t] = 0xFFFFFFFFu;
+        }
     }
-    return 0xFFFFFFFFu;   // unreachable
+    __syncthreads();
+    return new_tail;
 }
 
 // The whole QUEUE phase (:805-1349), executed by all 1024 threads. q is kept identical in every thread.
@@ -1127,12 +1217,13 @@ __device__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, uns
         if (tid == 0) { S.cut = n; S.fallback = (shape & SH_BIG) ? 1u : 0u; }
         __syncthreads();
         if (S.fallback) {
-            // a big row at the queue head: one sequential, wave-cooperative pop (wave 0)
+            // a big row at the queue head: popped alone. Wave 0 runs the wave-cooperative rules in emit
+            // mode; the whole workgroup then resolves its REQUEUE events in order.
             if (w == 0) {
                 const uint32_t r0 = __shfl(row, 0, 64);
-                QState qq = q;
-                qq.head++;
-                if (lane == 0) J.inq[r0] = 0;
+                QState qq;
+                qq.head = q.head + 1; qq.tail = q.tail; qq.evout = J.bigev; qq.nev = 0; qq.emit = (J.queue_mode == 2) ? 0u : 1u;
+                if (lane == 0) J.inq[r0] = (J.queue_mode == 2) ? 0 : 2;          // being popped at rank 0
                 wg_fence();
                 unsigned long long st = 0, nu = 0, ht[16];
                 for (int i = 0; i < 16; ++i) ht[i] = 0;
@@ -1142,11 +1233,17 @@ __device__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, uns
                     for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
                     S.acc[10] += 1;
                     S.acc[11] += (J.rpA[r0 + 1] - J.rpA[r0]) + (J.rpB[r0 + 1] - J.rpB[r0]) + (J.rpC[r0 + 1] - J.rpC[r0]);
-                    S.head = qq.head; S.tail = qq.tail;
+                    S.nbig = qq.nev;
+                    S.tail = qq.tail;
                 }
             }
             __syncthreads();
-            q.head = S.head; q.tail = S.tail;
+            {
+                const uint32_t nt = (J.queue_mode == 2) ? S.tail : resolve_pushes(J, S, J.bigev, false, S.nbig, (long long)q.head, 1, q.tail, &hits[15]);
+                if (tid == 0 && J.inq[row] >= 2) J.inq[row] = 0;
+                q.head += 1;
+                q.tail = nt;
+            }
             pops_total++;
             hits[14]++;
             __syncthreads();
@@ -1209,87 +1306,25 @@ __device__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, uns
                 if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }   // the pop's only effect
                 else exec_row_lane(J, row, J.evbuf + (size_t)tid * ECNE_EVCAP, nev, C);
             }
-            J.evcnt[tid] = nev;
         }
-        // ---- REQUEUE resolution in sequential order
-        uint32_t mycand = 0;
-        if ((uint32_t)tid < c) {
-            const uint32_t* ev = J.evbuf + (size_t)tid * ECNE_EVCAP;
-            for (uint32_t e = 0; e < nev; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+        // ---- REQUEUE resolution in sequential order: flatten the per-rank event lists, then resolve
+        uint32_t Nev;
+        {
+            const uint32_t eoff = wg_exclusive_scan(((uint32_t)tid < c) ? nev : 0u, S.scan, &Nev);
+            if ((uint32_t)tid < c) {
+                const uint32_t* ev = J.evbuf + (size_t)tid * ECNE_EVCAP;
+                for (uint32_t e = 0; e < nev; ++e) { J.fvar[eoff + e] = ev[e]; J.frank[eoff + e] = (uint32_t)tid; }
+            }
+            __syncthreads();   // the flat list is read across lanes
         }
-        uint32_t M;
-        uint32_t base = wg_exclusive_scan(mycand, S.scan, &M);   // (contains the barriers that publish evbuf)
-        if ((uint32_t)tid < c) S.bases[tid] = base;
-        if (tid == 0) S.bases[c] = M;
-        __syncthreads();
-        uint32_t new_tail = q.tail;
-        if (M > ECNE_CANDCAP) {
-            // rare (a variable with a huge fan-out): replay the events sequentially on wave 0
-            if (w == 0) {
-                QState qq = q;
-                for (uint32_t r = 0; r < c; ++r) {
-                    const uint32_t rr = J.queue[(q.head + r) & J.qmask];
-                    if (lane == 0) J.inq[rr] = 0;      // popped
-                    wg_fence();
-                    for (uint32_t e = 0; e < J.evcnt[r]; ++e) requeue(J, qq, J.evbuf[(size_t)r * ECNE_EVCAP + e]);
-                }
-                // rows of the prefix not re-pushed are left with inq == 0; later ranks still hold their tag
-                for (uint32_t r = lane; r < c; r += 64) {
-                    const uint32_t rr = J.queue[(q.head + r) & J.qmask];
-                    if (J.inq[rr] >= 2) J.inq[rr] = 0;
-                }
-                if (lane == 0) S.tail = qq.tail;
-            }
-            __syncthreads();
-            new_tail = S.tail;
-        } else if (M > 0) {
-            // a candidate (rank a, target t) may push iff t is not queued "as of rank a":
-            //   inq[t] == 0, or t is itself being popped in this prefix at a rank <= a
-            for (uint32_t j = tid; j < M; j += ECNE_WG) {
-                uint32_t a;
-                const uint32_t t = cand_target(J, S, j, c, a);
-                const uint32_t st = J.inq[t];
-                const bool elig = st == 0 || (st >= 2 && st - 2 <= a);
-                J.cand[j] = t | (elig ? 0x80000000u : 0u);
-                if (elig) atomicMin(&J.best[t], j);
-            }
-            __syncthreads();
-            // the earliest eligible candidate of each target wins; winners keep candidate order
-            for (uint32_t jb = 0; jb < M; jb += ECNE_WG) {
-                const uint32_t j = jb + tid;
-                uint32_t t = 0;
-                uint32_t win = 0;
-                if (j < M) {
-                    const uint32_t cw = J.cand[j];
-                    t = cw & 0x7FFFFFFFu;
-                    win = (cw & 0x80000000u) && J.best[t] == j;
-                }
-                uint32_t tot;
-                const uint32_t off = wg_exclusive_scan(win, S.scan, &tot);
-                if (win) J.queue[(new_tail + off) & J.qmask] = t;
-                new_tail += tot;
-            }
-            __syncthreads();
-            for (uint32_t j = tid; j < M; j += ECNE_WG) {
-                const uint32_t cw = J.cand[j];
-                const uint32_t t = cw & 0x7FFFFFFFu;
-                if ((cw & 0x80000000u) && J.best[t] == j) { J.inq[t] = 1; }
-            }
-            __syncthreads();
-            for (uint32_t j = tid; j < M; j += ECNE_WG) {
-                const uint32_t cw = J.cand[j];
-                if (cw & 0x80000000u) J.best[cw & 0x7FFFFFFFu] = 0xFFFFFFFFu;
-            }
-            if ((uint32_t)tid < c && J.inq[row] >= 2) J.inq[row] = 0;
-        } else {
-            if ((uint32_t)tid < c) J.inq[row] = 0;
-        }
+        const uint32_t new_tail = resolve_pushes(J, S, J.fvar, true, Nev, (long long)q.head, c, q.tail, &hits[15]);
+        // rows of the prefix that nobody re-queued are out of the queue now
+        if ((uint32_t)tid < c && J.inq[row] >= 2) J.inq[row] = 0;
         __syncthreads();
         q.head += c;
         q.tail = new_tail;
         pops_total += c;
         hits[13]++;
-        if (M > ECNE_CANDCAP) hits[15]++;
     }
     // ---- reduce the per-lane counters
     __syncthreads();
@@ -1308,7 +1343,53 @@ __device__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, uns
     __syncthreads();
 }
 
-__global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
+// ------------------------------------------------------------------------------------ job barrier
+// A job (one constraint system) is run by J.nwg co-resident workgroups: workgroup 0 (the "master")
+// executes everything whose order matters (P1, P2, the queue, the decisions of P3, P5, all REQUEUEs);
+// the others join for the row-parallel passes of the whole-system sweeps P3 / P4, the setup and the
+// verdict count. They meet at this barrier: sense-reversing counter, agent-scope release before
+// arriving (writes back this XCD's dirty L2 lines) and agent-scope acquire after leaving (drops
+// stale L1/L2 lines) — per-XCD L2s are not coherent with each other on MI355X. The last arriver
+// snapshots the job's error word, so every workgroup leaves with the SAME view of it and takes the
+// same branch. Spins are bounded.
+__device__ int job_barrier(const Job& J, int* s_err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Counters* c = J.ctr;
+        if (J.nwg == 1) {
+            *s_err = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned g = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned arrived = __hip_atomic_fetch_add(&c->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived == J.nwg - 1) {
+                const int e = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->error_snap, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&c->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1u << 27)) { raise(J, K_ECAPACITY); break; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *s_err = __hip_atomic_load(&c->error_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return *s_err;
+}
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------- k_solve
+struct WgDesc { uint32_t job, rank; };
+
+__global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc* wgs) {
     __shared__ Job J;
     __shared__ uint32_t s_scan[ECNE_NWAVES + 2];
     __shared__ uint32_t s_u32[8];
@@ -1318,15 +1399,19 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
     __shared__ QState s_q;
     __shared__ ChunkShared s_chunk;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    if (tid < (int)(sizeof(Job) / 4)) ((uint32_t*)&J)[tid] = ((const uint32_t*)&jobs[blockIdx.x])[tid];
+    const WgDesc me = wgs[blockIdx.x];
+    if (tid < (int)(sizeof(Job) / 4)) ((uint32_t*)&J)[tid] = ((const uint32_t*)&jobs[me.job])[tid];
     __syncthreads();
     const uint32_t nC = J.nC, nV = J.nV;
+    const bool master = me.rank == 0;
+    const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
+    Counters* const ctr = J.ctr;
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = wall_clock64();
 #define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
 
-    // ---------------- setup (:593-704)
-    for (uint32_t v = tid; v <= nV; v += ECNE_WG) {
+    // ---------------- setup (:593-704), all workgroups
+    for (uint32_t v = gtid; v <= nV; v += gstride) {
         J.flags[v] = 0;
         J.abz[v] = -1;
         J.nvalues[v] = 0;
@@ -1338,365 +1423,368 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
         J.wmarkB[v] = 0xFFFFFFFFu;
         J.rmarkB[v] = 0xFFFFFFFFu;
     }
-    for (uint32_t r = tid; r < nC; r += ECNE_WG) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; }
-    for (uint32_t r = tid; r < nC + J.nSp; r += ECNE_WG) J.fired[r] = 0;   // [nC..) = special_solved
-    for (uint32_t s = tid; s <= J.htmask; s += ECNE_WG) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
-    __syncthreads();
-    for (uint32_t i = tid; i < J.nKnown; i += ECNE_WG) {
+    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; }
+    for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
+    for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
+    if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_fire = 0xFFFFFFFFu; }
+    job_barrier(J, &s_err);
+    for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
         uint32_t v = J.knowns[i];
         J.flags[v] = 3;
         if (v == 1) { J.nvalues[1] = 1; st256(J.values + 8ull, fp::make(1)); }
     }
-    __syncthreads();
+    job_barrier(J, &s_err);
     // initial queue: rows with at most one variable outside known_variables, ascending (:621-627)
     QState q;
-    q.head = 0; q.tail = 0;
-    for (uint32_t base = 0; base < nC; base += ECNE_WG) {
-        uint32_t r = base + tid;
-        uint32_t push = 0;
-        if (r < nC) {
-            uint32_t first = 0, cnt = 0;
-            const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
-            const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
-            for (int p = 0; p < 3 && cnt < 2; ++p)
-                for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
-                    uint32_t v = cl[p][e];
-                    if (!(J.flags[v] & 1)) {
-                        if (cnt == 0) { first = v; cnt = 1; }
-                        else if (v != first) { cnt = 2; break; }
+    q.head = 0; q.tail = 0; q.evout = nullptr; q.nev = 0; q.emit = 0;
+    if (master) {
+        for (uint32_t base = 0; base < nC; base += ECNE_WG) {
+            uint32_t r = base + tid;
+            uint32_t push = 0;
+            if (r < nC) {
+                uint32_t first = 0, cnt = 0;
+                const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
+                const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
+                for (int p = 0; p < 3 && cnt < 2; ++p)
+                    for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
+                        uint32_t v = cl[p][e];
+                        if (!(J.flags[v] & 1)) {
+                            if (cnt == 0) { first = v; cnt = 1; }
+                            else if (v != first) { cnt = 2; break; }
+                        }
                     }
-                }
-            push = cnt <= 1;
+                push = cnt <= 1;
+            }
+            uint32_t total, off = wg_exclusive_scan(push, s_scan, &total);
+            if (push) { J.queue[(q.tail + off) & J.qmask] = r; J.inq[r] = 1; }
+            q.tail += total;
         }
-        uint32_t total, off = wg_exclusive_scan(push, s_scan, &total);
-        if (push) { J.queue[(q.tail + off) & J.qmask] = r; J.inq[r] = 1; }
-        q.tail += total;
+        __syncthreads();
     }
-    __syncthreads();
-
     ECNE_TICK(0);
     unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
     unsigned long long hits[16];
     for (int i = 0; i < 16; ++i) hits[i] = 0;
-    // `steps` is kept consistent across the workgroup through s_steps at phase boundaries
+    // `steps` is the loop-control value: the master publishes it in ctr->sync_steps before each barrier
 
     for (;;) {
-        if (wg_error(J, &s_err)) break;
+        if (master && tid == 0) ctr->sync_steps = steps;
+        if (job_barrier(J, &s_err)) break;
+        steps = __hip_atomic_load(&ctr->sync_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev_steps == steps) break;   // (:708-711)
         prev_steps = steps;
         outer++;
-        // ================= P1, P2 and the queue are driven by wave 0, in the reference's order
-        if (w == 0) {
-            // P1 (:718-747)
-            for (uint32_t i = 0; i < J.nSp; ++i) {
-                if (J.fired[nC + i]) continue;   // special_solved
-                bool ok = true;
-                for (uint32_t e = J.sp_in_ptr[i] + lane; e < J.sp_in_ptr[i + 1]; e += 64)
-                    if (!(J.flags[J.sp_in[e]] & 1)) ok = false;
-                if (__ballot(!ok)) continue;
-                if (lane == 0) J.fired[nC + i] = 1;
-                steps++; hits[8]++;
-                for (uint32_t e = J.sp_out_ptr[i]; e < J.sp_out_ptr[i + 1]; ++e) {
-                    uint32_t v = J.sp_out[e];
-                    if (J.flags[v] & 1) continue;
-                    mark_unique(J, v);
-                    requeue(J, q, v);
-                }
-            }
-            // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair
-            for (uint32_t i = 0; i < J.nSp; ++i) {
-                if (J.sp_kind[i] != 1) continue;
-                for (uint32_t j = 0; j < J.nSp; ++j) {
-                    if (J.sp_kind[j] != 2) continue;
-                    if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
-                    uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
-                    if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
-                    hits[9]++;
-                    for (uint32_t t = 0; t < 3; ++t) {                                   // constraint_j[2][1:3]
-                        uint32_t v = J.sp_in[J.sp_in_ptr[j] + t];
+        // ================= P1, P2 and the queue: master only, in the reference's order
+        if (master) {
+            if (w == 0) {
+                // P1 (:718-747)
+                for (uint32_t i = 0; i < J.nSp; ++i) {
+                    if (J.fired[nC + i]) continue;   // special_solved
+                    bool ok = true;
+                    for (uint32_t e = J.sp_in_ptr[i] + lane; e < J.sp_in_ptr[i + 1]; e += 64)
+                        if (!(J.flags[J.sp_in[e]] & 1)) ok = false;
+                    if (__ballot(!ok)) continue;
+                    if (lane == 0) J.fired[nC + i] = 1;
+                    steps++; hits[8]++;
+                    for (uint32_t e = J.sp_out_ptr[i]; e < J.sp_out_ptr[i + 1]; ++e) {
+                        uint32_t v = J.sp_out[e];
                         if (J.flags[v] & 1) continue;
                         mark_unique(J, v);
                         requeue(J, q, v);
                     }
                 }
-                if (J.ctr->error) break;
-            }
-            if (J.queue_mode == 1) {
-                // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
-                // watchdog: every pop is caused by a state change of one of the row's variables and each
-                // variable changes a bounded number of times, so pops <= c * nnz in any terminating run
-                const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
-                while (q.head != q.tail && !J.ctr->error) {
-                    if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
-                    uint32_t row = J.queue[q.head & J.qmask];
-                    q.head++;
-                    if (lane == 0) J.inq[row] = 0;
-                    wg_fence();
-                    pops++;
-                    pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
-                    if (J.solved[row]) continue;
-                    exec_row(J, q, row, hits, steps, nuniq);
+                // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair
+                for (uint32_t i = 0; i < J.nSp; ++i) {
+                    if (J.sp_kind[i] != 1) continue;
+                    for (uint32_t j = 0; j < J.nSp; ++j) {
+                        if (J.sp_kind[j] != 2) continue;
+                        if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
+                        uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
+                        if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
+                        hits[9]++;
+                        for (uint32_t t = 0; t < 3; ++t) {                                   // constraint_j[2][1:3]
+                            uint32_t v = J.sp_in[J.sp_in_ptr[j] + t];
+                            if (J.flags[v] & 1) continue;
+                            mark_unique(J, v);
+                            requeue(J, q, v);
+                        }
+                    }
+                    if (J.ctr->error) break;
                 }
+                if (J.queue_mode == 1) {
+                    // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
+                    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
+                    while (q.head != q.tail && !J.ctr->error) {
+                        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+                        uint32_t row = J.queue[q.head & J.qmask];
+                        q.head++;
+                        if (lane == 0) J.inq[row] = 0;
+                        wg_fence();
+                        pops++;
+                        pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+                        if (J.solved[row]) continue;
+                        exec_row(J, q, row, hits, steps, nuniq);
+                    }
+                }
+                if (lane == 0) { s_q = q; s_steps = steps; }
             }
-            if (lane == 0) { s_q = q; }
-            if (lane == 0) s_steps = steps;
+            __syncthreads();
+            steps = s_steps;
+            q = s_q;
+            if (J.queue_mode != 1 && !wg_error(J, &s_err)) {
+                // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
+                unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
+                for (int i = 0; i < 16; ++i) ht2[i] = 0;
+                queue_phase_chunked(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
+                steps = st2;
+                if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
+            }
         }
-        __syncthreads();
-        steps = s_steps;
-        q = s_q;
-        if (wg_error(J, &s_err)) break;
-        if (J.queue_mode != 1) {
-            // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
-            unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
-            for (int i = 0; i < 16; ++i) ht2[i] = 0;
-            queue_phase_chunked(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
-            steps = st2;
-            if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
-            if (wg_error(J, &s_err)) break;
-        }
+        if (job_barrier(J, &s_err)) break;      // publishes the queue phase's state changes to the helpers
         ECNE_TICK(1);
 
-        // ================= P3 linear systems (:1357-1417)
+        // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
         {
             uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
-            bool any_group = false;
+            bool any_total = false, p3_err = false;
             for (;;) {
                 tk[6]++;
-                if (tid == 0) { s_u32[0] = 0xFFFFFFFFu; s_u32[1] = 0; s_u32[2] = 0xFFFFFFFFu; s_u32[3] = 0; }
-                __syncthreads();
                 // phase 1: evaluate rows >= f against the current state
-                for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                for (uint32_t r = f + gtid; r < nC; r += gstride) {
                     uint32_t k; uint64_t h, h2;
                     p3_eval(J, r, k, h, h2);
                     if (k == 0xFFFFFFFFu) k = 0;
                     J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
                     J.p3h[r] = h; J.p3h2[r] = h2;
-                    if (k == 1) atomicMin(&s_u32[0], r);
+                    if (k == 1) atomicMin(&ctr->p3_cand1, r);
                     else if (k >= 2) {
                         uint32_t s = ht_slot(J, h, h2, true);
-                        if (s == 0xFFFFFFFFu) raise(J, K_ECAPACITY);
-                        else atomicAdd(&J.ht_new[s], 1u);
-                        s_u32[3] = 1;
+                        if (s != 0xFFFFFFFFu) atomicAdd(&J.ht_new[s], 1u);
+                        __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if (wg_error(J, &s_err)) break;
-                any_group = any_group || s_u32[3];
+                if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                const bool any = ld_agent(&ctr->p3_any) != 0;
+                any_total = any_total || any;
                 // phase 2: rows whose group could reach its size in this pass
-                if (s_u32[3]) {
-                    for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                if (any) {
+                    for (uint32_t r = f + gtid; r < nC; r += gstride) {
                         uint32_t k = J.p3k[r];
                         if (k < 2) continue;
                         uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        if (s == 0xFFFFFFFFu) continue;
                         uint32_t fr = J.ht_frozen[s];
                         if (fr < k && fr + J.ht_new[s] >= k) {
-                            uint32_t pos = atomicAdd(&s_u32[1], 1u);
+                            uint32_t pos = atomicAdd(&ctr->p3_nhot, 1u);
                             if (pos < J.hotcap) J.hot[pos] = r;
                         }
                     }
-                    __syncthreads();
-                    if (s_u32[1] > J.hotcap) raise(J, K_ECAPACITY);
+                    if (job_barrier(J, &s_err)) { p3_err = true; break; }
                 }
-                if (wg_error(J, &s_err)) break;
-                // phase 3 (wave 0): find the earliest trigger row that passes the test
-                if (w == 0) {
-                    uint32_t nhot = s_u32[1];
-                    uint32_t best = s_u32[0];   // k == 1: first arrival of a one-variable group always fires
-                    // ascending selection over the hot list; groups are tiny, the list is short
-                    for (uint32_t a = 0; a < nhot; ++a) {
-                        uint32_t t = J.hot[a];
-                        if (t >= best) continue;
-                        uint32_t k = J.p3k[t];
-                        if (k > 10) { if (k == J.p3k[t]) { /* trigger only if arrival == k, checked below */ } }
-                        uint64_t h = J.p3h[t], h2 = J.p3h2[t];
-                        uint32_t s = ht_slot(J, h, h2, false);
-                        uint32_t fr = J.ht_frozen[s];
-                        // arrival number of t = frozen + fresh members with index <= t
-                        uint32_t arr = fr;
-                        for (uint32_t b = lane; b < nhot; b += 64) {
-                            uint32_t o = J.hot[b];
-                            if (o <= t && J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k) arr++;
+                // phase 3 (master, wave 0): find the earliest trigger row that passes the test
+                if (master) {
+                    if (w == 0) {
+                        uint32_t nhot = any ? ld_agent(&ctr->p3_nhot) : 0;
+                        if (nhot > J.hotcap) { raise(J, K_ECAPACITY); nhot = 0; }
+                        uint32_t best = ld_agent(&ctr->p3_cand1);   // k == 1: first arrival of a one-variable group always fires
+                        for (uint32_t a = 0; a < nhot; ++a) {
+                            uint32_t t = J.hot[a];
+                            if (t >= best) continue;
+                            uint32_t k = J.p3k[t];
+                            uint64_t h = J.p3h[t], h2 = J.p3h2[t];
+                            uint32_t s = ht_slot(J, h, h2, false);
+                            uint32_t fr = (s == 0xFFFFFFFFu) ? 0 : J.ht_frozen[s];
+                            // arrival number of t = frozen + fresh members with index <= t
+                            uint32_t part = 0;
+                            for (uint32_t b = lane; b < nhot; b += 64) {
+                                uint32_t o = J.hot[b];
+                                if (o <= t && J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k) part++;
+                            }
+                            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                            if (fr + part != k) continue;
+                            if (k > 10) { raise(J, K_EDETSIZE); break; }
+                            // collect the k member rows in arrival (index) order and the k variables ascending
+                            if (lane == 0) {
+                                uint32_t n = 0;
+                                if (fr) {   // frozen members: rows < f with the same key at their time
+                                    for (uint32_t r = 0; r < f && n < k; ++r)
+                                        if (J.p3k[r] == k && J.p3h[r] == h && J.p3h2[r] == h2) m_rows[n++] = r;
+                                }
+                                uint32_t last = 0; bool have = false;
+                                while (n < k) {
+                                    uint32_t mn = 0xFFFFFFFFu;
+                                    for (uint32_t b = 0; b < nhot; ++b) {
+                                        uint32_t o = J.hot[b];
+                                        if (J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k && (!have || o > last) && o < mn) mn = o;
+                                    }
+                                    if (mn == 0xFFFFFFFFu) break;
+                                    m_rows[n++] = mn; last = mn; have = true;
+                                }
+                                uint32_t nv = 0;
+                                for (uint32_t e = J.rpC[t]; e < J.rpC[t + 1]; ++e) {
+                                    uint32_t v = J.colC[e];
+                                    if (!(J.flags[v] & 1)) {
+                                        uint32_t pos = nv++;
+                                        while (pos > 0 && m_vars[pos - 1] > v) { m_vars[pos] = m_vars[pos - 1]; --pos; }
+                                        m_vars[pos] = v;
+                                    }
+                                }
+                            }
+                            wg_fence();
+                            if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
                         }
-                        // lanes hold partial counts: reduce
-                        uint32_t part = arr - fr;
-                        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-                        arr = fr + part;
-                        if (arr != k) continue;
-                        if (k > 10) { raise(J, K_EDETSIZE); break; }
-                        // collect the k member rows in arrival (index) order and the k variables ascending
                         if (lane == 0) {
-                            uint32_t n = 0;
-                            if (fr) {   // frozen members: rows < f with the same key at their time
-                                for (uint32_t r = 0; r < f && n < k; ++r)
-                                    if (J.p3k[r] == k && J.p3h[r] == h && J.p3h2[r] == h2) m_rows[n++] = r;
-                            }
-                            // fresh members ascending (selection sort over the short hot list)
-                            uint32_t last = 0; bool have = false;
-                            while (n < k) {
-                                uint32_t mn = 0xFFFFFFFFu;
-                                for (uint32_t b = 0; b < nhot; ++b) {
-                                    uint32_t o = J.hot[b];
-                                    if (J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k && (!have || o > last) && o < mn) mn = o;
-                                }
-                                if (mn == 0xFFFFFFFFu) break;
-                                m_rows[n++] = mn; last = mn; have = true;
-                            }
-                            uint32_t nv = 0;
-                            for (uint32_t e = J.rpC[t]; e < J.rpC[t + 1]; ++e) {
-                                uint32_t v = J.colC[e];
-                                if (!(J.flags[v] & 1)) {
-                                    uint32_t pos = nv++;
-                                    while (pos > 0 && m_vars[pos - 1] > v) { m_vars[pos] = m_vars[pos - 1]; --pos; }
-                                    m_vars[pos] = v;
-                                }
-                            }
+                            ctr->p3_fire = best;
+                            ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0;   // ready for the next round
                         }
-                        wg_fence();
-                        if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
                     }
-                    if (lane == 0) s_u32[2] = best;
                 }
-                if (wg_error(J, &s_err)) break;
-                const uint32_t fire = s_u32[2];
-                const uint32_t upto = fire == 0xFFFFFFFFu ? nC : fire + 1;
+                if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                const uint32_t fire = ld_agent(&ctr->p3_fire);
+                if (fire == 0xFFFFFFFFu) break;
+                const uint32_t upto = fire + 1;
                 // phase 4: freeze rows [f, upto): their arrivals are now history; forget fresh counts
-                if (s_u32[3]) {
-                    for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
+                if (any) {
+                    for (uint32_t r = f + gtid; r < nC; r += gstride) {
                         uint32_t k = J.p3k[r];
                         if (k < 2) continue;
                         uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        if (s == 0xFFFFFFFFu) continue;
                         if (r < upto) atomicAdd(&J.ht_frozen[s], 1u);
-                    }
-                    __syncthreads();
-                    for (uint32_t r = f + tid; r < nC; r += ECNE_WG) {
-                        uint32_t k = J.p3k[r];
-                        if (k < 2) continue;
-                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
                         J.ht_new[s] = 0;
                     }
-                    __syncthreads();
                 }
-                if (fire == 0xFFFFFFFFu) break;
-                // apply the firing: the group's variables, ascending, become unique (:1403-1414)
-                if (w == 0) {
-                    uint32_t k = J.p3k[fire];
-                    steps += k; hits[10]++;
-                    // ascending variable order: repeatedly take the smallest not yet handled
-                    uint32_t lastv = 0;
-                    for (uint32_t n = 0; n < k; ++n) {
-                        uint32_t mn = 0xFFFFFFFFu;
-                        for (uint32_t e = J.rpC[fire] + lane; e < J.rpC[fire + 1]; e += 64) {
-                            uint32_t v = J.colC[e];
-                            if (!(J.flags[v] & 1) && v > lastv && v < mn) mn = v;
+                // apply the firing (master): the group's variables, ascending, become unique (:1403-1414)
+                if (master) {
+                    if (w == 0) {
+                        uint32_t k = J.p3k[fire];
+                        steps += k; hits[10]++;
+                        uint32_t lastv = 0;
+                        for (uint32_t n = 0; n < k; ++n) {
+                            uint32_t mn = 0xFFFFFFFFu;
+                            for (uint32_t e = J.rpC[fire] + lane; e < J.rpC[fire + 1]; e += 64) {
+                                uint32_t v = J.colC[e];
+                                if (!(J.flags[v] & 1) && v > lastv && v < mn) mn = v;
+                            }
+                            for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
+                            if (mn == 0xFFFFFFFFu) break;
+                            lastv = mn;
+                            J.events[n] = mn;
                         }
-                        for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
-                        if (mn == 0xFFFFFFFFu) break;
-                        lastv = mn;
-                        // defer the flag write until all k are collected? No: the reference marks them one by
-                        // one, and later variables of the same group are selected by the saved list `unk`.
-                        J.events[n] = mn;
+                        wg_fence();
+                        for (uint32_t n = 0; n < k; ++n) {
+                            uint32_t v = J.events[n];
+                            mark_unique(J, v);
+                            requeue(J, q, v);
+                        }
+                        if (lane == 0) s_steps = steps;
                     }
-                    wg_fence();
-                    for (uint32_t n = 0; n < k; ++n) {
-                        uint32_t v = J.events[n];
-                        mark_unique(J, v);
-                        requeue(J, q, v);
-                    }
-                    if (lane == 0) s_steps = steps;
+                    __syncthreads();
+                    steps = s_steps;
                 }
-                __syncthreads();
-                steps = s_steps;
+                if (job_barrier(J, &s_err)) { p3_err = true; break; }   // the firing's writes reach the helpers
                 f = fire + 1;
             }
+            if (p3_err) break;
             // leave the table clean for the next outer iteration
-            if (any_group) {
-                __syncthreads();
-                for (uint32_t s = tid; s <= J.htmask; s += ECNE_WG) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
-            }
-            if (wg_error(J, &s_err)) break;
+            if (any_total)
+                for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
         }
         ECNE_TICK(2);
 
-        // ================= P4 ABZ tagging (:1425-1483)
+        // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups
         {
-            if (tid == 0) s_u32[4] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
+            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
                 const RowInfo ri = J.rinfo[J.p4_list[i]];
                 const uint32_t b = ri.kpos;
                 if (J.flags[b] & 1) continue;
                 if (ri.shape & SH_P4_DIV0) { raise(J, K_EDIVZERO); continue; }
                 atomicMin(&J.varmin[b], i);
             }
-            __syncthreads();
-            uint32_t nfired_local = 0;
-            for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
+            if (job_barrier(J, &s_err)) break;
+            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
                 const RowInfo ri = J.rinfo[J.p4_list[i]];
                 const uint32_t b = ri.kpos;
-                J.fired[J.p4_list[i]] = 0;
-                if (J.flags[b] & 1) continue;
-                if (J.varmin[b] != i) continue;
-                if (J.abz[b] != -1) continue;
-                J.abz[b] = (int32_t)ri.kneg;
-                J.flags[b] |= 2;
-                J.fired[J.p4_list[i]] = 1;
-                nfired_local++;
+                uint8_t fl = 0;
+                if (!(J.flags[b] & 1) && ld_agent(&J.varmin[b]) == i && J.abz[b] == -1) {
+                    J.abz[b] = (int32_t)ri.kneg;
+                    J.flags[b] |= 2;
+                    fl = 1;
+                }
+                J.fired[J.p4_list[i]] = fl;
             }
-            __syncthreads();
-            // ordered event list = fired rows ascending -> their b variable
-            uint32_t nev = 0;
-            for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
-                uint32_t i = base + tid;
-                uint32_t fl = (i < J.nP4) ? J.fired[J.p4_list[i]] : 0;
-                uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
-                if (fl) J.events[nev + off] = J.rinfo[J.p4_list[i]].kpos;
-                nev += total;
+            if (job_barrier(J, &s_err)) break;
+            if (master) {
+                // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
+                if (w == 0 && lane == 0) s_q = q;
+                __syncthreads();
+                q = s_q;
+                // ordered event list = fired rows ascending -> their b variable
+                uint32_t nev = 0;
+                for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
+                    uint32_t i = base + tid;
+                    uint32_t fl = (i < J.nP4) ? J.fired[J.p4_list[i]] : 0;
+                    uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
+                    if (fl) J.events[nev + off] = J.rinfo[J.p4_list[i]].kpos;
+                    nev += total;
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
+                    const uint32_t b = J.rinfo[J.p4_list[i]].kpos;
+                    J.varmin[b] = 0xFFFFFFFFu;
+                    J.fired[J.p4_list[i]] = 0;
+                }
+                __syncthreads();
+                // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
+                {
+                    uint32_t tl = q.tail;
+                    if (J.queue_mode == 3) {
+                        if (w == 0) { requeue_events(J, q, J.events, nev); if (lane == 0) s_q = q; }
+                        __syncthreads();
+                        tl = s_q.tail;
+                    } else
+                    for (uint32_t eb = 0; eb < nev; eb += 4096) {
+                        const uint32_t cnt = (nev - eb) < 4096u ? (nev - eb) : 4096u;
+                        tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &hits[15]);
+                    }
+                    q.tail = tl;
+                    steps += nev;
+                    if (w == 0) hits[11] += nev;
+                }
             }
-            __syncthreads();
-            for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
-                const uint32_t b = J.rinfo[J.p4_list[i]].kpos;
-                J.varmin[b] = 0xFFFFFFFFu;
-                J.fired[J.p4_list[i]] = 0;
-            }
-            __syncthreads();
+        }
+        ECNE_TICK(3);
+
+        // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
+        if (master) {
             if (w == 0) {
-                steps += nev; hits[11] += nev;
-                requeue_events(J, q, J.events, nev);
+                for (uint32_t i = 0; i < J.nP5; ++i) {
+                    const uint32_t r = J.p5_rows[i], y = J.p5_y[i];
+                    bool nu = false;
+                    for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nu |= !(J.flags[J.colA[e]] & 1);
+                    if (__ballot(nu)) continue;
+                    if (J.flags[y] & 1) continue;
+                    mark_unique(J, y);
+                    if (lane == 0) { J.solved[r] = 1; J.solved[r + 1] = 1; }
+                    wg_fence();
+                    steps++; hits[12]++;
+                    requeue(J, q, y);
+                }
                 if (lane == 0) s_steps = steps;
             }
             __syncthreads();
             steps = s_steps;
-            if (wg_error(J, &s_err)) break;
         }
-        ECNE_TICK(3);
-
-        // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates
-        if (w == 0) {
-            for (uint32_t i = 0; i < J.nP5; ++i) {
-                const uint32_t r = J.p5_rows[i], y = J.p5_y[i];
-                bool nu = false;
-                for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nu |= !(J.flags[J.colA[e]] & 1);
-                if (__ballot(nu)) continue;
-                if (J.flags[y] & 1) continue;
-                mark_unique(J, y);
-                if (lane == 0) { J.solved[r] = 1; J.solved[r + 1] = 1; }
-                wg_fence();
-                steps++; hits[12]++;
-                requeue(J, q, y);
-            }
-            if (lane == 0) s_steps = steps;
-        }
-        __syncthreads();
-        steps = s_steps;
         ECNE_TICK(4);
     }
 
-    // ---------------- verdict counts (:1558-1597)
-    __syncthreads();
+    // ---------------- verdict counts (:1558-1597), all workgroups
+    job_barrier(J, &s_err);
     uint32_t un = 0, nn = 0, ut = 0;
-    for (uint32_t v = 1 + tid; v <= nV; v += ECNE_WG) {
+    for (uint32_t v = 1 + gtid; v <= nV; v += gstride) {
         if (J.nontrivial[v]) { nn++; if (J.flags[v] & 1) un++; }
     }
-    for (uint32_t i = tid; i < J.nTarget; i += ECNE_WG)
+    for (uint32_t i = gtid; i < J.nTarget; i += gstride)
         if (J.flags[J.targets[i]] & 1) ut++;
     {
         uint32_t t0, t1, t2;
@@ -1704,20 +1792,21 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs) {
         wg_exclusive_scan(nn, s_scan, &t1);
         wg_exclusive_scan(ut, s_scan, &t2);
         if (tid == 0) {
-            Counters* c = J.ctr;
-            c->successful_steps = steps;
-            c->num_unique = nuniq;
-            c->pops = pops;
-            c->pop_nnz = pop_nnz;
-            c->outer_iterations = outer;
-            for (int i = 0; i < 16; ++i) c->rule_hits[i] = hits[i];
-            c->unique_nontrivial = t0;
-            c->n_nontrivial = t1;
-            c->unique_targets = t2;
-            c->q_head = q.head;
-            c->q_tail = q.tail;
-            ECNE_TICK(5);
-            for (int i = 0; i < 8; ++i) c->phase_ticks[i] = tk[i];
+            atomicAdd(&ctr->unique_nontrivial, (unsigned long long)t0);
+            atomicAdd(&ctr->n_nontrivial, (unsigned long long)t1);
+            atomicAdd(&ctr->unique_targets, (unsigned long long)t2);
+            if (master) {
+                ctr->successful_steps = steps;
+                ctr->num_unique = nuniq;
+                ctr->pops = pops;
+                ctr->pop_nnz = pop_nnz;
+                ctr->outer_iterations = outer;
+                for (int i = 0; i < 16; ++i) ctr->rule_hits[i] = hits[i];
+                ctr->q_head = q.head;
+                ctr->q_tail = q.tail;
+                ECNE_TICK(5);
+                for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
+            }
         }
     }
 }

@@ -86,7 +86,7 @@ void ecne_system_free(ecne_system* sys);
 typedef struct ecne_opts {
     int32_t device;      /* HIP device ordinal                                                       */
     int32_t secp_solve;  /* kwarg secp_solve (:511): defines `dsu`, required when P2 has work (:762)  */
-    int32_t debug;       /* reserved                                                                 */
+    int32_t debug;       /* test hook: > 0 forces that many cooperating workgroups per system        */
     int32_t queue_mode;  /* 0 = default schedule; 1 = force strictly sequential pops (debug/parity)  */
     void* stream;        /* hipStream_t to launch on, or NULL for the device's default stream         */
 } ecne_opts;

@@ -67,6 +67,7 @@ def compare(rel, g, o):
 
 
 def main():
+    nwg = int(os.environ.get("ECNE_FORCE_NWG", "0"))
     subs = sys.argv[1:]
     cases = [c for c in CASES if not subs or any(s in c[0] for s in subs)]
     nbad = 0
@@ -74,7 +75,7 @@ def main():
     for rel, trusted, names, secp in cases:
         sysm = build_system(rel, trusted, names)
         t = time.time()
-        g = E.solve_batch([sysm], secp_solve=secp)[0]
+        g = E.solve_batch([sysm], secp_solve=secp, force_nwg=nwg)[0]
         tg = time.time() - t
         o = orc.run(fixtures.path(rel), [fixtures.path(x) for x in trusted], names, secp)
         msgs = compare(rel, g, o)

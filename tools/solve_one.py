@@ -12,7 +12,7 @@ else:
     s = E.System(E.R1CS(fixtures.path(sys.argv[1])))
 for mode in ([int(m) for m in sys.argv[4:]] if len(sys.argv) > 4 else [0]):
     for rep in range(2):
-        r = E.solve_batch([s], fetch_states=False, queue_mode=mode)[0]
+        r = E.solve_batch([s], fetch_states=False, queue_mode=mode, force_nwg=int(os.environ.get('ECNE_FORCE_NWG', '0')))[0]
     sm = r.summary
     print("mode", mode, "rows", len(s), "status", r.status, "good", r.function_good, "dev_ms %.2f" % sm.device_ms, "pops", sm.pops, "outer", sm.outer_iterations,
           "rounds", sm.rule_hits[13], "bigfb", sm.rule_hits[14], "candfb", sm.rule_hits[15],
