@@ -48,6 +48,9 @@ enum Status {
     ST_EKEY = -5,        // KeyError in abstraction's variable map (:381-382)
     ST_EDETSIZE = -6,    // slow_det on k > 10 unknowns: the reference would need k!*k steps
     ST_EIO = -7,
+    ST_EWATCHDOG = -10,  // the queue never drains (contradictory single-variable rows re-set each other's
+                         // value forever, :966-969): the reference would not terminate; the engine stops
+                         // with ECNE_ECAPACITY after 4096 + 64*nnz pops, and so does this restatement
 };
 struct OracleError {
     int code;
@@ -566,7 +569,9 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
         }
 
         // QUEUE :805-1349
+        const int64_t pop_cap = 4096 + 64 * R.nnz_reduced;
         while (!q.empty()) {
+            if (R.pops > pop_cap) throw OracleError{ST_EWATCHDOG};
             int64_t lead = q.front();                                    // :817
             q.pop_front();
             in_queue[lead - 1] = 0;

@@ -1,0 +1,158 @@
+"""Seeded random R1CS systems biased towards the shapes Ecne's rules look for (bit checks, x == y,
+1 = x + y, binary decompositions in both orientations, single-variable rows, mixed-radix sums,
+decoder / isZero pairs, small linear systems, products) plus degenerate rows (constants only,
+explicit zero coefficients, duplicate wire ids, coefficients >= p).  Used by the oracle invariants
+test and by the GPU parity fuzz."""
+import random
+
+import r1cs_py
+
+P = r1cs_py.P
+
+
+def make(seed, n_rows=None, n_vars=None, allow_errors=True):
+    """Rows are built around a random witness so that the system is satisfiable, like a real circuit
+    (contradictory single-variable or equality rows make the REFERENCE loop forever: two R3 rows with
+    different values for one variable re-set each other, :966-985). A small fraction of seeds adds
+    degenerate rows the reference raises on, or one contradiction (watchdog)."""
+    rng = random.Random(seed)
+    n_vars = n_vars or rng.randint(4, 48)
+    n_rows = n_rows or rng.randint(1, 70)
+    n_out = rng.randint(0, min(3, n_vars - 2))
+    n_in = rng.randint(0, min(4, n_vars - 1 - n_out))
+    nbits = rng.randint(1, max(1, n_vars // 2))
+    bits = set(rng.sample(range(2, n_vars + 1), min(nbits, n_vars - 1)))
+    w = {1: 1}
+    for v in range(2, n_vars + 1):
+        w[v] = rng.randint(0, 1) if v in bits else rng.choice([0, 1, 2, 3, 7, 255, 1 << 20, (1 << 86) - 5, P - 2])
+    V = lambda: rng.randint(2, n_vars)                                       # noqa: E731
+    B = lambda: rng.choice(sorted(bits))                                     # noqa: E731
+    small = [1, -1, 2, -2, 3, 5, -7, 1 << 8, -(1 << 20), (1 << 86) + 3, P - 5, 1 << 250, -(1 << 251)]
+    C = lambda: rng.choice(small)                                            # noqa: E731
+    rows = []
+    ev = lambda terms: sum(c * w[v] for v, c in terms) % P                   # noqa: E731
+
+    def lin_fixed(terms):
+        """0 = terms + k*one with k chosen so that the witness satisfies it"""
+        k = (-ev(terms)) % P
+        t = list(terms)
+        if k:
+            t.append((1, k))
+        rng.shuffle(t)
+        return ([], [], t)
+    weird = allow_errors and rng.random() < 0.12
+    for _ in range(n_rows):
+        kind = rng.random()
+        if kind < 0.14:      # bit check
+            b = B()
+            rows.append(([(b, 1), (1, -1)], [(b, 1)], []))
+        elif kind < 0.24:    # x == y between equal-valued variables (either orientation)
+            x = V()
+            same = [v for v in range(1, n_vars + 1) if v != x and w[v] == w[x]]
+            if same:
+                y = rng.choice(same)
+                s = rng.choice([1, -1])
+                rows.append(([], [], [(x, s), (y, -s)]))
+        elif kind < 0.30:    # 1 = x + y on complementary bits
+            x = B()
+            comp = [v for v in bits if v != x and w[v] == 1 - w[x]]
+            if comp:
+                rows.append(([], [], [(1, 1), (x, -1), (rng.choice(comp), -1)]))
+        elif kind < 0.42:    # binary decomposition of a fresh-valued sum variable, T or T2 orientation
+            k = rng.randint(1, 6)
+            bs = rng.sample(sorted(bits), min(k, len(bits)))
+            tot = sum(w[b] << i for i, b in enumerate(bs))
+            cands = [v for v in range(2, n_vars + 1) if v not in bits and v not in bs]
+            if cands:
+                sv = rng.choice(cands)
+                if w[sv] != tot and not any(sv in [vv for part in r for vv, _c in part] for r in rows):
+                    w[sv] = tot
+                if w[sv] == tot:
+                    s = rng.choice([1, -1])
+                    t = [(sv, s)] + [(b, -s * (1 << i)) for i, b in enumerate(bs)]
+                    rng.shuffle(t)
+                    rows.append(([], [], t))
+        elif kind < 0.50:    # single-variable row fixing x to its witness value
+            x = V()
+            rows.append(lin_fixed([(x, C())]))
+        elif kind < 0.58:    # mixed radix sum over bounded digits
+            k = rng.randint(2, 4)
+            vs = rng.sample(range(2, n_vars + 1), min(k, n_vars - 1))
+            radix, t = 1, []
+            for v in vs:
+                t.append((v, radix))
+                radix *= rng.choice([2, 3, 4])
+            rows.append(lin_fixed(t))
+        elif kind < 0.66:    # decoder row / isZero pair
+            x, y, z = V(), V(), V()
+            if rng.random() < 0.5:
+                kk = rng.randint(0, 3)
+                if (w[x] - kk) % P == 0 or w[y] == 0:
+                    rows.append(([(x, 1)] + ([(1, -kk)] if kk else []), [(y, 1)], []))
+            elif y != 1 and (w[x] * w[y]) % P == 0:
+                rows.append(([(x, 1)], [(z, 1)], [(1, 1), (y, -1)]))
+                rows.append(([(x, 1)], [(y, 1)], []))
+        elif kind < 0.76:    # small linear system rows over the same unknowns
+            k = rng.randint(2, 3)
+            vs = rng.sample(range(2, n_vars + 1), min(k, n_vars - 1))
+            for _r in range(rng.randint(1, k + 1)):
+                rows.append(lin_fixed([(v, C()) for v in vs]))
+        elif kind < 0.92:    # product a*b = c + const
+            a = [(V(), C()) for _ in range(rng.randint(1, 2))]
+            b = [(V(), C()) for _ in range(rng.randint(1, 2))]
+            c = [(V(), C()) for _ in range(rng.randint(0, 2))]
+            k = (ev(a) * ev(b) - ev(c)) % P
+            if k:
+                c.append((1, k))
+            rows.append((a, b, c))
+        elif kind < 0.96:    # general sum
+            vs = rng.sample(range(2, n_vars + 1), min(rng.randint(2, 6), n_vars - 1))
+            rows.append(lin_fixed([(v, C()) for v in vs]))
+        elif kind < 0.98:    # explicit zero coefficient / duplicate wire id (last wins)
+            x, y = V(), V()
+            c2 = rng.choice([-1, 2, 5])
+            k = (-(c2 * w[x])) % P
+            rows.append(([], [], [(x, 1), (y, 0), (x, c2)] + ([(1, k)] if k else [])))
+        else:                # coefficient written un-reduced (>= p):  x - w[x] = 0 with both terms + p
+            x = V()
+            rows.append(([], [], [(x, P + 1), (1, P + (-w[x]) % P)]))
+        if weird and rng.random() < 0.08:
+            r = rng.random()
+            if r < 0.35:
+                rows.append(([(1, 2)], [(1, 3)], []))                 # constants only: BoundsError (:916)
+            elif r < 0.7:
+                rows.append(([(1, 1)], [(V(), 1)], []))               # slope missing from A: DivideError (:919)
+            else:
+                x = V()
+                rows.append(([], [], [(x, 1), (1, (-(w[x] + 1)) % P)]))   # contradicts the witness
+    return dict(n_wires=n_vars - 1, n_out=n_out, n_pub=0, n_prv=n_in, rows=rows)
+
+
+def write(path, spec):
+    rows = []
+    for A, B, C in spec["rows"]:
+        rows.append(([(v, c % (1 << 256) if c >= 0 else c % P) for v, c in A],
+                     [(v, c % (1 << 256) if c >= 0 else c % P) for v, c in B],
+                     [(v, c % (1 << 256) if c >= 0 else c % P) for v, c in C]))
+    write_raw(path, spec["n_wires"], spec["n_out"], spec["n_pub"], spec["n_prv"], rows)
+
+
+def write_raw(path, nwires, nout, npub, nprv, rows, section_order=(2, 1, 3)):
+    """like r1cs_py.write but keeps coefficients un-reduced (< 2^256) and lets the caller pick the
+    section order"""
+    import struct
+    body2 = bytearray()
+    for parts in rows:
+        for terms in parts:
+            body2 += struct.pack("<I", len(terms))
+            for v, c in terms:
+                body2 += struct.pack("<I", v - 1) + int(c).to_bytes(32, "little")
+    body1 = struct.pack("<I", 32) + P.to_bytes(32, "little") + struct.pack("<IIII", nwires, nout, npub, nprv)
+    body1 += struct.pack("<QI", nwires, len(rows))
+    body3 = b"".join(struct.pack("<Q", i) for i in range(nwires))
+    bodies = {1: body1, 2: bytes(body2), 3: body3}
+    out = b"r1cs" + struct.pack("<II", 1, 3)
+    for t in section_order:
+        out += struct.pack("<IQ", t, len(bodies[t])) + bodies[t]
+    with open(path, "wb") as f:
+        f.write(out)
