@@ -346,11 +346,11 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
-    size_t o_wmark = c.take(4ull * (nV + 1)), o_rmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_rmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1));
-    size_t o_evbuf = c.take(4ull * ECNE_WG * ECNE_EVCAP), o_cand = c.take(4ull * ECNE_CANDCAP);
+    size_t o_wmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1));
+    size_t o_evbuf = c.take(4ull * 4 * ECNE_WG * ECNE_EVCAP), o_cand = c.take(4ull * ECNE_CANDCAP);
     uint32_t maxrowC = 0;
     for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
-    const size_t flatcap = std::max<size_t>((size_t)ECNE_WG * ECNE_EVCAP, 16384);
+    const size_t flatcap = std::max<size_t>((size_t)4 * ECNE_WG * ECNE_EVCAP, 16384);
     size_t o_fvar = c.take(4ull * flatcap), o_frank = c.take(4ull * flatcap), o_fbase = c.take(4ull * (flatcap + 1));
     size_t o_bigev = c.take(4ull * ((size_t)maxrowC * 3 + 64));
     size_t o_ctr = c.take(sizeof(Counters));
@@ -413,7 +413,7 @@ static int upload_system(ecne_system& S, int device) {
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
-    J.wmarkU = (uint32_t*)(base + o_wmark); J.rmarkU = (uint32_t*)(base + o_rmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.rmarkB = (uint32_t*)(base + o_rmarkB); J.best = (uint32_t*)(base + o_best);
+    J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best);
     J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
     J.fvar = (uint32_t*)(base + o_fvar); J.frank = (uint32_t*)(base + o_frank); J.fbase = (uint32_t*)(base + o_fbase);
     J.bigev = (uint32_t*)(base + o_bigev);
@@ -668,6 +668,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             s.pop_nnz = (int64_t)c.pop_nnz;
             s.device_ms = ms;
             s.classify_ms = S.dev.classify_ms;
+            for (int k = 0; k < 8; ++k) s.queue_ms[k] = (double)c.qticks[k] * 1e-5;
             for (int k = 0; k < 8; ++k) s.phase_ms[k] = (k == 6) ? (double)c.phase_ticks[k] : (double)c.phase_ticks[k] * 1e-5;
             out[i] = r;
         }

@@ -62,6 +62,7 @@ struct Counters {   // one per job, device memory
     unsigned int q_head, q_tail;
     unsigned int pad;
     unsigned long long phase_ticks[8];
+    unsigned long long qticks[8];        // queue phase breakdown: head, mark, check+unmark, exec, flatten, resolve, big rows
     // job-wide synchronisation words (zeroed before every launch)
     unsigned long long sync_steps;
     unsigned int bar_count, bar_gen;
@@ -105,9 +106,9 @@ struct Job {
     uint32_t* hot;
     uint8_t* fired;
     uint32_t* events;
-    // per variable: lowest chunk rank that may write / read its U-class state (unique, is_known bits:
+    // per variable: lowest chunk rank that may WRITE its U-class state (unique, is_known bits:
     // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
-    uint32_t *wmarkU, *rmarkU, *wmarkB, *rmarkB;
+    uint32_t *wmarkU, *wmarkB;
     uint32_t* best;            // per row: lowest candidate index that wants to push it
     uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there
     uint32_t *fvar, *frank, *fbase;   // flat event list of one resolution round: variable, rank, candidate base

@@ -23,7 +23,7 @@
 
 namespace ecne {
 
-#define ECNE_WG 1024
+#define ECNE_WG 512
 #define ECNE_NWAVES (ECNE_WG / 64)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -57,6 +57,10 @@ __device__ __forceinline__ fp::u256 r7_abs(const fp::u256& c) {
         return t;
     }
     return c;
+}
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ====================================================================================== classify
@@ -275,7 +279,7 @@ __device__ __forceinline__ void set_bounds(const Job& J, uint32_t v, const fp::u
 
 // REQUEUE(v): for each row r of variable_to_indices[v], ascending: push r unless already queued.
 // Wave-cooperative; exactly the sequential order because the rows of one list are distinct.
-__device__ void requeue(const Job& J, QState& q, uint32_t v) {
+__device__ __noinline__ void requeue(const Job& J, QState& q, uint32_t v) {
     const int lane = lane_id();
     if (q.emit) {
         if (lane == 0) q.evout[q.nev] = v;
@@ -307,7 +311,7 @@ __device__ __forceinline__ void mark_unique(const Job& J, uint32_t v) {
 
 // walk C entries [c0,c1) in stored (= reference Set) order; every non-unique variable other than
 // `skip` becomes unique and is re-queued, in order. Returns how many.
-__device__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0, uint32_t c1, uint32_t skip) {
+__device__ __noinline__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0, uint32_t c1, uint32_t skip) {
     const int lane = lane_id();
     uint32_t n = 0;
     for (uint32_t base = c0; base < c1; base += 64) {
@@ -337,7 +341,7 @@ __device__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0,
 }
 
 // ---- one queue pop: rules R1..R8 on row `row`, in the reference's order (:824-1348)
-__device__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
+__device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
                          unsigned long long& steps, unsigned long long& nuniq) {
     const int lane = lane_id();
     const RowInfo ri = J.rinfo[row];
@@ -650,7 +654,7 @@ __device__ __forceinline__ uint64_t mixB(uint64_t x) {
 
 // P3 eligibility of one row (one lane per row): no non-unique variable in A or B; k = number of
 // non-unique variables of C; h/h2 = commutative hash of that set (:1360-1386).
-__device__ void p3_eval(const Job& J, uint32_t row, uint32_t& k, uint64_t& h, uint64_t& h2) {
+__device__ __noinline__ void p3_eval(const Job& J, uint32_t row, uint32_t& k, uint64_t& h, uint64_t& h2) {
     k = 0; h = 0; h2 = 0;
     for (uint32_t e = J.rpA[row]; e < J.rpA[row + 1]; ++e)
         if (!(J.flags[J.colA[e]] & 1)) { k = 0xFFFFFFFFu; return; }
@@ -696,7 +700,7 @@ __device__ fp::u256 c_coef(const Job& J, uint32_t row, uint32_t v) {
 // slow_det (:1389-1400): sum over ODD permutations only (Combinatorics.parity is 0 for even and
 // 1 for odd permutations and is used as a factor). Wave-parallel over permutation indices.
 // rows[0..k) in arrival order, vars[0..k) ascending. Returns non-zero?
-__device__ bool p3_odd_perm_sum_nonzero(const Job& J, const uint32_t* rows, const uint32_t* vars, uint32_t k) {
+__device__ __noinline__ bool p3_odd_perm_sum_nonzero(const Job& J, const uint32_t* rows, const uint32_t* vars, uint32_t k) {
     const int lane = lane_id();
     uint64_t nperm = 1;
     for (uint32_t i = 2; i <= k; ++i) nperm *= i;
@@ -777,7 +781,7 @@ __device__ __forceinline__ uint32_t lane_uniq_range(const Job& J, uint32_t c0, u
 
 // One queue pop executed by ONE lane (rows with at most ECNE_SMALL_ROW entries). Statement-for-
 // statement the same rules as exec_row(); REQUEUE(v) becomes an event appended to ev[].
-__device__ void exec_row_lane(const Job& J, uint32_t row, uint32_t* ev, uint32_t& nev, LaneCtr& C) {
+__device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t* ev, uint32_t& nev, LaneCtr& C) {
     const RowInfo ri = J.rinfo[row];
     const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1];
     const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
@@ -1057,7 +1061,7 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
 // Exact "this pop changes no variable" test against the current state, for rows all of whose
 // variables are final. Such a pop only toggles the row's own R4 orientation byte (x == y rows).
 // reads_b tells whether the verdict depended on B-class state (then earlier B-writers still block it).
-__device__ bool row_is_noop(const Job& J, uint32_t row, const RowInfo& ri, bool& reads_b) {
+__device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowInfo& ri, bool& reads_b) {
     const uint32_t shape = ri.shape;
     reads_b = false;
     if (shape & SH_R2_BOUNDSERR) return false;
@@ -1093,6 +1097,7 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t scan[ECNE_NWAVES + 2];
     unsigned long long acc[12];   // steps, nuniq, hits[0..7], pops, pop_nnz
     uint32_t head, tail, fallback, nbig;
+    unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
 
 // Ordered multi-source REQUEUE by the whole workgroup. Input: a flat list of N events (variables) in
@@ -1102,7 +1107,7 @@ struct ChunkShared {   // LDS of the chunked queue phase
 // queue entries head.. being popped right now (their inq[] holds rank + 2: a push may re-queue a row
 // popped at the same or a lower rank, never one still waiting at a higher rank); head < 0: nothing is
 // being popped (sweep phases). Returns the new tail. All threads of the workgroup must call it.
-__device__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, const uint32_t* fvar, bool ranks, uint32_t N,
+__device__ __noinline__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, const uint32_t* fvar, bool ranks, uint32_t N,
                                    long long head, uint32_t nranks, uint32_t tail, unsigned long long* n_fallback) {
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     // candidate base of every event = exclusive scan of the fan-out sizes
@@ -1167,7 +1172,7 @@ __device__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, const uint32_t*
             if (j < M) {
                 const uint32_t cw = J.cand[j];
                 t = cw & 0x7FFFFFFFu;
-                win = (cw & 0x80000000u) && J.best[t] == j;
+                win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
             }
             uint32_t tot;
             const uint32_t off = wg_exclusive_scan(win, S.scan, &tot);
@@ -1189,142 +1194,223 @@ __device__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, const uint32_t*
 }
 
 // The whole QUEUE phase (:805-1349), executed by all 1024 threads. q is kept identical in every thread.
-__device__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
+// A round examines up to ECNE_RPL * 1024 queue entries; lane t owns the consecutive ranks
+// t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
+#define ECNE_RPL 4
+__device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
                                     unsigned long long& steps, unsigned long long& nuniq,
                                     unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
     if (tid < 12) S.acc[tid] = 0;
+    unsigned long long qt_last = wall_clock64();
+#define QTICK(slot) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); S.qt[slot] += t_ - qt_last; qt_last = t_; } } while (0)
     LaneCtr C;
     C.steps = C.nuniq = 0;
     for (int i = 0; i < 8; ++i) C.hits[i] = 0;
     uint32_t my_pops = 0, my_nnz = 0;
     unsigned long long pops_total = pops;
+    uint32_t round = 0, burst = 0, next_burst = 16, window = ECNE_RPL * ECNE_WG;
     __syncthreads();
     while (q.head != q.tail) {
-        if (wg_error(J, s_err)) break;
+        // the error word is polled every 8th round (a raised error only has to stop the solve soon)
+        if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
         if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
-        const uint32_t n = (q.tail - q.head) < ECNE_WG ? (q.tail - q.head) : ECNE_WG;
-        uint32_t row = 0, shape = 0, x = 0;
-        bool live = false;
-        if ((uint32_t)tid < n) {
-            row = J.queue[(q.head + tid) & J.qmask];
-            const RowInfo ri = J.rinfo[row];
-            shape = ri.shape;
-            x = ri.x;
-            live = !J.solved[row];
+        const uint32_t avail = q.tail - q.head;
+        if (burst) {
+            // The last chunk round committed only a handful of rows (a dependency chain): pop the next
+            // `burst` rows strictly sequentially on wave 0 (cheaper per pop than a round), then look again.
+            if (w == 0) {
+                QState qq = q;
+                qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                unsigned long long st = 0, nu = 0, ht[16], pn = 0;
+                for (int i = 0; i < 16; ++i) ht[i] = 0;
+                uint32_t done = 0;
+                while (done < burst && qq.head != qq.tail && !J.ctr->error) {
+                    const uint32_t rr = J.queue[qq.head & J.qmask];
+                    qq.head++;
+                    if (lane == 0) J.inq[rr] = 0;
+                    wg_fence();
+                    ++done;
+                    pn += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
+                    if (!J.solved[rr]) exec_row(J, qq, rr, ht, st, nu);
+                }
+                if (lane == 0) {
+                    S.acc[0] += st; S.acc[1] += nu;
+                    for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
+                    S.acc[10] += done; S.acc[11] += pn;
+                    S.head = qq.head; S.tail = qq.tail; S.nbig = done;
+                }
+            }
+            __syncthreads();
+            q.head = S.head; q.tail = S.tail;
+            pops_total += S.nbig;
+            burst = 0;
+            __syncthreads();
+            QTICK(6);
+            continue;
         }
-        if (tid == 0) { S.cut = n; S.fallback = (shape & SH_BIG) ? 1u : 0u; }
+        // adaptive window: examining rows that end up behind the cut is wasted work, so the window
+        // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
+        const uint32_t n = avail < window ? avail : window;
+        const uint32_t rpl = (n + ECNE_WG - 1) / ECNE_WG;          // rows per lane this round
+        const uint32_t r0 = (uint32_t)tid * rpl;                    // my first rank
+        uint32_t row[ECNE_RPL], shape[ECNE_RPL], xv[ECNE_RPL];
+        uint32_t live = 0, noop = 0, noop_b = 0;                    // bit s = slot s
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
+            if (sl < rpl && r0 + sl < n) {
+                row[sl] = J.queue[(q.head + r0 + sl) & J.qmask];
+                const RowInfo ri = J.rinfo[row[sl]];
+                shape[sl] = ri.shape;
+                xv[sl] = ri.x;
+                if (!J.solved[row[sl]]) live |= 1u << sl;
+            }
+        }
+        if (tid == 0) { S.cut = n; S.fallback = (shape[0] & SH_BIG) ? 1u : 0u; }
         __syncthreads();
+        QTICK(0);
         if (S.fallback) {
             // a big row at the queue head: popped alone. Wave 0 runs the wave-cooperative rules in emit
             // mode; the whole workgroup then resolves its REQUEUE events in order.
             if (w == 0) {
-                const uint32_t r0 = __shfl(row, 0, 64);
+                const uint32_t rr = __shfl(row[0], 0, 64);
                 QState qq;
-                qq.head = q.head + 1; qq.tail = q.tail; qq.evout = J.bigev; qq.nev = 0; qq.emit = (J.queue_mode == 2) ? 0u : 1u;
-                if (lane == 0) J.inq[r0] = (J.queue_mode == 2) ? 0 : 2;          // being popped at rank 0
+                qq.head = q.head + 1; qq.tail = q.tail; qq.evout = J.bigev; qq.nev = 0; qq.emit = 1;
+                if (lane == 0) J.inq[rr] = 2;          // being popped at rank 0
                 wg_fence();
                 unsigned long long st = 0, nu = 0, ht[16];
                 for (int i = 0; i < 16; ++i) ht[i] = 0;
-                if (!J.solved[r0]) exec_row(J, qq, r0, ht, st, nu);
+                if (!J.solved[rr]) exec_row(J, qq, rr, ht, st, nu);
                 if (lane == 0) {
                     S.acc[0] += st; S.acc[1] += nu;
                     for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
                     S.acc[10] += 1;
-                    S.acc[11] += (J.rpA[r0 + 1] - J.rpA[r0]) + (J.rpB[r0 + 1] - J.rpB[r0]) + (J.rpC[r0 + 1] - J.rpC[r0]);
+                    S.acc[11] += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
                     S.nbig = qq.nev;
-                    S.tail = qq.tail;
                 }
             }
             __syncthreads();
             {
-                const uint32_t nt = (J.queue_mode == 2) ? S.tail : resolve_pushes(J, S, J.bigev, false, S.nbig, (long long)q.head, 1, q.tail, &hits[15]);
-                if (tid == 0 && J.inq[row] >= 2) J.inq[row] = 0;
+                const uint32_t nt = resolve_pushes(J, S, J.bigev, false, S.nbig, (long long)q.head, 1, q.tail, &hits[15]);
+                if (tid == 0 && J.inq[row[0]] >= 2) J.inq[row[0]] = 0;
                 q.head += 1;
                 q.tail = nt;
             }
             pops_total++;
             hits[14]++;
             __syncthreads();
+            QTICK(6);
             continue;
         }
         // ---- mark
-        bool noop = false, noop_b = false;
-        RowInfo myri;
-        if ((uint32_t)tid < n) {
-            if (shape & SH_BIG) atomicMin(&S.cut, (uint32_t)tid);
-            else if (live) {
-                myri = J.rinfo[row];
-                noop = row_is_noop(J, row, myri, noop_b);
-                if (!noop)
-                    for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                        if (rd & 1) atomicMin(&J.rmarkU[v], (uint32_t)tid);
-                        if (wr & 1) atomicMin(&J.wmarkU[v], (uint32_t)tid);
-                        if (rd & 2) atomicMin(&J.rmarkB[v], (uint32_t)tid);
-                        if (wr & 2) atomicMin(&J.wmarkB[v], (uint32_t)tid);
-                    });
-            }
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            if (sl >= rpl || r0 + sl >= n) continue;
+            const uint32_t rank = r0 + sl;
+            if (shape[sl] & SH_BIG) { atomicMin(&S.cut, rank); continue; }
+            if (!(live & (1u << sl))) continue;
+            const RowInfo ri = J.rinfo[row[sl]];
+            bool nb = false;
+            if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
+            // only WRITE sets are marked: the readers find write-after-read hazards themselves (below)
+            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if (wr & 1) atomicMin(&J.wmarkU[v], rank);
+                if (wr & 2) atomicMin(&J.wmarkB[v], rank);
+            });
         }
         __syncthreads();
-        // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write
-        if ((uint32_t)tid < n && live && !(shape & SH_BIG)) {
+        QTICK(1);
+        // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
+        // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
+            const uint32_t rank = r0 + sl;
             bool blocked = false;
-            if (noop) {
-                // all U-class state is final; the verdict may have read B-class state of C's variables
-                if (noop_b)
-                    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k)
-                        if (J.wmarkB[J.colC[k]] < (uint32_t)tid) blocked = true;
+            if (noop & (1u << sl)) {
+                if (noop_b & (1u << sl))
+                    for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
+                        if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
             } else {
-                for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                    if (((rd | wr) & 1) && J.wmarkU[v] < (uint32_t)tid) blocked = true;
-                    if ((wr & 1) && J.rmarkU[v] < (uint32_t)tid) blocked = true;
-                    if (((rd | wr) & 2) && J.wmarkB[v] < (uint32_t)tid) blocked = true;
-                    if ((wr & 2) && J.rmarkB[v] < (uint32_t)tid) blocked = true;
+                // wmark holds the LOWEST rank that may write that state. Lower than mine: I would read
+                // (or overwrite) what an earlier row writes -> I am blocked. Higher than mine: that row
+                // would overwrite what I read -> it (and everything after it) is cut off.
+                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if ((rd | wr) & 1) {
+                        const uint32_t m = ld_agent(&J.wmarkU[v]);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                    if ((rd | wr) & 2) {
+                        const uint32_t m = ld_agent(&J.wmarkB[v]);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
                 });
             }
-            if (blocked) atomicMin(&S.cut, (uint32_t)tid);
+            if (blocked) atomicMin(&S.cut, rank);
         }
         __syncthreads();
         const uint32_t c = S.cut;   // >= 1: rank 0 is never blocked and not big
-        // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see below)
-        if ((uint32_t)tid < n && live && !(shape & SH_BIG) && !noop)
-            for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                if (rd & 1) J.rmarkU[v] = 0xFFFFFFFFu;
-                if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
-                if (rd & 2) J.rmarkB[v] = 0xFFFFFFFFu;
-                if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
-            });
-        if ((uint32_t)tid < c) J.inq[row] = (uint16_t)(tid + 2);
-        __syncthreads();
-        // ---- execute the independent prefix, one lane per row
-        uint32_t nev = 0;
-        if ((uint32_t)tid < c) {
-            my_pops++;
-            my_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
-            if (live) {
-                if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }   // the pop's only effect
-                else exec_row_lane(J, row, J.evbuf + (size_t)tid * ECNE_EVCAP, nev, C);
-            }
+        // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see resolve_pushes)
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            if (sl >= rpl || r0 + sl >= n) continue;
+            if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
+                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+                    if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+                });
+            if (r0 + sl < c) J.inq[row[sl]] = (uint16_t)(r0 + sl + 2);
         }
+        __syncthreads();
+        QTICK(2);
+        // ---- execute the independent prefix, one lane per row (rpl rows per lane, in rank order)
+        uint32_t nev[ECNE_RPL], nev_tot = 0;
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            nev[sl] = 0;
+            if (sl >= rpl || r0 + sl >= c) continue;
+            my_pops++;
+            my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
+            if (live & (1u << sl)) {
+                if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }   // the pop's only effect
+                else exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+            }
+            nev_tot += nev[sl];
+        }
+        QTICK(3);
         // ---- REQUEUE resolution in sequential order: flatten the per-rank event lists, then resolve
         uint32_t Nev;
         {
-            const uint32_t eoff = wg_exclusive_scan(((uint32_t)tid < c) ? nev : 0u, S.scan, &Nev);
-            if ((uint32_t)tid < c) {
-                const uint32_t* ev = J.evbuf + (size_t)tid * ECNE_EVCAP;
-                for (uint32_t e = 0; e < nev; ++e) { J.fvar[eoff + e] = ev[e]; J.frank[eoff + e] = (uint32_t)tid; }
+            const uint32_t eoff = wg_exclusive_scan(nev_tot, S.scan, &Nev);
+            uint32_t o = eoff;
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl) continue;
+                const uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
+                for (uint32_t e = 0; e < nev[sl]; ++e) { J.fvar[o] = ev[e]; J.frank[o] = r0 + sl; ++o; }
             }
             __syncthreads();   // the flat list is read across lanes
         }
+        QTICK(4);
         const uint32_t new_tail = resolve_pushes(J, S, J.fvar, true, Nev, (long long)q.head, c, q.tail, &hits[15]);
+        QTICK(5);
         // rows of the prefix that nobody re-queued are out of the queue now
-        if ((uint32_t)tid < c && J.inq[row] >= 2) J.inq[row] = 0;
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
+            if (sl < rpl && r0 + sl < c && J.inq[row[sl]] >= 2) J.inq[row[sl]] = 0;
         __syncthreads();
         q.head += c;
         q.tail = new_tail;
         pops_total += c;
         hits[13]++;
+        // adaptive: a short queue with a short independent prefix is a dependency chain -> sequential
+        // burst, doubling while it stays that way
+        if (c < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+        if (c == n) window = (window * 2 < ECNE_RPL * ECNE_WG) ? window * 2 : ECNE_RPL * ECNE_WG;
+        else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < 64 ? 64 : wn; }
+        else next_burst = 16;
     }
     // ---- reduce the per-lane counters
     __syncthreads();
@@ -1382,9 +1468,6 @@ __device__ int job_barrier(const Job& J, int* s_err) {
     __syncthreads();
     return *s_err;
 }
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ---------------------------------------------------------------------------------------- k_solve
 struct WgDesc { uint32_t job, rank; };
@@ -1404,6 +1487,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     __syncthreads();
     const uint32_t nC = J.nC, nV = J.nV;
     const bool master = me.rank == 0;
+    if (tid < 8) s_chunk.qt[tid] = 0;
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1419,9 +1503,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         st256(J.ub + 4ull * v, fp::pminus1());
         J.varmin[v] = 0xFFFFFFFFu;
         J.wmarkU[v] = 0xFFFFFFFFu;
-        J.rmarkU[v] = 0xFFFFFFFFu;
         J.wmarkB[v] = 0xFFFFFFFFu;
-        J.rmarkB[v] = 0xFFFFFFFFu;
     }
     for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; }
     for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
@@ -1573,8 +1655,8 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                         if (k < 2) continue;
                         uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
                         if (s == 0xFFFFFFFFu) continue;
-                        uint32_t fr = J.ht_frozen[s];
-                        if (fr < k && fr + J.ht_new[s] >= k) {
+                        uint32_t fr = ld_agent(&J.ht_frozen[s]);
+                        if (fr < k && fr + ld_agent(&J.ht_new[s]) >= k) {
                             uint32_t pos = atomicAdd(&ctr->p3_nhot, 1u);
                             if (pos < J.hotcap) J.hot[pos] = r;
                         }
@@ -1593,7 +1675,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                             uint32_t k = J.p3k[t];
                             uint64_t h = J.p3h[t], h2 = J.p3h2[t];
                             uint32_t s = ht_slot(J, h, h2, false);
-                            uint32_t fr = (s == 0xFFFFFFFFu) ? 0 : J.ht_frozen[s];
+                            uint32_t fr = (s == 0xFFFFFFFFu) ? 0 : ld_agent(&J.ht_frozen[s]);
                             // arrival number of t = frozen + fresh members with index <= t
                             uint32_t part = 0;
                             for (uint32_t b = lane; b < nhot; b += 64) {
@@ -1806,6 +1888,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 ctr->q_tail = q.tail;
                 ECNE_TICK(5);
                 for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
+                for (int i = 0; i < 8; ++i) ctr->qticks[i] = s_chunk.qt[i];
             }
         }
     }
