@@ -346,8 +346,11 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
-    size_t o_wmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1));
-    size_t o_evbuf = c.take(4ull * 4 * ECNE_WG * ECNE_EVCAP), o_cand = c.take(4ull * ECNE_CANDCAP);
+    size_t o_wmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1)), o_prank = c.take(4ull * std::max<size_t>(nC, 1));
+    // one event slot list per rank of a round: single-workgroup rounds examine <= 4 * 512 queue entries,
+    // multi-workgroup rounds <= min(rows, 96 workgroups * 512 lanes * 2)
+    const size_t max_ranks = std::max<size_t>((size_t)4 * ECNE_WG, std::min<size_t>((size_t)nC + 1, (size_t)96 * ECNE_WG * 2));
+    size_t o_evbuf = c.take(4ull * max_ranks * ECNE_EVCAP), o_cand = c.take(4ull * std::max<size_t>(ECNE_CANDCAP, 8ull * nC));
     uint32_t maxrowC = 0;
     for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
     const size_t flatcap = std::max<size_t>((size_t)4 * ECNE_WG * ECNE_EVCAP, 16384);
@@ -413,8 +416,9 @@ static int upload_system(ecne_system& S, int device) {
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
-    J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best);
+    J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best); J.prank = (uint32_t*)(base + o_prank);
     J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
+    J.candcap = (uint32_t)std::max<size_t>(ECNE_CANDCAP, 8ull * nC);
     J.fvar = (uint32_t*)(base + o_fvar); J.frank = (uint32_t*)(base + o_frank); J.fbase = (uint32_t*)(base + o_fbase);
     J.bigev = (uint32_t*)(base + o_bigev);
     J.ctr = (Counters*)(base + o_ctr);
@@ -669,6 +673,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             s.device_ms = ms;
             s.classify_ms = S.dev.classify_ms;
             for (int k = 0; k < 8; ++k) s.queue_ms[k] = (double)c.qticks[k] * 1e-5;
+            for (int k = 0; k < 8; ++k) s.multi_ms[k] = (double)c.mticks[k] * 1e-5;
             for (int k = 0; k < 8; ++k) s.phase_ms[k] = (k == 6) ? (double)c.phase_ticks[k] : (double)c.phase_ticks[k] * 1e-5;
             out[i] = r;
         }

@@ -62,12 +62,24 @@ struct Counters {   // one per job, device memory
     unsigned int q_head, q_tail;
     unsigned int pad;
     unsigned long long phase_ticks[8];
-    unsigned long long qticks[8];        // queue phase breakdown: head, mark, check+unmark, exec, flatten, resolve, big rows
+    unsigned long long qticks[8];
+    unsigned long long mticks[8];        // multi-workgroup round breakdown: mark, check, exec+scan, expand, compact+scan, final        // queue phase breakdown: head, mark, check+unmark, exec, flatten, resolve, big rows
     // job-wide synchronisation words (zeroed before every launch)
     unsigned long long sync_steps;
-    unsigned int bar_count, bar_gen;
     int error_snap;
-    unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
+    // the barrier words are polled by every waiting workgroup: keep them on a cache line of their own
+    alignas(128) unsigned int bar_count;          // top level: XCD leaders arrive here
+    alignas(128) unsigned int bar_gen;            // generation everybody waits on
+    alignas(128) unsigned int xcd_count[8][32];   // per-XCD arrival counters, one cache line each
+    unsigned int xcd_members[8];                  // workgroups of this job resident on each XCD
+    unsigned int n_xcd_active, bar_ready;
+    alignas(128) unsigned int pad_after_barrier;
+    unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;
+    // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
+    unsigned int q_cmd[4];          // mode (0 = queue phase over, 1 = run one multi round), head, tail, n
+    unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
+    unsigned int q_part[2][128];
+    unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 
 struct Job {
@@ -110,10 +122,12 @@ struct Job {
     // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
     uint32_t *wmarkU, *wmarkB;
     uint32_t* best;            // per row: lowest candidate index that wants to push it
+    uint32_t* prank;           // per row: its rank while it is being popped in a multi-workgroup round
     uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there
     uint32_t *fvar, *frank, *fbase;   // flat event list of one resolution round: variable, rank, candidate base
     uint32_t* bigev;           // events of a big row popped alone
     uint32_t* cand;            // per push candidate: target row | eligibility bit
+    uint32_t candcap;          // capacity of cand[] (single-workgroup rounds use the first ECNE_CANDCAP)
     Counters* ctr;
 };
 

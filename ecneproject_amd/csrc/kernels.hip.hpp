@@ -1097,8 +1097,43 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t scan[ECNE_NWAVES + 2];
     unsigned long long acc[12];   // steps, nuniq, hits[0..7], pops, pop_nnz
     uint32_t head, tail, fallback, nbig;
+    uint32_t nbigev, bigev_v[64], bigev_a[64], bigev_b[64];   // high-fan-out events expanded cooperatively
+    unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
+
+// one push candidate: event of rank a wants to push row t as candidate j (see resolve_pushes)
+__device__ __forceinline__ void expand_candidate(const Job& J, uint32_t t, uint32_t j, uint32_t a, bool multi) {
+    const uint32_t st = J.inq[t];
+    bool elig;
+    if (multi) elig = st == 0 || (st == 2 && J.prank[t] <= a);     // 2 = being popped in this multi round
+    else elig = st == 0 || (st >= 2 && st - 2 <= a);              // rank + 2 = being popped at that rank
+    J.cand[j] = t | (elig ? 0x80000000u : 0u);
+    // many candidates of one round can target the same row (a 1 000-term sum row is pushed by each of
+    // its terms): look before the atomic, most of them have already lost
+    if (elig && ld_agent(&J.best[t]) > j) atomicMin(&J.best[t], j);
+}
+// expand event (v, rank a, candidate base b0): small fan-outs inline, big ones go to the workgroup list
+__device__ __forceinline__ void expand_event(const Job& J, ChunkShared& S, uint32_t v, uint32_t a, uint32_t b0, bool multi) {
+    const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+    if (f1 - f0 > 48) {
+        const uint32_t slot = atomicAdd(&S.nbigev, 1u);
+        if (slot < 64) { S.bigev_v[slot] = v; S.bigev_a[slot] = a; S.bigev_b[slot] = b0; return; }
+    }
+    for (uint32_t k = f0; k < f1; ++k) expand_candidate(J, J.fo_rows[k], b0 + (k - f0), a, multi);
+}
+// all threads of the workgroup: expand the listed big events, lanes across fan-out positions
+__device__ __forceinline__ void expand_big_events(const Job& J, ChunkShared& S, bool multi) {
+    __syncthreads();
+    const uint32_t nb = S.nbigev < 64 ? S.nbigev : 64;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t v = S.bigev_v[i], a = S.bigev_a[i], b0 = S.bigev_b[i];
+        const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+        for (uint32_t k = f0 + threadIdx.x; k < f1; k += ECNE_WG) expand_candidate(J, J.fo_rows[k], b0 + (k - f0), a, multi);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) S.nbigev = 0;
+}
 
 // Ordered multi-source REQUEUE by the whole workgroup. Input: a flat list of N events (variables) in
 // the order the reference would issue REQUEUE(v), each tagged with the rank of the queue entry that
@@ -1153,17 +1188,11 @@ __device__ __noinline__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, co
     } else if (M > 0) {
         // event-parallel expansion. A candidate (rank a, target t) may push iff t is not queued
         // "as of rank a": inq[t] == 0, or t is itself being popped at a rank <= a
-        for (uint32_t e = tid; e < N; e += ECNE_WG) {
-            const uint32_t v = fvar[e], a = ranks ? J.frank[e] : 0, b0 = J.fbase[e];
-            const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
-            for (uint32_t k = f0; k < f1; ++k) {
-                const uint32_t t = J.fo_rows[k], j = b0 + (k - f0);
-                const uint32_t st = J.inq[t];
-                const bool elig = st == 0 || (st >= 2 && st - 2 <= a);
-                J.cand[j] = t | (elig ? 0x80000000u : 0u);
-                if (elig) atomicMin(&J.best[t], j);
-            }
-        }
+        if (tid == 0) S.nbigev = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < N; e += ECNE_WG)
+            expand_event(J, S, fvar[e], ranks ? J.frank[e] : 0, J.fbase[e], false);
+        expand_big_events(J, S, false);
         __syncthreads();
         // the earliest eligible candidate of each target wins; winners keep candidate order
         for (uint32_t jb = 0; jb < M; jb += ECNE_WG) {
@@ -1193,6 +1222,280 @@ __device__ __noinline__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, co
     return new_tail;
 }
 
+// ------------------------------------------------------------------------------------ job barrier
+// A job (one constraint system) is run by J.nwg co-resident workgroups: workgroup 0 (the "master")
+// executes everything whose order matters (P1, P2, the queue, the decisions of P3, P5, all REQUEUEs);
+// the others join for the row-parallel passes of the whole-system sweeps P3 / P4, the setup and the
+// verdict count. They meet at this barrier: sense-reversing counter, agent-scope release before
+// arriving (writes back this XCD's dirty L2 lines) and agent-scope acquire after leaving (drops
+// stale L1/L2 lines) — per-XCD L2s are not coherent with each other on MI355X. The last arriver
+// snapshots the job's error word, so every workgroup leaves with the SAME view of it and takes the
+// same branch. Spins are bounded.
+__device__ __forceinline__ uint32_t my_xcc_id() {
+    // HW_REG_XCC_ID (hwreg 20), bits [3:0]: which of the 8 XCDs this wave runs on
+    return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
+}
+
+__device__ int job_barrier(const Job& J, int* s_err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Counters* c = J.ctr;
+        if (J.nwg == 1) {
+            *s_err = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // XCD-hierarchical: workgroups of one XCD share its L2, so only the last of them to arrive
+            // (the XCD leader) pays for the agent-scope release (L2 write-back) before arriving at
+            // the top-level counter; everybody waits on one generation word and then drops its stale
+            // L1 lines. The first barrier of a launch is flat and establishes the XCD membership.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my stores have reached my XCD's L2
+            const unsigned g = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool hier = __hip_atomic_load(&c->bar_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            bool arrive_top = true;
+            const unsigned x = my_xcc_id();
+            if (hier) {
+                const unsigned a = __hip_atomic_fetch_add(&c->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a == __hip_atomic_load(&c->xcd_members[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1)
+                    __hip_atomic_store(&c->xcd_count[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else arrive_top = false;
+            } else {
+                __hip_atomic_fetch_add(&c->xcd_members[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (arrive_top) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned expect = hier ? __hip_atomic_load(&c->n_xcd_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : J.nwg;
+                const unsigned arrived = __hip_atomic_fetch_add(&c->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived == expect - 1) {
+                    if (!hier) {
+                        unsigned na = 0;
+                        for (int i = 0; i < 8; ++i)
+                            na += __hip_atomic_load(&c->xcd_members[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        __hip_atomic_store(&c->n_xcd_active, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&c->bar_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const int e = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->error_snap, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&c->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            unsigned spins = 0;
+            while (__hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 27)) { raise(J, K_ECAPACITY); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *s_err = __hip_atomic_load(&c->error_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return *s_err;
+}
+
+// ----------------------------------------------------------------- multi-workgroup queue round
+// Same round as in queue_phase_chunked, but executed by ALL workgroups of the job on a window of up
+// to nwg * 512 * 2 queue entries — for the thousand-row-wide frontiers of large circuits. Global
+// thread g owns ranks g*rpl .. g*rpl + rpl - 1. Cross-workgroup steps use job_barrier (6 per round)
+// and two job-wide scans; everything a lane needs later (its rows, its events) it produced itself,
+// except cand[] / best[] / inq[] / wmark, which are read after a barrier. Returns nonzero on error.
+__device__ uint32_t team_exclusive_scan(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t buf,
+                                        uint32_t* total, int* s_err, int* err_out) {
+    uint32_t wgtot;
+    const uint32_t local = wg_exclusive_scan(x, S.scan, &wgtot);
+    if (threadIdx.x == 0) __hip_atomic_store(&J.ctr->q_part[buf][wgrank], wgtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *err_out = job_barrier(J, s_err);
+    if (threadIdx.x < J.nwg) S.bases[threadIdx.x] = ld_agent(&J.ctr->q_part[buf][threadIdx.x]);
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t i = 0; i < J.nwg; ++i) { const uint32_t v = S.bases[i]; if (i < wgrank) pre += v; tot += v; }
+    __syncthreads();
+    *total = tot;
+    return pre + local;
+}
+
+__device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t head, uint32_t tail,
+                                             uint32_t n, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err,
+                                             uint32_t* out_c, uint32_t* out_tail) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    Counters* const ctr = J.ctr;
+    const uint32_t T = J.nwg * ECNE_WG, g = wgrank * ECNE_WG + tid;
+    const uint32_t rpl = (n + T - 1) / T;               // <= 2 by the caller's choice of n
+    const uint32_t r0 = g * rpl;
+    uint32_t row[2], shape[2], xv[2];
+    uint32_t live = 0, noop = 0, noop_b = 0;
+    int err;
+    unsigned long long mt_last = wall_clock64();
+#define MTICK(slot) do { if (g == 0) { unsigned long long t_ = wall_clock64(); S.mt[slot] += t_ - mt_last; mt_last = t_; } } while (0)
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
+        if (sl < rpl && r0 + sl < n) {
+            row[sl] = J.queue[(head + r0 + sl) & J.qmask];
+            const RowInfo ri = J.rinfo[row[sl]];
+            shape[sl] = ri.shape;
+            xv[sl] = ri.x;
+            if (!J.solved[row[sl]]) live |= 1u << sl;
+        }
+    }
+    if (tid == 0) S.cut = 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- mark (write sets)
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        if (sl >= rpl || r0 + sl >= n) continue;
+        const uint32_t rank = r0 + sl;
+        if (shape[sl] & SH_BIG) { atomicMin(&S.cut, rank); continue; }
+        if (!(live & (1u << sl))) continue;
+        const RowInfo ri = J.rinfo[row[sl]];
+        bool nb = false;
+        if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
+        for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+            if (wr & 1) atomicMin(&J.wmarkU[v], rank);
+            if (wr & 2) atomicMin(&J.wmarkB[v], rank);
+        });
+    }
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(0);
+    // ---- check
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
+        const uint32_t rank = r0 + sl;
+        bool blocked = false;
+        if (noop & (1u << sl)) {
+            if (noop_b & (1u << sl))
+                for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
+                    if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+        } else {
+            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if ((rd | wr) & 1) {
+                    const uint32_t m = ld_agent(&J.wmarkU[v]);
+                    if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                }
+                if ((rd | wr) & 2) {
+                    const uint32_t m = ld_agent(&J.wmarkB[v]);
+                    if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                }
+            });
+        }
+        if (blocked) atomicMin(&S.cut, rank);
+    }
+    // one global update per workgroup (thousands of lanes on one word would serialise)
+    __syncthreads();
+    if (tid == 0 && S.cut != 0xFFFFFFFFu) atomicMin(&ctr->q_cut, S.cut);
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(1);
+    uint32_t c = ld_agent(&ctr->q_cut);         // >= 1 (the master checked that rank 0 is not a big row)
+    if (c > n) c = n;                             // nobody blocked: the whole window commits
+    // ---- unmark, tag, execute my ranks below the cut
+    uint32_t nev[2], mycand = 0;
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        nev[sl] = 0;
+        if (sl >= rpl || r0 + sl >= n) continue;
+        if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
+            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+                if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+            });
+        if (r0 + sl >= c) continue;
+        // rank tags must fit inq's 16 bits: multi rounds tag with the rank's low part plus a flag that
+        // the row is in the current prefix; the exact rank is recovered from prank[] (see below)
+        J.inq[row[sl]] = (uint16_t)2;
+        my_pops++;
+        my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
+        if (live & (1u << sl)) {
+            if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }
+            else exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+        }
+        uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
+        for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+        ev[ECNE_EVCAP - 1] = nev[sl];    // for the sequential replay fallback
+        J.prank[row[sl]] = r0 + sl;      // rank of a row being popped in this round
+    }
+    uint32_t M;
+    const uint32_t cbase = team_exclusive_scan(J, S, wgrank, mycand, 0, &M, s_err, &err);
+    MTICK(2);
+    if (err) return err;
+    if (M > J.candcap) {
+        // a variable with a huge fan-out: the master replays all events sequentially (rare)
+        if (wgrank == 0) {
+            if (w == 0) {
+                QState qq;
+                qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                // event counts live in the executing lanes' registers: recount from the fan-out lists is not
+                // possible, so each rank's count was also stored behind its events (slot ECNE_EVCAP - 1)
+                for (uint32_t r = 0; r < c; ++r) {
+                    const uint32_t rr = J.queue[(head + r) & J.qmask];
+                    if (lane == 0) J.inq[rr] = 0;
+                    wg_fence();
+                    const uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
+                    for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, J.evbuf[(size_t)r * ECNE_EVCAP + e]);
+                }
+                if (lane == 0) { ctr->q_tail_out = qq.tail; ctr->q_c_out = c; ctr->q_cut = 0xFFFFFFFFu; }
+            }
+            __syncthreads();
+        }
+        if ((err = job_barrier(J, s_err))) return err;
+        *out_c = c;
+        *out_tail = ld_agent(&ctr->q_tail_out);
+        return 0;
+    }
+    // ---- expansion of my own events: candidate index = cbase + running offset
+    {
+        if (tid == 0) S.nbigev = 0;
+        __syncthreads();
+        uint32_t j = cbase;
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl) {
+            if (sl >= rpl || r0 + sl >= c) continue;
+            const uint32_t a = r0 + sl;
+            const uint32_t* ev = J.evbuf + (size_t)a * ECNE_EVCAP;
+            for (uint32_t e = 0; e < nev[sl]; ++e) {
+                const uint32_t v = ev[e];
+                expand_event(J, S, v, a, j, true);
+                j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+            }
+        }
+        expand_big_events(J, S, true);
+    }
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(3);
+    // ---- the prefix rows leave the queue (tags no longer needed); then winners in candidate order
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl)
+        if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
+    const uint32_t per = (M + T - 1) / T;
+    const uint32_t j0 = g * per < M ? g * per : M, j1 = (g + 1) * per < M ? (g + 1) * per : M;
+    uint32_t nwin = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t cw = J.cand[j];
+        const uint32_t t = cw & 0x7FFFFFFFu;
+        const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
+        J.cand[j] = t | (win ? 0x80000000u : 0u);
+        nwin += win;
+    }
+    uint32_t W;
+    const uint32_t wbase = team_exclusive_scan(J, S, wgrank, nwin, 1, &W, s_err, &err);
+    MTICK(4);
+    if (err) return err;
+    {
+        uint32_t o = tail + wbase;
+        for (uint32_t j = j0; j < j1; ++j) {
+            const uint32_t cw = J.cand[j];
+            const uint32_t t = cw & 0x7FFFFFFFu;
+            if (cw & 0x80000000u) { J.queue[o & J.qmask] = t; J.inq[t] = 1; ++o; }
+            J.best[t] = 0xFFFFFFFFu;
+        }
+    }
+    if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(5);
+    *out_c = c;
+    *out_tail = tail + W;
+    return 0;
+}
+
 // The whole QUEUE phase (:805-1349), executed by all 1024 threads. q is kept identical in every thread.
 // A round examines up to ECNE_RPL * 1024 queue entries; lane t owns the consecutive ranks
 // t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
@@ -1211,6 +1514,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     uint32_t my_pops = 0, my_nnz = 0;
     unsigned long long pops_total = pops;
     uint32_t round = 0, burst = 0, next_burst = 16, window = ECNE_RPL * ECNE_WG;
+    uint32_t mwindow = 16384;        // window of multi-workgroup rounds (adaptive like `window`)
+    bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
     __syncthreads();
     while (q.head != q.tail) {
         // the error word is polled every 8th round (a raised error only has to stop the solve soon)
@@ -1271,6 +1576,33 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (tid == 0) { S.cut = n; S.fallback = (shape[0] & SH_BIG) ? 1u : 0u; }
         __syncthreads();
         QTICK(0);
+        if (!S.fallback && J.nwg > 1 && avail >= 3072 && window == ECNE_RPL * ECNE_WG) {
+            // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
+            const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+            uint32_t nm = avail < cap_n ? avail : cap_n;
+            if (nm > mwindow) nm = mwindow;
+            if (tid == 0) {
+                J.ctr->q_cmd[1] = q.head; J.ctr->q_cmd[2] = q.tail; J.ctr->q_cmd[3] = nm;
+                __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (job_barrier(J, s_err)) { helpers_released = true; break; }
+            uint32_t cm = 0, ntm = q.tail;
+            if (queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { helpers_released = true; break; }
+            q.head += cm;
+            q.tail = ntm;
+            pops_total += cm;
+            hits[13]++;
+            hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
+            hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
+            if (cm == nm) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
+            else if (cm < nm / 4) {
+                const uint32_t wn = 4 * cm;
+                if (wn >= 4096) mwindow = wn;
+                else { mwindow = 4096; window = wn < 64 ? 64 : (wn < ECNE_RPL * ECNE_WG ? wn : ECNE_RPL * ECNE_WG); }
+            }
+            QTICK(7);
+            continue;
+        }
         if (S.fallback) {
             // a big row at the queue head: popped alone. Wave 0 runs the wave-cooperative rules in emit
             // mode; the whole workgroup then resolves its REQUEUE events in order.
@@ -1412,6 +1744,11 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < 64 ? 64 : wn; }
         else next_burst = 16;
     }
+    // ---- tell the helper workgroups (waiting at the command barrier) that the queue phase is over
+    if (J.nwg > 1 && !helpers_released) {
+        if (tid == 0) __hip_atomic_store(&J.ctr->q_cmd[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        job_barrier(J, s_err);
+    }
     // ---- reduce the per-lane counters
     __syncthreads();
     if (C.steps) atomicAdd(&S.acc[0], (unsigned long long)C.steps);
@@ -1429,44 +1766,26 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------ job barrier
-// A job (one constraint system) is run by J.nwg co-resident workgroups: workgroup 0 (the "master")
-// executes everything whose order matters (P1, P2, the queue, the decisions of P3, P5, all REQUEUEs);
-// the others join for the row-parallel passes of the whole-system sweeps P3 / P4, the setup and the
-// verdict count. They meet at this barrier: sense-reversing counter, agent-scope release before
-// arriving (writes back this XCD's dirty L2 lines) and agent-scope acquire after leaving (drops
-// stale L1/L2 lines) — per-XCD L2s are not coherent with each other on MI355X. The last arriver
-// snapshots the job's error word, so every workgroup leaves with the SAME view of it and takes the
-// same branch. Spins are bounded.
-__device__ int job_barrier(const Job& J, int* s_err) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Counters* c = J.ctr;
-        if (J.nwg == 1) {
-            *s_err = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned g = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned arrived = __hip_atomic_fetch_add(&c->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived == J.nwg - 1) {
-                const int e = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->error_snap, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(&c->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                unsigned spins = 0;
-                while (__hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1u << 27)) { raise(J, K_ECAPACITY); break; }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            *s_err = __hip_atomic_load(&c->error_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+// Queue phase as seen by a helper workgroup: wait for the master's commands, join multi rounds.
+__device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, uint32_t wgrank, int* s_err) {
+    LaneCtr C;
+    C.steps = C.nuniq = 0;
+    for (int i = 0; i < 8; ++i) C.hits[i] = 0;
+    uint32_t my_pops = 0, my_nnz = 0;
+    for (;;) {
+        if (job_barrier(J, s_err)) break;
+        if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
+        const uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
+        uint32_t c, nt;
+        if (queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) break;
     }
-    __syncthreads();
-    return *s_err;
+    Counters* ctr = J.ctr;
+    if (C.steps) atomicAdd(&ctr->q_acc[0], (unsigned long long)C.steps);
+    if (C.nuniq) atomicAdd(&ctr->q_acc[1], (unsigned long long)C.nuniq);
+    for (int i = 0; i < 8; ++i)
+        if (C.hits[i]) atomicAdd(&ctr->q_acc[2 + i], (unsigned long long)C.hits[i]);
+    if (my_pops) atomicAdd(&ctr->q_acc[10], (unsigned long long)my_pops);
+    if (my_nnz) atomicAdd(&ctr->q_acc[11], (unsigned long long)my_nnz);
 }
 
 // ---------------------------------------------------------------------------------------- k_solve
@@ -1487,7 +1806,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     __syncthreads();
     const uint32_t nC = J.nC, nV = J.nV;
     const bool master = me.rank == 0;
-    if (tid < 8) s_chunk.qt[tid] = 0;
+    if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1508,7 +1827,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; }
     for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
     for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
-    if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_fire = 0xFFFFFFFFu; }
+    if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }
     job_barrier(J, &s_err);
     for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
         uint32_t v = J.knowns[i];
@@ -1544,6 +1863,10 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         __syncthreads();
     }
     ECNE_TICK(0);
+    if (J.queue_mode == 7) {   // micro-benchmark hook: 200 back-to-back job barriers, time in phase slot 7
+        for (int i = 0; i < 200; ++i) job_barrier(J, &s_err);
+        ECNE_TICK(7);
+    }
     unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
     unsigned long long hits[16];
     for (int i = 0; i < 16; ++i) hits[i] = 0;
@@ -1613,7 +1936,11 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
             __syncthreads();
             steps = s_steps;
             q = s_q;
-            if (J.queue_mode != 1 && !wg_error(J, &s_err)) {
+            if (J.queue_mode != 1 && wg_error(J, &s_err)) {
+                // P1/P2 raised: the queue phase is skipped, but the helpers are waiting at its command
+                // barrier — meet them there (they leave on the error snapshot)
+                if (J.nwg > 1) job_barrier(J, &s_err);
+            } else if (J.queue_mode != 1) {
                 // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
                 unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
                 for (int i = 0; i < 16; ++i) ht2[i] = 0;
@@ -1622,7 +1949,18 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
             }
         }
+        else if (J.queue_mode != 1) queue_phase_helper(J, s_chunk, me.rank, &s_err);
         if (job_barrier(J, &s_err)) break;      // publishes the queue phase's state changes to the helpers
+        if (master && J.nwg > 1 && J.queue_mode != 1) {
+            // fold in what the helpers did during multi-workgroup rounds
+            steps += ctr->q_acc[0];
+            if (w == 0) {
+                nuniq += ctr->q_acc[1]; pops += ctr->q_acc[10]; pop_nnz += ctr->q_acc[11];
+                for (int i = 0; i < 8; ++i) hits[i] += ctr->q_acc[2 + i];
+            }
+            __syncthreads();
+            if (tid < 16) ctr->q_acc[tid] = 0;
+        }
         ECNE_TICK(1);
 
         // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
@@ -1889,6 +2227,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 ECNE_TICK(5);
                 for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
                 for (int i = 0; i < 8; ++i) ctr->qticks[i] = s_chunk.qt[i];
+                for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
             }
         }
     }

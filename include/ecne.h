@@ -103,6 +103,7 @@ typedef struct ecne_summary {
     double device_ms;        /* HIP-event time of the solve kernels on their stream              */
     double classify_ms;      /* HIP-event time of k_classify_rows                                */
     double queue_ms[8];      /* queue phase breakdown: head, mark, check+unmark, exec, flatten, resolve, big rows */
+    double multi_ms[8];      /* multi-workgroup round breakdown: mark, barriers, check, exec, expand, compact, final */
     double phase_ms[8];      /* in-kernel wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; [6] = P3 rounds (count) */
 } ecne_summary;
 

@@ -55,6 +55,23 @@ def test_secp_without_secp_solve_is_undefvar():
     assert g.status == -4
     with pytest.raises(E.UndefVarError):
         g.raise_for_status()
+    # same with helper workgroups: an error raised before the queue phase must not strand them at a
+    # barrier (regression: a one-barrier mismatch on this path made the helpers spin until their bound)
+    import time
+    t = time.time()
+    g = E.solve_batch([s], secp_solve=False, force_nwg=4)[0]
+    assert g.status == -4 and time.time() - t < 5.0
+
+
+@pytest.mark.parametrize("force_nwg", [2, 5])
+def test_helper_workgroups_do_not_change_results(force_nwg):
+    """multi-workgroup sweeps and multi-workgroup queue rounds on mid-size circuits"""
+    for rel, trusted, names, secp in [("secp256k1.r1cs", [], [], False), TRUSTED_CASES[2],
+                                      ("ecne_circomlib_tests/EdDSAMiMCSpongeVerifier@eddsamimcsponge.r1cs", [], [], False),
+                                      ("bigmultmodp.r1cs", [], [], False), ("poseidon.r1cs", [], [], False)]:
+        g = E.solve_batch([build_system(rel, trusted, names)], secp_solve=secp, force_nwg=force_nwg)[0]
+        o = orc.run(fixtures.path(rel), [fixtures.path(t) for t in trusted], names, secp)
+        assert_bit_exact("%s nwg=%d" % (rel, force_nwg), g, o)
 
 
 def test_config4_suite_as_one_batch():
