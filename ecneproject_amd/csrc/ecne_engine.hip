@@ -343,6 +343,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_inq = c.take(2 * std::max<size_t>(nC, 1)), o_solved = c.take((size_t)nC + 1), o_flip3 = c.take(std::max<size_t>(nC, 1));
     size_t o_queue = c.take(4ull * qcap);
     size_t o_varmin = c.take(4ull * (nV + 1));
+    size_t o_rdead = c.take(std::max<size_t>(nC, 1));
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
@@ -412,6 +413,7 @@ static int upload_system(ecne_system& S, int device) {
     J.inq = (uint16_t*)(base + o_inq); J.solved = (uint8_t*)(base + o_solved); J.flip3 = (uint8_t*)(base + o_flip3);
     J.queue = (uint32_t*)(base + o_queue);
     J.varmin = (uint32_t*)(base + o_varmin);
+    J.rdead = (uint8_t*)(base + o_rdead);
     J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);

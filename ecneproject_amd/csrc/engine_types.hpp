@@ -75,6 +75,7 @@ struct Counters {   // one per job, device memory
     unsigned int n_xcd_active, bar_ready;
     alignas(128) unsigned int pad_after_barrier;
     unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;
+    unsigned int p4_nfired, setup_tail;
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
     unsigned int q_cmd[4];          // mode (0 = queue phase over, 1 = run one multi round), head, tail, n
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
@@ -111,6 +112,7 @@ struct Job {
     uint32_t* queue;
     // scratch
     uint32_t* varmin;
+    uint8_t* rdead;            // row has no non-unique variable left (monotone): the sweeps skip it
     uint8_t* p3k;
     uint64_t *p3h, *p3h2;
     uint64_t *ht_key, *ht_key2;

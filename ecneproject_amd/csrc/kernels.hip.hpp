@@ -1313,6 +1313,13 @@ __device__ uint32_t team_exclusive_scan(const Job& J, ChunkShared& S, uint32_t w
     return pre + local;
 }
 
+// team scan that also works for a single workgroup (no job barrier needed then)
+__device__ uint32_t team_exclusive_scan_any(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t* total,
+                                            int* s_err, int* err_out) {
+    if (J.nwg == 1) { *err_out = 0; return wg_exclusive_scan(x, S.scan, total); }
+    return team_exclusive_scan(J, S, wgrank, x, 0, total, s_err, err_out);
+}
+
 __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t head, uint32_t tail,
                                              uint32_t n, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err,
                                              uint32_t* out_c, uint32_t* out_tail) {
@@ -1824,7 +1831,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         J.wmarkU[v] = 0xFFFFFFFFu;
         J.wmarkB[v] = 0xFFFFFFFFu;
     }
-    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; }
+    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
     for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
     for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
     if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }
@@ -1835,32 +1842,53 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         if (v == 1) { J.nvalues[1] = 1; st256(J.values + 8ull, fp::make(1)); }
     }
     job_barrier(J, &s_err);
-    // initial queue: rows with at most one variable outside known_variables, ascending (:621-627)
+    // initial queue: rows with at most one variable outside known_variables, ascending (:621-627).
+    // Every workgroup owns a contiguous block of rows: count, job-wide scan of the block totals, write.
     QState q;
     q.head = 0; q.tail = 0; q.evout = nullptr; q.nev = 0; q.emit = 0;
-    if (master) {
-        for (uint32_t base = 0; base < nC; base += ECNE_WG) {
-            uint32_t r = base + tid;
-            uint32_t push = 0;
-            if (r < nC) {
-                uint32_t first = 0, cnt = 0;
-                const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
-                const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
-                for (int p = 0; p < 3 && cnt < 2; ++p)
-                    for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
-                        uint32_t v = cl[p][e];
-                        if (!(J.flags[v] & 1)) {
-                            if (cnt == 0) { first = v; cnt = 1; }
-                            else if (v != first) { cnt = 2; break; }
-                        }
+    {
+        const uint32_t per = (nC + J.nwg - 1) / J.nwg;
+        const uint32_t blk0 = me.rank * per < nC ? me.rank * per : nC;
+        const uint32_t blk1 = (me.rank + 1) * per < nC ? (me.rank + 1) * per : nC;
+        auto wants = [&](uint32_t r) -> uint32_t {
+            uint32_t first = 0, cnt = 0;
+            const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
+            const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
+            for (int p = 0; p < 3 && cnt < 2; ++p)
+                for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
+                    uint32_t v = cl[p][e];
+                    if (!(J.flags[v] & 1)) {
+                        if (cnt == 0) { first = v; cnt = 1; }
+                        else if (v != first) { cnt = 2; break; }
                     }
-                push = cnt <= 1;
-            }
-            uint32_t total, off = wg_exclusive_scan(push, s_scan, &total);
-            if (push) { J.queue[(q.tail + off) & J.qmask] = r; J.inq[r] = 1; }
-            q.tail += total;
+                }
+            return cnt <= 1;
+        };
+        uint32_t mine = 0;
+        for (uint32_t r = blk0 + tid; r < blk1; r += ECNE_WG) mine += wants(r);
+        uint32_t total_pushes = 0;
+        int scan_err = 0;
+        uint32_t base = team_exclusive_scan_any(J, s_chunk, me.rank, mine, &total_pushes, &s_err, &scan_err);
+        // base = pushes of all lower workgroups + of lower threads of mine; but rows are interleaved
+        // across my threads, so redo my block in row order with workgroup scans from my block's base
+        uint32_t wg_base = base;
+        {   // subtract my own lower threads' share: block base = value at thread 0
+            if (tid == 0) s_u32[0] = base;
+            __syncthreads();
+            wg_base = s_u32[0];
+            __syncthreads();
         }
-        __syncthreads();
+        uint32_t off_run = wg_base;
+        for (uint32_t b = blk0; b < blk1; b += ECNE_WG) {
+            const uint32_t r = b + tid;
+            const uint32_t push = (r < blk1) ? wants(r) : 0u;
+            uint32_t tot;
+            const uint32_t off = wg_exclusive_scan(push, s_scan, &tot);
+            if (push) { J.queue[(off_run + off) & J.qmask] = r; J.inq[r] = 1; }
+            off_run += tot;
+        }
+        q.tail = total_pushes;
+        (void)scan_err;
     }
     ECNE_TICK(0);
     if (J.queue_mode == 7) {   // micro-benchmark hook: 200 back-to-back job barriers, time in phase slot 7
@@ -1971,8 +1999,10 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 tk[6]++;
                 // phase 1: evaluate rows >= f against the current state
                 for (uint32_t r = f + gtid; r < nC; r += gstride) {
+                    if (J.rdead[r]) continue;          // every variable unique already (p3k[r] stays 0)
                     uint32_t k; uint64_t h, h2;
                     p3_eval(J, r, k, h, h2);
+                    if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
                     if (k == 0xFFFFFFFFu) k = 0;
                     J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
                     J.p3h[r] = h; J.p3h2[r] = h2;
@@ -2130,11 +2160,19 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                     J.abz[b] = (int32_t)ri.kneg;
                     J.flags[b] |= 2;
                     fl = 1;
+                    atomicAdd(&ctr->p4_nfired, 1u);
                 }
                 J.fired[J.p4_list[i]] = fl;
             }
             if (job_barrier(J, &s_err)) break;
-            if (master) {
+            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);
+            if (master && p4_fired == 0) {
+                // nothing tagged in this sweep: only the per-variable minima have to be forgotten
+                for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) J.varmin[J.rinfo[J.p4_list[i]].kpos] = 0xFFFFFFFFu;
+                __syncthreads();
+            }
+            if (master && p4_fired != 0) {
+                if (tid == 0) ctr->p4_nfired = 0;
                 // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
                 if (w == 0 && lane == 0) s_q = q;
                 __syncthreads();
