@@ -118,6 +118,14 @@ def main():
         b_pops = 20 * int(s.pops) + 40 * int(s.pop_nnz)
         b_alg = b_pops + (3 * int(s.outer_iterations) + 1) * b_sweep
         k_ms = sum(dev_ms) / len(dev_ms)
+        # HBM bytes per k_solve launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE /
+        # --pmc WRITE_SIZE, separate runs; summaries under profiles/). Not measurable from inside this process.
+        traffic, traffic_src = None, None
+        tj = os.path.join(HERE, "profiles", "traffic_latest.json")
+        if os.path.exists(tj) and args.S == 26 and args.stride == 10 and world == 1:
+            with open(tj) as f:
+                t = json.load(f)
+            traffic, traffic_src = t.get("k_solve_bytes_per_launch"), t.get("source")
         achieved = b_alg / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "constraints resolved/sec (wall-clock to fixed point), ecdsa-scale R1CS",
@@ -134,7 +142,7 @@ def main():
                        "classify_kernel": {"ms": classify_ms, "bytes": classify_bytes,
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6}},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": b_alg, "kernel_ms": k_ms,
                          "phase_ms": {k: round(v, 3) for k, v in zip(["setup", "queue", "P3", "P4", "P5", "verdict", "P3_rounds"], list(s.phase_ms)[:7])},
                          "note": "fixed point is dependency-depth bound; see DESIGN.md"},

@@ -1145,6 +1145,7 @@ __device__ __forceinline__ void expand_big_events(const Job& J, ChunkShared& S, 
 __device__ __noinline__ uint32_t resolve_pushes(const Job& J, ChunkShared& S, const uint32_t* fvar, bool ranks, uint32_t N,
                                    long long head, uint32_t nranks, uint32_t tail, unsigned long long* n_fallback) {
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if (N == 0) return tail;   // uniform: nothing was emitted
     // candidate base of every event = exclusive scan of the fan-out sizes
     uint32_t M = 0;
     for (uint32_t eb = 0; eb < N; eb += ECNE_WG) {
