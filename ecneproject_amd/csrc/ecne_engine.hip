@@ -42,7 +42,7 @@ struct Layout {
     std::vector<uint8_t> sp_kind;
     std::vector<uint32_t> knowns, targets;
     std::vector<uint8_t> nontrivial;
-    std::vector<uint32_t> p4_list, p5_rows, p5_y;
+    std::vector<uint32_t> p4_list, p5_rows, p5_y, cls_list;
     uint64_t nnz[3] = {0, 0, 0};
     uint64_t stream_bytes = 0;   // bytes k_classify_rows reads + writes (roofline numerator)
 };
@@ -225,6 +225,7 @@ static void build_layout(ecne_system& S) {
             L.n_vals += 2;
         }
         L.rinfo[i] = ri;
+        if (nCc > 8) L.cls_list.push_back((uint32_t)i);
         // A-map equality with the next row, zeros included (:1512)
         if (i + 1 < nC) {
             const uint64_t x0 = R.ptr[0][i], x1 = R.ptr[0][i + 1], y0 = R.ptr[0][i + 1], y1 = R.ptr[0][i + 2];
@@ -335,6 +336,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_knowns = c.take(4ull * std::max<size_t>(L.knowns.size(), 1)), o_targets = c.take(4ull * std::max<size_t>(L.targets.size(), 1));
     size_t o_nontriv = c.take((size_t)nV + 1);
     size_t o_p4 = c.take(4ull * std::max<size_t>(L.p4_list.size(), 1));
+    size_t o_cls = c.take(4ull * std::max<size_t>(L.cls_list.size(), 1));
     size_t o_p5r = c.take(4ull * std::max<size_t>(L.p5_rows.size(), 1)), o_p5y = c.take(4ull * std::max<size_t>(L.p5_y.size(), 1));
     const size_t static_end = c.off;
     size_t o_flags = c.take((size_t)nV + 1), o_abz = c.take(4ull * (nV + 1));
@@ -385,6 +387,7 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
     HIP_TRY(up(o_nontriv, L.nontrivial.data(), L.nontrivial.size()));
     HIP_TRY(up(o_p4, L.p4_list.data(), 4ull * L.p4_list.size()));
+    HIP_TRY(up(o_cls, L.cls_list.data(), 4ull * L.cls_list.size()));
     HIP_TRY(up(o_p5r, L.p5_rows.data(), 4ull * L.p5_rows.size()));
     HIP_TRY(up(o_p5y, L.p5_y.data(), 4ull * L.p5_y.size()));
     Job& J = S.dev.job;
@@ -406,6 +409,8 @@ static int upload_system(ecne_system& S, int device) {
     J.knowns = (const uint32_t*)(base + o_knowns); J.targets = (const uint32_t*)(base + o_targets);
     J.nontrivial = (const uint8_t*)(base + o_nontriv);
     J.p4_list = (const uint32_t*)(base + o_p4);
+    J.cls_list = (const uint32_t*)(base + o_cls);
+    J.nBigCls = (uint32_t)L.cls_list.size();
     J.p5_rows = (const uint32_t*)(base + o_p5r); J.p5_y = (const uint32_t*)(base + o_p5y);
     J.flags = (uint8_t*)(base + o_flags); J.abz = (int32_t*)(base + o_abz);
     J.lb = (uint64_t*)(base + o_lb); J.ub = (uint64_t*)(base + o_ub);
@@ -435,11 +440,14 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    uint32_t nblk = (S.L.nC + 3) / 4;
-    if (nblk > 256 * 32) nblk = 256 * 32;   // >> 256 workgroups: fills all 8 XCDs, grid-strides the rest
-    if (nblk == 0) nblk = 1;
+    uint32_t nblk0 = (S.L.nC + 255) / 256;
+    if (nblk0 > 256 * 16) nblk0 = 256 * 16;   // >> 256 workgroups: fills all 8 XCDs, grid-strides the rest
+    if (nblk0 == 0) nblk0 = 1;
+    uint32_t nblk1 = ((uint32_t)S.L.cls_list.size() + 3) / 4;
+    if (nblk1 > 256 * 16) nblk1 = 256 * 16;
     HIP_TRY(hipEventRecord(e0, stream));
-    hipLaunchKernelGGL(k_classify_rows, dim3(nblk), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
+    hipLaunchKernelGGL(k_classify_rows, dim3(nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, 0u);
+    if (nblk1) hipLaunchKernelGGL(k_classify_rows, dim3(nblk1), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, 1u);
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());

@@ -86,7 +86,7 @@ struct Counters {   // one per job, device memory
 struct Job {
     // sizes
     uint32_t nC, nV, nSp, nKnown, nTarget, nP4, nP5, qmask, htmask, secp_solve, queue_mode, hotcap;
-    uint32_t nwg, pad_;   // workgroups cooperating on this job (1 = the master alone)
+    uint32_t nwg, nBigCls;   // nBigCls: rows with more than 8 entries in C (classified one wavefront each)   // workgroups cooperating on this job (1 = the master alone)
     // static system
     const uint32_t *rpA, *rpB, *rpC;
     const uint32_t *colA, *colB, *colC;
@@ -100,6 +100,7 @@ struct Job {
     const uint32_t *knowns, *targets;
     const uint8_t* nontrivial;
     const uint32_t* p4_list;
+    const uint32_t* cls_list;   // rows with lenC > 8, ascending
     const uint32_t *p5_rows, *p5_y;
     // mutable state
     uint8_t* flags;

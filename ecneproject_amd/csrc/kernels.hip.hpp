@@ -208,6 +208,26 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
         // A T2-only row has been negated by R4 before R7 first looks at it.
         {
             const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            // long sum rows usually carry one |coefficient| (all +-1): the stable order is then the stored one
+            bool all_same = true;
+            {
+                fp::u256 first = ld256(J.coefC + 4ull * c0);
+                if (negated) first = fp::neg(first);
+                first = r7_abs(first);
+                for (uint32_t base = c0; base < c1 && all_same; base += 64) {
+                    uint32_t k = base + lane;
+                    bool diff = false;
+                    if (k < c1) {
+                        fp::u256 c = ld256(J.coefC + 4ull * k);
+                        if (negated) c = fp::neg(c);
+                        diff = !fp::eq(r7_abs(c), first);
+                    }
+                    if (__ballot(diff)) all_same = false;
+                }
+            }
+            if (all_same)
+                for (uint32_t k = c0 + lane; k < c1; k += 64) J.csort[k] = k - c0;
+            else
             for (uint32_t base = c0; base < c1; base += 64) {
                 uint32_t k = base + lane;
                 bool act = k < c1;
@@ -247,14 +267,110 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
     }
 }
 
-__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index) {
+// Rows with at most ECNE_CLS_LANE entries in C (almost all of them) are classified by ONE lane each:
+// 64 rows per wavefront, so the field inversions of bit-check / single-variable rows run on full
+// SIMDs instead of one lane of a wave. Same results as classify_row, written serially.
+#define ECNE_CLS_LANE 8
+__device__ void classify_row_lane(const Job& J, uint32_t row) {
+    RowInfo ri = J.rinfo[row];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t l = c1 - c0;
+    uint32_t shape = ri.shape;
+    if ((shape & SH_R2) && !(shape & SH_R2_DIV0)) {
+        fp::u256 val[2];
+        for (int part = 0; part < 2; ++part) {
+            const uint32_t* rp = part == 0 ? J.rpA : J.rpB;
+            const uint32_t* col = part == 0 ? J.colA : J.colB;
+            const uint64_t* cf = part == 0 ? J.coefA : J.coefB;
+            fp::u256 slope = fp::make(0), icpt = fp::make(0);
+            for (uint32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                uint32_t v = col[k];
+                fp::u256 c = ld256(cf + 4ull * k);
+                if (v == ri.x) slope = c;
+                else if (v == 1) icpt = c;
+            }
+            val[part] = fp::mul(fp::neg(icpt), fp::inv(slope));
+            st256(J.vals + 4ull * (ri.validx + part), val[part]);
+        }
+        if ((fp::is_zero(val[0]) && fp::is_one(val[1])) || (fp::is_one(val[0]) && fp::is_zero(val[1]))) shape |= SH_R2_IS01;
+    }
+    if (!(shape & SH_HAS_AB) && l > 0) {
+        if (shape & SH_R3) {
+            fp::u256 c1v = fp::make(0), cx = fp::make(0);
+            for (uint32_t k = c0; k < c1; ++k) {
+                uint32_t v = J.colC[k];
+                if (v == 1) c1v = ld256(J.coefC + 4ull * k);
+                else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
+            }
+            st256(J.vals + 4ull * ri.validx, fp::mul(fp::neg(c1v), fp::inv(cx)));
+        }
+        fp::u256 key[ECNE_CLS_LANE];
+        if (!(shape & SH_CZERO)) {
+            uint32_t n_one = 0, n_mone = 0, kpos = 0, kneg = 0;
+            uint32_t maskT = 0, maskT2 = 0;     // exponents seen (l <= 8: exponents 0..6)
+            bool okT = true, okT2 = true;
+            for (uint32_t k = c0; k < c1; ++k) {
+                const fp::u256 c = ld256(J.coefC + 4ull * k);
+                const fp::u256 nc = fp::neg(c);
+                const bool one = fp::is_one(c), mone = fp::is_one(nc);
+                if (one) { ++n_one; if (n_one == 1) kpos = J.colC[k]; }
+                if (mone) { ++n_mone; if (n_mone == 1) kneg = J.colC[k]; }
+                if (!one) {
+                    int e = (popc256(nc) == 1) ? ctz256(nc) : 999;
+                    if (e > (int)l - 2 || (maskT >> e & 1)) okT = false; else maskT |= 1u << e;
+                }
+                if (!mone) {
+                    int e = (popc256(c) == 1) ? ctz256(c) : 999;
+                    if (e > (int)l - 2 || (maskT2 >> e & 1)) okT2 = false; else maskT2 |= 1u << e;
+                }
+            }
+            const bool isT = okT && n_one == 1, isT2 = okT2 && n_mone == 1;
+            if (isT) shape |= SH_R4_T;
+            if (isT2) shape |= SH_R4_T2;
+            if (isT || isT2) {
+                ri.kpos = kpos;
+                ri.kneg = kneg;
+                fp::u256 pw = fp::make(1);
+                for (uint32_t s = 0; s + 1 < l; ++s) pw = fp::add(pw, pw);
+                st256(J.vals + 4ull * (ri.validx + 1), fp::sub(pw, fp::make(1)));
+            }
+        }
+        // R7 order: stable insertion sort of the (at most 8) entries by |signed coefficient|
+        {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            uint32_t idx[ECNE_CLS_LANE];
+            for (uint32_t k = 0; k < l; ++k) {
+                fp::u256 c = ld256(J.coefC + 4ull * (c0 + k));
+                if (negated) c = fp::neg(c);
+                c = r7_abs(c);
+                uint32_t pos = k;
+                while (pos > 0 && fp::cmp(key[pos - 1], c) > 0) { key[pos] = key[pos - 1]; idx[pos] = idx[pos - 1]; --pos; }
+                key[pos] = c;
+                idx[pos] = k;
+            }
+            for (uint32_t k = 0; k < l; ++k) J.csort[c0 + k] = idx[k];
+            shape |= SH_R7_SORTED;
+        }
+    }
+    if ((shape & SH_C_HAS1) && (shape & (SH_R4_T | SH_R4_T2 | SH_R5))) shape |= SH_TOUCH1;
+    ri.shape = shape;
+    J.rinfo[row] = ri;
+}
+
+// pass 0: one lane per row for rows with lenC <= ECNE_CLS_LANE; pass 1: one wavefront per remaining row
+__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index, uint32_t pass) {
     __shared__ uint32_t scratch[4][16];
     __shared__ Job sJ;
     if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
     __syncthreads();
+    if (pass == 0) {
+        for (uint32_t row = blockIdx.x * 256 + threadIdx.x; row < sJ.nC; row += gridDim.x * 256)
+            if (sJ.rinfo[row].lenC <= ECNE_CLS_LANE) classify_row_lane(sJ, row);
+        return;
+    }
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t nw = gridDim.x * 4;
-    for (uint32_t row = blockIdx.x * 4 + wave; row < sJ.nC; row += nw) classify_row(sJ, row, scratch[wave]);
+    // the long rows are listed by the host (big_list): one wavefront each
+    for (uint32_t i = blockIdx.x * 4 + wave; i < sJ.nBigCls; i += gridDim.x * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
 }
 
 // ====================================================================================== solver
