@@ -466,6 +466,12 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
     const uint32_t shape = ri.shape;
 
+    // Long rows (popped alone) are walked once: the R1 pass also gathers the statistics R7 / R8 need,
+    // valid as long as no rule in between changes the state (R1 / R3..R6 firing invalidates them).
+    const bool fuse = (c1 - c0) > ECNE_SMALL_ROW;
+    bool st_valid = false, st_notknown = false, st_badgroup = false;
+    uint32_t st_cnt = 0;
+    int st_group = -2;
     // R1 check_unique (:827-873)
     {
         bool nu = false;
@@ -477,18 +483,30 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
                 uint32_t k = base + lane;
                 bool act = k < c1;
                 uint32_t v = act ? J.colC[k] : 0;
-                bool x = act && !(J.flags[v] & 1);
+                const uint8_t f = act ? J.flags[v] : 1;
+                bool x = act && !(f & 1);
                 uint64_t m = __ballot(x);
                 if (m && cnt == 0) u = __shfl(v, __ffsll((long long)m) - 1, 64);
                 cnt += (uint32_t)__popcll(m);
+                if (fuse && m) {
+                    // the same walk also collects what R7 and R8 ask of C's non-unique variables
+                    if (x && !(f & 2)) st_notknown = true;
+                    int a = x ? J.abz[v] : -1;
+                    if (st_group == -2) st_group = __shfl(a, __ffsll((long long)m) - 1, 64);
+                    if (x && (a == -1 || a != st_group)) st_badgroup = true;
+                }
             }
+            st_cnt = cnt;
+            st_valid = fuse;
             if (cnt == 1) {
                 mark_unique(J, u);
                 nuniq++; steps++; hits[0]++;
                 requeue(J, q, u);
+                st_valid = false;
             }
         }
     }
+    const unsigned long long steps_at_r1 = steps, nuniq_at_r1 = nuniq;
     // R2 check_quadratic (:875-942)
     if (shape & SH_C_EMPTY) {
         if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
@@ -629,9 +647,14 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
         }
     }
     // R7 checkModularArithmetic (:1235-1298)
+    // (statistics from the R1 walk stay valid only if nothing fired since: R3..R6 always count a step
+    //  or a new unique variable when they change anything, except R4's flip byte which no rule reads)
+    if (st_valid && (steps != steps_at_r1 || nuniq != nuniq_at_r1)) st_valid = false;
     if (l > 0) {
         uint32_t nunk = 0;
         bool notknown = false;
+        if (st_valid) { nunk = st_cnt; notknown = st_notknown; }
+        else
         for (uint32_t base = c0; base < c1; base += 64) {
             uint32_t k = base + lane;
             bool act = k < c1;
@@ -698,6 +721,8 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
         int group = -1;
         bool bad = false;
         uint32_t cnt = 0;
+        if (st_valid && steps == steps_at_r1 && nuniq == nuniq_at_r1) { cnt = st_cnt; bad = st_badgroup; }
+        else
         for (uint32_t base = c0; base < c1; base += 64) {
             uint32_t k = base + lane;
             bool act = k < c1;
