@@ -466,9 +466,9 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
     const uint32_t shape = ri.shape;
 
-    // Long rows (popped alone) are walked once: the R1 pass also gathers the statistics R7 / R8 need,
+    // C is walked once: the R1 pass also gathers the statistics R7 / R8 need,
     // valid as long as no rule in between changes the state (R1 / R3..R6 firing invalidates them).
-    const bool fuse = (c1 - c0) > ECNE_SMALL_ROW;
+    const bool fuse = true;
     bool st_valid = false, st_notknown = false, st_badgroup = false;
     uint32_t st_cnt = 0;
     int st_group = -2;
@@ -928,6 +928,9 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
     const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
     const uint32_t shape = ri.shape;
+    bool st_valid = false, st_notknown = false, st_badgroup = false;
+    uint32_t st_cnt = 0;
+    int st_group = -2;
     // R1 (:827-873)
     {
         bool nu = false;
@@ -935,17 +938,32 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
         for (uint32_t k = b0; k < b1 && !nu; ++k) nu = !(J.flags[J.colB[k]] & 1);
         if (!nu) {
             uint32_t cnt = 0, u = 0;
-            for (uint32_t k = c0; k < c1 && cnt < 2; ++k) {
+            const bool lin = !(shape & SH_HAS_AB);
+            for (uint32_t k = c0; k < c1 && (lin || cnt < 2); ++k) {
                 uint32_t v = J.colC[k];
-                if (!(J.flags[v] & 1)) { if (cnt == 0) u = v; ++cnt; }
+                const uint8_t f = J.flags[v];
+                if (!(f & 1)) {
+                    if (cnt == 0) u = v;
+                    ++cnt;
+                    if (lin) {   // the same walk collects what R7 and R8 ask of C's non-unique variables
+                        if (!(f & 2)) st_notknown = true;
+                        const int a = J.abz[v];
+                        if (st_group == -2) st_group = a;
+                        if (a == -1 || a != st_group) st_badgroup = true;
+                    }
+                }
             }
+            st_cnt = cnt;
+            st_valid = lin;
             if (cnt == 1) {
                 J.flags[u] |= 3;
                 C.nuniq++; C.steps++; C.hits[0]++;
                 ev[nev++] = u;
+                st_valid = false;
             }
         }
     }
+    const uint32_t steps_at_r1 = C.steps, nuniq_at_r1 = C.nuniq;
     // R2 (:875-942)
     if (shape & SH_C_EMPTY) {
         if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
@@ -1072,6 +1090,9 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
     if (l > 0) {
         uint32_t nunk = 0;
         bool notknown = false;
+        if (st_valid && (C.steps != steps_at_r1 || C.nuniq != nuniq_at_r1)) st_valid = false;   // something fired since R1
+        if (st_valid) { nunk = st_cnt; notknown = st_notknown; }
+        else
         for (uint32_t k = c0; k < c1; ++k) {
             uint8_t f = J.flags[J.colC[k]];
             if (!(f & 1)) { ++nunk; if (!(f & 2)) notknown = true; }
@@ -1122,6 +1143,8 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
         int group = -1;
         bool bad = false;
         uint32_t cnt = 0;
+        if (st_valid && C.steps == steps_at_r1 && C.nuniq == nuniq_at_r1) { cnt = st_cnt; bad = st_badgroup; }
+        else
         for (uint32_t k = c0; k < c1 && !bad; ++k) {
             uint32_t v = J.colC[k];
             if (J.flags[v] & 1) continue;
