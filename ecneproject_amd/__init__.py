@@ -157,6 +157,17 @@ class System:
     def __len__(self):
         return int(self.info.n_rows)
 
+    def rows(self, part):
+        """(rowptr, col, coeff[nnz,4]) of part 0/1/2 in the reference's nonzeroKeys order; copies."""
+        rp, col, cf = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)()
+        _check(_lib.lib().ecne_system_rows(self._h, part, C.byref(rp), C.byref(col), C.byref(cf)))
+        n = len(self)
+        rowptr = np.ctypeslib.as_array(rp, (n + 1,)).copy()
+        nnz = int(rowptr[-1])
+        c = np.ctypeslib.as_array(col, (max(nnz, 1),))[:nnz].copy()
+        v = np.ctypeslib.as_array(cf, (max(nnz, 1) * 4,))[:nnz * 4].reshape(nnz, 4).copy()
+        return rowptr, c, v
+
 
 class SolveResult:
     """Outcome of one solve. With fetch_states=False only the summary (verdict + counts) is read

@@ -41,7 +41,7 @@ class Summary(C.Structure):
 EXPORTS = [
     "ecne_r1cs_load", "ecne_r1cs_info", "ecne_r1cs_csr", "ecne_r1cs_io", "ecne_r1cs_free",
     "ecne_system_from_r1cs", "ecne_abstract", "ecne_system_info_get", "ecne_system_special",
-    "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_states",
+    "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_states",
     "ecne_result_bad_rows", "ecne_result_free", "ecne_classify", "ecne_fp_selftest", "ecne_fp_sqrt",
     "ecne_device_count", "ecne_strerror", "ecne_version",
 ]
@@ -71,6 +71,8 @@ def lib():
     L.ecne_system_info_get.argtypes = [vp, C.POINTER(SystemInfo)]
     L.ecne_system_special.argtypes = [vp, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(i64p), C.POINTER(C.c_size_t),
                                       C.POINTER(i64p), C.POINTER(C.c_size_t)]
+    L.ecne_system_rows.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)),
+                                   C.POINTER(C.POINTER(C.c_uint64))]
     L.ecne_system_free.argtypes = [vp]
     L.ecne_system_free.restype = None
     L.ecne_solve.argtypes = [vp, C.POINTER(Opts), C.POINTER(vp)]

@@ -579,6 +579,14 @@ int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, 
     if (nout) *nout = sp.outputs.size();
     return ECNE_OK;
 }
+int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
+    if (!sys || part < 0 || part > 2) return ECNE_EINVAL;
+    if (!sys->laid_out) build_layout(*sys);
+    if (rowptr) *rowptr = sys->L.rp[part].data();
+    if (col) *col = sys->L.col[part].data();
+    if (coeff) *coeff = sys->L.coef[part].data();
+    return ECNE_OK;
+}
 void ecne_system_free(ecne_system* sys) { delete sys; }
 
 int ecne_device_count(void) {

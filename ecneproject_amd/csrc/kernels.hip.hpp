@@ -2056,10 +2056,6 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         (void)scan_err;
     }
     ECNE_TICK(0);
-    if (J.queue_mode == 7) {   // micro-benchmark hook: 200 back-to-back job barriers, time in phase slot 7
-        for (int i = 0; i < 200; ++i) job_barrier(J, &s_err);
-        ECNE_TICK(7);
-    }
     unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
     unsigned long long hits[16];
     for (int i = 0; i < 16; ++i) hits[i] = 0;
@@ -2361,11 +2357,6 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
                 {
                     uint32_t tl = q.tail;
-                    if (J.queue_mode == 3) {
-                        if (w == 0) { requeue_events(J, q, J.events, nev); if (lane == 0) s_q = q; }
-                        __syncthreads();
-                        tl = s_q.tail;
-                    } else
                     for (uint32_t eb = 0; eb < nev; eb += 4096) {
                         const uint32_t cnt = (nev - eb) < 4096u ? (nev - eb) : 4096u;
                         tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &hits[15]);

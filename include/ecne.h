@@ -81,13 +81,18 @@ int ecne_system_info_get(const ecne_system* sys, ecne_system_info* out);
 /* special constraint idx: name and mapped input / output variable lists (borrowed) */
 int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, const int64_t** inputs,
                         size_t* n_inputs, const int64_t** outputs, size_t* n_outputs);
+/* CSR of the rows handed to the solver, part 0/1/2, non-zero terms only, each row part in the order the
+ * reference iterates nonzeroKeys(part) (a Julia Set): what printEquation (:431-456) walks when it
+ * renders a constraint. Borrowed pointers, valid until the system is freed or abstracted again. */
+int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff);
 void ecne_system_free(ecne_system* sys);
 
 typedef struct ecne_opts {
     int32_t device;      /* HIP device ordinal                                                       */
     int32_t secp_solve;  /* kwarg secp_solve (:511): defines `dsu`, required when P2 has work (:762)  */
     int32_t debug;       /* test hook: > 0 forces that many cooperating workgroups per system        */
-    int32_t queue_mode;  /* 0 = default schedule; 1 = force strictly sequential pops (debug/parity)  */
+    int32_t queue_mode;  /* 0 = default (chunk-parallel) schedule; 1 = strictly sequential pops on one
+                            wavefront: the reference's schedule verbatim, for debugging and parity   */
     void* stream;        /* hipStream_t to launch on, or NULL for the device's default stream         */
 } ecne_opts;
 
