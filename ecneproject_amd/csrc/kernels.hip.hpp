@@ -1266,6 +1266,85 @@ struct ChunkShared {   // LDS of the chunked queue phase
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
 
+// A big row (> ECNE_SMALL_ROW entries) popped alone, executed by the whole workgroup instead of one
+// wavefront: a 1 025-term sum row costs 2-3 dependent memory round trips instead of 17. Covers the shapes
+// long rows have in practice -- R1 on any row with a non-empty C, and R8 / "nothing fires" on a plain
+// linear sum -- with the same statistics exec_row() gathers in its fused R1 walk. Returns false, having
+// written nothing, when the row may need another rule (R2..R6 shapes, or R7's precondition holds); the
+// caller then runs exec_row() on one wavefront. REQUEUE events go to ev[] in the reference's order.
+__device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint32_t row, uint32_t* ev, uint32_t* nev_out) {
+    const int tid = threadIdx.x;
+    const uint32_t shape = J.rinfo[row].shape;
+    if (shape & (SH_C_EMPTY | SH_R2 | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6)) return false;   // uniform
+    const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1];
+    const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t l = c1 - c0;
+    uint32_t* sh = S.bases;   // [0] A/B non-unique, [1] count, [2] the variable, [3] not-known, [4] min tag, [5] max tag
+    if (tid == 0) { sh[0] = 0; sh[1] = 0; sh[2] = 0; sh[3] = 0; sh[4] = 0xFFFFFFFFu; sh[5] = 0; }
+    __syncthreads();
+    bool nuab = false;
+    for (uint32_t k = a0 + tid; k < a1; k += ECNE_WG) nuab |= !(J.flags[J.colA[k]] & 1);
+    for (uint32_t k = b0 + tid; k < b1; k += ECNE_WG) nuab |= !(J.flags[J.colB[k]] & 1);
+    // C in contiguous blocks per thread, so that a thread's events are contiguous in row order
+    const uint32_t per = (l + ECNE_WG - 1) / ECNE_WG;
+    const uint32_t k0 = c0 + ((uint32_t)tid * per < l ? (uint32_t)tid * per : l);
+    const uint32_t k1 = c0 + (((uint32_t)tid + 1) * per < l ? ((uint32_t)tid + 1) * per : l);
+    uint32_t cnt = 0, u = 0, amin = 0xFFFFFFFFu, amax = 0;
+    bool notknown = false;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t v = J.colC[k];
+        const uint8_t f = J.flags[v];
+        if (f & 1) continue;
+        if (!cnt) u = v;
+        ++cnt;
+        if (!(f & 2)) notknown = true;
+        const uint32_t a = (uint32_t)J.abz[v];   // -1 (no group) is the largest value
+        amin = a < amin ? a : amin;
+        amax = a > amax ? a : amax;
+    }
+    if (nuab) sh[0] = 1;
+    if (cnt) {
+        atomicAdd(&sh[1], cnt);
+        sh[2] = u;                    // only read when the total is 1
+        if (notknown) sh[3] = 1;
+        atomicMin(&sh[4], amin);
+        atomicMax(&sh[5], amax);
+    }
+    __syncthreads();
+    const uint32_t tot = sh[1];
+    const bool ab_unique = sh[0] == 0, any_notknown = sh[3] != 0;
+    const bool badgroup = sh[4] != sh[5] || sh[5] == 0xFFFFFFFFu;
+    const uint32_t the_u = sh[2];
+    __syncthreads();                  // sh[] is free again (S.bases is scratch of the scans below)
+    uint32_t nev = 0;
+    if (ab_unique && tot == 1) {      // R1 (:827-873); nothing is left for R7 / R8 afterwards
+        if (tid == 0) {
+            J.flags[the_u] |= 3;
+            ev[0] = the_u;
+            S.acc[0] += 1; S.acc[1] += 1; S.acc[2 + 0] += 1;
+        }
+        nev = 1;
+    } else if (!(shape & SH_HAS_AB) && tot > 0) {
+        if (!any_notknown) return false;          // R7's precondition (:1235-1298): the wavefront path decides
+        if (!badgroup) {                          // R8 (:1304-1348): every non-unique variable, in row order
+            uint32_t total;
+            uint32_t o = wg_exclusive_scan(cnt, S.scan, &total);
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t v = J.colC[k];
+                if (J.flags[v] & 1) continue;
+                J.flags[v] |= 3;
+                ev[o++] = v;
+            }
+            if (tid == 0) { S.acc[0] += tot; S.acc[1] += tot; S.acc[2 + 7] += 1; }
+            nev = tot;
+        }
+    }
+    if (tid == 0) *nev_out = nev;
+    __syncthreads();
+    return true;
+}
+
 // one push candidate: event of rank a wants to push row t as candidate j (see resolve_pushes)
 __device__ __forceinline__ void expand_candidate(const Job& J, uint32_t t, uint32_t j, uint32_t a, bool multi) {
     const uint32_t st = J.inq[t];
@@ -1778,27 +1857,33 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (S.fallback) {
             // a big row at the queue head: popped alone. Wave 0 runs the wave-cooperative rules in emit
             // mode; the whole workgroup then resolves its REQUEUE events in order.
-            if (w == 0) {
-                const uint32_t rr = __shfl(row[0], 0, 64);
+            const uint32_t brow = J.queue[q.head & J.qmask];
+            if (tid == 0) {
+                J.inq[brow] = 2;                       // being popped at rank 0
+                S.acc[10] += 1;
+                S.acc[11] += (J.rpA[brow + 1] - J.rpA[brow]) + (J.rpB[brow + 1] - J.rpB[brow]) + (J.rpC[brow + 1] - J.rpC[brow]);
+                S.nbig = 0;
+            }
+            __syncthreads();
+            if (J.solved[brow] || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig)) {
+                // done by the whole workgroup (or an already solved row: the pop is all that happens)
+            } else if (w == 0) {
+                const uint32_t rr = brow;
                 QState qq;
                 qq.head = q.head + 1; qq.tail = q.tail; qq.evout = J.bigev; qq.nev = 0; qq.emit = 1;
-                if (lane == 0) J.inq[rr] = 2;          // being popped at rank 0
-                wg_fence();
                 unsigned long long st = 0, nu = 0, ht[16];
                 for (int i = 0; i < 16; ++i) ht[i] = 0;
-                if (!J.solved[rr]) exec_row(J, qq, rr, ht, st, nu);
+                exec_row(J, qq, rr, ht, st, nu);
                 if (lane == 0) {
                     S.acc[0] += st; S.acc[1] += nu;
                     for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
-                    S.acc[10] += 1;
-                    S.acc[11] += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
                     S.nbig = qq.nev;
                 }
             }
             __syncthreads();
             {
                 const uint32_t nt = resolve_pushes(J, S, J.bigev, false, S.nbig, (long long)q.head, 1, q.tail, &hits[15]);
-                if (tid == 0 && J.inq[row[0]] >= 2) J.inq[row[0]] = 0;
+                if (tid == 0 && J.inq[brow] >= 2) J.inq[brow] = 0;
                 q.head += 1;
                 q.tail = nt;
             }
