@@ -18,6 +18,7 @@
 namespace ecne {
 
 #define ECNE_SMALL_ROW 64   // rows with more entries than this are popped alone (wave-cooperative path)
+#define ECNE_BIGTAB 2048    // big rows with an LDS slot for their push candidates (the rest use memory atomics directly)
 #define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
 #define ECNE_CANDCAP 65536  // push candidates resolved in parallel per round; beyond: sequential fallback
 
@@ -113,6 +114,9 @@ struct Job {
     uint32_t* queue;
     // scratch
     uint32_t* varmin;
+    const uint16_t* tbig;      // per row: 0, or 1 + index into bigrows[] (rows with > ECNE_SMALL_ROW entries, first ECNE_BIGTAB of them)
+    const uint32_t* bigrows;
+    uint32_t nBigRows;
     uint8_t* rdead;            // row has no non-unique variable left (monotone): the sweeps skip it
     uint8_t* p3k;
     uint64_t *p3h, *p3h2;

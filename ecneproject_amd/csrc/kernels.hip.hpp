@@ -456,6 +456,35 @@ __device__ __noinline__ uint32_t uniq_range_and_requeue(const Job& J, QState& q,
     return n;
 }
 
+// R7 (:1257-1272): entry k follows entry prev_k among the row's non-unique variables in sorted-|coefficient|
+// order. The link holds when |c_k| is a multiple of |c_prev| and the ratio exceeds the range of prev's variable.
+__device__ __noinline__ bool r7_link_fails(const Job& J, uint32_t k, uint32_t prev_k, bool negated) {
+    fp::u256 cn = ld256(J.coefC + 4ull * k), cc = ld256(J.coefC + 4ull * prev_k);
+    if (negated) { cn = fp::neg(cn); cc = fp::neg(cc); }
+    cn = r7_abs(cn); cc = r7_abs(cc);
+    fp::u256 qq, rem;
+    fp::divmod(cn, cc, qq, rem);
+    if (!fp::is_zero(rem)) return true;
+    const uint32_t pv = J.colC[prev_k];
+    const fp::u256 ub = ld256(J.ub + 4ull * pv), lb = ld256(J.lb + 4ull * pv);
+    if (fp::cmp(ub, lb) >= 0) {
+        fp::u256 diff;
+        fp::sub_raw(diff, ub, lb);
+        if (fp::cmp(qq, diff) <= 0) return true;
+    }
+    return false;
+}
+// R7's closing test (:1274): |c_last| * (ub(last) + 1) <= p
+__device__ __noinline__ bool r7_top_fits(const Job& J, uint32_t last_k, bool negated) {
+    const uint32_t lv = J.colC[last_k];
+    fp::u256 cl = ld256(J.coefC + 4ull * last_k);
+    if (negated) cl = fp::neg(cl);
+    cl = r7_abs(cl);
+    fp::u256 ub1;
+    fp::add_raw(ub1, ld256(J.ub + 4ull * lv), fp::make(1));
+    return !fp::mul_gt_p(cl, ub1);
+}
+
 // ---- one queue pop: rules R1..R8 on row `row`, in the reference's order (:824-1348)
 __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
                          unsigned long long& steps, unsigned long long& nuniq) {
@@ -681,34 +710,13 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
                 const int psrc = below ? 63 - __clzll((long long)below) : 0;
                 const uint32_t pk = __shfl(k, psrc, 64);
                 const uint32_t prev_k = below ? pk : carry_k;
-                if (nu && prev_k != 0xFFFFFFFFu) {
-                    fp::u256 cn = ld256(J.coefC + 4ull * k), cc = ld256(J.coefC + 4ull * prev_k);
-                    if (negated) { cn = fp::neg(cn); cc = fp::neg(cc); }
-                    cn = r7_abs(cn); cc = r7_abs(cc);
-                    fp::u256 qq, rem;
-                    fp::divmod(cn, cc, qq, rem);
-                    if (!fp::is_zero(rem)) fail = true;
-                    else {
-                        uint32_t pv = J.colC[prev_k];
-                        fp::u256 ub = ld256(J.ub + 4ull * pv), lb = ld256(J.lb + 4ull * pv);
-                        if (fp::cmp(ub, lb) >= 0) {
-                            fp::u256 diff;
-                            fp::sub_raw(diff, ub, lb);
-                            if (fp::cmp(qq, diff) <= 0) fail = true;
-                        }
-                    }
-                }
+                if (nu && prev_k != 0xFFFFFFFFu && r7_link_fails(J, k, prev_k, negated)) fail = true;
                 if (m) carry_k = __shfl(k, 63 - __clzll((long long)m), 64);
+                if (__ballot(fail)) { fail = true; break; }   // one broken link settles it: R7 does not fire
             }
             if (!__ballot(fail)) {
                 // coeffs[last] * (ub(last) + 1) <= p  (:1274)
-                uint32_t lv = J.colC[carry_k];
-                fp::u256 cl = ld256(J.coefC + 4ull * carry_k);
-                if (negated) cl = fp::neg(cl);
-                cl = r7_abs(cl);
-                fp::u256 ub1;
-                fp::add_raw(ub1, ld256(J.ub + 4ull * lv), fp::make(1));
-                if (!fp::mul_gt_p(cl, ub1)) {
+                if (r7_top_fits(J, carry_k, negated)) {
                     steps += nunk; hits[6]++;
                     uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
                     nuniq += n;
@@ -1260,8 +1268,9 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t bases[ECNE_WG + 1];
     uint32_t scan[ECNE_NWAVES + 2];
     unsigned long long acc[12];   // steps, nuniq, hits[0..7], pops, pop_nnz
-    uint32_t head, tail, fallback, nbig;
+    uint32_t head, tail, fallback, nbig, flag7;
     uint32_t nbigev, bigev_v[64], bigev_a[64], bigev_b[64];   // high-fan-out events expanded cooperatively
+    uint32_t bt[ECNE_BIGTAB];   // lowest candidate index per big target row of this expansion (slot = tbig[row] - 1)
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
@@ -1326,8 +1335,45 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
         }
         nev = 1;
     } else if (!(shape & SH_HAS_AB) && tot > 0) {
-        if (!any_notknown) return false;          // R7's precondition (:1235-1298): the wavefront path decides
-        if (!badgroup) {                          // R8 (:1304-1348): every non-unique variable, in row order
+        bool fire7 = false;
+        if (!any_notknown) {
+            // R7 (:1235-1298) over the sorted order csort[]: contiguous sorted positions per thread; the link
+            // across a thread boundary is checked by the later thread against the nearest earlier
+            // thread's last non-unique entry (S.bases[t], 0xFFFFFFFF = none)
+            const uint32_t s0 = (uint32_t)tid * per < l ? (uint32_t)tid * per : l;
+            const uint32_t s1 = ((uint32_t)tid + 1) * per < l ? ((uint32_t)tid + 1) * per : l;
+            uint32_t firstk = 0xFFFFFFFFu, lastk = 0xFFFFFFFFu;
+            bool fail = false;
+            for (uint32_t sp = s0; sp < s1; ++sp) {
+                const uint32_t k = c0 + J.csort[c0 + sp];
+                if (J.flags[J.colC[k]] & 1) continue;
+                if (lastk != 0xFFFFFFFFu) { if (!fail && r7_link_fails(J, k, lastk, false)) fail = true; }
+                else firstk = k;
+                lastk = k;
+            }
+            S.bases[tid] = lastk;
+            if (tid == 0) S.flag7 = 0;
+            __syncthreads();
+            if (firstk != 0xFFFFFFFFu && !fail) {
+                int t = tid - 1;
+                while (t >= 0 && S.bases[t] == 0xFFFFFFFFu) --t;
+                if (t >= 0 && r7_link_fails(J, firstk, S.bases[t], false)) fail = true;
+            }
+            if (fail) S.flag7 = 1;
+            __syncthreads();
+            if (!S.flag7) {
+                // the largest entry: the last thread that saw a non-unique variable holds it
+                if (tid == 0) {
+                    int t = ECNE_WG - 1;
+                    while (t >= 0 && S.bases[t] == 0xFFFFFFFFu) --t;
+                    S.flag7 = r7_top_fits(J, S.bases[t], false) ? 2u : 1u;
+                }
+                __syncthreads();
+            }
+            fire7 = S.flag7 == 2;
+            __syncthreads();
+        }
+        if (fire7 || !badgroup) {                 // R7, else R8 (:1304-1348): every non-unique variable, in row order
             uint32_t total;
             uint32_t o = wg_exclusive_scan(cnt, S.scan, &total);
             for (uint32_t k = k0; k < k1; ++k) {
@@ -1336,7 +1382,7 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
                 J.flags[v] |= 3;
                 ev[o++] = v;
             }
-            if (tid == 0) { S.acc[0] += tot; S.acc[1] += tot; S.acc[2 + 7] += 1; }
+            if (tid == 0) { S.acc[0] += tot; S.acc[1] += tot; S.acc[2 + (fire7 ? 6 : 7)] += 1; }
             nev = tot;
         }
     }
@@ -1346,15 +1392,21 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
 }
 
 // one push candidate: event of rank a wants to push row t as candidate j (see resolve_pushes)
-__device__ __forceinline__ void expand_candidate(const Job& J, uint32_t t, uint32_t j, uint32_t a, bool multi) {
+__device__ __forceinline__ void expand_candidate(const Job& J, ChunkShared& S, uint32_t t, uint32_t j, uint32_t a, bool multi) {
     const uint32_t st = J.inq[t];
+    const uint32_t bslot = J.tbig[t];
     bool elig;
     if (multi) elig = st == 0 || (st == 2 && J.prank[t] <= a);     // 2 = being popped in this multi round
     else elig = st == 0 || (st >= 2 && st - 2 <= a);              // rank + 2 = being popped at that rank
     J.cand[j] = t | (elig ? 0x80000000u : 0u);
     // many candidates of one round can target the same row (a 1 000-term sum row is pushed by each of
     // its terms): look before the atomic, most of them have already lost
-    if (elig && ld_agent(&J.best[t]) > j) atomicMin(&J.best[t], j);
+    // A long row is the target of up to one candidate per term (a 1 000-term sum row is pushed by each of
+    // its terms in the same round): those meet in an LDS slot first and one atomic per workgroup goes to
+    // memory (flush_big_targets); otherwise a thousand same-address atomics serialise at the L2.
+    if (!elig) return;
+    if (bslot) { if (S.bt[bslot - 1] > j) atomicMin(&S.bt[bslot - 1], j); }
+    else if (ld_agent(&J.best[t]) > j) atomicMin(&J.best[t], j);
 }
 // expand event (v, rank a, candidate base b0): small fan-outs inline, big ones go to the workgroup list
 __device__ __forceinline__ void expand_event(const Job& J, ChunkShared& S, uint32_t v, uint32_t a, uint32_t b0, bool multi) {
@@ -1363,7 +1415,33 @@ __device__ __forceinline__ void expand_event(const Job& J, ChunkShared& S, uint3
         const uint32_t slot = atomicAdd(&S.nbigev, 1u);
         if (slot < 64) { S.bigev_v[slot] = v; S.bigev_a[slot] = a; S.bigev_b[slot] = b0; return; }
     }
-    for (uint32_t k = f0; k < f1; ++k) expand_candidate(J, J.fo_rows[k], b0 + (k - f0), a, multi);
+    // four candidates at a time, stage by stage: the loads of one stage are independent of each other, so
+    // a lane waits for one memory round trip per stage and not per candidate
+    for (uint32_t k = f0; k < f1; k += 4) {
+        const uint32_t nn = f1 - k < 4 ? f1 - k : 4;
+        uint32_t t[4], st[4], bs[4], pre[4];
+        bool el[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) t[i] = i < nn ? J.fo_rows[k + i] : 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) { st[i] = i < nn ? J.inq[t[i]] : 1; bs[i] = i < nn ? J.tbig[t[i]] : 0; }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (multi) el[i] = st[i] == 0 || (st[i] == 2 && J.prank[t[i]] <= a);
+            else el[i] = st[i] == 0 || (st[i] >= 2 && st[i] - 2 <= a);
+            el[i] = el[i] && i < nn;
+            pre[i] = (el[i] && !bs[i]) ? ld_agent(&J.best[t[i]]) : 0;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (i >= nn) continue;
+            const uint32_t j = b0 + (k - f0) + i;
+            J.cand[j] = t[i] | (el[i] ? 0x80000000u : 0u);
+            if (!el[i]) continue;
+            if (bs[i]) { if (S.bt[bs[i] - 1] > j) atomicMin(&S.bt[bs[i] - 1], j); }
+            else if (pre[i] > j) atomicMin(&J.best[t[i]], j);
+        }
+    }
 }
 // all threads of the workgroup: expand the listed big events, lanes across fan-out positions
 __device__ __forceinline__ void expand_big_events(const Job& J, ChunkShared& S, bool multi) {
@@ -1372,10 +1450,16 @@ __device__ __forceinline__ void expand_big_events(const Job& J, ChunkShared& S, 
     for (uint32_t i = 0; i < nb; ++i) {
         const uint32_t v = S.bigev_v[i], a = S.bigev_a[i], b0 = S.bigev_b[i];
         const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
-        for (uint32_t k = f0 + threadIdx.x; k < f1; k += ECNE_WG) expand_candidate(J, J.fo_rows[k], b0 + (k - f0), a, multi);
+        for (uint32_t k = f0 + threadIdx.x; k < f1; k += ECNE_WG) expand_candidate(J, S, J.fo_rows[k], b0 + (k - f0), a, multi);
     }
     __syncthreads();
     if (threadIdx.x == 0) S.nbigev = 0;
+    // the workgroup's minima for big target rows go to best[]; the slots are left empty again
+    const uint32_t nb_rows = J.nBigRows < ECNE_BIGTAB ? J.nBigRows : ECNE_BIGTAB;
+    for (uint32_t i = threadIdx.x; i < nb_rows; i += ECNE_WG) {
+        const uint32_t j = S.bt[i];
+        if (j != 0xFFFFFFFFu) { atomicMin(&J.best[J.bigrows[i]], j); S.bt[i] = 0xFFFFFFFFu; }
+    }
 }
 
 // Ordered multi-source REQUEUE by the whole workgroup. Input: a flat list of N events (variables) in
@@ -1865,7 +1949,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 S.nbig = 0;
             }
             __syncthreads();
-            if (J.solved[brow] || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig)) {
+            const bool wgdone = J.solved[brow] || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig);
+            if (wgdone) {
                 // done by the whole workgroup (or an already solved row: the pop is all that happens)
             } else if (w == 0) {
                 const uint32_t rr = brow;
@@ -2071,6 +2156,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
 #define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
 
     // ---------------- setup (:593-704), all workgroups
+    for (uint32_t i = tid; i < ECNE_BIGTAB; i += ECNE_WG) s_chunk.bt[i] = 0xFFFFFFFFu;
     for (uint32_t v = gtid; v <= nV; v += gstride) {
         J.flags[v] = 0;
         J.abz[v] = -1;
