@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "engine_types.hpp"
+#define ECNE_FINE_TICKS 1   // in-kernel phase clocks (measured: no effect on the solve time)
 #include "fp256.hpp"
 
 namespace ecne {
@@ -939,28 +940,46 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
     bool st_valid = false, st_notknown = false, st_badgroup = false;
     uint32_t st_cnt = 0;
     int st_group = -2;
-    // R1 (:827-873)
+    // R1 (:827-873). Entries are fetched four per part at a time -- ids, then flag bytes and group tags --
+    // so that the lane waits per batch, not per entry (the constant wire pads the short parts).
     {
         bool nu = false;
-        for (uint32_t k = a0; k < a1 && !nu; ++k) nu = !(J.flags[J.colA[k]] & 1);
-        for (uint32_t k = b0; k < b1 && !nu; ++k) nu = !(J.flags[J.colB[k]] & 1);
-        if (!nu) {
-            uint32_t cnt = 0, u = 0;
-            const bool lin = !(shape & SH_HAS_AB);
-            for (uint32_t k = c0; k < c1 && (lin || cnt < 2); ++k) {
-                uint32_t v = J.colC[k];
-                const uint8_t f = J.flags[v];
-                if (!(f & 1)) {
-                    if (cnt == 0) u = v;
-                    ++cnt;
-                    if (lin) {   // the same walk collects what R7 and R8 ask of C's non-unique variables
-                        if (!(f & 2)) st_notknown = true;
-                        const int a = J.abz[v];
-                        if (st_group == -2) st_group = a;
-                        if (a == -1 || a != st_group) st_badgroup = true;
-                    }
+        uint32_t cnt = 0, u = 0;
+        const bool lin = !(shape & SH_HAS_AB);
+        uint32_t n = a1 - a0;
+        n = b1 - b0 > n ? b1 - b0 : n;
+        n = c1 - c0 > n ? c1 - c0 : n;
+        for (uint32_t off = 0; off < n && !nu; off += 4) {
+            uint32_t v[12];
+            uint8_t fl[12];
+            int ab[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                v[i] = a0 + off + i < a1 ? J.colA[a0 + off + i] : 1u;
+                v[4 + i] = b0 + off + i < b1 ? J.colB[b0 + off + i] : 1u;
+                v[8 + i] = c0 + off + i < c1 ? J.colC[c0 + off + i] : 1u;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 12; ++i) fl[i] = J.flags[v[i]];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) ab[i] = lin ? J.abz[v[8 + i]] : -1;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) nu |= !(fl[i] & 1);
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                if (c0 + off + i >= c1) continue;
+                const uint8_t f = fl[8 + i];
+                if (f & 1) continue;
+                if (cnt == 0) u = v[8 + i];
+                ++cnt;
+                if (lin) {   // the same walk collects what R7 and R8 ask of C's non-unique variables
+                    if (!(f & 2)) st_notknown = true;
+                    if (st_group == -2) st_group = ab[i];
+                    if (ab[i] == -1 || ab[i] != st_group) st_badgroup = true;
                 }
             }
+        }
+        if (!nu) {
             st_cnt = cnt;
             st_valid = lin;
             if (cnt == 1) {
@@ -1016,9 +1035,15 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
         } else if (shape & SH_R4_T2) new_key = ri.kneg;
         else new_key = ri.kpos;
         bool bad = false;
-        for (uint32_t k = c0; k < c1 && !bad; ++k) {
-            uint32_t v = J.colC[k];
-            if (v != new_key && !(J.flags[v] & 4)) bad = true;
+        for (uint32_t base = c0; base < c1 && !bad; base += 4) {
+            uint32_t v[4];
+            uint8_t fl[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) v[i] = base + i < c1 ? J.colC[base + i] : new_key;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) fl[i] = J.flags[v[i]];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) if (v[i] != new_key && !(fl[i] & 4)) bad = true;
         }
         if (!bad) {
             const fp::u256 fub = ld256(J.vals + 4ull * (ri.validx + 1));
@@ -1189,9 +1214,28 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
     }
     const bool lin = !(shape & SH_HAS_AB);
     if (!lin) {
-        for (uint32_t k = J.rpA[row]; k < J.rpA[row + 1]; ++k) { uint32_t v = J.colA[k]; if ((J.flags[v] & 3) != 3) f(v, 1u, 0u); }
-        for (uint32_t k = J.rpB[row]; k < J.rpB[row + 1]; ++k) { uint32_t v = J.colB[k]; if ((J.flags[v] & 3) != 3) f(v, 1u, 0u); }
-        for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) { uint32_t v = J.colC[k]; if ((J.flags[v] & 3) != 3) f(v, 1u, 1u); }
+        // Entries are fetched four per part at a time, all variable ids first and all flag bytes second:
+        // a lane then waits for two memory round trips per step instead of two per ENTRY (the constant
+        // wire, always unique and known, pads the short parts).
+        const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1], b0 = J.rpB[row], b1 = J.rpB[row + 1];
+        const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+        uint32_t n = a1 - a0;
+        n = b1 - b0 > n ? b1 - b0 : n;
+        n = c1 - c0 > n ? c1 - c0 : n;
+        for (uint32_t off = 0; off < n; off += 4) {
+            uint32_t v[12];
+            uint8_t fl[12];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                v[i] = a0 + off + i < a1 ? J.colA[a0 + off + i] : 1u;
+                v[4 + i] = b0 + off + i < b1 ? J.colB[b0 + off + i] : 1u;
+                v[8 + i] = c0 + off + i < c1 ? J.colC[c0 + off + i] : 1u;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 12; ++i) fl[i] = J.flags[v[i]];
+#pragma unroll
+            for (uint32_t i = 0; i < 12; ++i) if ((fl[i] & 3) != 3) f(v[i], 1u, i >= 8 ? 1u : 0u);
+        }
         return;
     }
     // linear row. B-class state is only ever WRITTEN by: R3 on x, R4 on its pivot(s), R5/R6 on k1, k2.
@@ -1204,15 +1248,18 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
     if (shape & SH_R3) {
         const RowInfo ri = J.rinfo[row];
         const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
-        const bool same = J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv) &&
-                          fp::eq(ld256(J.lb + 4ull * x), tv) && fp::eq(ld256(J.ub + 4ull * x), tv);
+        // (all four loads first: a short-circuit chain would wait for them one after the other)
+        const uint8_t nv = J.nvalues[x];
+        const fp::u256 va = ld256(J.values + 8ull * x), lbx = ld256(J.lb + 4ull * x), ubx = ld256(J.ub + 4ull * x);
+        const bool same = (nv == 1) & fp::eq(va, tv) & fp::eq(lbx, tv) & fp::eq(ubx, tv);
         if (!same) wb0 = x;
     }
     if (shape & (SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6)) {
         const RowInfo ri = J.rinfo[row];
         if (shape & (SH_R5 | SH_R6)) {
-            const bool eqb = fp::eq(ld256(J.lb + 4ull * ri.k1), ld256(J.lb + 4ull * ri.k2)) &&
-                             fp::eq(ld256(J.ub + 4ull * ri.k1), ld256(J.ub + 4ull * ri.k2));
+            const fp::u256 l1 = ld256(J.lb + 4ull * ri.k1), l2 = ld256(J.lb + 4ull * ri.k2);
+            const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
+            const bool eqb = fp::eq(l1, l2) & fp::eq(u1, u2);
             if (!eqb || wb0 != 0xFFFFFFFFu) { wb1 = ri.k1; wb2 = ri.k2; }   // R3 may first move x's bounds
         } else {
             // binary-decomposition row: only the pivot's bounds can be written
@@ -1221,12 +1268,21 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
             else wb1 = ri.kpos;
         }
     }
-    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) {
-        uint32_t v = J.colC[k];
-        if (v == 1 && !touch1) continue;
-        const uint32_t u = ((J.flags[v] & 3) == 3) ? 0u : 1u;
-        const uint32_t wb = (v == wb0 || v == wb1 || v == wb2) ? 2u : 0u;
-        f(v, u | 2u, u | wb);
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    for (uint32_t base = c0; base < c1; base += 4) {
+        uint32_t v[4];
+        uint8_t fl[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) v[i] = base + i < c1 ? J.colC[base + i] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) fl[i] = v[i] != 0xFFFFFFFFu ? J.flags[v[i]] : (uint8_t)3;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (v[i] == 0xFFFFFFFFu || (v[i] == 1 && !touch1)) continue;
+            const uint32_t u = ((fl[i] & 3) == 3) ? 0u : 1u;
+            const uint32_t wb = (v[i] == wb0 || v[i] == wb1 || v[i] == wb2) ? 2u : 0u;
+            f(v[i], u | 2u, u | wb);
+        }
     }
 }
 
@@ -1237,9 +1293,27 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
     const uint32_t shape = ri.shape;
     reads_b = false;
     if (shape & SH_R2_BOUNDSERR) return false;
-    for (uint32_t k = J.rpA[row]; k < J.rpA[row + 1]; ++k) if ((J.flags[J.colA[k]] & 3) != 3) return false;
-    for (uint32_t k = J.rpB[row]; k < J.rpB[row + 1]; ++k) if ((J.flags[J.colB[k]] & 3) != 3) return false;
-    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) if ((J.flags[J.colC[k]] & 3) != 3) return false;
+    {
+        // (batched like for_row_sets: ids of up to four entries per part, then their flag bytes)
+        const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1], b0 = J.rpB[row], b1 = J.rpB[row + 1];
+        const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+        uint32_t n = a1 - a0;
+        n = b1 - b0 > n ? b1 - b0 : n;
+        n = c1 - c0 > n ? c1 - c0 : n;
+        for (uint32_t off = 0; off < n; off += 4) {
+            uint32_t v[12];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                v[i] = a0 + off + i < a1 ? J.colA[a0 + off + i] : 1u;
+                v[4 + i] = b0 + off + i < b1 ? J.colB[b0 + off + i] : 1u;
+                v[8 + i] = c0 + off + i < c1 ? J.colC[c0 + off + i] : 1u;
+            }
+            uint32_t all = 3;
+#pragma unroll
+            for (uint32_t i = 0; i < 12; ++i) all &= J.flags[v[i]];
+            if (all != 3) return false;
+        }
+    }
     if (shape & SH_HAS_AB) return true;            // R1 needs a non-unique variable; R2 needs !is_known(x)
     if (shape & SH_C_EMPTY) return true;
     // linear row, every variable unique and known: R1, R7, R8 cannot fire. R3 / R4 / R5 / R6 may still
@@ -1251,14 +1325,16 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
         reads_b = true;
         const uint32_t x = ri.x;
         const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
-        if (!(J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv))) return false;
-        if (!fp::eq(ld256(J.lb + 4ull * x), tv) || !fp::eq(ld256(J.ub + 4ull * x), tv)) return false;
+        const uint8_t nv = J.nvalues[x];
+        const fp::u256 va = ld256(J.values + 8ull * x), lbx = ld256(J.lb + 4ull * x), ubx = ld256(J.ub + 4ull * x);
+        if (!(nv == 1 && fp::eq(va, tv) && fp::eq(lbx, tv) && fp::eq(ubx, tv))) return false;
     }
     if (r56) {
         reads_b = true;   // equal bounds (and equal unique bits, given above): R5/R6 return at their first test,
         // and R4 on an x == y row finds either a non-[0,1] partner or already-equal [0,1] bounds
-        if (!fp::eq(ld256(J.lb + 4ull * ri.k1), ld256(J.lb + 4ull * ri.k2))) return false;
-        if (!fp::eq(ld256(J.ub + 4ull * ri.k1), ld256(J.ub + 4ull * ri.k2))) return false;
+        const fp::u256 l1 = ld256(J.lb + 4ull * ri.k1), l2 = ld256(J.lb + 4ull * ri.k2);
+        const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
+        if (!(fp::eq(l1, l2) && fp::eq(u1, u2))) return false;
     }
     return true;
 }
@@ -1660,7 +1736,11 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     uint32_t live = 0, noop = 0, noop_b = 0;
     int err;
     unsigned long long mt_last = wall_clock64();
+#ifdef ECNE_FINE_TICKS
 #define MTICK(slot) do { if (g == 0) { unsigned long long t_ = wall_clock64(); S.mt[slot] += t_ - mt_last; mt_last = t_; } } while (0)
+#else
+#define MTICK(slot) do { } while (0)
+#endif
 #pragma unroll
     for (uint32_t sl = 0; sl < 2; ++sl) {
         row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
@@ -1703,15 +1783,15 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
                     if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
         } else {
             for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                if ((rd | wr) & 1) {
-                    const uint32_t m = ld_agent(&J.wmarkU[v]);
-                    if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
-                }
-                if ((rd | wr) & 2) {
-                    const uint32_t m = ld_agent(&J.wmarkB[v]);
-                    if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
-                }
-            });
+                    if ((rd | wr) & 1) {
+                        const uint32_t m = ld_agent(&J.wmarkU[v]);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                    if ((rd | wr) & 2) {
+                        const uint32_t m = ld_agent(&J.wmarkB[v]);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                });
         }
         if (blocked) atomicMin(&S.cut, rank);
     }
@@ -1842,7 +1922,11 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
     if (tid < 12) S.acc[tid] = 0;
     unsigned long long qt_last = wall_clock64();
+#ifdef ECNE_FINE_TICKS
 #define QTICK(slot) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); S.qt[slot] += t_ - qt_last; qt_last = t_; } } while (0)
+#else
+#define QTICK(slot) do { } while (0)
+#endif
     LaneCtr C;
     C.steps = C.nuniq = 0;
     for (int i = 0; i < 8; ++i) C.hits[i] = 0;
