@@ -336,6 +336,13 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_knowns = c.take(4ull * std::max<size_t>(L.knowns.size(), 1)), o_targets = c.take(4ull * std::max<size_t>(L.targets.size(), 1));
     size_t o_nontriv = c.take((size_t)nV + 1);
     size_t o_p4 = c.take(4ull * std::max<size_t>(L.p4_list.size(), 1));
+    std::vector<uint32_t> p4_b(L.p4_list.size()), p4_s(L.p4_list.size());
+    for (size_t i = 0; i < L.p4_list.size(); ++i) {
+        const RowInfo& ri = L.rinfo[L.p4_list[i]];
+        p4_b[i] = ri.kpos;
+        p4_s[i] = ri.kneg | ((ri.shape & SH_P4_DIV0) ? 0x80000000u : 0u);
+    }
+    size_t o_p4b = c.take(4ull * std::max<size_t>(p4_b.size(), 1)), o_p4s = c.take(4ull * std::max<size_t>(p4_s.size(), 1));
     size_t o_cls = c.take(4ull * std::max<size_t>(L.cls_list.size(), 1));
     std::vector<uint16_t> tbig(std::max<size_t>(nC, 1), 0);
     std::vector<uint32_t> bigrows;
@@ -350,7 +357,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_inq = c.take(2 * std::max<size_t>(nC, 1)), o_solved = c.take((size_t)nC + 1), o_flip3 = c.take(std::max<size_t>(nC, 1));
     size_t o_queue = c.take(4ull * qcap);
     size_t o_varmin = c.take(4ull * (nV + 1));
-    size_t o_rdead = c.take(std::max<size_t>(nC, 1));
+    size_t o_rdead = c.take(std::max<size_t>(nC, 1) + 4);   // read four rows at a time
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
@@ -392,6 +399,8 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
     HIP_TRY(up(o_nontriv, L.nontrivial.data(), L.nontrivial.size()));
     HIP_TRY(up(o_p4, L.p4_list.data(), 4ull * L.p4_list.size()));
+    HIP_TRY(up(o_p4b, p4_b.data(), 4ull * p4_b.size()));
+    HIP_TRY(up(o_p4s, p4_s.data(), 4ull * p4_s.size()));
     HIP_TRY(up(o_cls, L.cls_list.data(), 4ull * L.cls_list.size()));
     HIP_TRY(up(o_tbig, tbig.data(), 2ull * tbig.size()));
     HIP_TRY(up(o_bigrows, bigrows.data(), 4ull * bigrows.size()));
@@ -416,6 +425,7 @@ static int upload_system(ecne_system& S, int device) {
     J.knowns = (const uint32_t*)(base + o_knowns); J.targets = (const uint32_t*)(base + o_targets);
     J.nontrivial = (const uint8_t*)(base + o_nontriv);
     J.p4_list = (const uint32_t*)(base + o_p4);
+    J.p4_b = (const uint32_t*)(base + o_p4b); J.p4_s = (const uint32_t*)(base + o_p4s);
     J.cls_list = (const uint32_t*)(base + o_cls);
     J.nBigCls = (uint32_t)L.cls_list.size();
     J.p5_rows = (const uint32_t*)(base + o_p5r); J.p5_y = (const uint32_t*)(base + o_p5y);

@@ -101,6 +101,8 @@ struct Job {
     const uint32_t *knowns, *targets;
     const uint8_t* nontrivial;
     const uint32_t* p4_list;
+    const uint32_t* p4_b;      // per P4 row: the B variable
+    const uint32_t* p4_s;      // per P4 row: slope variable of A; bit 31 set = none (divexact by zero, :1467)
     const uint32_t* cls_list;   // rows with lenC > 8, ascending
     const uint32_t *p5_rows, *p5_y;
     // mutable state

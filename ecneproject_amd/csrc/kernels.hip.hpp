@@ -806,13 +806,30 @@ __device__ __forceinline__ uint64_t mixB(uint64_t x) {
 // non-unique variables of C; h/h2 = commutative hash of that set (:1360-1386).
 __device__ __noinline__ void p3_eval(const Job& J, uint32_t row, uint32_t& k, uint64_t& h, uint64_t& h2) {
     k = 0; h = 0; h2 = 0;
-    for (uint32_t e = J.rpA[row]; e < J.rpA[row + 1]; ++e)
-        if (!(J.flags[J.colA[e]] & 1)) { k = 0xFFFFFFFFu; return; }
-    for (uint32_t e = J.rpB[row]; e < J.rpB[row + 1]; ++e)
-        if (!(J.flags[J.colB[e]] & 1)) { k = 0xFFFFFFFFu; return; }
-    for (uint32_t e = J.rpC[row]; e < J.rpC[row + 1]; ++e) {
-        uint32_t v = J.colC[e];
-        if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
+    // entries four per part at a time: ids first, then flag bytes (the constant wire pads short parts)
+    const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1], b0 = J.rpB[row], b1 = J.rpB[row + 1];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    uint32_t n = a1 - a0;
+    n = b1 - b0 > n ? b1 - b0 : n;
+    n = c1 - c0 > n ? c1 - c0 : n;
+    for (uint32_t off = 0; off < n; off += 4) {
+        uint32_t v[12];
+        uint8_t fl[12];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            v[i] = a0 + off + i < a1 ? J.colA[a0 + off + i] : 1u;
+            v[4 + i] = b0 + off + i < b1 ? J.colB[b0 + off + i] : 1u;
+            v[8 + i] = c0 + off + i < c1 ? J.colC[c0 + off + i] : 1u;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 12; ++i) fl[i] = J.flags[v[i]];
+        uint32_t ab = 1;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) ab &= fl[i];
+        if (!(ab & 1)) { k = 0xFFFFFFFFu; return; }
+#pragma unroll
+        for (uint32_t i = 8; i < 12; ++i)
+            if (!(fl[i] & 1)) { ++k; h += mixA(v[i]); h2 += mixB(v[i]); }
     }
     h = mixA(h + k);   // never 0-sensitive: empty sets are not inserted
 }
@@ -2414,19 +2431,24 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
             for (;;) {
                 tk[6]++;
                 // phase 1: evaluate rows >= f against the current state
-                for (uint32_t r = f + gtid; r < nC; r += gstride) {
-                    if (J.rdead[r]) continue;          // every variable unique already (p3k[r] stays 0)
-                    uint32_t k; uint64_t h, h2;
-                    p3_eval(J, r, k, h, h2);
-                    if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
-                    if (k == 0xFFFFFFFFu) k = 0;
-                    J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
-                    J.p3h[r] = h; J.p3h2[r] = h2;
-                    if (k == 1) atomicMin(&ctr->p3_cand1, r);
-                    else if (k >= 2) {
-                        uint32_t s = ht_slot(J, h, h2, true);
-                        if (s != 0xFFFFFFFFu) atomicAdd(&J.ht_new[s], 1u);
-                        __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
+                for (uint32_t r4 = (f & ~3u) + 4u * gtid; r4 < nC; r4 += 4u * gstride) {
+                    const uint32_t dead4 = *reinterpret_cast<const uint32_t*>(J.rdead + r4);   // padded to a multiple of 4
+                    if (dead4 == 0x01010101u) continue;
+                    for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r) {
+                        if ((dead4 >> (8 * (r - r4))) & 1) continue;   // every variable unique already (p3k[r] stays 0)
+                        uint32_t k; uint64_t h, h2;
+                        p3_eval(J, r, k, h, h2);
+                        if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
+                        if (k == 0xFFFFFFFFu) k = 0;
+                        J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+                        if (k == 1) atomicMin(&ctr->p3_cand1, r);
+                        else if (k >= 2) {
+                            J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
+                            uint32_t s = ht_slot(J, h, h2, true);
+                            if (s != 0xFFFFFFFFu) atomicAdd(&J.ht_new[s], 1u);
+                            __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
@@ -2558,36 +2580,35 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         }
         ECNE_TICK(2);
 
-        // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups
+        // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups.
+        // p4_b[i] / p4_s[i]: B variable and slope variable (bit 31: no slope -> DivideError) of the i-th
+        // statically eligible row. A row tags b iff b is not unique, still untagged, and the row is the
+        // FIRST such row of b in index order (varmin[b]).
         {
             for (uint32_t i = gtid; i < J.nP4; i += gstride) {
-                const RowInfo ri = J.rinfo[J.p4_list[i]];
-                const uint32_t b = ri.kpos;
+                const uint32_t b = J.p4_b[i];
                 if (J.flags[b] & 1) continue;
-                if (ri.shape & SH_P4_DIV0) { raise(J, K_EDIVZERO); continue; }
-                atomicMin(&J.varmin[b], i);
+                if (J.p4_s[i] & 0x80000000u) { raise(J, K_EDIVZERO); continue; }
+                if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
             }
             if (job_barrier(J, &s_err)) break;
             for (uint32_t i = gtid; i < J.nP4; i += gstride) {
-                const RowInfo ri = J.rinfo[J.p4_list[i]];
-                const uint32_t b = ri.kpos;
-                uint8_t fl = 0;
-                if (!(J.flags[b] & 1) && ld_agent(&J.varmin[b]) == i && J.abz[b] == -1) {
-                    J.abz[b] = (int32_t)ri.kneg;
-                    J.flags[b] |= 2;
-                    fl = 1;
-                    atomicAdd(&ctr->p4_nfired, 1u);
-                }
-                J.fired[J.p4_list[i]] = fl;
+                const uint32_t b = J.p4_b[i];
+                if ((J.flags[b] & 1) || ld_agent(&J.varmin[b]) != i || J.abz[b] != -1) continue;
+                J.abz[b] = (int32_t)(J.p4_s[i] & 0x7FFFFFFFu);
+                J.flags[b] |= 2;
+                J.fired[i] = 1;          // by list position; cleared again when the events are collected
+                atomicAdd(&ctr->p4_nfired, 1u);
             }
             if (job_barrier(J, &s_err)) break;
-            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);
-            if (master && p4_fired == 0) {
-                // nothing tagged in this sweep: only the per-variable minima have to be forgotten
-                for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) J.varmin[J.rinfo[J.p4_list[i]].kpos] = 0xFFFFFFFFu;
-                __syncthreads();
+            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // every thread reads it before anyone clears it
+            // forget the per-variable minima (all workgroups; the next use is a whole queue phase away)
+            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+                const uint32_t b = J.p4_b[i];
+                if (!(J.flags[b] & 1)) J.varmin[b] = 0xFFFFFFFFu;
             }
             if (master && p4_fired != 0) {
+                __syncthreads();
                 if (tid == 0) ctr->p4_nfired = 0;
                 // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
                 if (w == 0 && lane == 0) s_q = q;
@@ -2597,16 +2618,10 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 uint32_t nev = 0;
                 for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
                     uint32_t i = base + tid;
-                    uint32_t fl = (i < J.nP4) ? J.fired[J.p4_list[i]] : 0;
+                    uint32_t fl = (i < J.nP4) ? J.fired[i] : 0;
                     uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
-                    if (fl) J.events[nev + off] = J.rinfo[J.p4_list[i]].kpos;
+                    if (fl) { J.events[nev + off] = J.p4_b[i]; J.fired[i] = 0; }
                     nev += total;
-                }
-                __syncthreads();
-                for (uint32_t i = tid; i < J.nP4; i += ECNE_WG) {
-                    const uint32_t b = J.rinfo[J.p4_list[i]].kpos;
-                    J.varmin[b] = 0xFFFFFFFFu;
-                    J.fired[J.p4_list[i]] = 0;
                 }
                 __syncthreads();
                 // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
@@ -2627,17 +2642,27 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
         if (master) {
             if (w == 0) {
-                for (uint32_t i = 0; i < J.nP5; ++i) {
-                    const uint32_t r = J.p5_rows[i], y = J.p5_y[i];
-                    bool nu = false;
-                    for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nu |= !(J.flags[J.colA[e]] & 1);
-                    if (__ballot(nu)) continue;
-                    if (J.flags[y] & 1) continue;
-                    mark_unique(J, y);
-                    if (lane == 0) { J.solved[r] = 1; J.solved[r + 1] = 1; }
-                    wg_fence();
-                    steps++; hits[12]++;
-                    requeue(J, q, y);
+                // 64 candidates are tested at a time, one per lane; the ones that pass fire in index order,
+                // and after every firing the later lanes look again (its newly unique y may complete their A)
+                for (uint32_t base = 0; base < J.nP5; base += 64) {
+                    const uint32_t i = base + lane;
+                    const uint32_t r = i < J.nP5 ? J.p5_rows[i] : 0, y = i < J.nP5 ? J.p5_y[i] : 0;
+                    int from = 0;            // lanes below `from` are done
+                    for (;;) {
+                        bool can = i < J.nP5 && lane >= from && !(J.flags[y] & 1);
+                        if (can)
+                            for (uint32_t e = J.rpA[r]; e < J.rpA[r + 1] && can; ++e) can = (J.flags[J.colA[e]] & 1) != 0;
+                        const uint64_t m = __ballot(can);
+                        if (!m) break;
+                        const int src = __ffsll((long long)m) - 1;
+                        const uint32_t rs = __shfl(r, src, 64), ys = __shfl(y, src, 64);
+                        mark_unique(J, ys);
+                        if (lane == 0) { J.solved[rs] = 1; J.solved[rs + 1] = 1; }
+                        wg_fence();
+                        steps++; hits[12]++;
+                        requeue(J, q, ys);
+                        from = src + 1;
+                    }
                 }
                 if (lane == 0) s_steps = steps;
             }
