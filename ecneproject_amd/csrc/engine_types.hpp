@@ -119,6 +119,7 @@ struct Job {
     const uint16_t* tbig;      // per row: 0, or 1 + index into bigrows[] (rows with > ECNE_SMALL_ROW entries, first ECNE_BIGTAB of them)
     const uint32_t* bigrows;
     uint32_t nBigRows;
+    uint32_t* ht_list;         // group-table slots created in the current P3 sweep, one region per workgroup
     uint8_t* rdead;            // row has no non-unique variable left (monotone): the sweeps skip it
     uint8_t* p3k;
     uint64_t *p3h, *p3h2;

@@ -836,15 +836,15 @@ __device__ __noinline__ void p3_eval(const Job& J, uint32_t row, uint32_t& k, ui
 // Open-addressing table keyed by the 64-bit half of the group hash; the other half is recorded with
 // a second CAS by every visitor, so two different keys that agree on 64 bits are DETECTED (the solve
 // stops with ECNE_ECAPACITY) instead of being merged. No lane ever spins on another lane.
-__device__ __forceinline__ uint32_t ht_slot(const Job& J, uint64_t h, uint64_t h2, bool insert) {
+__device__ __forceinline__ uint32_t ht_slot(const Job& J, uint64_t h, uint64_t h2, bool insert, bool* created = nullptr) {
     const unsigned long long key = (unsigned long long)(h | 1ull), key2 = (unsigned long long)(h2 | 1ull);
     uint32_t s = (uint32_t)((h >> 1) & J.htmask);
     for (uint32_t probe = 0; probe <= J.htmask; ++probe) {
-        unsigned long long cur = atomicAdd((unsigned long long*)&J.ht_key[s], 0ull);
+        unsigned long long cur = __hip_atomic_load((unsigned long long*)&J.ht_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0ull) {
             if (!insert) return 0xFFFFFFFFu;
             cur = atomicCAS((unsigned long long*)&J.ht_key[s], 0ull, key);
-            if (cur == 0ull) cur = key;
+            if (cur == 0ull) { cur = key; if (created) *created = true; }
         }
         if (cur == key) {
             unsigned long long o2 = atomicCAS((unsigned long long*)&J.ht_key2[s], 0ull, key2);
@@ -2238,6 +2238,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     __shared__ Job J;
     __shared__ uint32_t s_scan[ECNE_NWAVES + 2];
     __shared__ uint32_t s_u32[8];
+    __shared__ uint32_t s_htn;          // P3 group-table slots this workgroup created in the current sweep
     __shared__ unsigned long long s_steps;
     __shared__ uint32_t m_rows[10], m_vars[10];
     __shared__ int s_err;
@@ -2252,6 +2253,8 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
+    const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
+    if (tid == 0) s_htn = 0;
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = wall_clock64();
 #define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
@@ -2445,8 +2448,13 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                         if (k == 1) atomicMin(&ctr->p3_cand1, r);
                         else if (k >= 2) {
                             J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
-                            uint32_t s = ht_slot(J, h, h2, true);
+                            bool created = false;
+                            uint32_t s = ht_slot(J, h, h2, true, &created);
                             if (s != 0xFFFFFFFFu) atomicAdd(&J.ht_new[s], 1u);
+                            if (created) {   // remembered, so that only the slots in use are wiped afterwards
+                                const uint32_t pos = atomicAdd(&s_htn, 1u);
+                                if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                            }
                             __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
@@ -2574,9 +2582,17 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 f = fire + 1;
             }
             if (p3_err) break;
-            // leave the table clean for the next outer iteration
-            if (any_total)
-                for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
+            // leave the table clean for the next outer iteration: every workgroup wipes the slots it created
+            __syncthreads();
+            {
+                const uint32_t nmine = s_htn < ht_cap ? s_htn : ht_cap;
+                for (uint32_t i = tid; i < nmine; i += ECNE_WG) {
+                    const uint32_t s = J.ht_list[(size_t)me.rank * ht_cap + i];
+                    J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0;
+                }
+                __syncthreads();
+                if (tid == 0) s_htn = 0;
+            }
         }
         ECNE_TICK(2);
 
