@@ -256,12 +256,39 @@ FPQ u256 shl(const u256& a, int s) {  // 0 <= s < 256
     }
     return r;
 }
+FPQ u256 shr(const u256& a, int s) {  // 0 <= s < 256
+    u256 r = make(0);
+    int ws = s >> 6, bs = s & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int src = i + ws;
+        uint64_t v = 0;
+        if (src <= 3) {
+            v = a.w[src] >> bs;
+            if (bs && src <= 2) v |= a.w[src + 1] << (64 - bs);
+        }
+        r.w[i] = v;
+    }
+    return r;
+}
 // integer division a = q*b + r, b != 0 (mixed-radix rule, reference :1267-1268)
 FPQ void divmod(const u256& a, const u256& b, u256& q, u256& r) {
     q = make(0);
     r = a;
     int la = bitlen(a), lb = bitlen(b);
     if (la < lb) return;
+    // the divisors circuits produce are almost always 1, a power of two or a small integer
+    if (la <= 64) { q.w[0] = a.w[0] / b.w[0]; r = make(a.w[0] % b.w[0]); return; }
+    {
+        const u256 low = shl(make(1), lb - 1);
+        if (eq(b, low)) {   // b = 2^(lb-1)
+            q = lb == 1 ? a : shr(a, lb - 1);
+            u256 m;
+            sub_raw(m, b, make(1));
+            for (int i = 0; i < 4; ++i) r.w[i] = a.w[i] & m.w[i];
+            return;
+        }
+    }
     for (int s = la - lb; s >= 0; --s) {
         u256 bs = shl(b, s);
         // shl may drop bits only if lb + s > 256, which cannot happen since lb + s <= la <= 256

@@ -1356,6 +1356,8 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
     return true;
 }
 
+#define ECNE_HSLOTS 4096
+#define ECNE_ASET 6
 struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t cut;
     uint32_t bases[ECNE_WG + 1];
@@ -1364,9 +1366,41 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t head, tail, fallback, nbig, flag7;
     uint32_t nbigev, bigev_v[64], bigev_a[64], bigev_b[64];   // high-fan-out events expanded cooperatively
     uint32_t bt[ECNE_BIGTAB];   // lowest candidate index per big target row of this expansion (slot = tbig[row] - 1)
+    // small rounds (at most one row per lane): write-marks in an exact LDS hash table instead of device
+    // memory, and every lane's access set kept here between the mark and the check pass
+    uint32_t hkey[ECNE_HSLOTS], hrank[ECNE_HSLOTS];   // key = 1 + 2 * variable + class (0 = empty); lowest writer rank
+    uint32_t aset[ECNE_WG][ECNE_ASET];                // variable | rd << 28 | wr << 30
+    uint32_t acnt[ECNE_WG];                           // entries cached; ECNE_ASET + 1 = too many, walk the row again
+    uint32_t small_ovf;
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
+
+// ---- exact LDS hash table of write-marks (small rounds). hmark: record that `rank` may write (v, cls);
+// hlook: lowest rank that may write it, 0xFFFFFFFF if nobody. Linear probing; the table is wiped as a
+// whole after every round. A probe sequence longer than 64 raises small_ovf (the round then falls back
+// to the marks in device memory).
+__device__ __forceinline__ void hmark(ChunkShared& S, uint32_t v, uint32_t cls, uint32_t rank) {
+    const uint32_t key = 1u + 2u * v + cls;
+    uint32_t s = (key * 2654435761u) >> (32 - 12);
+    for (int probe = 0; probe < 64; ++probe) {
+        const uint32_t k = atomicCAS(&S.hkey[s], 0u, key);
+        if (k == 0u || k == key) { atomicMin(&S.hrank[s], rank); return; }
+        s = (s + 1) & (ECNE_HSLOTS - 1);
+    }
+    S.small_ovf = 1;
+}
+__device__ __forceinline__ uint32_t hlook(const ChunkShared& S, uint32_t v, uint32_t cls) {
+    const uint32_t key = 1u + 2u * v + cls;
+    uint32_t s = (key * 2654435761u) >> (32 - 12);
+    for (int probe = 0; probe < 64; ++probe) {
+        const uint32_t k = S.hkey[s];
+        if (k == key) return S.hrank[s];
+        if (k == 0u) return 0xFFFFFFFFu;
+        s = (s + 1) & (ECNE_HSLOTS - 1);
+    }
+    return 0xFFFFFFFFu;   // unreachable when no insertion overflowed (overflow abandons the small path)
+}
 
 // A big row (> ECNE_SMALL_ROW entries) popped alone, executed by the whole workgroup instead of one
 // wavefront: a 1 025-term sum row costs 2-3 dependent memory round trips instead of 17. Covers the shapes
@@ -1938,6 +1972,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
     if (tid < 12) S.acc[tid] = 0;
+    for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+    if (tid == 0) S.small_ovf = 0;
     unsigned long long qt_last = wall_clock64();
 #ifdef ECNE_FINE_TICKS
 #define QTICK(slot) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); S.qt[slot] += t_ - qt_last; qt_last = t_; } } while (0)
@@ -2079,67 +2115,144 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             QTICK(6);
             continue;
         }
-        // ---- mark
-#pragma unroll
-        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
-            if (sl >= rpl || r0 + sl >= n) continue;
-            const uint32_t rank = r0 + sl;
-            if (shape[sl] & SH_BIG) { atomicMin(&S.cut, rank); continue; }
-            if (!(live & (1u << sl))) continue;
-            const RowInfo ri = J.rinfo[row[sl]];
-            bool nb = false;
-            if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
-            // only WRITE sets are marked: the readers find write-after-read hazards themselves (below)
-            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                if (wr & 1) atomicMin(&J.wmarkU[v], rank);
-                if (wr & 2) atomicMin(&J.wmarkB[v], rank);
-            });
+        uint32_t c;
+        // ---- small round (at most one row per lane): write-marks in the LDS hash table, every lane's
+        // access set cached in LDS between the two passes -- no device-memory atomics, one walk per row
+        bool small = n <= ECNE_WG;
+        uint32_t acnt = 0;
+        if (small) {
+            if ((uint32_t)tid < n) {
+                const uint32_t rank = (uint32_t)tid;
+                if (shape[0] & SH_BIG) atomicMin(&S.cut, rank);
+                else if (live & 1u) {
+                    const RowInfo ri = J.rinfo[row[0]];
+                    bool nb = false;
+                    if (row_is_noop(J, row[0], ri, nb)) {
+                        noop |= 1u;
+                        if (nb) {
+                            noop_b |= 1u;
+                            for (uint32_t k = J.rpC[row[0]]; k < J.rpC[row[0] + 1]; ++k) {
+                                if (acnt < ECNE_ASET) S.aset[tid][acnt] = J.colC[k] | (2u << 28);
+                                ++acnt;
+                            }
+                        }
+                    } else {
+                        for_row_sets(J, row[0], shape[0], xv[0], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                            if (acnt < ECNE_ASET) S.aset[tid][acnt] = v | (rd << 28) | (wr << 30);
+                            ++acnt;
+                            if (wr & 1) hmark(S, v, 0, rank);
+                            if (wr & 2) hmark(S, v, 1, rank);
+                        });
+                    }
+                }
+            }
+            __syncthreads();
+            QTICK(1);
+            if (S.small_ovf) {   // (uniform) the table overflowed: wipe it and take the general path
+                __syncthreads();
+                for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+                if (tid == 0) { S.small_ovf = 0; S.cut = n; }
+                noop = noop_b = 0;
+                small = false;
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        QTICK(1);
-        // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
-        // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
-#pragma unroll
-        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
-            if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
-            const uint32_t rank = r0 + sl;
-            bool blocked = false;
-            if (noop & (1u << sl)) {
-                if (noop_b & (1u << sl))
-                    for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
-                        if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
-            } else {
-                // wmark holds the LOWEST rank that may write that state. Lower than mine: I would read
-                // (or overwrite) what an earlier row writes -> I am blocked. Higher than mine: that row
-                // would overwrite what I read -> it (and everything after it) is cut off.
-                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+        if (small) {
+            // ---- check against the table. Lower rank than mine: I would read (or overwrite) what an earlier
+            // row writes -> blocked. Higher: that row would overwrite what I read -> the prefix is cut there.
+            if ((uint32_t)tid < n && (live & 1u) && !(shape[0] & SH_BIG)) {
+                const uint32_t rank = (uint32_t)tid;
+                bool blocked = false;
+                auto test = [&](uint32_t v, uint32_t rd, uint32_t wr) {
                     if ((rd | wr) & 1) {
-                        const uint32_t m = ld_agent(&J.wmarkU[v]);
+                        const uint32_t m = hlook(S, v, 0);
                         if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
                     }
                     if ((rd | wr) & 2) {
-                        const uint32_t m = ld_agent(&J.wmarkB[v]);
+                        const uint32_t m = hlook(S, v, 1);
                         if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
                     }
+                };
+                if (noop & 1u) {
+                    if (noop_b & 1u) {
+                        if (acnt <= ECNE_ASET) { for (uint32_t i = 0; i < acnt; ++i) if (hlook(S, S.aset[tid][i] & 0x0FFFFFFFu, 1) < rank) blocked = true; }
+                        else for (uint32_t k = J.rpC[row[0]]; k < J.rpC[row[0] + 1]; ++k) if (hlook(S, J.colC[k], 1) < rank) blocked = true;
+                    }
+                } else if (acnt <= ECNE_ASET) {
+                    for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[tid][i]; test(e & 0x0FFFFFFFu, (e >> 28) & 3u, e >> 30); }
+                } else for_row_sets(J, row[0], shape[0], xv[0], test);
+                if (blocked) atomicMin(&S.cut, rank);
+            }
+            __syncthreads();
+            c = S.cut;   // >= 1: rank 0 is never blocked and not big
+            // ---- wipe the table; tag the rows being popped with their rank (see resolve_pushes)
+            for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+            if ((uint32_t)tid < c) J.inq[row[0]] = (uint16_t)(tid + 2);
+            __syncthreads();
+            QTICK(2);
+        } else {
+            // ---- mark
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl || r0 + sl >= n) continue;
+                const uint32_t rank = r0 + sl;
+                if (shape[sl] & SH_BIG) { atomicMin(&S.cut, rank); continue; }
+                if (!(live & (1u << sl))) continue;
+                const RowInfo ri = J.rinfo[row[sl]];
+                bool nb = false;
+                if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
+                // only WRITE sets are marked: the readers find write-after-read hazards themselves (below)
+                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if (wr & 1) atomicMin(&J.wmarkU[v], rank);
+                    if (wr & 2) atomicMin(&J.wmarkB[v], rank);
                 });
             }
-            if (blocked) atomicMin(&S.cut, rank);
-        }
-        __syncthreads();
-        const uint32_t c = S.cut;   // >= 1: rank 0 is never blocked and not big
-        // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see resolve_pushes)
+            __syncthreads();
+            QTICK(1);
+            // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
+            // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
 #pragma unroll
-        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
-            if (sl >= rpl || r0 + sl >= n) continue;
-            if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
-                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                    if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
-                    if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
-                });
-            if (r0 + sl < c) J.inq[row[sl]] = (uint16_t)(r0 + sl + 2);
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
+                const uint32_t rank = r0 + sl;
+                bool blocked = false;
+                if (noop & (1u << sl)) {
+                    if (noop_b & (1u << sl))
+                        for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
+                            if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+                } else {
+                    // wmark holds the LOWEST rank that may write that state. Lower than mine: I would read
+                    // (or overwrite) what an earlier row writes -> I am blocked. Higher than mine: that row
+                    // would overwrite what I read -> it (and everything after it) is cut off.
+                    for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                        if ((rd | wr) & 1) {
+                            const uint32_t m = ld_agent(&J.wmarkU[v]);
+                            if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        }
+                        if ((rd | wr) & 2) {
+                            const uint32_t m = ld_agent(&J.wmarkB[v]);
+                            if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        }
+                    });
+                }
+                if (blocked) atomicMin(&S.cut, rank);
+            }
+            __syncthreads();
+            c = S.cut;   // >= 1: rank 0 is never blocked and not big
+            // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see resolve_pushes)
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl || r0 + sl >= n) continue;
+                if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
+                    for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                        if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+                        if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+                    });
+                if (r0 + sl < c) J.inq[row[sl]] = (uint16_t)(r0 + sl + 2);
+            }
+            __syncthreads();
+            QTICK(2);
         }
-        __syncthreads();
-        QTICK(2);
         // ---- execute the independent prefix, one lane per row (rpl rows per lane, in rank order)
         uint32_t nev[ECNE_RPL], nev_tot = 0;
 #pragma unroll

@@ -130,7 +130,8 @@ int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out /
                   uint64_t* bytes_streamed);
 
 /* device self-tests of the field arithmetic: runs `n` vectors op(a,b) on the GPU.
- * op: 0 add, 1 sub, 2 mul, 3 inv(a), 4 neg(a), 5 a/b. a, b, out: n x 4 limbs. */
+ * op: 0 add, 1 sub, 2 mul, 3 inv(a), 4 neg(a), 5 a/b (field ops, operands < p); 6 integer quotient
+ * a div b (R7, :1267-1268), 7 a*b > p as integers (R7, :1274; out = 0 or 1). a, b, out: n x 4 limbs. */
 int ecne_fp_selftest(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
 /* host-side utilities named by the north star (src/Math.jl:14-90 is dead code in the reference;
  * provided with self-consistency tests only): sqrt returns 1 and a root when one exists, else 0. */
