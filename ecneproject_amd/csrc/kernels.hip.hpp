@@ -1260,6 +1260,18 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
     // would not happen (equal bounds on an x == y / 1 = x + y row), it is not counted as a write;
     // the row still READS that state, so an earlier writer in the chunk blocks it and the
     // observation cannot go stale.
+    if ((shape & SH_R5) && !(shape & SH_R3)) {
+        // plain x == y row: both variables come from the descriptor, one batch of loads (see row_is_noop)
+        const RowInfo ri = J.rinfo[row];
+        const uint8_t f1 = J.flags[ri.k1], f2 = J.flags[ri.k2];
+        const fp::u256 l1 = ld256(J.lb + 4ull * ri.k1), l2 = ld256(J.lb + 4ull * ri.k2);
+        const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
+        const uint32_t wb = (fp::eq(l1, l2) & fp::eq(u1, u2)) ? 0u : 2u;
+        const uint32_t o1 = ((f1 & 3) == 3) ? 0u : 1u, o2 = ((f2 & 3) == 3) ? 0u : 1u;
+        f(ri.k1, o1 | 2u, o1 | wb);
+        f(ri.k2, o2 | 2u, o2 | wb);
+        return;
+    }
     const bool touch1 = (shape & SH_TOUCH1) != 0;
     uint32_t wb0 = 0xFFFFFFFFu, wb1 = 0xFFFFFFFFu, wb2 = 0xFFFFFFFFu;   // variables whose B-state may be written
     if (shape & SH_R3) {
@@ -1310,6 +1322,16 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
     const uint32_t shape = ri.shape;
     reads_b = false;
     if (shape & SH_R2_BOUNDSERR) return false;
+    if ((shape & SH_R5) && !(shape & (SH_R3 | SH_HAS_AB | SH_C_EMPTY))) {
+        // plain x == y row (the bulk of an --O0 circuit): its two variables are in the descriptor, so
+        // everything the general test below reads comes back in ONE batch of loads
+        const uint8_t f1 = J.flags[ri.k1], f2 = J.flags[ri.k2];
+        const fp::u256 l1 = ld256(J.lb + 4ull * ri.k1), l2 = ld256(J.lb + 4ull * ri.k2);
+        const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
+        if ((f1 & f2 & 3) != 3) return false;
+        reads_b = true;
+        return fp::eq(l1, l2) & fp::eq(u1, u2);
+    }
     {
         // (batched like for_row_sets: ids of up to four entries per part, then their flag bytes)
         const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1], b0 = J.rpB[row], b1 = J.rpB[row + 1];
@@ -1373,6 +1395,7 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t acnt[ECNE_WG];                           // entries cached; ECNE_ASET + 1 = too many, walk the row again
     uint32_t small_ovf;
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
+    unsigned long long dbg[16];
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
 
@@ -1966,6 +1989,9 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
 // A round examines up to ECNE_RPL * 1024 queue entries; lane t owns the consecutive ranks
 // t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
 #define ECNE_RPL 4
+#ifndef ECNE_MULTI_MIN
+#define ECNE_MULTI_MIN 128    // queued rows from which a round runs on all workgroups of the job (measured optimum)
+#endif
 __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
                                     unsigned long long& steps, unsigned long long& nuniq,
                                     unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
@@ -2048,7 +2074,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (tid == 0) { S.cut = n; S.fallback = (shape[0] & SH_BIG) ? 1u : 0u; }
         __syncthreads();
         QTICK(0);
-        if (!S.fallback && J.nwg > 1 && avail >= 3072 && window == ECNE_RPL * ECNE_WG) {
+        if (!S.fallback && J.nwg > 1 && avail >= ECNE_MULTI_MIN && window >= ECNE_MULTI_MIN) {
             // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
             const uint32_t cap_n = J.nwg * ECNE_WG * 2;
             uint32_t nm = avail < cap_n ? avail : cap_n;
@@ -2364,6 +2390,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     const uint32_t nC = J.nC, nV = J.nV;
     const bool master = me.rank == 0;
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
+    if (tid < 16) s_chunk.dbg[tid] = 0;
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
     const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
@@ -2831,6 +2858,9 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
                 for (int i = 0; i < 8; ++i) ctr->qticks[i] = s_chunk.qt[i];
                 for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
+#ifdef ECNE_DBG
+                for (int i = 0; i < 8; ++i) { ctr->qticks[i] = s_chunk.dbg[i]; ctr->mticks[i] = s_chunk.dbg[8 + i] * 100000ull; }
+#endif
             }
         }
     }

@@ -54,6 +54,23 @@ __global__ void phase(uint32_t* a, int n, unsigned long long* ticks) {
     unsigned long long t1 = wall_clock64();
     if (threadIdx.x == 0) { *ticks = t1 - t0; a[0] = acc; }
 }
+// gather throughput: every lane issues 32 INDEPENDENT scattered 4-byte loads per iteration
+__global__ void gather(const uint32_t* a, int iters, uint32_t span_mask, unsigned long long* ticks, uint32_t* out) {
+    uint32_t acc = 0, x = threadIdx.x * 2654435761u + 12345u;
+    __syncthreads();
+    unsigned long long t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        uint32_t v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { x = x * 1664525u + 1013904223u; v[i] = a[(x >> 4) & span_mask]; }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc += v[i];
+    }
+    __syncthreads();
+    unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) *ticks = t1 - t0;
+    out[threadIdx.x] = acc;
+}
 int main() {
     unsigned long long* dt; uint32_t* dout;
     hipMalloc(&dt, 8); hipMalloc(&dout, 4);
@@ -81,6 +98,20 @@ int main() {
     atom<<<1, 512>>>(a, 2000, dt); hipDeviceSynchronize();
     hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
     printf("atomicMin + sync + sc1 load + sync: %.1f ns per iteration\n", t * 10.0 / 2000);
+    {
+        uint32_t* g; hipMalloc(&g, 256 << 20); hipMemset(g, 1, 256 << 20);
+        uint32_t* go; hipMalloc(&go, 4096);
+        for (uint32_t span_mb : {1u, 64u, 256u})
+            for (int threads : {64, 192, 512}) {
+                int iters = 200;
+                gather<<<1, threads>>>(g, iters, span_mb * 262144u - 1u, dt, go); hipDeviceSynchronize();
+                gather<<<1, threads>>>(g, iters, span_mb * 262144u - 1u, dt, go); hipDeviceSynchronize();
+                hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
+                double ns = t * 10.0;
+                printf("gather span %3u MB, %3d threads: %.1f ns per wave-load-instruction per wave (%.2f ns per lane-load overall)\n",
+                       span_mb, threads, ns / (iters * 32.0), ns / (iters * 32.0 * threads));
+            }
+    }
     uint32_t* b; hipMalloc(&b, 64 << 20); hipMemset(b, 0xFF, 64 << 20);
     const char* names[] = {"atomicMin(no ret)", "sc1 load", "plain store", "plain load", "atomicMin(ret)", "2 dependent plain loads"};
     for (int threads : {64, 512}) {
