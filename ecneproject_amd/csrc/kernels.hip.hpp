@@ -1379,6 +1379,7 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
 }
 
 #define ECNE_HSLOTS 4096
+#define ECNE_BIGK 4
 #define ECNE_ASET 6
 struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t cut;
@@ -1394,6 +1395,12 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t aset[ECNE_WG][ECNE_ASET];                // variable | rd << 28 | wr << 30
     uint32_t acnt[ECNE_WG];                           // entries cached; ECNE_ASET + 1 = too many, walk the row again
     uint32_t small_ovf;
+    // long rows (> ECNE_SMALL_ROW entries) riding along in a round, at most ECNE_BIGK per workgroup: marked,
+    // checked and executed by the whole workgroup, lanes across the row's entries
+    uint32_t bl_n, bl_rank[ECNE_BIGK], bl_row[ECNE_BIGK], bl_nev[ECNE_BIGK], bl_deg[ECNE_BIGK], bl_base[ECNE_BIGK];
+    uint32_t bl_off[ECNE_BIGK][ECNE_EVCAP];   // multi rounds: candidate offset of every event of a long row
+    uint32_t bl_tmp[8];
+    uint32_t hasbig;
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
     unsigned long long dbg[16];
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
@@ -1539,6 +1546,110 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
     if (tid == 0) *nev_out = nev;
     __syncthreads();
     return true;
+}
+
+// ---- long rows inside a round. Only "plain" long rows qualify (the shapes exec_big_row_wg executes:
+// R1 on anything with a non-empty C, R7 / R8 on a linear sum); the others still end the prefix.
+__device__ __forceinline__ bool big_plain(uint32_t shape) {
+    return !(shape & (SH_C_EMPTY | SH_R2 | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+}
+// a lane registers its long row; false = no slot left (the caller cuts the prefix there)
+__device__ __forceinline__ bool big_register(ChunkShared& S, uint32_t row, uint32_t rank) {
+    const uint32_t slot = atomicAdd(&S.bl_n, 1u);
+    if (slot >= ECNE_BIGK) return false;
+    S.bl_rank[slot] = rank;
+    S.bl_row[slot] = row;
+    S.bl_nev[slot] = 0;
+    return true;
+}
+// write-marks of the registered long rows: U class of every non-final variable of C (R1 / R7 / R8 may set it)
+__device__ __noinline__ void big_rows_mark(const Job& J, ChunkShared& S) {
+    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t row = S.bl_row[k], rank = S.bl_rank[k];
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            if ((J.flags[v] & 3) != 3) atomicMin(&J.wmarkU[v], rank);
+        }
+    }
+}
+__device__ __noinline__ void big_rows_unmark(const Job& J, ChunkShared& S) {
+    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t row = S.bl_row[k];
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            if ((J.flags[v] & 3) != 3) J.wmarkU[v] = 0xFFFFFFFFu;
+        }
+    }
+}
+// hazards of the registered long rows against the marks (same rule as for a lane's row: a lower mark
+// blocks it, a higher one cuts the prefix there). The row reads U of all its variables and B (bounds,
+// group tag) of C's non-unique ones. The same walk counts C's non-unique variables: a long row that
+// could emit more REQUEUE events than a rank's event slot holds is not taken along (cut at its rank; it
+// is then popped alone). All threads of the workgroup; updates S.cut.
+__device__ __noinline__ void big_rows_check(const Job& J, ChunkShared& S) {
+    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t row = S.bl_row[k], rank = S.bl_rank[k];
+        if (threadIdx.x == 0) { S.bl_tmp[0] = 0; S.bl_tmp[1] = 0; S.bl_tmp[2] = 0xFFFFFFFFu; S.bl_tmp[3] = 0; }
+        __syncthreads();
+        bool blocked = false, notknown = false;
+        uint32_t cutm = 0xFFFFFFFFu, cnt = 0, amin = 0xFFFFFFFFu, amax = 0;
+        auto see = [&](uint32_t m) { if (m < rank) blocked = true; else if (m > rank && m < cutm) cutm = m; };
+        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colA[e];
+            if ((J.flags[v] & 3) != 3) see(ld_agent(&J.wmarkU[v]));
+        }
+        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colB[e];
+            if ((J.flags[v] & 3) != 3) see(ld_agent(&J.wmarkU[v]));
+        }
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            const uint8_t f = J.flags[v];
+            if ((f & 3) != 3) see(ld_agent(&J.wmarkU[v]));
+            if (!(f & 1)) {
+                see(ld_agent(&J.wmarkB[v]));
+                ++cnt;
+                if (!(f & 2)) notknown = true;
+                const uint32_t a = (uint32_t)J.abz[v];
+                amin = a < amin ? a : amin;
+                amax = a > amax ? a : amax;
+            }
+        }
+        if (blocked) atomicMin(&S.cut, rank);
+        else if (cutm != 0xFFFFFFFFu) atomicMin(&S.cut, cutm);
+        if (cnt) {
+            atomicAdd(&S.bl_tmp[0], cnt);
+            if (notknown) S.bl_tmp[1] = 1;
+            atomicMin(&S.bl_tmp[2], amin);
+            atomicMax(&S.bl_tmp[3], amax);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const bool badgroup = S.bl_tmp[2] != S.bl_tmp[3] || S.bl_tmp[3] == 0xFFFFFFFFu;
+            const bool may_fire_all = !(J.rinfo[row].shape & SH_HAS_AB) && (S.bl_tmp[1] == 0 || !badgroup);   // R7 or R8
+            if (S.bl_tmp[0] > ECNE_EVCAP - 2 && may_fire_all) atomicMin(&S.cut, rank);
+        }
+        __syncthreads();
+    }
+}
+// execute the registered long rows that made it into the prefix (rank < c); events go to the rank's slot
+__device__ __noinline__ void big_rows_exec(const Job& J, ChunkShared& S, uint32_t c) {
+    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t row = S.bl_row[k], rank = S.bl_rank[k];
+        if (rank >= c) continue;                                   // uniform
+        exec_big_row_wg(J, S, row, J.evbuf + (size_t)rank * ECNE_EVCAP, &S.bl_nev[k]);
+    }
+    __syncthreads();
+}
+// number of events a lane's long row emitted (0 if it is none of the registered ones)
+__device__ __forceinline__ int big_slot_of(const ChunkShared& S, uint32_t rank) {
+    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+    for (uint32_t k = 0; k < nb; ++k) if (S.bl_rank[k] == rank) return (int)k;
+    return -1;
 }
 
 // one push candidate: event of rank a wants to push row t as candidate j (see resolve_pushes)
@@ -1833,8 +1944,11 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     for (uint32_t sl = 0; sl < 2; ++sl) {
         if (sl >= rpl || r0 + sl >= n) continue;
         const uint32_t rank = r0 + sl;
-        if (shape[sl] & SH_BIG) { atomicMin(&S.cut, rank); continue; }
         if (!(live & (1u << sl))) continue;
+        if (shape[sl] & SH_BIG) {   // plain long rows ride along, handled by this workgroup as a whole (see big_rows_*)
+            if (!big_plain(shape[sl]) || !big_register(S, row[sl], rank)) atomicMin(&S.cut, rank);
+            continue;
+        }
         const RowInfo ri = J.rinfo[row[sl]];
         bool nb = false;
         if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
@@ -1843,6 +1957,8 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
             if (wr & 2) atomicMin(&J.wmarkB[v], rank);
         });
     }
+    __syncthreads();
+    if (S.bl_n) big_rows_mark(J, S);
     if ((err = job_barrier(J, s_err))) return err;
     MTICK(0);
     // ---- check
@@ -1869,6 +1985,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         }
         if (blocked) atomicMin(&S.cut, rank);
     }
+    if (S.bl_n) big_rows_check(J, S);
     // one global update per workgroup (thousands of lanes on one word would serialise)
     __syncthreads();
     if (tid == 0 && S.cut != 0xFFFFFFFFu) atomicMin(&ctr->q_cut, S.cut);
@@ -1877,7 +1994,8 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     uint32_t c = ld_agent(&ctr->q_cut);         // >= 1 (the master checked that rank 0 is not a big row)
     if (c > n) c = n;                             // nobody blocked: the whole window commits
     // ---- unmark, tag, execute my ranks below the cut
-    uint32_t nev[2], mycand = 0;
+    if (S.bl_n) big_rows_unmark(J, S);
+    uint32_t nev[2], mycand = 0, bigsl = 0;
 #pragma unroll
     for (uint32_t sl = 0; sl < 2; ++sl) {
         nev[sl] = 0;
@@ -1893,14 +2011,38 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         J.inq[row[sl]] = (uint16_t)2;
         my_pops++;
         my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
+        J.prank[row[sl]] = r0 + sl;      // rank of a row being popped in this round
         if (live & (1u << sl)) {
             if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }
+            else if (shape[sl] & SH_BIG) { bigsl |= 1u << sl; continue; }   // executed below by the whole workgroup
             else exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
         }
         uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
         for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
         ev[ECNE_EVCAP - 1] = nev[sl];    // for the sequential replay fallback
-        J.prank[row[sl]] = r0 + sl;      // rank of a row being popped in this round
+    }
+    if (S.bl_n) {   // (uniform per workgroup) long rows of the prefix: execute, then candidate offsets of their events
+        big_rows_exec(J, S, c);
+        const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+        for (uint32_t k = 0; k < nb; ++k) {
+            if (S.bl_rank[k] >= c) continue;
+            uint32_t* ev = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+            const uint32_t ne = S.bl_nev[k];          // <= ECNE_EVCAP - 2 (big_rows_check)
+            uint32_t d = 0;
+            if ((uint32_t)tid < ne) { const uint32_t v = ev[tid]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+            uint32_t tot;
+            const uint32_t off = wg_exclusive_scan(d, S.scan, &tot);
+            if ((uint32_t)tid < ne) S.bl_off[k][tid] = off;
+            if (tid == 0) { S.bl_deg[k] = tot; ev[ECNE_EVCAP - 1] = ne; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl)
+            if (bigsl & (1u << sl)) {
+                const int k = big_slot_of(S, r0 + sl);
+                nev[sl] = S.bl_nev[k];
+                mycand += S.bl_deg[k];
+            }
     }
     uint32_t M;
     const uint32_t cbase = team_exclusive_scan(J, S, wgrank, mycand, 0, &M, s_err, &err);
@@ -1939,11 +2081,26 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         for (uint32_t sl = 0; sl < 2; ++sl) {
             if (sl >= rpl || r0 + sl >= c) continue;
             const uint32_t a = r0 + sl;
+            if (bigsl & (1u << sl)) {   // a long row's events are expanded by the whole workgroup, below
+                const int k = big_slot_of(S, a);
+                S.bl_base[k] = j;
+                j += S.bl_deg[k];
+                continue;
+            }
             const uint32_t* ev = J.evbuf + (size_t)a * ECNE_EVCAP;
             for (uint32_t e = 0; e < nev[sl]; ++e) {
                 const uint32_t v = ev[e];
                 expand_event(J, S, v, a, j, true);
                 j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+            }
+        }
+        if (S.bl_n) {
+            __syncthreads();
+            const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+            for (uint32_t k = 0; k < nb; ++k) {
+                if (S.bl_rank[k] >= c) continue;
+                const uint32_t* ev = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+                if ((uint32_t)tid < S.bl_nev[k]) expand_event(J, S, ev[tid], S.bl_rank[k], S.bl_base[k] + S.bl_off[k][tid], true);
             }
         }
         expand_big_events(J, S, true);
@@ -1978,6 +2135,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         }
     }
     if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
+    if (tid == 0) { S.bl_n = 0; S.hasbig = 0; }
     if ((err = job_barrier(J, s_err))) return err;
     MTICK(5);
     *out_c = c;
@@ -1989,6 +2147,12 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
 // A round examines up to ECNE_RPL * 1024 queue entries; lane t owns the consecutive ranks
 // t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
 #define ECNE_RPL 4
+#ifndef ECNE_WGROW
+#define ECNE_WGROW 2
+#endif
+#ifndef ECNE_WMIN
+#define ECNE_WMIN 64
+#endif
 #ifndef ECNE_MULTI_MIN
 #define ECNE_MULTI_MIN 128    // queued rows from which a round runs on all workgroups of the job (measured optimum)
 #endif
@@ -1999,7 +2163,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
     if (tid < 12) S.acc[tid] = 0;
     for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
-    if (tid == 0) S.small_ovf = 0;
+    if (tid == 0) { S.small_ovf = 0; S.bl_n = 0; S.hasbig = 0; }
     unsigned long long qt_last = wall_clock64();
 #ifdef ECNE_FINE_TICKS
 #define QTICK(slot) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); S.qt[slot] += t_ - qt_last; qt_last = t_; } } while (0)
@@ -2072,6 +2236,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             }
         }
         if (tid == 0) { S.cut = n; S.fallback = (shape[0] & SH_BIG) ? 1u : 0u; }
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
+            if ((shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl]) && r0 + sl > 0) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
         if (!S.fallback && J.nwg > 1 && avail >= ECNE_MULTI_MIN && window >= ECNE_MULTI_MIN) {
@@ -2096,7 +2263,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             else if (cm < nm / 4) {
                 const uint32_t wn = 4 * cm;
                 if (wn >= 4096) mwindow = wn;
-                else { mwindow = 4096; window = wn < 64 ? 64 : (wn < ECNE_RPL * ECNE_WG ? wn : ECNE_RPL * ECNE_WG); }
+                else { mwindow = 4096; window = wn < ECNE_WMIN ? ECNE_WMIN : (wn < ECNE_RPL * ECNE_WG ? wn : ECNE_RPL * ECNE_WG); }
             }
             QTICK(7);
             continue;
@@ -2137,6 +2304,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             }
             pops_total++;
             hits[14]++;
+            if (tid == 0) S.hasbig = 0;
             __syncthreads();
             QTICK(6);
             continue;
@@ -2144,7 +2312,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         uint32_t c;
         // ---- small round (at most one row per lane): write-marks in the LDS hash table, every lane's
         // access set cached in LDS between the two passes -- no device-memory atomics, one walk per row
-        bool small = n <= ECNE_WG;
+        bool small = n <= ECNE_WG && !S.hasbig;
         uint32_t acnt = 0;
         if (small) {
             if ((uint32_t)tid < n) {
@@ -2222,8 +2390,13 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
                 if (sl >= rpl || r0 + sl >= n) continue;
                 const uint32_t rank = r0 + sl;
-                if (shape[sl] & SH_BIG) { atomicMin(&S.cut, rank); continue; }
                 if (!(live & (1u << sl))) continue;
+                if (shape[sl] & SH_BIG) {
+                    // a plain long row rides along (marked / checked / executed by the whole workgroup, below);
+                    // any other long row ends the prefix and is popped alone
+                    if (!big_plain(shape[sl]) || !big_register(S, row[sl], rank)) atomicMin(&S.cut, rank);
+                    continue;
+                }
                 const RowInfo ri = J.rinfo[row[sl]];
                 bool nb = false;
                 if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
@@ -2234,6 +2407,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 });
             }
             __syncthreads();
+            if (S.bl_n) { big_rows_mark(J, S); __syncthreads(); }
             QTICK(1);
             // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
             // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
@@ -2263,8 +2437,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 }
                 if (blocked) atomicMin(&S.cut, rank);
             }
+            if (S.bl_n) big_rows_check(J, S);
             __syncthreads();
             c = S.cut;   // >= 1: rank 0 is never blocked and not big
+            if (S.bl_n) big_rows_unmark(J, S);
             // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see resolve_pushes)
 #pragma unroll
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
@@ -2289,9 +2465,19 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
             if (live & (1u << sl)) {
                 if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }   // the pop's only effect
-                else exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+                else if (!(shape[sl] & SH_BIG)) exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
             }
             nev_tot += nev[sl];
+        }
+        uint32_t bigsl = 0;          // slots of mine that hold a long row executed in this round
+        if (S.bl_n) {                // (uniform) the long rows of the prefix, by the whole workgroup
+            big_rows_exec(J, S, c);
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
+                if (sl < rpl && r0 + sl < c && (shape[sl] & SH_BIG) && (live & (1u << sl))) {
+                    const int k = big_slot_of(S, r0 + sl);
+                    if (k >= 0) { nev[sl] = S.bl_nev[k]; nev_tot += nev[sl]; bigsl |= 1u << sl; }
+                }
         }
         QTICK(3);
         // ---- REQUEUE resolution in sequential order: flatten the per-rank event lists, then resolve
@@ -2302,8 +2488,22 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #pragma unroll
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
                 if (sl >= rpl) continue;
+                if (bigsl & (1u << sl)) {   // a long row's events are copied by the whole workgroup, below
+                    S.bl_base[big_slot_of(S, r0 + sl)] = o;
+                    o += nev[sl];
+                    continue;
+                }
                 const uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
                 for (uint32_t e = 0; e < nev[sl]; ++e) { J.fvar[o] = ev[e]; J.frank[o] = r0 + sl; ++o; }
+            }
+            if (S.bl_n) {
+                __syncthreads();
+                const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
+                for (uint32_t k = 0; k < nb; ++k) {
+                    if (S.bl_rank[k] >= c) continue;
+                    const uint32_t* ev = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+                    for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) { J.fvar[S.bl_base[k] + e] = ev[e]; J.frank[S.bl_base[k] + e] = S.bl_rank[k]; }
+                }
             }
             __syncthreads();   // the flat list is read across lanes
         }
@@ -2314,6 +2514,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
             if (sl < rpl && r0 + sl < c && J.inq[row[sl]] >= 2) J.inq[row[sl]] = 0;
+        if (tid == 0) { S.bl_n = 0; S.hasbig = 0; }
         __syncthreads();
         q.head += c;
         q.tail = new_tail;
@@ -2322,8 +2523,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // adaptive: a short queue with a short independent prefix is a dependency chain -> sequential
         // burst, doubling while it stays that way
         if (c < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
-        if (c == n) window = (window * 2 < ECNE_RPL * ECNE_WG) ? window * 2 : ECNE_RPL * ECNE_WG;
-        else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < 64 ? 64 : wn; }
+        if (c == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+        else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
         else next_burst = 16;
     }
     // ---- tell the helper workgroups (waiting at the command barrier) that the queue phase is over
@@ -2354,6 +2555,9 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
     C.steps = C.nuniq = 0;
     for (int i = 0; i < 8; ++i) C.hits[i] = 0;
     uint32_t my_pops = 0, my_nnz = 0;
+    if (threadIdx.x < 12) S.acc[threadIdx.x] = 0;   // long rows executed by this workgroup count here
+    if (threadIdx.x == 0) { S.bl_n = 0; S.hasbig = 0; }
+    __syncthreads();
     for (;;) {
         if (job_barrier(J, s_err)) break;
         if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
@@ -2368,6 +2572,8 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
         if (C.hits[i]) atomicAdd(&ctr->q_acc[2 + i], (unsigned long long)C.hits[i]);
     if (my_pops) atomicAdd(&ctr->q_acc[10], (unsigned long long)my_pops);
     if (my_nnz) atomicAdd(&ctr->q_acc[11], (unsigned long long)my_nnz);
+    __syncthreads();
+    if (threadIdx.x < 10 && S.acc[threadIdx.x]) atomicAdd(&ctr->q_acc[threadIdx.x], S.acc[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------- k_solve
