@@ -76,6 +76,7 @@ struct Counters {   // one per job, device memory
     unsigned int n_xcd_active, bar_ready;
     alignas(128) unsigned int pad_after_barrier;
     unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;
+    unsigned int p3_hot;   // some k >= 2 group could be complete in this pass (else nobody looks at the table)
     unsigned int p4_nfired, setup_tail;
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
     unsigned int q_cmd[4];          // mode (0 = queue phase over, 1 = run one multi round), head, tail, n

@@ -2620,7 +2620,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
     for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
     for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
-    if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }
+    if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }
     job_barrier(J, &s_err);
     for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
         uint32_t v = J.knowns[i];
@@ -2796,20 +2796,27 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                             J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
                             bool created = false;
                             uint32_t s = ht_slot(J, h, h2, true, &created);
-                            if (s != 0xFFFFFFFFu) atomicAdd(&J.ht_new[s], 1u);
+                            if (s != 0xFFFFFFFFu) {
+                                // p3_hot is raised only when this group could be complete with this member (k rows
+                                // counting the frozen ones): otherwise nobody has to look for trigger rows this pass
+                                const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
+                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k)
+                                    __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (created) {   // remembered, so that only the slots in use are wiped afterwards
                                 const uint32_t pos = atomicAdd(&s_htn, 1u);
                                 if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
                             }
-                            __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 }
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
                 const bool any = ld_agent(&ctr->p3_any) != 0;
+                const bool hot = ld_agent(&ctr->p3_hot) != 0;
                 any_total = any_total || any;
                 // phase 2: rows whose group could reach its size in this pass
-                if (any) {
+                if (hot) {
                     for (uint32_t r = f + gtid; r < nC; r += gstride) {
                         uint32_t k = J.p3k[r];
                         if (k < 2) continue;
@@ -2826,7 +2833,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 // phase 3 (master, wave 0): find the earliest trigger row that passes the test
                 if (master) {
                     if (w == 0) {
-                        uint32_t nhot = any ? ld_agent(&ctr->p3_nhot) : 0;
+                        uint32_t nhot = hot ? ld_agent(&ctr->p3_nhot) : 0;
                         if (nhot > J.hotcap) { raise(J, K_ECAPACITY); nhot = 0; }
                         uint32_t best = ld_agent(&ctr->p3_cand1);   // k == 1: first arrival of a one-variable group always fires
                         for (uint32_t a = 0; a < nhot; ++a) {
@@ -2877,7 +2884,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                         }
                         if (lane == 0) {
                             ctr->p3_fire = best;
-                            ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0;   // ready for the next round
+                            ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0;   // ready for the next round
                         }
                     }
                 }
