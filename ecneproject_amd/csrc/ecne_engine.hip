@@ -369,9 +369,11 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_evbuf = c.take(4ull * max_ranks * ECNE_EVCAP), o_cand = c.take(4ull * std::max<size_t>(ECNE_CANDCAP, 8ull * nC));
     uint32_t maxrowC = 0;
     for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
-    const size_t flatcap = std::max<size_t>((size_t)4 * ECNE_WG * ECNE_EVCAP, 16384);
+    const size_t flatcap = std::max<size_t>((size_t)4 * ECNE_WG * ECNE_EVCAP, 16384) + (size_t)ECNE_BIGK * (maxrowC + 8);
     size_t o_fvar = c.take(4ull * flatcap), o_frank = c.take(4ull * flatcap), o_fbase = c.take(4ull * (flatcap + 1));
     size_t o_bigev = c.take(4ull * ((size_t)maxrowC * 3 + 64));
+    const uint32_t bigstride = 2 * (maxrowC + 8);
+    size_t o_bigpool = c.take(4ull * 96 * ECNE_BIGK * bigstride);
     size_t o_ctr = c.take(sizeof(Counters));
     (void)static_end;
     char* base = nullptr;
@@ -448,6 +450,7 @@ static int upload_system(ecne_system& S, int device) {
     J.candcap = (uint32_t)std::max<size_t>(ECNE_CANDCAP, 8ull * nC);
     J.fvar = (uint32_t*)(base + o_fvar); J.frank = (uint32_t*)(base + o_frank); J.fbase = (uint32_t*)(base + o_fbase);
     J.bigev = (uint32_t*)(base + o_bigev);
+    J.bigpool = (uint32_t*)(base + o_bigpool); J.bigstride = bigstride;
     J.ctr = (Counters*)(base + o_ctr);
     S.dev.classified = false;
     return K_OK;

@@ -1379,7 +1379,6 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
 }
 
 #define ECNE_HSLOTS 4096
-#define ECNE_BIGK 4
 #define ECNE_ASET 6
 struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t cut;
@@ -1397,8 +1396,7 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t small_ovf;
     // long rows (> ECNE_SMALL_ROW entries) riding along in a round, at most ECNE_BIGK per workgroup: marked,
     // checked and executed by the whole workgroup, lanes across the row's entries
-    uint32_t bl_n, bl_rank[ECNE_BIGK], bl_row[ECNE_BIGK], bl_nev[ECNE_BIGK], bl_deg[ECNE_BIGK], bl_base[ECNE_BIGK];
-    uint32_t bl_off[ECNE_BIGK][ECNE_EVCAP];   // multi rounds: candidate offset of every event of a long row
+    uint32_t bl_n, bl_any, bl_rank[ECNE_BIGK], bl_row[ECNE_BIGK], bl_nev[ECNE_BIGK], bl_deg[ECNE_BIGK], bl_base[ECNE_BIGK];
     uint32_t bl_tmp[8];
     uint32_t hasbig;
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
@@ -1553,20 +1551,30 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
 __device__ __forceinline__ bool big_plain(uint32_t shape) {
     return !(shape & (SH_C_EMPTY | SH_R2 | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
 }
-// a lane registers its long row; false = no slot left (the caller cuts the prefix there)
+// a lane registers its long row; false = no slot left (the caller cuts the prefix there). Slot 0 is kept
+// for the row at rank 0, which must never be refused: the prefix always contains rank 0.
 __device__ __forceinline__ bool big_register(ChunkShared& S, uint32_t row, uint32_t rank) {
-    const uint32_t slot = atomicAdd(&S.bl_n, 1u);
-    if (slot >= ECNE_BIGK) return false;
+    uint32_t slot = 0;
+    if (rank != 0) {
+        slot = 1 + atomicAdd(&S.bl_n, 1u);
+        if (slot >= ECNE_BIGK) return false;
+    }
     S.bl_rank[slot] = rank;
     S.bl_row[slot] = row;
     S.bl_nev[slot] = 0;
+    S.bl_any = 1;
     return true;
+}
+// (thread 0, between rounds) forget the registrations
+__device__ __forceinline__ void big_reset(ChunkShared& S) {
+    S.bl_n = 0; S.bl_any = 0; S.hasbig = 0;
+    for (int k = 0; k < ECNE_BIGK; ++k) S.bl_rank[k] = 0xFFFFFFFFu;
 }
 // write-marks of the registered long rows: U class of every non-final variable of C (R1 / R7 / R8 may set it)
 __device__ __noinline__ void big_rows_mark(const Job& J, ChunkShared& S) {
-    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-    for (uint32_t k = 0; k < nb; ++k) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         const uint32_t row = S.bl_row[k], rank = S.bl_rank[k];
+        if (rank == 0xFFFFFFFFu) continue;   // (uniform) empty slot
         for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colC[e];
             if ((J.flags[v] & 3) != 3) atomicMin(&J.wmarkU[v], rank);
@@ -1574,9 +1582,9 @@ __device__ __noinline__ void big_rows_mark(const Job& J, ChunkShared& S) {
     }
 }
 __device__ __noinline__ void big_rows_unmark(const Job& J, ChunkShared& S) {
-    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-    for (uint32_t k = 0; k < nb; ++k) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         const uint32_t row = S.bl_row[k];
+        if (S.bl_rank[k] == 0xFFFFFFFFu) continue;   // (uniform) empty slot
         for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colC[e];
             if ((J.flags[v] & 3) != 3) J.wmarkU[v] = 0xFFFFFFFFu;
@@ -1585,17 +1593,13 @@ __device__ __noinline__ void big_rows_unmark(const Job& J, ChunkShared& S) {
 }
 // hazards of the registered long rows against the marks (same rule as for a lane's row: a lower mark
 // blocks it, a higher one cuts the prefix there). The row reads U of all its variables and B (bounds,
-// group tag) of C's non-unique ones. The same walk counts C's non-unique variables: a long row that
-// could emit more REQUEUE events than a rank's event slot holds is not taken along (cut at its rank; it
-// is then popped alone). All threads of the workgroup; updates S.cut.
+// group tag) of C's non-unique ones. All threads of the workgroup; updates S.cut.
 __device__ __noinline__ void big_rows_check(const Job& J, ChunkShared& S) {
-    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-    for (uint32_t k = 0; k < nb; ++k) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         const uint32_t row = S.bl_row[k], rank = S.bl_rank[k];
-        if (threadIdx.x == 0) { S.bl_tmp[0] = 0; S.bl_tmp[1] = 0; S.bl_tmp[2] = 0xFFFFFFFFu; S.bl_tmp[3] = 0; }
-        __syncthreads();
-        bool blocked = false, notknown = false;
-        uint32_t cutm = 0xFFFFFFFFu, cnt = 0, amin = 0xFFFFFFFFu, amax = 0;
+        if (rank == 0xFFFFFFFFu) continue;   // (uniform) empty slot
+        bool blocked = false;
+        uint32_t cutm = 0xFFFFFFFFu;
         auto see = [&](uint32_t m) { if (m < rank) blocked = true; else if (m > rank && m < cutm) cutm = m; };
         for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colA[e];
@@ -1609,46 +1613,34 @@ __device__ __noinline__ void big_rows_check(const Job& J, ChunkShared& S) {
             const uint32_t v = J.colC[e];
             const uint8_t f = J.flags[v];
             if ((f & 3) != 3) see(ld_agent(&J.wmarkU[v]));
-            if (!(f & 1)) {
-                see(ld_agent(&J.wmarkB[v]));
-                ++cnt;
-                if (!(f & 2)) notknown = true;
-                const uint32_t a = (uint32_t)J.abz[v];
-                amin = a < amin ? a : amin;
-                amax = a > amax ? a : amax;
-            }
+            if (!(f & 1)) see(ld_agent(&J.wmarkB[v]));
         }
         if (blocked) atomicMin(&S.cut, rank);
         else if (cutm != 0xFFFFFFFFu) atomicMin(&S.cut, cutm);
-        if (cnt) {
-            atomicAdd(&S.bl_tmp[0], cnt);
-            if (notknown) S.bl_tmp[1] = 1;
-            atomicMin(&S.bl_tmp[2], amin);
-            atomicMax(&S.bl_tmp[3], amax);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const bool badgroup = S.bl_tmp[2] != S.bl_tmp[3] || S.bl_tmp[3] == 0xFFFFFFFFu;
-            const bool may_fire_all = !(J.rinfo[row].shape & SH_HAS_AB) && (S.bl_tmp[1] == 0 || !badgroup);   // R7 or R8
-            if (S.bl_tmp[0] > ECNE_EVCAP - 2 && may_fire_all) atomicMin(&S.cut, rank);
-        }
-        __syncthreads();
     }
 }
-// execute the registered long rows that made it into the prefix (rank < c); events go to the rank's slot
-__device__ __noinline__ void big_rows_exec(const Job& J, ChunkShared& S, uint32_t c) {
-    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-    for (uint32_t k = 0; k < nb; ++k) {
+// Events of a long row executed inside a round go to a slot of the job's pool (a long row can emit one
+// event per term, more than a rank's regular event list holds): [0, maxrow) events, then their
+// candidate offsets (multi-workgroup rounds). One slot per (workgroup, registration index).
+__device__ __forceinline__ uint32_t* big_ev(const Job& J, uint32_t wgrank, uint32_t k) {
+    return J.bigpool + (size_t)(wgrank * ECNE_BIGK + k) * J.bigstride;
+}
+__device__ __forceinline__ uint32_t* big_off(const Job& J, uint32_t wgrank, uint32_t k) {
+    return big_ev(J, wgrank, k) + J.bigstride / 2;
+}
+// execute the registered long rows that made it into the prefix (rank < c); events go to their pool slot
+__device__ __noinline__ void big_rows_exec(const Job& J, ChunkShared& S, uint32_t c, uint32_t wgrank) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         const uint32_t row = S.bl_row[k], rank = S.bl_rank[k];
+        if (rank == 0xFFFFFFFFu) continue;   // (uniform) empty slot
         if (rank >= c) continue;                                   // uniform
-        exec_big_row_wg(J, S, row, J.evbuf + (size_t)rank * ECNE_EVCAP, &S.bl_nev[k]);
+        exec_big_row_wg(J, S, row, big_ev(J, wgrank, k), &S.bl_nev[k]);
     }
     __syncthreads();
 }
 // number of events a lane's long row emitted (0 if it is none of the registered ones)
 __device__ __forceinline__ int big_slot_of(const ChunkShared& S, uint32_t rank) {
-    const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-    for (uint32_t k = 0; k < nb; ++k) if (S.bl_rank[k] == rank) return (int)k;
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) if (S.bl_rank[k] == rank) return (int)k;
     return -1;
 }
 
@@ -1958,7 +1950,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         });
     }
     __syncthreads();
-    if (S.bl_n) big_rows_mark(J, S);
+    if (S.bl_any) big_rows_mark(J, S);
     if ((err = job_barrier(J, s_err))) return err;
     MTICK(0);
     // ---- check
@@ -1985,7 +1977,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         }
         if (blocked) atomicMin(&S.cut, rank);
     }
-    if (S.bl_n) big_rows_check(J, S);
+    if (S.bl_any) big_rows_check(J, S);
     // one global update per workgroup (thousands of lanes on one word would serialise)
     __syncthreads();
     if (tid == 0 && S.cut != 0xFFFFFFFFu) atomicMin(&ctr->q_cut, S.cut);
@@ -1994,7 +1986,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     uint32_t c = ld_agent(&ctr->q_cut);         // >= 1 (the master checked that rank 0 is not a big row)
     if (c > n) c = n;                             // nobody blocked: the whole window commits
     // ---- unmark, tag, execute my ranks below the cut
-    if (S.bl_n) big_rows_unmark(J, S);
+    if (S.bl_any) big_rows_unmark(J, S);
     uint32_t nev[2], mycand = 0, bigsl = 0;
 #pragma unroll
     for (uint32_t sl = 0; sl < 2; ++sl) {
@@ -2021,19 +2013,30 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
         ev[ECNE_EVCAP - 1] = nev[sl];    // for the sequential replay fallback
     }
-    if (S.bl_n) {   // (uniform per workgroup) long rows of the prefix: execute, then candidate offsets of their events
-        big_rows_exec(J, S, c);
-        const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-        for (uint32_t k = 0; k < nb; ++k) {
+    if (S.bl_any) {   // (uniform per workgroup) long rows of the prefix: execute, then candidate offsets of their events
+        big_rows_exec(J, S, c, wgrank);
+        for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
             if (S.bl_rank[k] >= c) continue;
-            uint32_t* ev = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
-            const uint32_t ne = S.bl_nev[k];          // <= ECNE_EVCAP - 2 (big_rows_check)
-            uint32_t d = 0;
-            if ((uint32_t)tid < ne) { const uint32_t v = ev[tid]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
-            uint32_t tot;
-            const uint32_t off = wg_exclusive_scan(d, S.scan, &tot);
-            if ((uint32_t)tid < ne) S.bl_off[k][tid] = off;
-            if (tid == 0) { S.bl_deg[k] = tot; ev[ECNE_EVCAP - 1] = ne; }
+            const uint32_t* ev = big_ev(J, wgrank, k);
+            uint32_t* off = big_off(J, wgrank, k);
+            const uint32_t ne = S.bl_nev[k];
+            uint32_t run = 0;
+            for (uint32_t eb = 0; eb < ne; eb += ECNE_WG) {          // (uniform trip count)
+                const uint32_t e = eb + tid;
+                uint32_t d = 0;
+                if (e < ne) { const uint32_t v = ev[e]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+                uint32_t tot;
+                const uint32_t o = wg_exclusive_scan(d, S.scan, &tot);
+                if (e < ne) off[e] = run + o;
+                run += tot;
+            }
+            if (tid == 0) {
+                S.bl_deg[k] = run;
+                // the rank's regular slot only says where the events are (for the sequential replay fallback)
+                uint32_t* slot = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+                slot[ECNE_EVCAP - 1] = 0x80000000u | (wgrank * ECNE_BIGK + k);
+                slot[ECNE_EVCAP - 2] = ne;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -2060,8 +2063,13 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
                     const uint32_t rr = J.queue[(head + r) & J.qmask];
                     if (lane == 0) J.inq[rr] = 0;
                     wg_fence();
-                    const uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
-                    for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, J.evbuf[(size_t)r * ECNE_EVCAP + e]);
+                    uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
+                    const uint32_t* evs = J.evbuf + (size_t)r * ECNE_EVCAP;
+                    if (ne & 0x80000000u) {   // a long row: its events are in the pool
+                        evs = J.bigpool + (size_t)(ne & 0x7FFFFFFFu) * J.bigstride;
+                        ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 2];
+                    }
+                    for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, evs[e]);
                 }
                 if (lane == 0) { ctr->q_tail_out = qq.tail; ctr->q_c_out = c; ctr->q_cut = 0xFFFFFFFFu; }
             }
@@ -2094,13 +2102,13 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
                 j += J.fo_ptr[v + 1] - J.fo_ptr[v];
             }
         }
-        if (S.bl_n) {
+        if (S.bl_any) {
             __syncthreads();
-            const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-            for (uint32_t k = 0; k < nb; ++k) {
+            for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
                 if (S.bl_rank[k] >= c) continue;
-                const uint32_t* ev = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
-                if ((uint32_t)tid < S.bl_nev[k]) expand_event(J, S, ev[tid], S.bl_rank[k], S.bl_base[k] + S.bl_off[k][tid], true);
+                const uint32_t* ev = big_ev(J, wgrank, k);
+                const uint32_t* off = big_off(J, wgrank, k);
+                for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) expand_event(J, S, ev[e], S.bl_rank[k], S.bl_base[k] + off[e], true);
             }
         }
         expand_big_events(J, S, true);
@@ -2135,7 +2143,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         }
     }
     if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
-    if (tid == 0) { S.bl_n = 0; S.hasbig = 0; }
+    if (tid == 0) big_reset(S);
     if ((err = job_barrier(J, s_err))) return err;
     MTICK(5);
     *out_c = c;
@@ -2163,7 +2171,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
     if (tid < 12) S.acc[tid] = 0;
     for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
-    if (tid == 0) { S.small_ovf = 0; S.bl_n = 0; S.hasbig = 0; }
+    if (tid == 0) { S.small_ovf = 0; big_reset(S); }
     unsigned long long qt_last = wall_clock64();
 #ifdef ECNE_FINE_TICKS
 #define QTICK(slot) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); S.qt[slot] += t_ - qt_last; qt_last = t_; } } while (0)
@@ -2235,10 +2243,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 if (!J.solved[row[sl]]) live |= 1u << sl;
             }
         }
-        if (tid == 0) { S.cut = n; S.fallback = (shape[0] & SH_BIG) ? 1u : 0u; }
+        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && !big_plain(shape[0])) ? 1u : 0u; }
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
-            if ((shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl]) && r0 + sl > 0) S.hasbig = 1;
+            if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
         if (!S.fallback && J.nwg > 1 && avail >= ECNE_MULTI_MIN && window >= ECNE_MULTI_MIN) {
@@ -2317,8 +2325,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (small) {
             if ((uint32_t)tid < n) {
                 const uint32_t rank = (uint32_t)tid;
-                if (shape[0] & SH_BIG) atomicMin(&S.cut, rank);
-                else if (live & 1u) {
+                if (!(live & 1u)) { }                                     // solved row: the pop is all that happens
+                else if (shape[0] & SH_BIG) atomicMin(&S.cut, rank);   // (a long row of the R2..R6 shapes, rank > 0)
+                else {
                     const RowInfo ri = J.rinfo[row[0]];
                     bool nb = false;
                     if (row_is_noop(J, row[0], ri, nb)) {
@@ -2407,7 +2416,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 });
             }
             __syncthreads();
-            if (S.bl_n) { big_rows_mark(J, S); __syncthreads(); }
+            if (S.bl_any) { big_rows_mark(J, S); __syncthreads(); }
             QTICK(1);
             // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
             // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
@@ -2437,10 +2446,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 }
                 if (blocked) atomicMin(&S.cut, rank);
             }
-            if (S.bl_n) big_rows_check(J, S);
+            if (S.bl_any) big_rows_check(J, S);
             __syncthreads();
             c = S.cut;   // >= 1: rank 0 is never blocked and not big
-            if (S.bl_n) big_rows_unmark(J, S);
+            if (S.bl_any) big_rows_unmark(J, S);
             // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see resolve_pushes)
 #pragma unroll
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
@@ -2470,8 +2479,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             nev_tot += nev[sl];
         }
         uint32_t bigsl = 0;          // slots of mine that hold a long row executed in this round
-        if (S.bl_n) {                // (uniform) the long rows of the prefix, by the whole workgroup
-            big_rows_exec(J, S, c);
+        if (S.bl_any) {                // (uniform) the long rows of the prefix, by the whole workgroup
+            big_rows_exec(J, S, c, 0);
 #pragma unroll
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
                 if (sl < rpl && r0 + sl < c && (shape[sl] & SH_BIG) && (live & (1u << sl))) {
@@ -2496,12 +2505,11 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 const uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
                 for (uint32_t e = 0; e < nev[sl]; ++e) { J.fvar[o] = ev[e]; J.frank[o] = r0 + sl; ++o; }
             }
-            if (S.bl_n) {
+            if (S.bl_any) {
                 __syncthreads();
-                const uint32_t nb = S.bl_n < ECNE_BIGK ? S.bl_n : ECNE_BIGK;
-                for (uint32_t k = 0; k < nb; ++k) {
+                for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
                     if (S.bl_rank[k] >= c) continue;
-                    const uint32_t* ev = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+                    const uint32_t* ev = big_ev(J, 0, k);
                     for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) { J.fvar[S.bl_base[k] + e] = ev[e]; J.frank[S.bl_base[k] + e] = S.bl_rank[k]; }
                 }
             }
@@ -2514,7 +2522,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
             if (sl < rpl && r0 + sl < c && J.inq[row[sl]] >= 2) J.inq[row[sl]] = 0;
-        if (tid == 0) { S.bl_n = 0; S.hasbig = 0; }
+        if (tid == 0) big_reset(S);
         __syncthreads();
         q.head += c;
         q.tail = new_tail;
@@ -2556,7 +2564,7 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
     for (int i = 0; i < 8; ++i) C.hits[i] = 0;
     uint32_t my_pops = 0, my_nnz = 0;
     if (threadIdx.x < 12) S.acc[threadIdx.x] = 0;   // long rows executed by this workgroup count here
-    if (threadIdx.x == 0) { S.bl_n = 0; S.hasbig = 0; }
+    if (threadIdx.x == 0) big_reset(S);
     __syncthreads();
     for (;;) {
         if (job_barrier(J, s_err)) break;
