@@ -547,6 +547,10 @@ int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* o) {
 }
 int ecne_r1cs_csr(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
     if (!f || part < 0 || part > 2) return ECNE_EINVAL;
+    if (!f->f.csr_built) {   // (a handle is used by one thread at a time, include/ecne.h)
+        const int st = build_file_csr(const_cast<ecne_r1cs*>(f)->f);
+        if (st != K_OK) return st;
+    }
     if (rowptr) *rowptr = f->f.csr_ptr[part].data();
     if (col) *col = f->f.csr_col[part].data();
     if (coeff) *coeff = f->f.csr_coef[part].data();

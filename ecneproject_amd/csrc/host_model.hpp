@@ -64,7 +64,10 @@ struct R1CSFile {
     std::vector<int64_t> knowns, outputs;
     int64_t n_vars = 0;
     uint64_t nnz[3] = {0, 0, 0};
-    // file-order CSR views handed out by ecne_r1cs_csr (non-zero entries only)
+    // file-order CSR views handed out by ecne_r1cs_csr (non-zero entries only): built on first use from
+    // the file (the solve path never needs them)
+    std::string path;
+    bool csr_built = false;
     std::vector<uint64_t> csr_ptr[3];
     std::vector<uint32_t> csr_col[3];
     std::vector<uint64_t> csr_coef[3];
@@ -125,42 +128,57 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
     out.n_labels = rd64(b + h + 16);
     out.n_cons = rd32(b + h + 24);
 
+    // pass 1 over the constraint section: term counts per part (bounds-checks the section, sizes the arrays)
+    uint64_t terms[3] = {0, 0, 0};
+    {
+        size_t c = start[2];
+        for (uint32_t r = 0; r < out.n_cons; ++r)
+            for (int p = 0; p < 3; ++p) {
+                if (!need(c, 4)) return K_EFORMAT;
+                const uint32_t n = rd32(b + c);
+                c += 4;
+                if (!need(c, (size_t)n * 36)) return K_EFORMAT;
+                c += (size_t)n * 36;
+                terms[p] += n ? n : 1;   // an empty part is stored as {1 => 0}
+            }
+    }
     size_t c = start[2];
     out.rows.start();
     for (int p = 0; p < 3; ++p) {
-        out.csr_ptr[p].assign(1, 0);
-        out.csr_col[p].clear();
-        out.csr_coef[p].clear();
+        out.rows.ptr[p].reserve((size_t)out.n_cons + 1);
+        out.rows.var[p].reserve(terms[p]);
+        out.rows.coef[p].reserve(terms[p]);
     }
+    out.path = path;
+    out.csr_built = false;
     jl::SlotTable tab;
     std::vector<fp::u256> tmpc;
     for (uint32_t r = 0; r < out.n_cons; ++r) {
         for (int p = 0; p < 3; ++p) {
-            if (!need(c, 4)) return K_EFORMAT;
             uint32_t n = rd32(b + c);
             c += 4;
-            if (!need(c, (size_t)n * 36)) return K_EFORMAT;
-            tab.reset();
-            tmpc.clear();
-            for (uint32_t k = 0; k < n; ++k) {
-                uint32_t wire = rd32(b + c);
-                fp::u256 v = fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28));
-                c += 36;
-                v = fp::reduce(v);
-                bool ins;
-                int64_t& slot = tab.upsert((int64_t)wire + 1, (int64_t)tmpc.size(), ins);
-                if (ins) tmpc.push_back(v); else tmpc[(size_t)slot] = v;
-                // file-order view (non-zero terms, as stored)
-                if (!fp::is_zero(v)) {
-                    out.csr_col[p].push_back(wire + 1);
-                    for (int w = 0; w < 4; ++w) out.csr_coef[p].push_back(v.w[w]);
-                }
-            }
-            out.csr_ptr[p].push_back(out.csr_col[p].size());
             if (n == 0) {
                 out.rows.var[p].push_back(1);
                 out.rows.coef[p].push_back(fp::make(0));
+            } else if (n == 1) {   // one term: no dictionary order to reproduce
+                const uint32_t wire = rd32(b + c);
+                const fp::u256 v = fp::reduce(fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28)));
+                c += 36;
+                out.rows.var[p].push_back(wire + 1);
+                out.rows.coef[p].push_back(v);
+                if (!fp::is_zero(v)) out.nnz[p]++;
             } else {
+                tab.reset();
+                tmpc.clear();
+                for (uint32_t k = 0; k < n; ++k) {
+                    uint32_t wire = rd32(b + c);
+                    fp::u256 v = fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28));
+                    c += 36;
+                    v = fp::reduce(v);
+                    bool ins;
+                    int64_t& slot = tab.upsert((int64_t)wire + 1, (int64_t)tmpc.size(), ins);
+                    if (ins) tmpc.push_back(v); else tmpc[(size_t)slot] = v;
+                }
                 tab.for_each([&](int64_t key, int64_t pay) {
                     out.rows.var[p].push_back((uint32_t)key);
                     out.rows.coef[p].push_back(tmpc[(size_t)pay]);
@@ -176,6 +194,60 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
     out.outputs.clear();
     for (int64_t i = 2; i <= 1 + (int64_t)out.n_pub_out; ++i) out.outputs.push_back(i);
     out.n_vars = (int64_t)out.n_wires + 1;
+    return K_OK;
+}
+
+// file-order CSR of a loaded file (what ecne_r1cs_csr hands out): every non-zero term as stored, duplicates
+// included, coefficients reduced. Built on first use by reading the file again.
+inline int build_file_csr(R1CSFile& out) {
+    if (out.csr_built) return K_OK;
+    std::vector<uint8_t> buf;
+    {
+        FILE* f = std::fopen(out.path.c_str(), "rb");
+        if (!f) return K_EIO;
+        std::fseek(f, 0, SEEK_END);
+        long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        buf.resize((size_t)(n < 0 ? 0 : n));
+        size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
+        std::fclose(f);
+        if (got != buf.size()) return K_EIO;
+    }
+    const size_t N = buf.size();
+    const uint8_t* b = buf.data();
+    auto need = [&](size_t off, size_t len) { return off + len <= N; };
+    if (!need(0, 12)) return K_EFORMAT;
+    size_t cur = 12, start2 = 0;
+    for (int s = 0; s < 3; ++s) {
+        if (!need(cur, 12)) return K_EFORMAT;
+        if (rd32(b + cur) == 2) start2 = cur + 12;
+        cur += 12 + (size_t)rd64(b + cur + 4);
+    }
+    if (!start2) return K_EFORMAT;
+    size_t c = start2;
+    for (int p = 0; p < 3; ++p) {
+        out.csr_ptr[p].assign(1, 0);
+        out.csr_col[p].clear();
+        out.csr_coef[p].clear();
+    }
+    for (uint32_t r = 0; r < out.n_cons; ++r)
+        for (int p = 0; p < 3; ++p) {
+            if (!need(c, 4)) return K_EFORMAT;
+            const uint32_t n = rd32(b + c);
+            c += 4;
+            if (!need(c, (size_t)n * 36)) return K_EFORMAT;
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t wire = rd32(b + c);
+                const fp::u256 v = fp::reduce(fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28)));
+                c += 36;
+                if (!fp::is_zero(v)) {
+                    out.csr_col[p].push_back(wire + 1);
+                    for (int w = 0; w < 4; ++w) out.csr_coef[p].push_back(v.w[w]);
+                }
+            }
+            out.csr_ptr[p].push_back(out.csr_col[p].size());
+        }
+    out.csr_built = true;
     return K_OK;
 }
 
@@ -199,10 +271,9 @@ inline void part_values(const Rows& R, int p, size_t i, std::vector<fp::u256>& o
     out.clear();
     for (uint64_t k = R.ptr[p][i]; k < R.ptr[p][i + 1]; ++k)
         if (!fp::is_zero(R.coef[p][k])) out.push_back(R.coef[p][k]);
-    std::sort(out.begin(), out.end(), LessU256());
+    if (out.size() > 1) std::sort(out.begin(), out.end(), LessU256());
 }
-inline uint64_t row_fingerprint(const Rows& R, size_t i) {
-    std::vector<fp::u256> v;
+inline uint64_t row_fingerprint(const Rows& R, size_t i, std::vector<fp::u256>& v) {   // v: scratch
     uint64_t h = 0x1234567;
     for (int p = 0; p < 3; ++p) {
         part_values(R, p, i, v);
@@ -229,11 +300,16 @@ inline bool appear_eq(const Appear& x, const Appear& y) {
 }
 struct AppearMap {
     jl::SlotTable tab;
-    std::vector<Appear> lists;
+    std::vector<Appear> lists;   // lists[0 .. used): one per variable; the vectors are reused across clear()
+    size_t used = 0;
+    void clear() { tab.reset(); used = 0; }
     void add(int64_t var, int64_t where, const fp::u256& c) {
         bool ins;
-        int64_t& s = tab.upsert(var, (int64_t)lists.size(), ins);
-        if (ins) lists.emplace_back();
+        int64_t& s = tab.upsert(var, (int64_t)used, ins);
+        if (ins) {
+            if (used == lists.size()) lists.emplace_back(); else lists[used].clear();
+            ++used;
+        }
         lists[(size_t)s].push_back({where, c});
     }
     // (variable, list index) sorted by list, stable w.r.t. table order
@@ -256,8 +332,9 @@ inline int abstract_one(const std::string& name, Rows& rows, const R1CSFile& sub
     std::vector<size_t> cand;
     if (nC + 1 >= nS + 1 && nC >= nS) {
         std::vector<uint64_t> fb(nC), fs(nS);
-        for (size_t i = 0; i < nC; ++i) fb[i] = row_fingerprint(rows, i);
-        for (size_t i = 0; i < nS; ++i) fs[i] = row_fingerprint(sub.rows, i);
+        std::vector<fp::u256> scratch;
+        for (size_t i = 0; i < nC; ++i) fb[i] = row_fingerprint(rows, i, scratch);
+        for (size_t i = 0; i < nS; ++i) fs[i] = row_fingerprint(sub.rows, i, scratch);
         for (size_t i = 0; i + nS <= nC; ++i) {
             bool m = true;
             for (size_t j = 0; j + 1 < nS; ++j)
@@ -279,18 +356,29 @@ inline int abstract_one(const std::string& name, Rows& rows, const R1CSFile& sub
     struct Match { size_t at; std::unordered_map<int64_t, int64_t> map; };
     std::vector<Match> matches;
     std::vector<fp::u256> va, vb;
+    // the pattern's sorted coefficient lists, once (every candidate window is compared against them)
+    std::vector<fp::u256> subvals;
+    std::vector<size_t> subptr(1, 0);
+    if (!cand.empty())
+        for (size_t j = 0; j < nS; ++j)
+            for (int p = 0; p < 3; ++p) {
+                part_values(sub.rows, p, j, vb);
+                subvals.insert(subvals.end(), vb.begin(), vb.end());
+                subptr.push_back(subvals.size());
+            }
+    AppearMap cur;
     for (size_t at : cand) {
-        AppearMap cur;
+        cur.clear();
         int64_t counter = 0;
         bool ok = true;
         for (size_t j = 0; j < nS && ok; ++j)
             for (int p = 0; p < 3 && ok; ++p) {
                 ++counter;
                 part_values(rows, p, at + j, va);
-                part_values(sub.rows, p, j, vb);
-                if (va.size() != vb.size()) { ok = false; break; }
+                const size_t s0 = subptr[j * 3 + (size_t)p], s1 = subptr[j * 3 + (size_t)p + 1];
+                if (va.size() != s1 - s0) { ok = false; break; }
                 for (size_t t = 0; t < va.size(); ++t)
-                    if (!fp::eq(va[t], vb[t])) { ok = false; break; }
+                    if (!fp::eq(va[t], subvals[s0 + t])) { ok = false; break; }
                 if (!ok) break;
                 for (uint64_t k = rows.ptr[p][at + j]; k < rows.ptr[p][at + j + 1]; ++k)
                     if (!fp::is_zero(rows.coef[p][k])) cur.add(rows.var[p][k], counter, rows.coef[p][k]);
@@ -308,29 +396,45 @@ inline int abstract_one(const std::string& name, Rows& rows, const R1CSFile& sub
     }
     Rows red;
     red.start();
-    size_t mi = 0, i = 0;
-    while (i < nC) {
-        if (mi >= matches.size() || i != matches[mi].at) {
-            red.append_row_from(rows, i);
-            ++i;
-        } else {
-            Special sp;
-            sp.name = name;
-            for (int64_t x : sub.knowns)
-                if (x != 1) {
-                    auto it = matches[mi].map.find(x);
-                    if (it == matches[mi].map.end()) return K_EKEY;
-                    sp.inputs.push_back(it->second);
-                }
-            for (int64_t x : sub.outputs) {
+    for (int p = 0; p < 3; ++p) {
+        red.ptr[p].reserve(rows.ptr[p].size());
+        red.var[p].reserve(rows.var[p].size());
+        red.coef[p].reserve(rows.coef[p].size());
+    }
+    // rows outside the matched windows are copied range by range
+    auto copy_range = [&](size_t a, size_t b) {   // rows [a, b)
+        for (int p = 0; p < 3; ++p) {
+            const uint64_t k0 = rows.ptr[p][a], k1 = rows.ptr[p][b];
+            const uint64_t shift = (uint64_t)red.var[p].size() - k0;
+            red.var[p].insert(red.var[p].end(), rows.var[p].begin() + (ptrdiff_t)k0, rows.var[p].begin() + (ptrdiff_t)k1);
+            red.coef[p].insert(red.coef[p].end(), rows.coef[p].begin() + (ptrdiff_t)k0, rows.coef[p].begin() + (ptrdiff_t)k1);
+            for (size_t r = a + 1; r <= b; ++r) red.ptr[p].push_back(rows.ptr[p][r] + shift);
+        }
+    };
+    size_t i = 0;
+    for (size_t mi = 0; mi <= matches.size(); ++mi) {
+        // greedy left to right with the reference's stuck cursor (:368-388): a match that starts inside the
+        // previous window is never reached again, and neither is any later one
+        const size_t stop = mi < matches.size() ? matches[mi].at : nC;
+        if (stop < i) { copy_range(i, nC); i = nC; break; }
+        copy_range(i, stop);
+        i = stop;
+        if (mi == matches.size()) break;
+        Special sp;
+        sp.name = name;
+        for (int64_t x : sub.knowns)
+            if (x != 1) {
                 auto it = matches[mi].map.find(x);
                 if (it == matches[mi].map.end()) return K_EKEY;
-                sp.outputs.push_back(it->second);
+                sp.inputs.push_back(it->second);
             }
-            specials.push_back(std::move(sp));
-            i += nS;
-            ++mi;
+        for (int64_t x : sub.outputs) {
+            auto it = matches[mi].map.find(x);
+            if (it == matches[mi].map.end()) return K_EKEY;
+            sp.outputs.push_back(it->second);
         }
+        specials.push_back(std::move(sp));
+        i += nS;
     }
     rows = std::move(red);
     return K_OK;
