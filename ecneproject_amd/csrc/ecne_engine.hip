@@ -105,7 +105,10 @@ static void build_layout(ecne_system& S) {
     }
     const uint32_t nVall = maxv;   // arrays hold ids 0..nVall
     L.nV = nVall;
-    for (int p = 0; p < 3; ++p) { L.rp[p].assign(1, 0); L.col[p].clear(); L.coef[p].clear(); }
+    for (int p = 0; p < 3; ++p) {
+        L.rp[p].assign(1, 0); L.col[p].clear(); L.coef[p].clear();
+        L.rp[p].reserve(nC + 1); L.col[p].reserve(R.var[p].size()); L.coef[p].reserve(4 * R.var[p].size());
+    }
     L.rinfo.assign(nC, RowInfo());
     L.nontrivial.assign((size_t)nVall + 1, 0);
     std::vector<uint32_t> deg((size_t)nVall + 2, 0);
@@ -113,7 +116,7 @@ static void build_layout(ecne_system& S) {
     const fp::u256 ONE = fp::make(1), PM1 = fp::pminus1();
     jl::SlotTable set;
     struct E { uint32_t v; fp::u256 c; };
-    std::vector<E> nz[3];
+    std::vector<E> nz[3], tmp;
     std::vector<uint32_t> zeros_c;   // unused beyond counting
     std::vector<uint8_t> a_equal_next(nC, 0);
     std::vector<uint32_t> seen_stamp((size_t)nVall + 1, 0xFFFFFFFFu);
@@ -127,16 +130,19 @@ static void build_layout(ecne_system& S) {
         for (int p = 0; p < 3; ++p) {
             // nonzeroKeys(part): a Set filled in dictionary order, iterated in slot order (:26-34)
             nz[p].clear();
-            set.reset();
-            std::vector<E> tmp;
+            tmp.clear();
             for (uint64_t k = R.ptr[p][i]; k < R.ptr[p][i + 1]; ++k) {
                 if (p == 2 && R.var[p][k] == 1) c_has_key1 = true;
                 if (fp::is_zero(R.coef[p][k])) { zc[p]++; continue; }
-                bool ins;
-                set.upsert((int64_t)R.var[p][k], (int64_t)tmp.size(), ins);
                 tmp.push_back({R.var[p][k], R.coef[p][k]});
             }
-            set.for_each([&](int64_t, int64_t pay) { nz[p].push_back(tmp[(size_t)pay]); });
+            if (tmp.size() <= 1) {   // nothing to order
+                nz[p] = tmp;
+            } else {
+                set.reset();
+                for (size_t t = 0; t < tmp.size(); ++t) { bool ins; set.upsert((int64_t)tmp[t].v, (int64_t)t, ins); }
+                set.for_each([&](int64_t, int64_t pay) { nz[p].push_back(tmp[(size_t)pay]); });
+            }
             for (auto& e : nz[p]) {
                 L.col[p].push_back(e.v);
                 for (int w = 0; w < 4; ++w) L.coef[p].push_back(e.c.w[w]);
