@@ -28,6 +28,19 @@ def test_small_ecdsa_like_bit_exact(S, stride):
     assert_bit_exact("ecdsa_like(%d,%d)" % (S, stride), g, o)
 
 
+@pytest.mark.parametrize("S,stride", [(3, 7), (4, 8), (3, 9)])
+@pytest.mark.parametrize("force_nwg", [0, 3, 16])
+def test_long_rows_ride_along_bit_exact(S, stride, force_nwg):
+    """Sum rows of 129 / 257 / 513 terms (8 per stride): they are marked, checked and executed inside the
+    queue rounds by whole workgroups, on one workgroup and on forced teams of 3 and 16."""
+    path = ecdsa_like.cached(S, stride)
+    s = build_system(None, *TRUSTED, path=path)
+    g = E.solve_batch([s], force_nwg=force_nwg)[0]
+    o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
+    assert o.verdict is True
+    assert_bit_exact("ecdsa_like(%d,%d) nwg=%d" % (S, stride, force_nwg), g, o)
+
+
 def test_full_size_properties():
     """ecdsa_like(26): 25 adders abstracted, chained one per outer iteration (P1 fires one special per
     iteration), every variable the circuit mentions resolved, idempotent."""
