@@ -64,8 +64,8 @@ struct Counters {   // one per job, device memory
     unsigned int q_head, q_tail;
     unsigned int pad;
     unsigned long long phase_ticks[8];
-    unsigned long long qticks[8];
-    unsigned long long mticks[8];        // multi-workgroup round breakdown: mark, check, exec+scan, expand, compact+scan, final        // queue phase breakdown: head, mark, check+unmark, exec, flatten, resolve, big rows
+    unsigned long long qticks[8];        // queue phase (master): head, mark, check+unmark, exec, flatten, resolve, alone+bursts, multi rounds
+    unsigned long long mticks[8];        // multi-workgroup rounds: mark, check+cut, exec+scan, expand, count+scan, write
     // job-wide synchronisation words (zeroed before every launch)
     unsigned long long sync_steps;
     int error_snap;

@@ -1400,7 +1400,6 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t bl_tmp[8];
     uint32_t hasbig;
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
-    unsigned long long dbg[16];
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };
 
@@ -2604,7 +2603,6 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     const uint32_t nC = J.nC, nV = J.nV;
     const bool master = me.rank == 0;
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
-    if (tid < 16) s_chunk.dbg[tid] = 0;
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
     const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
@@ -2784,7 +2782,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
         {
             uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
-            bool any_total = false, p3_err = false;
+            bool p3_err = false;
             for (;;) {
                 tk[6]++;
                 // phase 1: evaluate rows >= f against the current state
@@ -2822,7 +2820,6 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
                 const bool any = ld_agent(&ctr->p3_any) != 0;
                 const bool hot = ld_agent(&ctr->p3_hot) != 0;
-                any_total = any_total || any;
                 // phase 2: rows whose group could reach its size in this pass
                 if (hot) {
                     for (uint32_t r = f + gtid; r < nC; r += gstride) {
@@ -3079,9 +3076,6 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
                 for (int i = 0; i < 8; ++i) ctr->qticks[i] = s_chunk.qt[i];
                 for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
-#ifdef ECNE_DBG
-                for (int i = 0; i < 8; ++i) { ctr->qticks[i] = s_chunk.dbg[i]; ctr->mticks[i] = s_chunk.dbg[8 + i] * 100000ull; }
-#endif
             }
         }
     }
