@@ -1239,6 +1239,12 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
         uint32_t n = a1 - a0;
         n = b1 - b0 > n ? b1 - b0 : n;
         n = c1 - c0 > n ? c1 - c0 : n;
+        // Only R1 can write here, and it writes exactly one variable: the single non-unique one of C when
+        // every variable of A and B is unique. Decided on the state this row reads -- if an earlier row of
+        // the window changes that state the row is blocked anyway, so the observation cannot go stale.
+        // Rows that fit one batch (the usual a * b = c) get the exact write set; longer ones the
+        // conservative one (any non-final variable of C).
+        const bool one_batch = n <= 4;
         for (uint32_t off = 0; off < n; off += 4) {
             uint32_t v[12];
             uint8_t fl[12];
@@ -1250,8 +1256,18 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
             }
 #pragma unroll
             for (uint32_t i = 0; i < 12; ++i) fl[i] = J.flags[v[i]];
+            bool may_write = true;
+            if (one_batch) {
+                uint32_t ab = 1, cnt = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 12; ++i) if ((fl[i] & 3) != 3) f(v[i], 1u, i >= 8 ? 1u : 0u);
+                for (uint32_t i = 0; i < 8; ++i) ab &= fl[i];
+#pragma unroll
+                for (uint32_t i = 8; i < 12; ++i) cnt += !(fl[i] & 1);   // (padding is the constant wire: unique)
+                may_write = (ab & 1) && cnt == 1;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 12; ++i)
+                if ((fl[i] & 3) != 3) f(v[i], 1u, (i >= 8 && may_write && !(one_batch && (fl[i] & 1))) ? 1u : 0u);
         }
         return;
     }
