@@ -88,7 +88,7 @@ class R1CS:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:          # (module globals are gone at interpreter shutdown)
             _lib.lib().ecne_r1cs_free(h)
             self._h = None
 
@@ -129,7 +129,7 @@ class System:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:
             _lib.lib().ecne_system_free(h)
             self._h = None
 
