@@ -55,6 +55,21 @@ def r8_decoder(n=100, with_success_input=True):
     return dict(nwires=3 + n, nout=0, npub=npub, nprv=0, rows=rows)
 
 
+def hub_fanout(n_rows=8200, n_hubs=10):
+    """n_hubs variables that each occur in ALL n_rows rows and all become unique in the same round: their
+    REQUEUE lists (n_hubs * n_rows candidates) exceed the engine's candidate buffer, which must then replay
+    the events sequentially (resolve_pushes / queue_round_multi fallback)."""
+    ins = list(range(2 + n_rows, 2 + n_rows + n_hubs + n_rows))      # public inputs: n_hubs sources, n_rows addends
+    zs = list(range(2, 2 + n_rows))                                    # outputs z_j
+    src, ws = ins[:n_hubs], ins[n_hubs:]
+    first_internal = 2 + n_rows + n_hubs + n_rows
+    hubs = list(range(first_internal, first_internal + n_hubs))
+    rows = [([], [], [(h, 1), (sv, (-1) % P)]) for h, sv in zip(hubs, src)]          # h_i == source_i
+    for j in range(n_rows):
+        rows.append(([], [], [(zs[j], (-1) % P), (ws[j], 1)] + [(h, 2 + i) for i, h in enumerate(hubs)]))
+    return dict(nwires=first_internal + n_hubs - 1, nout=n_rows, npub=n_hubs + n_rows, nprv=0, rows=rows)
+
+
 CASES = {
     # name: (spec, rule index, must fire)
     "r7_chain_100": (r7_chain(100), 6, True),
@@ -68,6 +83,7 @@ CASES = {
     "r8_decoder_100": (r8_decoder(100), 7, True),
     "r8_decoder_700": (r8_decoder(700), 7, True),
     "r8_decoder_open": (r8_decoder(100, with_success_input=False), 7, False),
+    "hub_fanout": (hub_fanout(), 0, True),
 }
 
 

@@ -35,3 +35,5 @@ def test_gpu_bigrow_parity(big_dir, force_nwg):
     systems = [E.System(E.R1CS(str(big_dir / (n + ".r1cs")))) for n in names]
     for n, g in zip(names, E.solve_batch(systems, force_nwg=force_nwg)):
         assert_bit_exact("bigrow " + n, g, orc.run(str(big_dir / (n + ".r1cs"))))
+        if n == "hub_fanout":      # the sequential replay of an over-long candidate list really ran
+            assert g.summary.rule_hits[15] & 0xFF, "candidate-buffer fallback not exercised"
