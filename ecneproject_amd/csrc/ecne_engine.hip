@@ -366,12 +366,12 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_rdead = c.take(std::max<size_t>(nC, 1) + 4);   // read four rows at a time
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
-    size_t o_htlist = c.take(4ull * ((size_t)nC + 96ull * 2049 + 64));
+    size_t o_htlist = c.take(4ull * ((size_t)nC + (size_t)ECNE_MAX_NWG * 2049 + 64));
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
     size_t o_wmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1)), o_prank = c.take(4ull * std::max<size_t>(nC, 1));
     // one event slot list per rank of a round: single-workgroup rounds examine <= 4 * 512 queue entries,
-    // multi-workgroup rounds <= min(rows, 96 workgroups * 512 lanes * 2)
-    const size_t max_ranks = std::max<size_t>((size_t)4 * ECNE_WG, std::min<size_t>((size_t)nC + 1, (size_t)96 * ECNE_WG * 2));
+    // multi-workgroup rounds <= min(rows, ECNE_MAX_NWG workgroups * 512 lanes * 2)
+    const size_t max_ranks = std::max<size_t>((size_t)4 * ECNE_WG, std::min<size_t>((size_t)nC + 1, (size_t)ECNE_MAX_NWG * ECNE_WG * 2));
     size_t o_evbuf = c.take(4ull * max_ranks * ECNE_EVCAP), o_cand = c.take(4ull * std::max<size_t>(ECNE_CANDCAP, 8ull * nC));
     uint32_t maxrowC = 0;
     for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
@@ -379,7 +379,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_fvar = c.take(4ull * flatcap), o_frank = c.take(4ull * flatcap), o_fbase = c.take(4ull * (flatcap + 1));
     size_t o_bigev = c.take(4ull * ((size_t)maxrowC * 3 + 64));
     const uint32_t bigstride = 2 * (maxrowC + 8);
-    size_t o_bigpool = c.take(4ull * 96 * ECNE_BIGK * bigstride);
+    size_t o_bigpool = c.take(4ull * ECNE_MAX_NWG * ECNE_BIGK * bigstride);
     size_t o_ctr = c.take(sizeof(Counters));
     (void)static_end;
     char* base = nullptr;
@@ -658,15 +658,15 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
         if (rc != ECNE_OK) break;
         // Workgroups per job: large systems get helpers for the row-parallel sweep passes. All
         // workgroups of one launch must be co-resident (they meet at a hand-rolled barrier), and
-        // k_solve occupies a whole CU per workgroup (1024 threads x 128 VGPRs), so a launch never
+        // k_solve occupies a whole CU per workgroup (512 threads x 256 VGPRs), so a launch never
         // holds more workgroups than the device has CUs; a batch that needs more is split.
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) != hipSuccess || n_cu < 1) { rc = ECNE_ENODEVICE; break; }
         const uint32_t cap = (uint32_t)std::max(1, n_cu - 8);   // margin: never rely on the last CU being free
         for (size_t i = 0; i < n; ++i) {
-            uint32_t want = (hj[i].nC + 8191u) / 8192u;
+            uint32_t want = (hj[i].nC + ECNE_ROWS_PER_WG - 1u) / ECNE_ROWS_PER_WG;
             if (o.debug > 0) want = (uint32_t)o.debug;          // test hook: force the helper count
-            hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, 96u)));
+            hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
         }
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         hipEvent_t e0, e1;

@@ -18,6 +18,12 @@
 namespace ecne {
 
 #define ECNE_SMALL_ROW 64   // rows with more entries than this are popped alone (wave-cooperative path)
+#ifndef ECNE_MAX_NWG
+#define ECNE_MAX_NWG 96      // workgroups one system can get (q_part[][128] and the scratch sizes follow it)
+#endif
+#ifndef ECNE_ROWS_PER_WG
+#define ECNE_ROWS_PER_WG 16384   // measured on ecdsa_like(26): 32-64 workgroups beat 85 (cheaper job barriers), 16 are too few
+#endif
 #define ECNE_BIGK 4         // long rows one workgroup takes along in one round
 #define ECNE_BIGTAB 2048    // big rows with an LDS slot for their push candidates (the rest use memory atomics directly)
 #define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
@@ -138,7 +144,7 @@ struct Job {
     uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there
     uint32_t *fvar, *frank, *fbase;   // flat event list of one resolution round: variable, rank, candidate base
     uint32_t* bigev;           // events of a big row popped alone
-    uint32_t* bigpool;         // events (+ candidate offsets) of long rows executed inside rounds: 96 * ECNE_BIGK slots
+    uint32_t* bigpool;         // events (+ candidate offsets) of long rows executed inside rounds: ECNE_MAX_NWG * ECNE_BIGK slots
     uint32_t bigstride;        // u32 words per pool slot (2 * (longest C part + 8))
     uint32_t* cand;            // per push candidate: target row | eligibility bit
     uint32_t candcap;          // capacity of cand[] (single-workgroup rounds use the first ECNE_CANDCAP)
