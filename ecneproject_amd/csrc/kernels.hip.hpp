@@ -1832,6 +1832,19 @@ __device__ __forceinline__ uint32_t my_xcc_id() {
     return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
 }
 
+// What a workgroup remembers between job barriers (LDS): the generation it waits for next and, once the
+// first barrier of the launch has established them, its XCD's member count and the number of XCDs in use
+// -- so that a barrier costs one atomic per level and one polled word, no other memory round trips.
+struct BarLocal { unsigned gen, members, nxcd, ready; };
+__device__ __forceinline__ BarLocal& bar_local() {
+    __shared__ BarLocal b;
+    return b;
+}
+__device__ __forceinline__ void job_barrier_init() {   // thread 0, once per launch (the device words are zeroed by the host)
+    BarLocal& b = bar_local();
+    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0;
+}
+
 __device__ int job_barrier(const Job& J, int* s_err) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1843,14 +1856,17 @@ __device__ int job_barrier(const Job& J, int* s_err) {
             // (the XCD leader) pays for the agent-scope release (L2 write-back) before arriving at
             // the top-level counter; everybody waits on one generation word and then drops its stale
             // L1 lines. The first barrier of a launch is flat and establishes the XCD membership.
+            // The generation word carries the generation in its upper bits and "an error was raised" in
+            // bit 0, so the waiters learn both from the one word they poll.
+            BarLocal& b = bar_local();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my stores have reached my XCD's L2
-            const unsigned g = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool hier = __hip_atomic_load(&c->bar_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const unsigned g = b.gen;
+            const bool hier = b.ready != 0;
             bool arrive_top = true;
             const unsigned x = my_xcc_id();
             if (hier) {
                 const unsigned a = __hip_atomic_fetch_add(&c->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a == __hip_atomic_load(&c->xcd_members[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1)
+                if (a == b.members - 1)
                     __hip_atomic_store(&c->xcd_count[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else arrive_top = false;
             } else {
@@ -1859,7 +1875,7 @@ __device__ int job_barrier(const Job& J, int* s_err) {
             if (arrive_top) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned expect = hier ? __hip_atomic_load(&c->n_xcd_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : J.nwg;
+                const unsigned expect = hier ? b.nxcd : J.nwg;
                 const unsigned arrived = __hip_atomic_fetch_add(&c->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (arrived == expect - 1) {
                     if (!hier) {
@@ -1867,21 +1883,25 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                         for (int i = 0; i < 8; ++i)
                             na += __hip_atomic_load(&c->xcd_members[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                         __hip_atomic_store(&c->n_xcd_active, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&c->bar_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     const int e = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&c->error_snap, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&c->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(&c->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->bar_gen, ((g + 1u) << 1) | (e != 0 ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            unsigned spins = 0;
-            while (__hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 27)) { raise(J, K_ECAPACITY); break; }
+            unsigned spins = 0, w;
+            while (((w = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 28)) { raise(J, K_ECAPACITY); w = 1; break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            *s_err = __hip_atomic_load(&c->error_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b.gen = g + 1;
+            if (!hier) {   // the first barrier of the launch just completed: remember the XCD layout
+                b.members = __hip_atomic_load(&c->xcd_members[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.nxcd = __hip_atomic_load(&c->n_xcd_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.ready = 1;
+            }
+            *s_err = (w & 1u) ? __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         }
     }
     __syncthreads();
@@ -2622,7 +2642,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
     const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
-    if (tid == 0) s_htn = 0;
+    if (tid == 0) { s_htn = 0; job_barrier_init(); }
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = wall_clock64();
 #define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
