@@ -17,14 +17,16 @@
 
 namespace ecne {
 
-#define ECNE_SMALL_ROW 64   // rows with more entries than this are popped alone (wave-cooperative path)
+#define ECNE_SMALL_ROW 64   // rows with more entries than this are "long": handled by a whole workgroup
 #ifndef ECNE_MAX_NWG
 #define ECNE_MAX_NWG 96      // workgroups one system can get (q_part[][128] and the scratch sizes follow it)
 #endif
 #ifndef ECNE_ROWS_PER_WG
 #define ECNE_ROWS_PER_WG 16384   // measured on ecdsa_like(26): 32-64 workgroups beat 85 (cheaper job barriers), 16 are too few
 #endif
-#define ECNE_BIGK 4         // long rows one workgroup takes along in one round
+#ifndef ECNE_BIGK
+#define ECNE_BIGK 8         // long rows one workgroup takes along in one round
+#endif
 #define ECNE_BIGTAB 2048    // big rows with an LDS slot for their push candidates (the rest use memory atomics directly)
 #define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
 #define ECNE_CANDCAP 65536  // push candidates resolved in parallel per round; beyond: sequential fallback
