@@ -339,6 +339,9 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_spinptr = c.take(4ull * L.sp_in_ptr.size()), o_spin = c.take(4ull * std::max<size_t>(L.sp_in.size(), 1));
     size_t o_spoutptr = c.take(4ull * L.sp_out_ptr.size()), o_spout = c.take(4ull * std::max<size_t>(L.sp_out.size(), 1));
     size_t o_spkind = c.take(std::max<size_t>(nSp, 1));
+    std::vector<uint32_t> k1_list, k2_list;
+    for (uint32_t i = 0; i < nSp; ++i) { if (L.sp_kind[i] == 1) k1_list.push_back(i); else if (L.sp_kind[i] == 2) k2_list.push_back(i); }
+    size_t o_k1 = c.take(4ull * std::max<size_t>(k1_list.size(), 1)), o_k2 = c.take(4ull * std::max<size_t>(k2_list.size(), 1));
     size_t o_knowns = c.take(4ull * std::max<size_t>(L.knowns.size(), 1)), o_targets = c.take(4ull * std::max<size_t>(L.targets.size(), 1));
     size_t o_nontriv = c.take((size_t)nV + 1);
     size_t o_p4 = c.take(4ull * std::max<size_t>(L.p4_list.size(), 1));
@@ -404,6 +407,8 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_spoutptr, L.sp_out_ptr.data(), 4ull * L.sp_out_ptr.size()));
     HIP_TRY(up(o_spout, L.sp_out.data(), 4ull * L.sp_out.size()));
     HIP_TRY(up(o_spkind, L.sp_kind.data(), L.sp_kind.size()));
+    HIP_TRY(up(o_k1, k1_list.data(), 4ull * k1_list.size()));
+    HIP_TRY(up(o_k2, k2_list.data(), 4ull * k2_list.size()));
     HIP_TRY(up(o_knowns, L.knowns.data(), 4ull * L.knowns.size()));
     HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
     HIP_TRY(up(o_nontriv, L.nontrivial.data(), L.nontrivial.size()));
@@ -431,6 +436,8 @@ static int upload_system(ecne_system& S, int device) {
     J.sp_in_ptr = (const uint32_t*)(base + o_spinptr); J.sp_in = (const uint32_t*)(base + o_spin);
     J.sp_out_ptr = (const uint32_t*)(base + o_spoutptr); J.sp_out = (const uint32_t*)(base + o_spout);
     J.sp_kind = (const uint8_t*)(base + o_spkind);
+    J.k1_list = (const uint32_t*)(base + o_k1); J.k2_list = (const uint32_t*)(base + o_k2);
+    J.nK1 = (uint32_t)k1_list.size(); J.nK2 = (uint32_t)k2_list.size();
     J.knowns = (const uint32_t*)(base + o_knowns); J.targets = (const uint32_t*)(base + o_targets);
     J.nontrivial = (const uint8_t*)(base + o_nontriv);
     J.p4_list = (const uint32_t*)(base + o_p4);

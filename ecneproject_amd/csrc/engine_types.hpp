@@ -108,6 +108,9 @@ struct Job {
     const uint32_t *fo_ptr, *fo_rows;
     const uint32_t *sp_in_ptr, *sp_in, *sp_out_ptr, *sp_out;
     const uint8_t* sp_kind;   // 1 = "BigMultModP", 2 = "BigLessThan", 0 = anything else (:751, :755)
+    const uint32_t* k1_list;  // indices of the "BigMultModP" specials, ascending
+    const uint32_t* k2_list;  // indices of the "BigLessThan" specials, ascending
+    uint32_t nK1, nK2;
     const uint32_t *knowns, *targets;
     const uint8_t* nontrivial;
     const uint32_t* p4_list;

@@ -2734,27 +2734,36 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         // ================= P1, P2 and the queue: master only, in the reference's order
         if (master) {
             if (w == 0) {
-                // P1 (:718-747)
-                for (uint32_t i = 0; i < J.nSp; ++i) {
-                    if (J.fired[nC + i]) continue;   // special_solved
-                    bool ok = true;
-                    for (uint32_t e = J.sp_in_ptr[i] + lane; e < J.sp_in_ptr[i + 1]; e += 64)
-                        if (!(J.flags[J.sp_in[e]] & 1)) ok = false;
-                    if (__ballot(!ok)) continue;
-                    if (lane == 0) J.fired[nC + i] = 1;
-                    steps++; hits[8]++;
-                    for (uint32_t e = J.sp_out_ptr[i]; e < J.sp_out_ptr[i + 1]; ++e) {
-                        uint32_t v = J.sp_out[e];
-                        if (J.flags[v] & 1) continue;
-                        mark_unique(J, v);
-                        requeue(J, q, v);
+                // P1 (:718-747). 64 specials are tested at a time, one per lane; the ones whose inputs are all
+                // unique fire in index order, and after every firing the later lanes look again (its outputs
+                // may complete their inputs), which is what the one-by-one sweep would have seen.
+                for (uint32_t base = 0; base < J.nSp; base += 64) {
+                    const uint32_t i = base + lane;
+                    int from = 0;
+                    for (;;) {
+                        bool can = i < J.nSp && lane >= from && !J.fired[nC + i];   // [nC..) = special_solved
+                        if (can)
+                            for (uint32_t e = J.sp_in_ptr[i]; e < J.sp_in_ptr[i + 1] && can; ++e) can = (J.flags[J.sp_in[e]] & 1) != 0;
+                        const uint64_t m = __ballot(can);
+                        if (!m) break;
+                        const int src = __ffsll((long long)m) - 1;
+                        const uint32_t is = base + (uint32_t)src;
+                        if (lane == 0) J.fired[nC + is] = 1;
+                        steps++; hits[8]++;
+                        for (uint32_t e = J.sp_out_ptr[is]; e < J.sp_out_ptr[is + 1]; ++e) {
+                            uint32_t v = J.sp_out[e];
+                            if (J.flags[v] & 1) continue;
+                            mark_unique(J, v);
+                            requeue(J, q, v);
+                        }
+                        from = src + 1;
                     }
                 }
-                // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair
-                for (uint32_t i = 0; i < J.nSp; ++i) {
-                    if (J.sp_kind[i] != 1) continue;
-                    for (uint32_t j = 0; j < J.nSp; ++j) {
-                        if (J.sp_kind[j] != 2) continue;
+                // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair, from the two index lists
+                for (uint32_t a = 0; a < J.nK1; ++a) {
+                    const uint32_t i = J.k1_list[a];
+                    for (uint32_t bj = 0; bj < J.nK2; ++bj) {
+                        const uint32_t j = J.k2_list[bj];
                         if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
                         uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
                         if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
