@@ -3019,14 +3019,110 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 J.fired[i] = 1;          // by list position; cleared again when the events are collected
                 atomicAdd(&ctr->p4_nfired, 1u);
             }
+            if (master && tid == 0) ctr->q_cmd[2] = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
             if (job_barrier(J, &s_err)) break;
-            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // every thread reads it before anyone clears it
+            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // stable until the master clears it at the end of P4
             // forget the per-variable minima (all workgroups; the next use is a whole queue phase away)
             for (uint32_t i = gtid; i < J.nP4; i += gstride) {
                 const uint32_t b = J.p4_b[i];
                 if (!(J.flags[b] & 1)) J.varmin[b] = 0xFFFFFFFFu;
             }
-            if (master && p4_fired != 0) {
+            bool p4_done = false, p4_err = false;
+            if (J.nwg > 1 && p4_fired >= 2048) {
+                // Many rows tagged (the first sweep of a large circuit tags every decoder output): the ordered
+                // REQUEUE of their B variables runs on ALL workgroups -- same steps as resolve_pushes, with
+                // contiguous blocks per thread and job-wide scans (nothing is being popped: a candidate may
+                // push iff its row is not queued; the lowest candidate index per row wins).
+                const uint32_t tail0 = ld_agent(&ctr->q_cmd[2]);
+                const uint32_t T = gstride;
+                int err = 0;
+                // 1. the event list: B variables of the fired rows, ascending
+                const uint32_t iper = (J.nP4 + T - 1) / T;
+                const uint32_t i0 = gtid * iper < J.nP4 ? gtid * iper : J.nP4, i1 = (gtid + 1) * iper < J.nP4 ? (gtid + 1) * iper : J.nP4;
+                uint32_t cnt = 0;
+                for (uint32_t i = i0; i < i1; ++i) cnt += J.fired[i];
+                uint32_t nev = 0;
+                uint32_t o = team_exclusive_scan(J, s_chunk, me.rank, cnt, 0, &nev, &s_err, &err);
+                if (!err) {
+                    for (uint32_t i = i0; i < i1; ++i)
+                        if (J.fired[i]) { J.events[o++] = J.p4_b[i]; J.fired[i] = 0; }
+                    err = job_barrier(J, &s_err);
+                }
+                // 2. candidates
+                uint32_t M = 0, e0 = 0, e1 = 0, cbase = 0;
+                if (!err) {
+                    const uint32_t eper = (nev + T - 1) / T;
+                    e0 = gtid * eper < nev ? gtid * eper : nev;
+                    e1 = (gtid + 1) * eper < nev ? (gtid + 1) * eper : nev;
+                    uint32_t deg = 0;
+                    for (uint32_t e = e0; e < e1; ++e) { const uint32_t v = J.events[e]; deg += J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+                    cbase = team_exclusive_scan(J, s_chunk, me.rank, deg, 1, &M, &s_err, &err);
+                }
+                if (!err && M <= J.candcap) {
+                    if (tid == 0) s_chunk.nbigev = 0;
+                    __syncthreads();
+                    uint32_t j = cbase;
+                    for (uint32_t e = e0; e < e1; ++e) {
+                        const uint32_t v = J.events[e];
+                        expand_event(J, s_chunk, v, 0, j, false);
+                        j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+                    }
+                    expand_big_events(J, s_chunk, false);
+                    err = job_barrier(J, &s_err);
+                    // 3. winners, in candidate order
+                    uint32_t W = 0;
+                    if (!err) {
+                        const uint32_t cper = (M + T - 1) / T;
+                        const uint32_t j0 = gtid * cper < M ? gtid * cper : M, j1 = (gtid + 1) * cper < M ? (gtid + 1) * cper : M;
+                        uint32_t nwin = 0;
+                        for (uint32_t jj = j0; jj < j1; ++jj) {
+                            const uint32_t cw = J.cand[jj];
+                            const uint32_t t = cw & 0x7FFFFFFFu;
+                            const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == jj;
+                            J.cand[jj] = t | (win ? 0x80000000u : 0u);
+                            nwin += win;
+                        }
+                        const uint32_t wbase = team_exclusive_scan(J, s_chunk, me.rank, nwin, 0, &W, &s_err, &err);
+                        if (!err) {
+                            uint32_t oq = tail0 + wbase;
+                            for (uint32_t jj = j0; jj < j1; ++jj) {
+                                const uint32_t cw = J.cand[jj];
+                                const uint32_t t = cw & 0x7FFFFFFFu;
+                                if (cw & 0x80000000u) { J.queue[oq & J.qmask] = t; J.inq[t] = 1; ++oq; }
+                                J.best[t] = 0xFFFFFFFFu;
+                            }
+                            err = job_barrier(J, &s_err);
+                        }
+                    }
+                    if (!err) {
+                        p4_done = true;
+                        if (master) {
+                            if (w == 0 && lane == 0) { q.tail = tail0 + W; s_q = q; ctr->p4_nfired = 0; }
+                            __syncthreads();
+                            q = s_q;
+                            steps += nev;
+                            if (w == 0) hits[11] += nev;
+                        }
+                    }
+                } else if (!err) {
+                    // (a B variable with a huge fan-out) the master replays the events one by one
+                    if (master) {
+                        if (w == 0) {
+                            for (uint32_t e = 0; e < nev; ++e) requeue(J, q, J.events[e]);
+                            if (lane == 0) { s_q = q; ctr->p4_nfired = 0; }
+                        }
+                        __syncthreads();
+                        q = s_q;
+                        steps += nev;
+                        if (w == 0) { hits[11] += nev; hits[15]++; }
+                    }
+                    err = job_barrier(J, &s_err);
+                    if (!err) p4_done = true;
+                }
+                if (err) p4_err = true;
+            }
+            if (p4_err) break;
+            if (master && p4_fired != 0 && !p4_done) {
                 __syncthreads();
                 if (tid == 0) ctr->p4_nfired = 0;
                 // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
