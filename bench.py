@@ -145,7 +145,7 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": b_alg, "kernel_ms": k_ms,
                          "phase_ms": {k: round(v, 3) for k, v in zip(["setup", "queue", "P3", "P4", "P5", "verdict", "P3_rounds"], list(s.phase_ms)[:7])},
-                         "queue_ms": {k: round(v, 3) for k, v in zip(["head", "mark", "check", "exec", "flatten", "resolve", "big_rows_and_bursts", "multi_rounds"], list(s.queue_ms)[:8])},
+                         "queue_ms": {k: round(v, 3) for k, v in zip(["head", "mark", "check", "exec", "flatten", "resolve", "alone_bursts_wave_rounds", "multi_rounds"], list(s.queue_ms)[:8])},
                          "multi_ms": {k: round(v, 3) for k, v in zip(["mark", "check_and_cut", "exec_and_scan", "expand", "count_and_scan", "write"], list(s.multi_ms)[:6])},
                          "note": "fixed point is dependency-depth bound; see DESIGN.md"},
         }

@@ -2186,6 +2186,223 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     return 0;
 }
 
+// ------------------------------------------------------------------------------- wavefront round
+// The same round as in queue_phase_chunked for a window of at most 64 queue entries, executed by ONE
+// wavefront (lane = rank) without a single workgroup barrier: narrow dependency levels (a dozen rows
+// wide) are the bulk of the rounds of a deep circuit and a workgroup round costs them ~20 us of barriers
+// and idle lanes. Write-marks use the first 1024 slots of the LDS hash table (wiped afterwards), the
+// REQUEUE events are resolved with wave scans. Returns the number of committed rows, or 0xFFFFFFFF
+// without having touched anything when the window starts with a live long row (the caller's general path
+// takes it). Wave 0 only, all 64 lanes.
+#define ECNE_WSLOTS 1024
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t* total) {
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += y; }
+    *total = __shfl(incl, 63, 64);
+    return incl - x;
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
+    return x;
+}
+__device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n,
+                                                  LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail,
+                                                  unsigned long long* n_fallback) {
+    const int lane = lane_id();
+    const uint32_t rank = (uint32_t)lane;
+    const bool mine = rank < n;
+    uint32_t row = 0, shape = 0, xv = 0;
+    bool live = false;
+    if (mine) {
+        row = J.queue[(head + rank) & J.qmask];
+        const RowInfo ri = J.rinfo[row];
+        shape = ri.shape;
+        xv = ri.x;
+        live = !J.solved[row];
+    }
+    const uint64_t bigm = __ballot(mine && live && (shape & SH_BIG));
+    if (bigm & 1ull) return 0xFFFFFFFFu;
+    uint32_t cut = bigm ? (uint32_t)(__ffsll((long long)bigm) - 1) : n;    // a long row ends the prefix
+    // ---- mark (LDS hash, slots [0, ECNE_WSLOTS)); the access set is cached for the check
+    bool noop = false, noop_b = false;
+    uint32_t acnt = 0;
+    auto wmark = [&](uint32_t v, uint32_t cls) {
+        const uint32_t key = 1u + 2u * v + cls;
+        uint32_t sl = (key * 2654435761u) >> (32 - 10);
+        for (int probe = 0; probe < ECNE_WSLOTS; ++probe) {
+            const uint32_t k = atomicCAS(&S.hkey[sl], 0u, key);
+            if (k == 0u || k == key) { atomicMin(&S.hrank[sl], rank); return; }
+            sl = (sl + 1) & (ECNE_WSLOTS - 1);
+        }
+    };
+    auto wlook = [&](uint32_t v, uint32_t cls) -> uint32_t {
+        const uint32_t key = 1u + 2u * v + cls;
+        uint32_t sl = (key * 2654435761u) >> (32 - 10);
+        for (int probe = 0; probe < ECNE_WSLOTS; ++probe) {
+            const uint32_t k = S.hkey[sl];
+            if (k == key) return S.hrank[sl];
+            if (k == 0u) return 0xFFFFFFFFu;
+            sl = (sl + 1) & (ECNE_WSLOTS - 1);
+        }
+        return 0xFFFFFFFFu;
+    };
+    uint32_t nmarks = 0;
+    if (mine && live && rank < cut) {
+        const RowInfo ri = J.rinfo[row];
+        bool nb = false;
+        if (row_is_noop(J, row, ri, nb)) {
+            noop = true;
+            if (nb) {
+                noop_b = true;
+                for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) {
+                    if (acnt < ECNE_ASET) S.aset[lane][acnt] = J.colC[k] | (2u << 28);
+                    ++acnt;
+                }
+            }
+        } else {
+            for_row_sets(J, row, shape, xv, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if (acnt < ECNE_ASET) S.aset[lane][acnt] = v | (rd << 28) | (wr << 30);
+                ++acnt;
+                nmarks += (wr & 1) + ((wr >> 1) & 1);
+            });
+        }
+    }
+    // a window that would load the table beyond a quarter is cut down to the rows that fit (rank 0 always does:
+    // a small row has at most 2 * 64 marks)
+    {
+        uint32_t tot;
+        const uint32_t before = wave_excl_scan(nmarks, &tot);
+        if (tot > ECNE_WSLOTS / 4) {
+            const uint64_t over = __ballot(before + nmarks > ECNE_WSLOTS / 4);
+            const uint32_t first = over ? (uint32_t)(__ffsll((long long)over) - 1) : n;
+            if (first < cut) cut = first < 1 ? 1 : first;
+        }
+    }
+    if (mine && live && rank < cut && !noop) {
+        if (acnt <= ECNE_ASET) {
+            for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[lane][i]; if ((e >> 30) & 1) wmark(e & 0x0FFFFFFFu, 0); if (e >> 31) wmark(e & 0x0FFFFFFFu, 1); }
+        } else {
+            for_row_sets(J, row, shape, xv, [&](uint32_t v, uint32_t rd, uint32_t wr) { if (wr & 1) wmark(v, 0); if (wr & 2) wmark(v, 1); });
+        }
+    }
+    lds_fence();
+    // ---- check
+    uint32_t mycut = 0xFFFFFFFFu;
+    if (mine && live && rank < cut) {
+        bool blocked = false;
+        auto test = [&](uint32_t v, uint32_t rd, uint32_t wr) {
+            if ((rd | wr) & 1) { const uint32_t m = wlook(v, 0); if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m; }
+            if ((rd | wr) & 2) { const uint32_t m = wlook(v, 1); if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m; }
+        };
+        if (noop) {
+            if (noop_b) {
+                if (acnt <= ECNE_ASET) { for (uint32_t i = 0; i < acnt; ++i) if (wlook(S.aset[lane][i] & 0x0FFFFFFFu, 1) < rank) blocked = true; }
+                else for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) if (wlook(J.colC[k], 1) < rank) blocked = true;
+            }
+        } else if (acnt <= ECNE_ASET) {
+            for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[lane][i]; test(e & 0x0FFFFFFFu, (e >> 28) & 3u, e >> 30); }
+        } else for_row_sets(J, row, shape, xv, test);
+        if (blocked) mycut = rank;
+    }
+    {
+        const uint32_t m = wave_min(mycut);
+        if (m < cut) cut = m;
+    }
+    const uint32_t c = cut;    // >= 1
+    lds_fence();
+    for (uint32_t i = lane; i < ECNE_WSLOTS; i += 64) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+    // ---- tag, execute
+    uint32_t nev = 0;
+    if (mine && rank < c) {
+        J.inq[row] = (uint16_t)(rank + 2);
+        my_pops++;
+        my_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+    }
+    wg_fence();
+    if (mine && rank < c && live) {
+        if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }
+        else exec_row_lane(J, row, J.evbuf + (size_t)rank * ECNE_EVCAP, nev, C);
+    }
+    wg_fence();
+    // ---- REQUEUE resolution in sequential order (rank, emission index), see resolve_pushes
+    uint32_t new_tail = tail;
+    uint32_t Nev;
+    wave_excl_scan(nev, &Nev);
+    if (Nev) {
+        const uint32_t* ev = J.evbuf + (size_t)rank * ECNE_EVCAP;
+        uint32_t deg = 0;
+        for (uint32_t e = 0; e < nev; ++e) deg += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+        uint32_t M;
+        const uint32_t cbase = wave_excl_scan(deg, &M);
+        if (M > ECNE_CANDCAP) {
+            // (a variable with a huge fan-out) replay the events one by one, ranks leaving the queue in order
+            if (n_fallback) (*n_fallback)++;
+            QState qq;
+            qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+            for (uint32_t r = 0; r < c; ++r) {
+                const uint32_t rr = J.queue[(head + r) & J.qmask];
+                if (lane == 0) J.inq[rr] = 0;
+                wg_fence();
+                const uint32_t ne = __shfl(nev, (int)r, 64);
+                for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, J.evbuf[(size_t)r * ECNE_EVCAP + e]);
+            }
+            *out_tail = qq.tail;
+            return c;
+        }
+        // expansion: my events, in emission order; long fan-out lists are shared out across the lanes afterwards
+        auto cand1 = [&](uint32_t t, uint32_t j, uint32_t a) {
+            const uint32_t st = J.inq[t];
+            const bool elig = st == 0 || (st >= 2 && st - 2 <= a);
+            J.cand[j] = t | (elig ? 0x80000000u : 0u);
+            if (elig && ld_agent(&J.best[t]) > j) atomicMin(&J.best[t], j);
+        };
+        uint32_t nlong = 0, lv = 0, lb = 0;      // at most one long-fan-out event per lane is deferred
+        {
+            uint32_t j = cbase;
+            for (uint32_t e = 0; e < nev; ++e) {
+                const uint32_t v = ev[e];
+                const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+                if (f1 - f0 > 64 && !nlong) { nlong = 1; lv = v; lb = j; }
+                else for (uint32_t k = f0; k < f1; ++k) cand1(J.fo_rows[k], j + (k - f0), rank);
+                j += f1 - f0;
+            }
+        }
+        for (uint64_t lm = __ballot(nlong != 0); lm; lm &= lm - 1) {
+            const int src = __ffsll((long long)lm) - 1;
+            const uint32_t v = __shfl(lv, src, 64), b0 = __shfl(lb, src, 64);
+            const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+            for (uint32_t k = f0 + lane; k < f1; k += 64) cand1(J.fo_rows[k], b0 + (k - f0), (uint32_t)src);
+        }
+        wg_fence();
+        // winners, in candidate order
+        for (uint32_t jb = 0; jb < M; jb += 64) {
+            const uint32_t j = jb + lane;
+            uint32_t t = 0;
+            bool win = false;
+            if (j < M) {
+                const uint32_t cw = J.cand[j];
+                t = cw & 0x7FFFFFFFu;
+                win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
+            }
+            const uint64_t wm = __ballot(win);
+            if (win) { J.queue[(new_tail + (uint32_t)__popcll(wm & lanes_below())) & J.qmask] = t; J.inq[t] = 1; }
+            new_tail += (uint32_t)__popcll(wm);
+        }
+        // (best[] is reset only now: every candidate above was judged against the same minima)
+        wg_fence();
+        for (uint32_t j = lane; j < M; j += 64) J.best[J.cand[j] & 0x7FFFFFFFu] = 0xFFFFFFFFu;
+        wg_fence();
+    }
+    // rows of the prefix that nobody re-queued are out of the queue now
+    if (mine && rank < c && J.inq[row] >= 2) J.inq[row] = 0;
+    wg_fence();
+    *out_tail = new_tail;
+    return c;
+}
+
 // The whole QUEUE phase (:805-1349), executed by all 1024 threads. q is kept identical in every thread.
 // A round examines up to ECNE_RPL * 1024 queue entries; lane t owns the consecutive ranks
 // t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
@@ -2263,6 +2480,30 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // adaptive window: examining rows that end up behind the cut is wasted work, so the window
         // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
         const uint32_t n = avail < window ? avail : window;
+        if (n <= 64) {
+            // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
+            if (w == 0) {
+                uint32_t nt = q.tail;
+                const uint32_t cw = queue_round_wave(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &hits[15]);
+                if (lane == 0) { S.nbig = cw; S.tail = nt; }
+            }
+            __syncthreads();
+            const uint32_t cw = S.nbig, ntw = S.tail;
+            __syncthreads();
+            if (cw != 0xFFFFFFFFu) {
+                q.head += cw;
+                q.tail = ntw;
+                pops_total += cw;
+                hits[13]++;
+                if (cw < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+                if (cw == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+                else if (cw < n / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
+                else next_burst = 16;
+                QTICK(6);
+                continue;
+            }
+            // (the window starts with a live long row: the general path below takes this round)
+        }
         const uint32_t rpl = (n + ECNE_WG - 1) / ECNE_WG;          // rows per lane this round
         const uint32_t r0 = (uint32_t)tid * rpl;                    // my first rank
         uint32_t row[ECNE_RPL], shape[ECNE_RPL], xv[ECNE_RPL];

@@ -108,7 +108,7 @@ typedef struct ecne_summary {
     double device_ms;        /* HIP-event time of the solve kernels on their stream              */
     double classify_ms;      /* HIP-event time of k_classify_rows                                */
     double queue_ms[8];      /* queue phase, master workgroup: head, mark, check+unmark, exec, flatten, resolve,
-                                long rows popped alone + sequential bursts, multi-workgroup rounds */
+                                long rows popped alone + sequential bursts + wavefront rounds, multi-workgroup rounds */
     double multi_ms[8];      /* multi-workgroup rounds: mark, check + cut, exec + scan, expand, count + scan, write */
     double phase_ms[8];      /* in-kernel wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; [6] = P3 rounds (count) */
 } ecne_summary;
