@@ -125,7 +125,81 @@ def make(seed, n_rows=None, n_vars=None, allow_errors=True):
             else:
                 x = V()
                 rows.append(([], [], [(x, 1), (1, (-(w[x] + 1)) % P)]))   # contradicts the witness
-    return dict(n_wires=n_vars - 1, n_out=n_out, n_pub=0, n_prv=n_in, rows=rows)
+    return dict(n_wires=n_vars - 1, n_out=n_out, n_pub=0, n_prv=n_in, rows=rows, witness=w)
+
+
+def make_wide(seed):
+    """A larger random system (100-400 variables, 150-700 small rows from make()) with LONG rows woven in --
+    plain sums of 65-300 terms, decoder groups closed by a long sum (R8), mixed-radix sums over bit
+    variables (R7), long binary decompositions (R4 shape: popped alone) -- over a mix of the base system's
+    variables and fresh ones, all consistent with one witness. Exercises the engine's long-row paths
+    (rows riding along in rounds, wavefront rounds, multi-workgroup rounds) in random surroundings."""
+    rng = random.Random(1000003 * seed + 17)
+    base = make(seed + 5000, n_rows=rng.randint(150, 700), n_vars=rng.randint(100, 400), allow_errors=False)
+    w = dict(base["witness"])
+    rows = list(base["rows"])
+    nv = base["n_wires"] + 1
+
+    def fresh(val):
+        nonlocal nv
+        nv += 1
+        w[nv] = val % P
+        return nv
+
+    def fix(v):      # v = its witness value (R3 makes it unique)
+        rows.append(([], [], [(v, 1), (1, (-w[v]) % P)] if w[v] else [(v, 1)]))
+
+    def bit():
+        b = fresh(rng.randint(0, 1))
+        rows.append(([(b, 1), (1, -1)], [(b, 1)], []))
+        return b
+
+    old = list(range(2, base["n_wires"] + 2))
+    for _ in range(rng.randint(2, 6)):
+        kind = rng.random()
+        n = rng.randint(65, 300)
+        if kind < 0.3:       # plain long sum, sometimes every addend pinned (R1 fires), sometimes not
+            xs = [rng.choice(old) if rng.random() < 0.5 else fresh(rng.choice([0, 1, 5, 1 << 40])) for _ in range(n)]
+            xs = list(dict.fromkeys(xs))
+            cs = [rng.choice([1, 2, 3, -1, 7, 1 << 30]) for _ in xs]
+            y = fresh(sum(c * w[x] for c, x in zip(cs, xs)))
+            rows.append(([], [], [(y, -1)] + list(zip(xs, cs))))
+            if rng.random() < 0.6:
+                for x in xs:
+                    if rng.random() < 0.9:
+                        fix(x)
+        elif kind < 0.55:    # decoder: out_i * (inp - i) = 0, sum out_i = s
+            t = rng.randrange(n)
+            inp = fresh(t)
+            outs = [fresh(1 if i == t else 0) for i in range(n)]
+            sv = fresh(1)
+            for i, o in enumerate(outs):
+                rows.append(([(inp, 1)] + ([(1, -i)] if i else []), [(o, 1)], []))
+            rows.append(([], [], [(sv, -1)] + [(o, 1) for o in outs]))
+            if rng.random() < 0.7:
+                fix(sv)
+            if rng.random() < 0.5:
+                fix(inp)
+        elif kind < 0.8:     # mixed radix over bits, not the binary-decomposition pattern (coefficient 5 on y)
+            n = min(n, 250)
+            bs = [bit() for _ in range(n)]
+            tot = sum(w[b] << i for i, b in enumerate(bs))
+            y = fresh(tot * pow(5, -1, P))
+            rows.append(([], [], [(y, 5)] + [(b, -(1 << i)) for i, b in enumerate(bs)]))
+            if rng.random() < 0.7:
+                fix(y)
+        else:                # long binary decomposition (either orientation)
+            n = min(n, 200)
+            bs = [bit() for _ in range(n)]
+            y = fresh(sum(w[b] << i for i, b in enumerate(bs)))
+            sgn = rng.choice([1, -1])
+            rows.append(([], [], [(y, sgn)] + [(b, -sgn * (1 << i)) for i, b in enumerate(bs)]))
+            if rng.random() < 0.7:
+                fix(y)
+    order = list(range(len(rows)))
+    if rng.random() < 0.5:
+        rng.shuffle(order)        # long rows early / late / in between
+    return dict(n_wires=nv - 1, n_out=base["n_out"], n_pub=0, n_prv=base["n_prv"], rows=[rows[i] for i in order], witness=w)
 
 
 def write(path, spec):

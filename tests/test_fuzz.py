@@ -13,6 +13,7 @@ import fuzz_r1cs
 import orc
 
 N_SEEDS = 400
+N_WIDE = 120
 
 
 @pytest.fixture(scope="module")
@@ -81,3 +82,32 @@ def test_gpu_fuzz_parity(fuzz_dir, force_nwg):
         assert_bit_exact("fuzz seed %d" % seed, g, o)
         n_err += o.status != 0
     assert n_err > 5
+
+
+@pytest.fixture(scope="module")
+def wide_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fuzz_wide")
+    for seed in range(N_WIDE):
+        fuzz_r1cs.write(str(d / ("%d.r1cs" % seed)), fuzz_r1cs.make_wide(seed))
+    return d
+
+
+def test_wide_fuzz_oracle_hits_the_long_row_rules(wide_dir):
+    hit = [0] * 13
+    for seed in range(N_WIDE):
+        r = orc.run(str(wide_dir / ("%d.r1cs" % seed)))
+        assert r.status == 0, seed
+        for i in range(13):
+            hit[i] += r.summary.rule_hits[i] > 0
+    assert all(hit[i] > 0 for i in (0, 1, 2, 3, 6, 7, 11)), hit      # R1-R4, R7, R8, P4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_nwg", [0, 3])
+def test_gpu_wide_fuzz_parity(wide_dir, force_nwg):
+    import ecneproject_amd as E
+    from gpu_common import assert_bit_exact
+    paths = [str(wide_dir / ("%d.r1cs" % seed)) for seed in range(N_WIDE)]
+    systems = [E.System(E.R1CS(p)) for p in paths]
+    for seed, (p, g) in enumerate(zip(paths, E.solve_batch(systems, force_nwg=force_nwg))):
+        assert_bit_exact("wide fuzz seed %d" % seed, g, orc.run(p))
