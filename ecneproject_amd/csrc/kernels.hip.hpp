@@ -1,18 +1,20 @@
 // kernels.hip.hpp — gfx950 device code of the Ecne propagation engine (included by ecne_engine.hip).
 //
 // Kernels
-//   k_classify_rows   one wavefront per row: streams the row's (col, coeff) pairs once, decides the
-//                     static shape of the row (which of the reference's rules R2..R8 it can ever
-//                     feed), computes the rule constants that need field arithmetic (the two roots
-//                     of a bit-check row, the value of a single-variable linear row, the power-of-two
-//                     bound of a binary-decomposition row) and the |coefficient| order rule R7 walks.
-//                     HBM-bound streaming pass: ~36 B per non-zero in, 32 B per row + 4 B per C
-//                     non-zero out.  Reference: the pattern tests re-done on every queue visit at
-//                     src/R1CSConstraintSolver.jl:875-927, :949-964, :999-1013, :1245-1265.
-//   k_solve           one 1024-thread workgroup per constraint system, persistent for the whole
-//                     fixed point (outer loop :706-1556): FIFO worklist in HBM/L2, rules R1-R8,
-//                     batch phases P1-P5, verdict counts.  All ordering-sensitive steps follow the
-//                     reference's sequential order exactly (see DESIGN.md "Schedule").
+//   k_classify_rows   two passes (one lane per short row, one wavefront per longer row): streams the
+//                     row's (col, coeff) pairs once, decides the static shape of the row (which of the
+//                     reference's rules R2..R8 it can ever feed), computes the rule constants that need
+//                     field arithmetic (the two roots of a bit-check row, the value of a
+//                     single-variable linear row, the power-of-two bound of a binary-decomposition
+//                     row) and the |coefficient| order rule R7 walks. HBM-bound streaming pass: ~36 B
+//                     per non-zero in, 32 B per row + 4 B per C non-zero out.  Reference: the pattern
+//                     tests re-done on every queue visit at src/R1CSConstraintSolver.jl:875-927,
+//                     :949-964, :999-1013, :1245-1265.
+//   k_solve           the whole fixed point (outer loop :706-1556) in one persistent launch: per system
+//                     1..96 cooperating workgroups of 512 threads (SPMD, hand-rolled job barrier), FIFO
+//                     worklist in HBM/L2, rules R1-R8, batch phases P1-P5, verdict counts.  All
+//                     ordering-sensitive steps follow the reference's sequential order exactly (see
+//                     DESIGN.md "Schedule").
 //   k_fp_selftest     field-arithmetic known-answer vectors on the device.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -756,7 +758,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
 
 
 // ---------------------------------------------------------------------------------- workgroup tools
-// exclusive prefix sum of one value per thread over the 1024-thread workgroup; returns the
+// exclusive prefix sum of one value per thread over the workgroup; returns the
 // thread's offset, *total receives the sum. lds: ECNE_NWAVES + 1 words.
 __device__ uint32_t wg_exclusive_scan(uint32_t x, uint32_t* lds, uint32_t* total) {
     const int lane = lane_id(), w = wave_id();
@@ -912,7 +914,7 @@ __device__ __forceinline__ int wg_error(const Job& J, int* s_err) {
 }
 
 // ================================================================== chunk-parallel queue schedule
-// The reference pops one row at a time. Here the first n <= 1024 queue entries ("chunk", ranks
+// The reference pops one row at a time. Here the first n queue entries ("chunk", ranks
 // 0..n-1) are examined together and the longest prefix of pairwise independent rows is executed in
 // parallel, one lane per row, directly on the shared state. Two rows are independent when neither
 // can write a variable the other reads or writes; the read/write sets are static supersets derived
@@ -925,8 +927,9 @@ __device__ __forceinline__ int wg_error(const Job& J, int* s_err) {
 // SH_TOUCH1). Independent rows commute, so executing the prefix in parallel gives exactly the state
 // the sequential pops give; the queue itself is then rebuilt in sequential order by resolving all
 // REQUEUE events of the prefix in (rank, emission order, fan-out position) order with the reference's
-// in_queue semantics. Rows with more than ECNE_SMALL_ROW entries are popped alone through the
-// wave-cooperative exec_row().  DESIGN.md "Schedule" has the equivalence argument.
+// in_queue semantics. Rows with more than ECNE_SMALL_ROW entries ("long rows") are handled by a whole
+// workgroup, inside the round where possible (big_rows_*), alone otherwise.  DESIGN.md "Schedule" has
+// the equivalence argument.
 
 struct LaneCtr {   // per-lane counter deltas of one queue phase (reduced at the end)
     uint32_t steps, nuniq, hits[8];
@@ -2403,8 +2406,8 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
     return c;
 }
 
-// The whole QUEUE phase (:805-1349), executed by all 1024 threads. q is kept identical in every thread.
-// A round examines up to ECNE_RPL * 1024 queue entries; lane t owns the consecutive ranks
+// The whole QUEUE phase (:805-1349) as the master workgroup sees it. q is kept identical in every thread.
+// A single-workgroup round examines up to ECNE_RPL * ECNE_WG queue entries; lane t owns the consecutive ranks
 // t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
 #define ECNE_RPL 4
 #ifndef ECNE_WGROW
