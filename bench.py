@@ -149,7 +149,7 @@ def main():
                          "multi_ms": {k: round(v, 3) for k, v in zip(["mark", "check_and_cut", "exec_and_scan", "expand", "count_and_scan", "write"], list(s.multi_ms)[:6])},
                          "note": "fixed point is dependency-depth bound; see DESIGN.md"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             import orc
             sp = ecdsa_like.cached(args.cpu_sample_S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid())
             o = orc.run(sp, [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"], want_states=False)
