@@ -951,8 +951,153 @@ __device__ __forceinline__ uint32_t lane_uniq_range(const Job& J, uint32_t c0, u
 
 // One queue pop executed by ONE lane (rows with at most ECNE_SMALL_ROW entries). Statement-for-
 // statement the same rules as exec_row(); REQUEUE(v) becomes an event appended to ev[].
+// R7 then R8 of a small row from the state in memory (no statistics carried over from R1): the closing part
+// of exec_row_lane(), also used by the x == y fast path when one of the two could fire.
+__device__ __noinline__ void lane_r78_tail(const Job& J, uint32_t c0, uint32_t c1, uint32_t shape, uint32_t* ev, uint32_t& nev, LaneCtr& C) {
+    const uint32_t l = c1 - c0;
+    if (l == 0) return;
+    // R7 (:1235-1298)
+    {
+        uint32_t nunk = 0;
+        bool notknown = false;
+        for (uint32_t k = c0; k < c1; ++k) {
+            uint8_t f = J.flags[J.colC[k]];
+            if (!(f & 1)) { ++nunk; if (!(f & 2)) notknown = true; }
+        }
+        if (nunk > 0 && !notknown) {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            bool fail = false;
+            uint32_t prev_k = 0xFFFFFFFFu;
+            for (uint32_t s = 0; s < l && !fail; ++s) {
+                uint32_t k = c0 + J.csort[c0 + s];
+                uint32_t v = J.colC[k];
+                if (J.flags[v] & 1) continue;
+                if (prev_k != 0xFFFFFFFFu && r7_link_fails(J, k, prev_k, negated)) fail = true;
+                prev_k = k;
+            }
+            if (!fail && r7_top_fits(J, prev_k, negated)) {
+                C.steps += nunk; C.hits[6]++;
+                C.nuniq += lane_uniq_range(J, c0, c1, 0xFFFFFFFFu, ev, nev);
+            }
+        }
+    }
+    // R8 (:1304-1348)
+    {
+        int group = -1;
+        bool bad = false;
+        uint32_t cnt = 0;
+        for (uint32_t k = c0; k < c1 && !bad; ++k) {
+            uint32_t v = J.colC[k];
+            if (J.flags[v] & 1) continue;
+            int a = J.abz[v];
+            if (a == -1) bad = true;
+            else if (group == -1) group = a;
+            else if (a != group) bad = true;
+            ++cnt;
+        }
+        if (cnt > 0 && !bad) {
+            C.hits[7]++;
+            uint32_t n = lane_uniq_range(J, c0, c1, 0xFFFFFFFFu, ev, nev);
+            C.nuniq += n; C.steps += n;
+        }
+    }
+}
+
+// One pop of a plain x == y row (C = {k1: +-1, k2: -+1}, nothing else; the bulk of an --O0 circuit) on one
+// lane: R1, R4 and R5 of exec_row_lane() on a register copy of the two variables' state -- one batch of
+// loads, one batch of stores -- instead of a memory round trip per rule step. R7 / R8 run from memory
+// afterwards (lane_r78_tail) in the rare case their preconditions hold. Statement for statement the same
+// effects, counters and REQUEUE events as the general executor.
+__device__ __noinline__ void exec_xy_lane(const Job& J, uint32_t row, const RowInfo& ri, uint32_t* ev, uint32_t& nev, LaneCtr& C) {
+    const uint32_t shape = ri.shape;
+    const uint32_t kv[2] = {ri.k1, ri.k2};                       // dictionary order (R5's key_1, key_2)
+    const bool sw = (shape & SH_R56_SWAP) != 0;                  // the Set / stored order of C starts with k2
+    const int o0 = sw ? 1 : 0, o1 = sw ? 0 : 1;                  // indices in C order
+    uint8_t f[2] = {J.flags[kv[0]], J.flags[kv[1]]};
+    const int ab[2] = {J.abz[kv[0]], J.abz[kv[1]]};
+    fp::u256 lb[2] = {ld256(J.lb + 4ull * kv[0]), ld256(J.lb + 4ull * kv[1])};
+    fp::u256 ub[2] = {ld256(J.ub + 4ull * kv[0]), ld256(J.ub + 4ull * kv[1])};
+    const uint8_t flip = J.flip3[row];
+    const uint8_t f_in[2] = {f[0], f[1]};
+    bool bdirty[2] = {false, false};
+    auto set_b = [&](int i, const fp::u256& nlb, const fp::u256& nub) {   // set_bounds()
+        lb[i] = nlb; ub[i] = nub; bdirty[i] = true;
+        f[i] = (uint8_t)((f[i] & ~4u) | ((fp::is_zero(nlb) && fp::is_one(nub)) ? 4u : 0u));
+    };
+    // R1 (:827-873): no A / B; exactly one non-unique variable of C becomes unique
+    {
+        const uint32_t cnt = (uint32_t)!(f[o0] & 1) + (uint32_t)!(f[o1] & 1);
+        if (cnt == 1) {
+            const int u = !(f[o0] & 1) ? o0 : o1;
+            f[u] |= 3;
+            C.nuniq++; C.steps++; C.hits[0]++;
+            ev[nev++] = kv[u];
+        }
+    }
+    // R4 (:991-1076) with l == 2: the row is negated on every visit, the pivot alternates
+    {
+        const uint8_t o = (uint8_t)(flip ^ 1);
+        J.flip3[row] = o;
+        const uint32_t new_key = o ? ri.kneg : ri.kpos;
+        const int n = new_key == kv[0] ? 0 : 1, ot = 1 - n;
+        if (f[ot] & 4) {                                          // the other variable has bounds exactly [0,1]
+            if (!(fp::is_zero(lb[n]) && fp::is_one(ub[n]))) {
+                if (fp::cmp(ub[n], fp::make(1)) > 0) {             // ub.d > 2^(l-1) - 1
+                    set_b(n, fp::make(0), fp::make(1));
+                    f[n] |= 2;
+                    C.steps++; C.hits[3]++;
+                    ev[nev++] = new_key;
+                }
+            }
+            if (f[n] & 1) {                                       // pivot unique: the others become unique, C order
+                for (int t = 0; t < 2; ++t) {
+                    const int i = t == 0 ? o0 : o1;
+                    if (i != n && !(f[i] & 1)) { f[i] |= 3; ev[nev++] = kv[i]; C.nuniq++; C.steps++; C.hits[3]++; }
+                }
+            }
+        }
+    }
+    // R5 (:1078-1146)
+    if (!fp::eq(ub[1], ub[0]) || !fp::eq(lb[1], lb[0]) || ((f[0] ^ f[1]) & 1)) {
+        bool ch0 = false, ch1 = false;
+        if ((f[0] ^ f[1]) & 1) { f[0] |= 3; C.nuniq += 2; ch0 = ch1 = true; }   // key_1 written twice (sic)
+        const fp::u256 mn = fp::cmp(ub[0], ub[1]) <= 0 ? ub[0] : ub[1];
+        const fp::u256 mx = fp::cmp(lb[0], lb[1]) >= 0 ? lb[0] : lb[1];
+        const bool w0 = fp::cmp(ub[0], mn) > 0 || fp::cmp(lb[0], mx) < 0;
+        const bool w1 = fp::cmp(ub[1], mn) > 0 || fp::cmp(lb[1], mx) < 0;
+        if (w0) { f[0] |= 2; set_b(0, mx, mn); }
+        if (w1) { f[1] |= 2; set_b(1, mx, mn); }
+        ch0 |= w0; ch1 |= w1;
+        const uint32_t nset = (ch0 ? 1u : 0u) + (ch1 ? 1u : 0u);
+        C.steps += nset;
+        if (nset) C.hits[4]++;
+        if (sw) { if (ch1) ev[nev++] = kv[1]; if (ch0) ev[nev++] = kv[0]; }
+        else { if (ch0) ev[nev++] = kv[0]; if (ch1) ev[nev++] = kv[1]; }
+    }
+    // write back what changed
+    for (int i = 0; i < 2; ++i) {
+        if (bdirty[i]) { st256(J.lb + 4ull * kv[i], lb[i]); st256(J.ub + 4ull * kv[i], ub[i]); }
+        if (f[i] != f_in[i]) J.flags[kv[i]] = f[i];
+    }
+    // R7 / R8 (:1235-1348): only when one of them could fire
+    {
+        const bool nu0 = !(f[o0] & 1), nu1 = !(f[o1] & 1);
+        if (nu0 || nu1) {
+            const bool notknown = (nu0 && !(f[o0] & 2)) || (nu1 && !(f[o1] & 2));
+            bool badgroup;
+            if (nu0 && nu1) badgroup = ab[o0] == -1 || ab[o1] != ab[o0];
+            else badgroup = (nu0 ? ab[o0] : ab[o1]) == -1;
+            if (!notknown || !badgroup) {
+                const uint32_t c0 = J.rpC[row];
+                lane_r78_tail(J, c0, c0 + 2, shape, ev, nev, C);
+            }
+        }
+    }
+}
+
 __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t* ev, uint32_t& nev, LaneCtr& C) {
     const RowInfo ri = J.rinfo[row];
+    if ((ri.shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2)) { exec_xy_lane(J, row, ri, ev, nev, C); return; }
     const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1];
     const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
