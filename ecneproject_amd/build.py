@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libecne_hip.so")
-SOURCES = ["ecne_engine.hip", "kernels.hip.hpp", "host_model.hpp", "engine_types.hpp", "fp256.hpp", "jlorder.hpp"]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))   # every file under csrc/ is a dependency
 
 
 def hipcc():

@@ -1,0 +1,318 @@
+// classify.hip.hpp — k_classify_rows: static shape of every row, rule constants, R7 order.
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+#pragma once
+#include "dev_common.hip.hpp"
+
+namespace ecne {
+
+// ====================================================================================== classify
+// popcount / ctz of a 256-bit value
+__device__ __forceinline__ int popc256(const fp::u256& a) {
+    return __popcll(a.w[0]) + __popcll(a.w[1]) + __popcll(a.w[2]) + __popcll(a.w[3]);
+}
+__device__ __forceinline__ int ctz256(const fp::u256& a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (a.w[i]) return 64 * i + (__ffsll((long long)a.w[i]) - 1);
+    return 256;
+}
+
+// One wavefront classifies one row. wave_scratch: 8 u32 of LDS per wave (256-bit exponent bitmap).
+__device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch) {
+    const int lane = lane_id();
+    RowInfo ri = J.rinfo[row];   // structural bits and keys were laid down by the host
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t l = c1 - c0;
+    uint32_t shape = ri.shape;
+    // ---- R2 constants: values = [-a1/ax, -b1/bx]  (:916-927)
+    if ((shape & SH_R2) && !(shape & SH_R2_DIV0)) {
+        // lanes 0 and 1 each handle one part
+        fp::u256 val = fp::make(0);
+        if (lane < 2) {
+            const uint32_t* rp = lane == 0 ? J.rpA : J.rpB;
+            const uint32_t* col = lane == 0 ? J.colA : J.colB;
+            const uint64_t* cf = lane == 0 ? J.coefA : J.coefB;
+            fp::u256 slope = fp::make(0), icpt = fp::make(0);
+            for (uint32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                uint32_t v = col[k];
+                fp::u256 c = ld256(cf + 4ull * k);
+                if (v == ri.x) slope = c;
+                else if (v == 1) icpt = c;
+            }
+            val = fp::mul(fp::neg(icpt), fp::inv(slope));
+            st256(J.vals + 4ull * (ri.validx + lane), val);
+        }
+        fp::u256 v0 = shfl256(val, 0), v1 = shfl256(val, 1);
+        if ((fp::is_zero(v0) && fp::is_one(v1)) || (fp::is_one(v0) && fp::is_zero(v1))) shape |= SH_R2_IS01;
+    }
+    if (!(shape & SH_HAS_AB) && l > 0) {
+        // ---- R3 constant: -c[1]/c[x]  (:961-964)
+        if ((shape & SH_R3) && lane == 0) {
+            fp::u256 c1v = fp::make(0), cx = fp::make(0);
+            for (uint32_t k = c0; k < c1; ++k) {
+                uint32_t v = J.colC[k];
+                if (v == 1) c1v = ld256(J.coefC + 4ull * k);
+                else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
+            }
+            st256(J.vals + 4ull * ri.validx, fp::mul(fp::neg(c1v), fp::inv(cx)));
+        }
+        // ---- R4 pattern: multiset {1, -2^0..-2^(l-2)} (T) or its negation (T2)  (:999-1013)
+        if (!(shape & SH_CZERO)) {
+            bool isT = false, isT2 = false;
+            uint32_t kpos = 0, kneg = 0;
+            if (l <= 255) {
+                if (lane < 8) wave_scratch[lane] = 0;       // T bitmap
+                if (lane < 8) wave_scratch[8 + lane] = 0;   // T2 bitmap
+                wg_fence();
+                int n_one = 0, n_mone = 0, okT = 1, okT2 = 1;
+                for (uint32_t base = c0; base < c1; base += 64) {
+                    uint32_t k = base + lane;
+                    bool act = k < c1;
+                    fp::u256 c = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
+                    uint32_t v = act ? J.colC[k] : 0;
+                    bool one = act && fp::is_one(c);
+                    fp::u256 nc = fp::neg(c);
+                    bool mone = act && fp::is_one(nc);
+                    uint64_t m1 = __ballot(one), m2 = __ballot(mone);
+                    n_one += __popcll(m1);
+                    n_mone += __popcll(m2);
+                    if (m1) kpos = __shfl(v, __ffsll((long long)m1) - 1, 64);
+                    if (m2) kneg = __shfl(v, __ffsll((long long)m2) - 1, 64);
+                    // exponent of -c (T) / of c (T2); the "1" / "-1" entries are the pivots
+                    bool badT = false, badT2 = false;
+                    if (act && !one) {           // T: every non-1 entry must be -2^k, k <= l-2, distinct
+                        int e = (popc256(nc) == 1) ? ctz256(nc) : 999;
+                        if (e > (int)l - 2) badT = true;
+                        else if (atomicOr(&wave_scratch[e >> 5], 1u << (e & 31)) & (1u << (e & 31))) badT = true;
+                    }
+                    if (act && !mone) {          // T2: every non-(-1) entry must be 2^k
+                        int e = (popc256(c) == 1) ? ctz256(c) : 999;
+                        if (e > (int)l - 2) badT2 = true;
+                        else if (atomicOr(&wave_scratch[8 + (e >> 5)], 1u << (e & 31)) & (1u << (e & 31))) badT2 = true;
+                    }
+                    if (__ballot(badT)) okT = 0;
+                    if (__ballot(badT2)) okT2 = 0;
+                }
+                // l == 1: T = [1], T2 = [p-1]
+                isT = okT && n_one == 1;
+                isT2 = okT2 && n_mone == 1;
+            } else {
+                // l > 255: powers 2^k wrap modulo p for k >= 254. Quick reject (exactly one 1 / one -1),
+                // then the literal multiset comparison, lanes striding over targets.
+                int n_one = 0, n_mone = 0;
+                for (uint32_t base = c0; base < c1; base += 64) {
+                    uint32_t k = base + lane;
+                    bool act = k < c1;
+                    fp::u256 c = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
+                    uint32_t v = act ? J.colC[k] : 0;
+                    uint64_t m1 = __ballot(act && fp::is_one(c)), m2 = __ballot(act && fp::is_one(fp::neg(c)));
+                    n_one += __popcll(m1);
+                    n_mone += __popcll(m2);
+                    if (m1) kpos = __shfl(v, __ffsll((long long)m1) - 1, 64);
+                    if (m2) kneg = __shfl(v, __ffsll((long long)m2) - 1, 64);
+                }
+                if (n_one == 1 && n_mone == 1) {
+                    // T  <=> one "1"  and every 2^k mod p (k = 0..l-2) occurs exactly once among the -c
+                    // T2 <=> one "-1" and every 2^k mod p occurs exactly once among the c
+                    int okT = 1, okT2 = 1;
+                    for (uint32_t tb = 0; tb < l - 1; tb += 64) {
+                        uint32_t t = tb + lane;
+                        bool act = t < l - 1;
+                        fp::u256 pw = fp::make(1);
+                        for (uint32_t s = 0; act && s < t; ++s) pw = fp::add(pw, pw);
+                        int cntT = 0, cntT2 = 0;
+                        if (act)
+                            for (uint32_t k = c0; k < c1; ++k) {
+                                fp::u256 c = ld256(J.coefC + 4ull * k);
+                                if (fp::eq(c, pw)) cntT2++;
+                                if (fp::eq(fp::neg(c), pw)) cntT++;
+                            }
+                        if (__ballot(act && cntT != 1)) okT = 0;
+                        if (__ballot(act && cntT2 != 1)) okT2 = 0;
+                    }
+                    isT = okT;
+                    isT2 = okT2;
+                }
+            }
+            if (isT) shape |= SH_R4_T;
+            if (isT2) shape |= SH_R4_T2;
+            if (isT || isT2) {
+                ri.kpos = kpos;
+                ri.kneg = kneg;
+                if (lane == 0) {   // F(2)^(l-1) - F(1), field arithmetic (:1033)
+                    fp::u256 pw = fp::make(1);
+                    for (uint32_t s = 0; s + 1 < l; ++s) pw = fp::add(pw, pw);
+                    st256(J.vals + 4ull * (ri.validx + 1), fp::sub(pw, fp::make(1)));
+                }
+            }
+        }
+        // ---- R7 order: stable rank of |coefficient| in the orientation R7 will see (:1256-1265).
+        // A T2-only row has been negated by R4 before R7 first looks at it.
+        {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            // long sum rows usually carry one |coefficient| (all +-1): the stable order is then the stored one
+            bool all_same = true;
+            {
+                fp::u256 first = ld256(J.coefC + 4ull * c0);
+                if (negated) first = fp::neg(first);
+                first = r7_abs(first);
+                for (uint32_t base = c0; base < c1 && all_same; base += 64) {
+                    uint32_t k = base + lane;
+                    bool diff = false;
+                    if (k < c1) {
+                        fp::u256 c = ld256(J.coefC + 4ull * k);
+                        if (negated) c = fp::neg(c);
+                        diff = !fp::eq(r7_abs(c), first);
+                    }
+                    if (__ballot(diff)) all_same = false;
+                }
+            }
+            if (all_same)
+                for (uint32_t k = c0 + lane; k < c1; k += 64) J.csort[k] = k - c0;
+            else
+            for (uint32_t base = c0; base < c1; base += 64) {
+                uint32_t k = base + lane;
+                bool act = k < c1;
+                fp::u256 mine = fp::make(0);
+                if (act) {
+                    mine = ld256(J.coefC + 4ull * k);
+                    if (negated) mine = fp::neg(mine);
+                    mine = r7_abs(mine);
+                }
+                uint32_t rank = 0;
+                for (uint32_t ob = c0; ob < c1; ob += 64) {
+                    uint32_t ok_ = ob + lane;
+                    fp::u256 oth = fp::make(0);
+                    bool oact = ok_ < c1;
+                    if (oact) {
+                        oth = ld256(J.coefC + 4ull * ok_);
+                        if (negated) oth = fp::neg(oth);
+                        oth = r7_abs(oth);
+                    }
+                    uint32_t cnt = (c1 - ob) < 64 ? (c1 - ob) : 64;
+                    for (uint32_t s = 0; s < cnt; ++s) {
+                        fp::u256 o = shfl256(oth, (int)s);
+                        uint32_t oidx = ob + s;
+                        int cm = fp::cmp(o, mine);
+                        if (act && (cm < 0 || (cm == 0 && oidx < k))) rank++;
+                    }
+                }
+                if (act) J.csort[c0 + rank] = k - c0;
+            }
+            shape |= SH_R7_SORTED;
+        }
+    }
+    if ((shape & SH_C_HAS1) && (shape & (SH_R4_T | SH_R4_T2 | SH_R5))) shape |= SH_TOUCH1;
+    if (lane == 0) {
+        ri.shape = shape;
+        J.rinfo[row] = ri;
+    }
+}
+
+// Rows with at most ECNE_CLS_LANE entries in C (almost all of them) are classified by ONE lane each:
+// 64 rows per wavefront, so the field inversions of bit-check / single-variable rows run on full
+// SIMDs instead of one lane of a wave. Same results as classify_row, written serially.
+#define ECNE_CLS_LANE 8
+__device__ void classify_row_lane(const Job& J, uint32_t row) {
+    RowInfo ri = J.rinfo[row];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t l = c1 - c0;
+    uint32_t shape = ri.shape;
+    if ((shape & SH_R2) && !(shape & SH_R2_DIV0)) {
+        fp::u256 val[2];
+        for (int part = 0; part < 2; ++part) {
+            const uint32_t* rp = part == 0 ? J.rpA : J.rpB;
+            const uint32_t* col = part == 0 ? J.colA : J.colB;
+            const uint64_t* cf = part == 0 ? J.coefA : J.coefB;
+            fp::u256 slope = fp::make(0), icpt = fp::make(0);
+            for (uint32_t k = rp[row]; k < rp[row + 1]; ++k) {
+                uint32_t v = col[k];
+                fp::u256 c = ld256(cf + 4ull * k);
+                if (v == ri.x) slope = c;
+                else if (v == 1) icpt = c;
+            }
+            val[part] = fp::mul(fp::neg(icpt), fp::inv(slope));
+            st256(J.vals + 4ull * (ri.validx + part), val[part]);
+        }
+        if ((fp::is_zero(val[0]) && fp::is_one(val[1])) || (fp::is_one(val[0]) && fp::is_zero(val[1]))) shape |= SH_R2_IS01;
+    }
+    if (!(shape & SH_HAS_AB) && l > 0) {
+        if (shape & SH_R3) {
+            fp::u256 c1v = fp::make(0), cx = fp::make(0);
+            for (uint32_t k = c0; k < c1; ++k) {
+                uint32_t v = J.colC[k];
+                if (v == 1) c1v = ld256(J.coefC + 4ull * k);
+                else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
+            }
+            st256(J.vals + 4ull * ri.validx, fp::mul(fp::neg(c1v), fp::inv(cx)));
+        }
+        fp::u256 key[ECNE_CLS_LANE];
+        if (!(shape & SH_CZERO)) {
+            uint32_t n_one = 0, n_mone = 0, kpos = 0, kneg = 0;
+            uint32_t maskT = 0, maskT2 = 0;     // exponents seen (l <= 8: exponents 0..6)
+            bool okT = true, okT2 = true;
+            for (uint32_t k = c0; k < c1; ++k) {
+                const fp::u256 c = ld256(J.coefC + 4ull * k);
+                const fp::u256 nc = fp::neg(c);
+                const bool one = fp::is_one(c), mone = fp::is_one(nc);
+                if (one) { ++n_one; if (n_one == 1) kpos = J.colC[k]; }
+                if (mone) { ++n_mone; if (n_mone == 1) kneg = J.colC[k]; }
+                if (!one) {
+                    int e = (popc256(nc) == 1) ? ctz256(nc) : 999;
+                    if (e > (int)l - 2 || (maskT >> e & 1)) okT = false; else maskT |= 1u << e;
+                }
+                if (!mone) {
+                    int e = (popc256(c) == 1) ? ctz256(c) : 999;
+                    if (e > (int)l - 2 || (maskT2 >> e & 1)) okT2 = false; else maskT2 |= 1u << e;
+                }
+            }
+            const bool isT = okT && n_one == 1, isT2 = okT2 && n_mone == 1;
+            if (isT) shape |= SH_R4_T;
+            if (isT2) shape |= SH_R4_T2;
+            if (isT || isT2) {
+                ri.kpos = kpos;
+                ri.kneg = kneg;
+                fp::u256 pw = fp::make(1);
+                for (uint32_t s = 0; s + 1 < l; ++s) pw = fp::add(pw, pw);
+                st256(J.vals + 4ull * (ri.validx + 1), fp::sub(pw, fp::make(1)));
+            }
+        }
+        // R7 order: stable insertion sort of the (at most 8) entries by |signed coefficient|
+        {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            uint32_t idx[ECNE_CLS_LANE];
+            for (uint32_t k = 0; k < l; ++k) {
+                fp::u256 c = ld256(J.coefC + 4ull * (c0 + k));
+                if (negated) c = fp::neg(c);
+                c = r7_abs(c);
+                uint32_t pos = k;
+                while (pos > 0 && fp::cmp(key[pos - 1], c) > 0) { key[pos] = key[pos - 1]; idx[pos] = idx[pos - 1]; --pos; }
+                key[pos] = c;
+                idx[pos] = k;
+            }
+            for (uint32_t k = 0; k < l; ++k) J.csort[c0 + k] = idx[k];
+            shape |= SH_R7_SORTED;
+        }
+    }
+    if ((shape & SH_C_HAS1) && (shape & (SH_R4_T | SH_R4_T2 | SH_R5))) shape |= SH_TOUCH1;
+    ri.shape = shape;
+    J.rinfo[row] = ri;
+}
+
+// pass 0: one lane per row for rows with lenC <= ECNE_CLS_LANE; pass 1: one wavefront per remaining row
+__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index, uint32_t pass) {
+    __shared__ uint32_t scratch[4][16];
+    __shared__ Job sJ;
+    if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
+    __syncthreads();
+    if (pass == 0) {
+        for (uint32_t row = blockIdx.x * 256 + threadIdx.x; row < sJ.nC; row += gridDim.x * 256)
+            if (sJ.rinfo[row].lenC <= ECNE_CLS_LANE) classify_row_lane(sJ, row);
+        return;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    // the long rows are listed by the host (big_list): one wavefront each
+    for (uint32_t i = blockIdx.x * 4 + wave; i < sJ.nBigCls; i += gridDim.x * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
+}
+
+}  // namespace ecne

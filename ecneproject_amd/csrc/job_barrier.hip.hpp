@@ -1,0 +1,98 @@
+// job_barrier.hip.hpp — the XCD-hierarchical barrier of the workgroups of one job, job-wide scans.
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+#pragma once
+#include "schedule.hip.hpp"
+
+namespace ecne {
+
+// ------------------------------------------------------------------------------------ job barrier
+// A job (one constraint system) is run by J.nwg co-resident workgroups: workgroup 0 (the "master")
+// executes everything whose order matters (P1, P2, the queue, the decisions of P3, P5, all REQUEUEs);
+// the others join for the row-parallel passes of the whole-system sweeps P3 / P4, the setup and the
+// verdict count. They meet at this barrier: sense-reversing counter, agent-scope release before
+// arriving (writes back this XCD's dirty L2 lines) and agent-scope acquire after leaving (drops
+// stale L1/L2 lines) — per-XCD L2s are not coherent with each other on MI355X. The last arriver
+// snapshots the job's error word, so every workgroup leaves with the SAME view of it and takes the
+// same branch. Spins are bounded.
+__device__ __forceinline__ uint32_t my_xcc_id() {
+    // HW_REG_XCC_ID (hwreg 20), bits [3:0]: which of the 8 XCDs this wave runs on
+    return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
+}
+
+// What a workgroup remembers between job barriers (LDS): the generation it waits for next and, once the
+// first barrier of the launch has established them, its XCD's member count and the number of XCDs in use
+// -- so that a barrier costs one atomic per level and one polled word, no other memory round trips.
+struct BarLocal { unsigned gen, members, nxcd, ready; };
+__device__ __forceinline__ BarLocal& bar_local() {
+    __shared__ BarLocal b;
+    return b;
+}
+__device__ __forceinline__ void job_barrier_init() {   // thread 0, once per launch (the device words are zeroed by the host)
+    BarLocal& b = bar_local();
+    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0;
+}
+
+__device__ int job_barrier(const Job& J, int* s_err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Counters* c = J.ctr;
+        if (J.nwg == 1) {
+            *s_err = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // XCD-hierarchical: workgroups of one XCD share its L2, so only the last of them to arrive
+            // (the XCD leader) pays for the agent-scope release (L2 write-back) before arriving at
+            // the top-level counter; everybody waits on one generation word and then drops its stale
+            // L1 lines. The first barrier of a launch is flat and establishes the XCD membership.
+            // The generation word carries the generation in its upper bits and "an error was raised" in
+            // bit 0, so the waiters learn both from the one word they poll.
+            BarLocal& b = bar_local();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my stores have reached my XCD's L2
+            const unsigned g = b.gen;
+            const bool hier = b.ready != 0;
+            bool arrive_top = true;
+            const unsigned x = my_xcc_id();
+            if (hier) {
+                const unsigned a = __hip_atomic_fetch_add(&c->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a == b.members - 1)
+                    __hip_atomic_store(&c->xcd_count[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else arrive_top = false;
+            } else {
+                __hip_atomic_fetch_add(&c->xcd_members[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (arrive_top) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned expect = hier ? b.nxcd : J.nwg;
+                const unsigned arrived = __hip_atomic_fetch_add(&c->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived == expect - 1) {
+                    if (!hier) {
+                        unsigned na = 0;
+                        for (int i = 0; i < 8; ++i)
+                            na += __hip_atomic_load(&c->xcd_members[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        __hip_atomic_store(&c->n_xcd_active, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const int e = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->bar_gen, ((g + 1u) << 1) | (e != 0 ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            unsigned spins = 0, w;
+            while (((w = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 28)) { raise(J, K_ECAPACITY); w = 1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            b.gen = g + 1;
+            if (!hier) {   // the first barrier of the launch just completed: remember the XCD layout
+                b.members = __hip_atomic_load(&c->xcd_members[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.nxcd = __hip_atomic_load(&c->n_xcd_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.ready = 1;
+            }
+            *s_err = (w & 1u) ? __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+    }
+    __syncthreads();
+    return *s_err;
+}
+
+}  // namespace ecne

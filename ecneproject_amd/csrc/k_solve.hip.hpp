@@ -1,0 +1,611 @@
+// k_solve.hip.hpp — k_solve: setup, outer loop with P1/P2, the queue phase, P3, P4, P5, verdict counts (SPMD over the workgroups of a job).
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+#pragma once
+#include "rounds.hip.hpp"
+
+namespace ecne {
+
+// ---------------------------------------------------------------------------------------- k_solve
+struct WgDesc { uint32_t job, rank; };
+
+__global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc* wgs) {
+    __shared__ Job J;
+    __shared__ uint32_t s_scan[ECNE_NWAVES + 2];
+    __shared__ uint32_t s_u32[8];
+    __shared__ uint32_t s_htn;          // P3 group-table slots this workgroup created in the current sweep
+    __shared__ unsigned long long s_steps;
+    __shared__ uint32_t m_rows[10], m_vars[10];
+    __shared__ int s_err;
+    __shared__ QState s_q;
+    __shared__ ChunkShared s_chunk;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const WgDesc me = wgs[blockIdx.x];
+    if (tid < (int)(sizeof(Job) / 4)) ((uint32_t*)&J)[tid] = ((const uint32_t*)&jobs[me.job])[tid];
+    __syncthreads();
+    const uint32_t nC = J.nC, nV = J.nV;
+    const bool master = me.rank == 0;
+    if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
+    const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
+    Counters* const ctr = J.ctr;
+    const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
+    if (tid == 0) { s_htn = 0; job_barrier_init(); }
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = wall_clock64();
+#define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
+
+    // ---------------- setup (:593-704), all workgroups
+    for (uint32_t i = tid; i < ECNE_BIGTAB; i += ECNE_WG) s_chunk.bt[i] = 0xFFFFFFFFu;
+    for (uint32_t v = gtid; v <= nV; v += gstride) {
+        J.flags[v] = 0;
+        J.abz[v] = -1;
+        J.nvalues[v] = 0;
+        st256(J.lb + 4ull * v, fp::make(0));
+        st256(J.ub + 4ull * v, fp::pminus1());
+        J.varmin[v] = 0xFFFFFFFFu;
+        J.wmarkU[v] = 0xFFFFFFFFu;
+        J.wmarkB[v] = 0xFFFFFFFFu;
+    }
+    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
+    for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
+    for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
+    if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }
+    job_barrier(J, &s_err);
+    for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
+        uint32_t v = J.knowns[i];
+        J.flags[v] = 3;
+        if (v == 1) { J.nvalues[1] = 1; st256(J.values + 8ull, fp::make(1)); }
+    }
+    job_barrier(J, &s_err);
+    // initial queue: rows with at most one variable outside known_variables, ascending (:621-627).
+    // Every workgroup owns a contiguous block of rows: count, job-wide scan of the block totals, write.
+    QState q;
+    q.head = 0; q.tail = 0; q.evout = nullptr; q.nev = 0; q.emit = 0;
+    {
+        const uint32_t per = (nC + J.nwg - 1) / J.nwg;
+        const uint32_t blk0 = me.rank * per < nC ? me.rank * per : nC;
+        const uint32_t blk1 = (me.rank + 1) * per < nC ? (me.rank + 1) * per : nC;
+        auto wants = [&](uint32_t r) -> uint32_t {
+            uint32_t first = 0, cnt = 0;
+            const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
+            const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
+            for (int p = 0; p < 3 && cnt < 2; ++p)
+                for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
+                    uint32_t v = cl[p][e];
+                    if (!(J.flags[v] & 1)) {
+                        if (cnt == 0) { first = v; cnt = 1; }
+                        else if (v != first) { cnt = 2; break; }
+                    }
+                }
+            return cnt <= 1;
+        };
+        uint32_t mine = 0;
+        for (uint32_t r = blk0 + tid; r < blk1; r += ECNE_WG) mine += wants(r);
+        uint32_t total_pushes = 0;
+        int scan_err = 0;
+        uint32_t base = team_exclusive_scan_any(J, s_chunk, me.rank, mine, &total_pushes, &s_err, &scan_err);
+        // base = pushes of all lower workgroups + of lower threads of mine; but rows are interleaved
+        // across my threads, so redo my block in row order with workgroup scans from my block's base
+        uint32_t wg_base = base;
+        {   // subtract my own lower threads' share: block base = value at thread 0
+            if (tid == 0) s_u32[0] = base;
+            __syncthreads();
+            wg_base = s_u32[0];
+            __syncthreads();
+        }
+        uint32_t off_run = wg_base;
+        for (uint32_t b = blk0; b < blk1; b += ECNE_WG) {
+            const uint32_t r = b + tid;
+            const uint32_t push = (r < blk1) ? wants(r) : 0u;
+            uint32_t tot;
+            const uint32_t off = wg_exclusive_scan(push, s_scan, &tot);
+            if (push) { J.queue[(off_run + off) & J.qmask] = r; J.inq[r] = 1; }
+            off_run += tot;
+        }
+        q.tail = total_pushes;
+        (void)scan_err;
+    }
+    ECNE_TICK(0);
+    unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
+    unsigned long long hits[16];
+    for (int i = 0; i < 16; ++i) hits[i] = 0;
+    // `steps` is the loop-control value: the master publishes it in ctr->sync_steps before each barrier
+
+    for (;;) {
+        if (master && tid == 0) ctr->sync_steps = steps;
+        if (job_barrier(J, &s_err)) break;
+        steps = __hip_atomic_load(&ctr->sync_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev_steps == steps) break;   // (:708-711)
+        prev_steps = steps;
+        outer++;
+        // ================= P1, P2 and the queue: master only, in the reference's order
+        if (master) {
+            if (w == 0) {
+                // P1 (:718-747). 64 specials are tested at a time, one per lane; the ones whose inputs are all
+                // unique fire in index order, and after every firing the later lanes look again (its outputs
+                // may complete their inputs), which is what the one-by-one sweep would have seen.
+                for (uint32_t base = 0; base < J.nSp; base += 64) {
+                    const uint32_t i = base + lane;
+                    int from = 0;
+                    for (;;) {
+                        bool can = i < J.nSp && lane >= from && !J.fired[nC + i];   // [nC..) = special_solved
+                        if (can)
+                            for (uint32_t e = J.sp_in_ptr[i]; e < J.sp_in_ptr[i + 1] && can; ++e) can = (J.flags[J.sp_in[e]] & 1) != 0;
+                        const uint64_t m = __ballot(can);
+                        if (!m) break;
+                        const int src = __ffsll((long long)m) - 1;
+                        const uint32_t is = base + (uint32_t)src;
+                        if (lane == 0) J.fired[nC + is] = 1;
+                        steps++; hits[8]++;
+                        for (uint32_t e = J.sp_out_ptr[is]; e < J.sp_out_ptr[is + 1]; ++e) {
+                            uint32_t v = J.sp_out[e];
+                            if (J.flags[v] & 1) continue;
+                            mark_unique(J, v);
+                            requeue(J, q, v);
+                        }
+                        from = src + 1;
+                    }
+                }
+                // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair, from the two index lists
+                for (uint32_t a = 0; a < J.nK1; ++a) {
+                    const uint32_t i = J.k1_list[a];
+                    for (uint32_t bj = 0; bj < J.nK2; ++bj) {
+                        const uint32_t j = J.k2_list[bj];
+                        if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
+                        uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
+                        if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
+                        hits[9]++;
+                        for (uint32_t t = 0; t < 3; ++t) {                                   // constraint_j[2][1:3]
+                            uint32_t v = J.sp_in[J.sp_in_ptr[j] + t];
+                            if (J.flags[v] & 1) continue;
+                            mark_unique(J, v);
+                            requeue(J, q, v);
+                        }
+                    }
+                    if (J.ctr->error) break;
+                }
+                if (J.queue_mode == 1) {
+                    // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
+                    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
+                    while (q.head != q.tail && !J.ctr->error) {
+                        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+                        uint32_t row = J.queue[q.head & J.qmask];
+                        q.head++;
+                        if (lane == 0) J.inq[row] = 0;
+                        wg_fence();
+                        pops++;
+                        pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+                        if (J.solved[row]) continue;
+                        exec_row(J, q, row, hits, steps, nuniq);
+                    }
+                }
+                if (lane == 0) { s_q = q; s_steps = steps; }
+            }
+            __syncthreads();
+            steps = s_steps;
+            q = s_q;
+            if (J.queue_mode != 1 && wg_error(J, &s_err)) {
+                // P1/P2 raised: the queue phase is skipped, but the helpers are waiting at its command
+                // barrier — meet them there (they leave on the error snapshot)
+                if (J.nwg > 1) job_barrier(J, &s_err);
+            } else if (J.queue_mode != 1) {
+                // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
+                unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
+                for (int i = 0; i < 16; ++i) ht2[i] = 0;
+                queue_phase_chunked(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
+                steps = st2;
+                if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
+            }
+        }
+        else if (J.queue_mode != 1) queue_phase_helper(J, s_chunk, me.rank, &s_err);
+        if (job_barrier(J, &s_err)) break;      // publishes the queue phase's state changes to the helpers
+        if (master && J.nwg > 1 && J.queue_mode != 1) {
+            // fold in what the helpers did during multi-workgroup rounds
+            steps += ctr->q_acc[0];
+            if (w == 0) {
+                nuniq += ctr->q_acc[1]; pops += ctr->q_acc[10]; pop_nnz += ctr->q_acc[11];
+                for (int i = 0; i < 8; ++i) hits[i] += ctr->q_acc[2 + i];
+            }
+            __syncthreads();
+            if (tid < 16) ctr->q_acc[tid] = 0;
+        }
+        ECNE_TICK(1);
+
+        // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
+        {
+            uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
+            bool p3_err = false;
+            for (;;) {
+                tk[6]++;
+                // phase 1: evaluate rows >= f against the current state
+                // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
+                for (uint32_t r4 = (f & ~3u) + 4u * gtid; r4 < nC; r4 += 4u * gstride) {
+                    const uint32_t dead4 = *reinterpret_cast<const uint32_t*>(J.rdead + r4);   // padded to a multiple of 4
+                    if (dead4 == 0x01010101u) continue;
+                    for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r) {
+                        if ((dead4 >> (8 * (r - r4))) & 1) continue;   // every variable unique already (p3k[r] stays 0)
+                        uint32_t k; uint64_t h, h2;
+                        p3_eval(J, r, k, h, h2);
+                        if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
+                        if (k == 0xFFFFFFFFu) k = 0;
+                        J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+                        if (k == 1) atomicMin(&ctr->p3_cand1, r);
+                        else if (k >= 2) {
+                            J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
+                            bool created = false;
+                            uint32_t s = ht_slot(J, h, h2, true, &created);
+                            if (s != 0xFFFFFFFFu) {
+                                // p3_hot is raised only when this group could be complete with this member (k rows
+                                // counting the frozen ones): otherwise nobody has to look for trigger rows this pass
+                                const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
+                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k)
+                                    __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (created) {   // remembered, so that only the slots in use are wiped afterwards
+                                const uint32_t pos = atomicAdd(&s_htn, 1u);
+                                if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                            }
+                        }
+                    }
+                }
+                if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                const bool any = ld_agent(&ctr->p3_any) != 0;
+                const bool hot = ld_agent(&ctr->p3_hot) != 0;
+                // phase 2: rows whose group could reach its size in this pass
+                if (hot) {
+                    for (uint32_t r = f + gtid; r < nC; r += gstride) {
+                        uint32_t k = J.p3k[r];
+                        if (k < 2) continue;
+                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        if (s == 0xFFFFFFFFu) continue;
+                        uint32_t fr = ld_agent(&J.ht_frozen[s]);
+                        if (fr < k && fr + ld_agent(&J.ht_new[s]) >= k) {
+                            uint32_t pos = atomicAdd(&ctr->p3_nhot, 1u);
+                            if (pos < J.hotcap) J.hot[pos] = r;
+                        }
+                    }
+                    if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                }
+                // phase 3 (master, wave 0): find the earliest trigger row that passes the test
+                if (master) {
+                    if (w == 0) {
+                        uint32_t nhot = hot ? ld_agent(&ctr->p3_nhot) : 0;
+                        if (nhot > J.hotcap) { raise(J, K_ECAPACITY); nhot = 0; }
+                        uint32_t best = ld_agent(&ctr->p3_cand1);   // k == 1: first arrival of a one-variable group always fires
+                        for (uint32_t a = 0; a < nhot; ++a) {
+                            uint32_t t = J.hot[a];
+                            if (t >= best) continue;
+                            uint32_t k = J.p3k[t];
+                            uint64_t h = J.p3h[t], h2 = J.p3h2[t];
+                            uint32_t s = ht_slot(J, h, h2, false);
+                            uint32_t fr = (s == 0xFFFFFFFFu) ? 0 : ld_agent(&J.ht_frozen[s]);
+                            // arrival number of t = frozen + fresh members with index <= t
+                            uint32_t part = 0;
+                            for (uint32_t b = lane; b < nhot; b += 64) {
+                                uint32_t o = J.hot[b];
+                                if (o <= t && J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k) part++;
+                            }
+                            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                            if (fr + part != k) continue;
+                            if (k > 10) { raise(J, K_EDETSIZE); break; }
+                            // collect the k member rows in arrival (index) order and the k variables ascending
+                            if (lane == 0) {
+                                uint32_t n = 0;
+                                if (fr) {   // frozen members: rows < f with the same key at their time
+                                    for (uint32_t r = 0; r < f && n < k; ++r)
+                                        if (J.p3k[r] == k && J.p3h[r] == h && J.p3h2[r] == h2) m_rows[n++] = r;
+                                }
+                                uint32_t last = 0; bool have = false;
+                                while (n < k) {
+                                    uint32_t mn = 0xFFFFFFFFu;
+                                    for (uint32_t b = 0; b < nhot; ++b) {
+                                        uint32_t o = J.hot[b];
+                                        if (J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k && (!have || o > last) && o < mn) mn = o;
+                                    }
+                                    if (mn == 0xFFFFFFFFu) break;
+                                    m_rows[n++] = mn; last = mn; have = true;
+                                }
+                                uint32_t nv = 0;
+                                for (uint32_t e = J.rpC[t]; e < J.rpC[t + 1]; ++e) {
+                                    uint32_t v = J.colC[e];
+                                    if (!(J.flags[v] & 1)) {
+                                        uint32_t pos = nv++;
+                                        while (pos > 0 && m_vars[pos - 1] > v) { m_vars[pos] = m_vars[pos - 1]; --pos; }
+                                        m_vars[pos] = v;
+                                    }
+                                }
+                            }
+                            wg_fence();
+                            if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
+                        }
+                        if (lane == 0) {
+                            ctr->p3_fire = best;
+                            ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0;   // ready for the next round
+                        }
+                    }
+                }
+                if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                const uint32_t fire = ld_agent(&ctr->p3_fire);
+                if (fire == 0xFFFFFFFFu) break;
+                const uint32_t upto = fire + 1;
+                // phase 4: freeze rows [f, upto): their arrivals are now history; forget fresh counts
+                if (any) {
+                    for (uint32_t r = f + gtid; r < nC; r += gstride) {
+                        uint32_t k = J.p3k[r];
+                        if (k < 2) continue;
+                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                        if (s == 0xFFFFFFFFu) continue;
+                        if (r < upto) atomicAdd(&J.ht_frozen[s], 1u);
+                        J.ht_new[s] = 0;
+                    }
+                }
+                // apply the firing (master): the group's variables, ascending, become unique (:1403-1414)
+                if (master) {
+                    if (w == 0) {
+                        uint32_t k = J.p3k[fire];
+                        steps += k; hits[10]++;
+                        uint32_t lastv = 0;
+                        for (uint32_t n = 0; n < k; ++n) {
+                            uint32_t mn = 0xFFFFFFFFu;
+                            for (uint32_t e = J.rpC[fire] + lane; e < J.rpC[fire + 1]; e += 64) {
+                                uint32_t v = J.colC[e];
+                                if (!(J.flags[v] & 1) && v > lastv && v < mn) mn = v;
+                            }
+                            for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
+                            if (mn == 0xFFFFFFFFu) break;
+                            lastv = mn;
+                            J.events[n] = mn;
+                        }
+                        wg_fence();
+                        for (uint32_t n = 0; n < k; ++n) {
+                            uint32_t v = J.events[n];
+                            mark_unique(J, v);
+                            requeue(J, q, v);
+                        }
+                        if (lane == 0) s_steps = steps;
+                    }
+                    __syncthreads();
+                    steps = s_steps;
+                }
+                if (job_barrier(J, &s_err)) { p3_err = true; break; }   // the firing's writes reach the helpers
+                f = fire + 1;
+            }
+            if (p3_err) break;
+            // leave the table clean for the next outer iteration: every workgroup wipes the slots it created
+            __syncthreads();
+            {
+                const uint32_t nmine = s_htn < ht_cap ? s_htn : ht_cap;
+                for (uint32_t i = tid; i < nmine; i += ECNE_WG) {
+                    const uint32_t s = J.ht_list[(size_t)me.rank * ht_cap + i];
+                    J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0;
+                }
+                __syncthreads();
+                if (tid == 0) s_htn = 0;
+            }
+        }
+        ECNE_TICK(2);
+
+        // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups.
+        // p4_b[i] / p4_s[i]: B variable and slope variable (bit 31: no slope -> DivideError) of the i-th
+        // statically eligible row. A row tags b iff b is not unique, still untagged, and the row is the
+        // FIRST such row of b in index order (varmin[b]).
+        {
+            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+                const uint32_t b = J.p4_b[i];
+                if (J.flags[b] & 1) continue;
+                if (J.p4_s[i] & 0x80000000u) { raise(J, K_EDIVZERO); continue; }
+                if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
+            }
+            if (job_barrier(J, &s_err)) break;
+            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+                const uint32_t b = J.p4_b[i];
+                if ((J.flags[b] & 1) || ld_agent(&J.varmin[b]) != i || J.abz[b] != -1) continue;
+                J.abz[b] = (int32_t)(J.p4_s[i] & 0x7FFFFFFFu);
+                J.flags[b] |= 2;
+                J.fired[i] = 1;          // by list position; cleared again when the events are collected
+                atomicAdd(&ctr->p4_nfired, 1u);
+            }
+            if (master && tid == 0) ctr->q_cmd[2] = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
+            if (job_barrier(J, &s_err)) break;
+            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // stable until the master clears it at the end of P4
+            // forget the per-variable minima (all workgroups; the next use is a whole queue phase away)
+            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+                const uint32_t b = J.p4_b[i];
+                if (!(J.flags[b] & 1)) J.varmin[b] = 0xFFFFFFFFu;
+            }
+            bool p4_done = false, p4_err = false;
+            if (J.nwg > 1 && p4_fired >= 2048) {
+                // Many rows tagged (the first sweep of a large circuit tags every decoder output): the ordered
+                // REQUEUE of their B variables runs on ALL workgroups -- same steps as resolve_pushes, with
+                // contiguous blocks per thread and job-wide scans (nothing is being popped: a candidate may
+                // push iff its row is not queued; the lowest candidate index per row wins).
+                const uint32_t tail0 = ld_agent(&ctr->q_cmd[2]);
+                const uint32_t T = gstride;
+                int err = 0;
+                // 1. the event list: B variables of the fired rows, ascending
+                const uint32_t iper = (J.nP4 + T - 1) / T;
+                const uint32_t i0 = gtid * iper < J.nP4 ? gtid * iper : J.nP4, i1 = (gtid + 1) * iper < J.nP4 ? (gtid + 1) * iper : J.nP4;
+                uint32_t cnt = 0;
+                for (uint32_t i = i0; i < i1; ++i) cnt += J.fired[i];
+                uint32_t nev = 0;
+                uint32_t o = team_exclusive_scan(J, s_chunk, me.rank, cnt, 0, &nev, &s_err, &err);
+                if (!err) {
+                    for (uint32_t i = i0; i < i1; ++i)
+                        if (J.fired[i]) { J.events[o++] = J.p4_b[i]; J.fired[i] = 0; }
+                    err = job_barrier(J, &s_err);
+                }
+                // 2. candidates
+                uint32_t M = 0, e0 = 0, e1 = 0, cbase = 0;
+                if (!err) {
+                    const uint32_t eper = (nev + T - 1) / T;
+                    e0 = gtid * eper < nev ? gtid * eper : nev;
+                    e1 = (gtid + 1) * eper < nev ? (gtid + 1) * eper : nev;
+                    uint32_t deg = 0;
+                    for (uint32_t e = e0; e < e1; ++e) { const uint32_t v = J.events[e]; deg += J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+                    cbase = team_exclusive_scan(J, s_chunk, me.rank, deg, 1, &M, &s_err, &err);
+                }
+                if (!err && M <= J.candcap) {
+                    if (tid == 0) s_chunk.nbigev = 0;
+                    __syncthreads();
+                    uint32_t j = cbase;
+                    for (uint32_t e = e0; e < e1; ++e) {
+                        const uint32_t v = J.events[e];
+                        expand_event(J, s_chunk, v, 0, j, false);
+                        j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+                    }
+                    expand_big_events(J, s_chunk, false);
+                    err = job_barrier(J, &s_err);
+                    // 3. winners, in candidate order
+                    uint32_t W = 0;
+                    if (!err) {
+                        const uint32_t cper = (M + T - 1) / T;
+                        const uint32_t j0 = gtid * cper < M ? gtid * cper : M, j1 = (gtid + 1) * cper < M ? (gtid + 1) * cper : M;
+                        uint32_t nwin = 0;
+                        for (uint32_t jj = j0; jj < j1; ++jj) {
+                            const uint32_t cw = J.cand[jj];
+                            const uint32_t t = cw & 0x7FFFFFFFu;
+                            const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == jj;
+                            J.cand[jj] = t | (win ? 0x80000000u : 0u);
+                            nwin += win;
+                        }
+                        const uint32_t wbase = team_exclusive_scan(J, s_chunk, me.rank, nwin, 0, &W, &s_err, &err);
+                        if (!err) {
+                            uint32_t oq = tail0 + wbase;
+                            for (uint32_t jj = j0; jj < j1; ++jj) {
+                                const uint32_t cw = J.cand[jj];
+                                const uint32_t t = cw & 0x7FFFFFFFu;
+                                if (cw & 0x80000000u) { J.queue[oq & J.qmask] = t; J.inq[t] = 1; ++oq; }
+                                J.best[t] = 0xFFFFFFFFu;
+                            }
+                            err = job_barrier(J, &s_err);
+                        }
+                    }
+                    if (!err) {
+                        p4_done = true;
+                        if (master) {
+                            if (w == 0 && lane == 0) { q.tail = tail0 + W; s_q = q; ctr->p4_nfired = 0; }
+                            __syncthreads();
+                            q = s_q;
+                            steps += nev;
+                            if (w == 0) hits[11] += nev;
+                        }
+                    }
+                } else if (!err) {
+                    // (a B variable with a huge fan-out) the master replays the events one by one
+                    if (master) {
+                        if (w == 0) {
+                            for (uint32_t e = 0; e < nev; ++e) requeue(J, q, J.events[e]);
+                            if (lane == 0) { s_q = q; ctr->p4_nfired = 0; }
+                        }
+                        __syncthreads();
+                        q = s_q;
+                        steps += nev;
+                        if (w == 0) { hits[11] += nev; hits[15]++; }
+                    }
+                    err = job_barrier(J, &s_err);
+                    if (!err) p4_done = true;
+                }
+                if (err) p4_err = true;
+            }
+            if (p4_err) break;
+            if (master && p4_fired != 0 && !p4_done) {
+                __syncthreads();
+                if (tid == 0) ctr->p4_nfired = 0;
+                // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
+                if (w == 0 && lane == 0) s_q = q;
+                __syncthreads();
+                q = s_q;
+                // ordered event list = fired rows ascending -> their b variable
+                uint32_t nev = 0;
+                for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
+                    uint32_t i = base + tid;
+                    uint32_t fl = (i < J.nP4) ? J.fired[i] : 0;
+                    uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
+                    if (fl) { J.events[nev + off] = J.p4_b[i]; J.fired[i] = 0; }
+                    nev += total;
+                }
+                __syncthreads();
+                // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
+                {
+                    uint32_t tl = q.tail;
+                    for (uint32_t eb = 0; eb < nev; eb += 4096) {
+                        const uint32_t cnt = (nev - eb) < 4096u ? (nev - eb) : 4096u;
+                        tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &hits[15]);
+                    }
+                    q.tail = tl;
+                    steps += nev;
+                    if (w == 0) hits[11] += nev;
+                }
+            }
+        }
+        ECNE_TICK(3);
+
+        // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
+        if (master) {
+            if (w == 0) {
+                // 64 candidates are tested at a time, one per lane; the ones that pass fire in index order,
+                // and after every firing the later lanes look again (its newly unique y may complete their A)
+                for (uint32_t base = 0; base < J.nP5; base += 64) {
+                    const uint32_t i = base + lane;
+                    const uint32_t r = i < J.nP5 ? J.p5_rows[i] : 0, y = i < J.nP5 ? J.p5_y[i] : 0;
+                    int from = 0;            // lanes below `from` are done
+                    for (;;) {
+                        bool can = i < J.nP5 && lane >= from && !(J.flags[y] & 1);
+                        if (can)
+                            for (uint32_t e = J.rpA[r]; e < J.rpA[r + 1] && can; ++e) can = (J.flags[J.colA[e]] & 1) != 0;
+                        const uint64_t m = __ballot(can);
+                        if (!m) break;
+                        const int src = __ffsll((long long)m) - 1;
+                        const uint32_t rs = __shfl(r, src, 64), ys = __shfl(y, src, 64);
+                        mark_unique(J, ys);
+                        if (lane == 0) { J.solved[rs] = 1; J.solved[rs + 1] = 1; }
+                        wg_fence();
+                        steps++; hits[12]++;
+                        requeue(J, q, ys);
+                        from = src + 1;
+                    }
+                }
+                if (lane == 0) s_steps = steps;
+            }
+            __syncthreads();
+            steps = s_steps;
+        }
+        ECNE_TICK(4);
+    }
+
+    // ---------------- verdict counts (:1558-1597), all workgroups
+    job_barrier(J, &s_err);
+    uint32_t un = 0, nn = 0, ut = 0;
+    for (uint32_t v = 1 + gtid; v <= nV; v += gstride) {
+        if (J.nontrivial[v]) { nn++; if (J.flags[v] & 1) un++; }
+    }
+    for (uint32_t i = gtid; i < J.nTarget; i += gstride)
+        if (J.flags[J.targets[i]] & 1) ut++;
+    {
+        uint32_t t0, t1, t2;
+        wg_exclusive_scan(un, s_scan, &t0);
+        wg_exclusive_scan(nn, s_scan, &t1);
+        wg_exclusive_scan(ut, s_scan, &t2);
+        if (tid == 0) {
+            atomicAdd(&ctr->unique_nontrivial, (unsigned long long)t0);
+            atomicAdd(&ctr->n_nontrivial, (unsigned long long)t1);
+            atomicAdd(&ctr->unique_targets, (unsigned long long)t2);
+            if (master) {
+                ctr->successful_steps = steps;
+                ctr->num_unique = nuniq;
+                ctr->pops = pops;
+                ctr->pop_nnz = pop_nnz;
+                ctr->outer_iterations = outer;
+                for (int i = 0; i < 16; ++i) ctr->rule_hits[i] = hits[i];
+                ctr->q_head = q.head;
+                ctr->q_tail = q.tail;
+                ECNE_TICK(5);
+                for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
+                for (int i = 0; i < 8; ++i) ctr->qticks[i] = s_chunk.qt[i];
+                for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
+            }
+        }
+    }
+}
+
+}  // namespace ecne

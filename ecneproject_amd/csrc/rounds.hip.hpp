@@ -1,0 +1,960 @@
+// rounds.hip.hpp — the queue phase: multi-workgroup rounds, wavefront rounds, the master loop (single-workgroup rounds, bursts, long rows popped alone) and the helper loop.
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+#pragma once
+#include "job_barrier.hip.hpp"
+
+namespace ecne {
+
+// ----------------------------------------------------------------- multi-workgroup queue round
+// Same round as in queue_phase_chunked, but executed by ALL workgroups of the job on a window of up
+// to nwg * 512 * 2 queue entries — for the thousand-row-wide frontiers of large circuits. Global
+// thread g owns ranks g*rpl .. g*rpl + rpl - 1. Cross-workgroup steps use job_barrier (6 per round)
+// and two job-wide scans; everything a lane needs later (its rows, its events) it produced itself,
+// except cand[] / best[] / inq[] / wmark, which are read after a barrier. Returns nonzero on error.
+__device__ uint32_t team_exclusive_scan(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t buf,
+                                        uint32_t* total, int* s_err, int* err_out) {
+    uint32_t wgtot;
+    const uint32_t local = wg_exclusive_scan(x, S.scan, &wgtot);
+    if (threadIdx.x == 0) __hip_atomic_store(&J.ctr->q_part[buf][wgrank], wgtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *err_out = job_barrier(J, s_err);
+    if (threadIdx.x < J.nwg) S.bases[threadIdx.x] = ld_agent(&J.ctr->q_part[buf][threadIdx.x]);
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t i = 0; i < J.nwg; ++i) { const uint32_t v = S.bases[i]; if (i < wgrank) pre += v; tot += v; }
+    __syncthreads();
+    *total = tot;
+    return pre + local;
+}
+
+// team scan that also works for a single workgroup (no job barrier needed then)
+__device__ uint32_t team_exclusive_scan_any(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t* total,
+                                            int* s_err, int* err_out) {
+    if (J.nwg == 1) { *err_out = 0; return wg_exclusive_scan(x, S.scan, total); }
+    return team_exclusive_scan(J, S, wgrank, x, 0, total, s_err, err_out);
+}
+
+__device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t head, uint32_t tail,
+                                             uint32_t n, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err,
+                                             uint32_t* out_c, uint32_t* out_tail) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    Counters* const ctr = J.ctr;
+    const uint32_t T = J.nwg * ECNE_WG, g = wgrank * ECNE_WG + tid;
+    const uint32_t rpl = (n + T - 1) / T;               // <= 2 by the caller's choice of n
+    const uint32_t r0 = g * rpl;
+    uint32_t row[2], shape[2], xv[2];
+    uint32_t live = 0, noop = 0, noop_b = 0;
+    int err;
+    unsigned long long mt_last = wall_clock64();
+#ifdef ECNE_FINE_TICKS
+#define MTICK(slot) do { if (g == 0) { unsigned long long t_ = wall_clock64(); S.mt[slot] += t_ - mt_last; mt_last = t_; } } while (0)
+#else
+#define MTICK(slot) do { } while (0)
+#endif
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
+        if (sl < rpl && r0 + sl < n) {
+            row[sl] = J.queue[(head + r0 + sl) & J.qmask];
+            const RowInfo ri = J.rinfo[row[sl]];
+            shape[sl] = ri.shape;
+            xv[sl] = ri.x;
+            if (!J.solved[row[sl]]) live |= 1u << sl;
+        }
+    }
+    if (tid == 0) S.cut = 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- mark (write sets)
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        if (sl >= rpl || r0 + sl >= n) continue;
+        const uint32_t rank = r0 + sl;
+        if (!(live & (1u << sl))) continue;
+        if (shape[sl] & SH_BIG) {   // plain long rows ride along, handled by this workgroup as a whole (see big_rows_*)
+            if (!big_plain(shape[sl]) || !big_register(S, row[sl], rank)) atomicMin(&S.cut, rank);
+            continue;
+        }
+        const RowInfo ri = J.rinfo[row[sl]];
+        bool nb = false;
+        if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
+        for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+            if (wr & 1) atomicMin(&J.wmarkU[v], rank);
+            if (wr & 2) atomicMin(&J.wmarkB[v], rank);
+        });
+    }
+    __syncthreads();
+    if (S.bl_any) big_rows_mark(J, S);
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(0);
+    // ---- check
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
+        const uint32_t rank = r0 + sl;
+        bool blocked = false;
+        if (noop & (1u << sl)) {
+            if (noop_b & (1u << sl))
+                for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
+                    if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+        } else {
+            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if ((rd | wr) & 1) {
+                        const uint32_t m = ld_agent(&J.wmarkU[v]);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                    if ((rd | wr) & 2) {
+                        const uint32_t m = ld_agent(&J.wmarkB[v]);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                });
+        }
+        if (blocked) atomicMin(&S.cut, rank);
+    }
+    if (S.bl_any) big_rows_check(J, S);
+    // one global update per workgroup (thousands of lanes on one word would serialise)
+    __syncthreads();
+    if (tid == 0 && S.cut != 0xFFFFFFFFu) atomicMin(&ctr->q_cut, S.cut);
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(1);
+    uint32_t c = ld_agent(&ctr->q_cut);         // >= 1 (the master checked that rank 0 is not a big row)
+    if (c > n) c = n;                             // nobody blocked: the whole window commits
+    // ---- unmark, tag, execute my ranks below the cut
+    if (S.bl_any) big_rows_unmark(J, S);
+    uint32_t nev[2], mycand = 0, bigsl = 0;
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl) {
+        nev[sl] = 0;
+        if (sl >= rpl || r0 + sl >= n) continue;
+        if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
+            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+                if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+            });
+        if (r0 + sl >= c) continue;
+        // rank tags must fit inq's 16 bits: multi rounds tag with the rank's low part plus a flag that
+        // the row is in the current prefix; the exact rank is recovered from prank[] (see below)
+        J.inq[row[sl]] = (uint16_t)2;
+        my_pops++;
+        my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
+        J.prank[row[sl]] = r0 + sl;      // rank of a row being popped in this round
+        if (live & (1u << sl)) {
+            if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }
+            else if (shape[sl] & SH_BIG) { bigsl |= 1u << sl; continue; }   // executed below by the whole workgroup
+            else exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+        }
+        uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
+        for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+        ev[ECNE_EVCAP - 1] = nev[sl];    // for the sequential replay fallback
+    }
+    if (S.bl_any) {   // (uniform per workgroup) long rows of the prefix: execute, then candidate offsets of their events
+        big_rows_exec(J, S, c, wgrank);
+        for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+            if (S.bl_rank[k] >= c) continue;
+            const uint32_t* ev = big_ev(J, wgrank, k);
+            uint32_t* off = big_off(J, wgrank, k);
+            const uint32_t ne = S.bl_nev[k];
+            uint32_t run = 0;
+            for (uint32_t eb = 0; eb < ne; eb += ECNE_WG) {          // (uniform trip count)
+                const uint32_t e = eb + tid;
+                uint32_t d = 0;
+                if (e < ne) { const uint32_t v = ev[e]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+                uint32_t tot;
+                const uint32_t o = wg_exclusive_scan(d, S.scan, &tot);
+                if (e < ne) off[e] = run + o;
+                run += tot;
+            }
+            if (tid == 0) {
+                S.bl_deg[k] = run;
+                // the rank's regular slot only says where the events are (for the sequential replay fallback)
+                uint32_t* slot = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+                slot[ECNE_EVCAP - 1] = 0x80000000u | (wgrank * ECNE_BIGK + k);
+                slot[ECNE_EVCAP - 2] = ne;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl)
+            if (bigsl & (1u << sl)) {
+                const int k = big_slot_of(S, r0 + sl);
+                nev[sl] = S.bl_nev[k];
+                mycand += S.bl_deg[k];
+            }
+    }
+    uint32_t M;
+    const uint32_t cbase = team_exclusive_scan(J, S, wgrank, mycand, 0, &M, s_err, &err);
+    MTICK(2);
+    if (err) return err;
+    if (M > J.candcap) {
+        // a variable with a huge fan-out: the master replays all events sequentially (rare)
+        if (wgrank == 0) {
+            if (w == 0) {
+                QState qq;
+                qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                // event counts live in the executing lanes' registers: recount from the fan-out lists is not
+                // possible, so each rank's count was also stored behind its events (slot ECNE_EVCAP - 1)
+                for (uint32_t r = 0; r < c; ++r) {
+                    const uint32_t rr = J.queue[(head + r) & J.qmask];
+                    if (lane == 0) J.inq[rr] = 0;
+                    wg_fence();
+                    uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
+                    const uint32_t* evs = J.evbuf + (size_t)r * ECNE_EVCAP;
+                    if (ne & 0x80000000u) {   // a long row: its events are in the pool
+                        evs = J.bigpool + (size_t)(ne & 0x7FFFFFFFu) * J.bigstride;
+                        ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 2];
+                    }
+                    for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, evs[e]);
+                }
+                if (lane == 0) { ctr->q_tail_out = qq.tail; ctr->q_c_out = c; ctr->q_cut = 0xFFFFFFFFu; }
+            }
+            __syncthreads();
+        }
+        if ((err = job_barrier(J, s_err))) return err;
+        *out_c = c;
+        *out_tail = ld_agent(&ctr->q_tail_out);
+        return 0;
+    }
+    // ---- expansion of my own events: candidate index = cbase + running offset
+    {
+        if (tid == 0) S.nbigev = 0;
+        __syncthreads();
+        uint32_t j = cbase;
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl) {
+            if (sl >= rpl || r0 + sl >= c) continue;
+            const uint32_t a = r0 + sl;
+            if (bigsl & (1u << sl)) {   // a long row's events are expanded by the whole workgroup, below
+                const int k = big_slot_of(S, a);
+                S.bl_base[k] = j;
+                j += S.bl_deg[k];
+                continue;
+            }
+            const uint32_t* ev = J.evbuf + (size_t)a * ECNE_EVCAP;
+            for (uint32_t e = 0; e < nev[sl]; ++e) {
+                const uint32_t v = ev[e];
+                expand_event(J, S, v, a, j, true);
+                j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+            }
+        }
+        if (S.bl_any) {
+            __syncthreads();
+            for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+                if (S.bl_rank[k] >= c) continue;
+                const uint32_t* ev = big_ev(J, wgrank, k);
+                const uint32_t* off = big_off(J, wgrank, k);
+                for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) expand_event(J, S, ev[e], S.bl_rank[k], S.bl_base[k] + off[e], true);
+            }
+        }
+        expand_big_events(J, S, true);
+    }
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(3);
+    // ---- the prefix rows leave the queue (tags no longer needed); then winners in candidate order
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl)
+        if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
+    const uint32_t per = (M + T - 1) / T;
+    const uint32_t j0 = g * per < M ? g * per : M, j1 = (g + 1) * per < M ? (g + 1) * per : M;
+    uint32_t nwin = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t cw = J.cand[j];
+        const uint32_t t = cw & 0x7FFFFFFFu;
+        const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
+        J.cand[j] = t | (win ? 0x80000000u : 0u);
+        nwin += win;
+    }
+    uint32_t W;
+    const uint32_t wbase = team_exclusive_scan(J, S, wgrank, nwin, 1, &W, s_err, &err);
+    MTICK(4);
+    if (err) return err;
+    {
+        uint32_t o = tail + wbase;
+        for (uint32_t j = j0; j < j1; ++j) {
+            const uint32_t cw = J.cand[j];
+            const uint32_t t = cw & 0x7FFFFFFFu;
+            if (cw & 0x80000000u) { J.queue[o & J.qmask] = t; J.inq[t] = 1; ++o; }
+            J.best[t] = 0xFFFFFFFFu;
+        }
+    }
+    if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
+    if (tid == 0) big_reset(S);
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(5);
+    *out_c = c;
+    *out_tail = tail + W;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- wavefront round
+// The same round as in queue_phase_chunked for a window of at most 64 queue entries, executed by ONE
+// wavefront (lane = rank) without a single workgroup barrier: narrow dependency levels (a dozen rows
+// wide) are the bulk of the rounds of a deep circuit and a workgroup round costs them ~20 us of barriers
+// and idle lanes. Write-marks use the first 1024 slots of the LDS hash table (wiped afterwards), the
+// REQUEUE events are resolved with wave scans. Returns the number of committed rows, or 0xFFFFFFFF
+// without having touched anything when the window starts with a live long row (the caller's general path
+// takes it). Wave 0 only, all 64 lanes.
+#define ECNE_WSLOTS 1024
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t* total) {
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += y; }
+    *total = __shfl(incl, 63, 64);
+    return incl - x;
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
+    return x;
+}
+__device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n,
+                                                  LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail,
+                                                  unsigned long long* n_fallback) {
+    const int lane = lane_id();
+    const uint32_t rank = (uint32_t)lane;
+    const bool mine = rank < n;
+    uint32_t row = 0, shape = 0, xv = 0;
+    bool live = false;
+    if (mine) {
+        row = J.queue[(head + rank) & J.qmask];
+        const RowInfo ri = J.rinfo[row];
+        shape = ri.shape;
+        xv = ri.x;
+        live = !J.solved[row];
+    }
+    const uint64_t bigm = __ballot(mine && live && (shape & SH_BIG));
+    if (bigm & 1ull) return 0xFFFFFFFFu;
+    uint32_t cut = bigm ? (uint32_t)(__ffsll((long long)bigm) - 1) : n;    // a long row ends the prefix
+    // ---- mark (LDS hash, slots [0, ECNE_WSLOTS)); the access set is cached for the check
+    bool noop = false, noop_b = false;
+    uint32_t acnt = 0;
+    auto wmark = [&](uint32_t v, uint32_t cls) {
+        const uint32_t key = 1u + 2u * v + cls;
+        uint32_t sl = (key * 2654435761u) >> (32 - 10);
+        for (int probe = 0; probe < ECNE_WSLOTS; ++probe) {
+            const uint32_t k = atomicCAS(&S.hkey[sl], 0u, key);
+            if (k == 0u || k == key) { atomicMin(&S.hrank[sl], rank); return; }
+            sl = (sl + 1) & (ECNE_WSLOTS - 1);
+        }
+    };
+    auto wlook = [&](uint32_t v, uint32_t cls) -> uint32_t {
+        const uint32_t key = 1u + 2u * v + cls;
+        uint32_t sl = (key * 2654435761u) >> (32 - 10);
+        for (int probe = 0; probe < ECNE_WSLOTS; ++probe) {
+            const uint32_t k = S.hkey[sl];
+            if (k == key) return S.hrank[sl];
+            if (k == 0u) return 0xFFFFFFFFu;
+            sl = (sl + 1) & (ECNE_WSLOTS - 1);
+        }
+        return 0xFFFFFFFFu;
+    };
+    uint32_t nmarks = 0;
+    if (mine && live && rank < cut) {
+        const RowInfo ri = J.rinfo[row];
+        bool nb = false;
+        if (row_is_noop(J, row, ri, nb)) {
+            noop = true;
+            if (nb) {
+                noop_b = true;
+                for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) {
+                    if (acnt < ECNE_ASET) S.aset[lane][acnt] = J.colC[k] | (2u << 28);
+                    ++acnt;
+                }
+            }
+        } else {
+            for_row_sets(J, row, shape, xv, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                if (acnt < ECNE_ASET) S.aset[lane][acnt] = v | (rd << 28) | (wr << 30);
+                ++acnt;
+                nmarks += (wr & 1) + ((wr >> 1) & 1);
+            });
+        }
+    }
+    // a window that would load the table beyond a quarter is cut down to the rows that fit (rank 0 always does:
+    // a small row has at most 2 * 64 marks)
+    {
+        uint32_t tot;
+        const uint32_t before = wave_excl_scan(nmarks, &tot);
+        if (tot > ECNE_WSLOTS / 4) {
+            const uint64_t over = __ballot(before + nmarks > ECNE_WSLOTS / 4);
+            const uint32_t first = over ? (uint32_t)(__ffsll((long long)over) - 1) : n;
+            if (first < cut) cut = first < 1 ? 1 : first;
+        }
+    }
+    if (mine && live && rank < cut && !noop) {
+        if (acnt <= ECNE_ASET) {
+            for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[lane][i]; if ((e >> 30) & 1) wmark(e & 0x0FFFFFFFu, 0); if (e >> 31) wmark(e & 0x0FFFFFFFu, 1); }
+        } else {
+            for_row_sets(J, row, shape, xv, [&](uint32_t v, uint32_t rd, uint32_t wr) { if (wr & 1) wmark(v, 0); if (wr & 2) wmark(v, 1); });
+        }
+    }
+    lds_fence();
+    // ---- check
+    uint32_t mycut = 0xFFFFFFFFu;
+    if (mine && live && rank < cut) {
+        bool blocked = false;
+        auto test = [&](uint32_t v, uint32_t rd, uint32_t wr) {
+            if ((rd | wr) & 1) { const uint32_t m = wlook(v, 0); if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m; }
+            if ((rd | wr) & 2) { const uint32_t m = wlook(v, 1); if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m; }
+        };
+        if (noop) {
+            if (noop_b) {
+                if (acnt <= ECNE_ASET) { for (uint32_t i = 0; i < acnt; ++i) if (wlook(S.aset[lane][i] & 0x0FFFFFFFu, 1) < rank) blocked = true; }
+                else for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k) if (wlook(J.colC[k], 1) < rank) blocked = true;
+            }
+        } else if (acnt <= ECNE_ASET) {
+            for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[lane][i]; test(e & 0x0FFFFFFFu, (e >> 28) & 3u, e >> 30); }
+        } else for_row_sets(J, row, shape, xv, test);
+        if (blocked) mycut = rank;
+    }
+    {
+        const uint32_t m = wave_min(mycut);
+        if (m < cut) cut = m;
+    }
+    const uint32_t c = cut;    // >= 1
+    lds_fence();
+    for (uint32_t i = lane; i < ECNE_WSLOTS; i += 64) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+    // ---- tag, execute
+    uint32_t nev = 0;
+    if (mine && rank < c) {
+        J.inq[row] = (uint16_t)(rank + 2);
+        my_pops++;
+        my_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+    }
+    wg_fence();
+    if (mine && rank < c && live) {
+        if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }
+        else exec_row_lane(J, row, J.evbuf + (size_t)rank * ECNE_EVCAP, nev, C);
+    }
+    wg_fence();
+    // ---- REQUEUE resolution in sequential order (rank, emission index), see resolve_pushes
+    uint32_t new_tail = tail;
+    uint32_t Nev;
+    wave_excl_scan(nev, &Nev);
+    if (Nev) {
+        const uint32_t* ev = J.evbuf + (size_t)rank * ECNE_EVCAP;
+        uint32_t deg = 0;
+        for (uint32_t e = 0; e < nev; ++e) deg += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+        uint32_t M;
+        const uint32_t cbase = wave_excl_scan(deg, &M);
+        if (M > ECNE_CANDCAP) {
+            // (a variable with a huge fan-out) replay the events one by one, ranks leaving the queue in order
+            if (n_fallback) (*n_fallback)++;
+            QState qq;
+            qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+            for (uint32_t r = 0; r < c; ++r) {
+                const uint32_t rr = J.queue[(head + r) & J.qmask];
+                if (lane == 0) J.inq[rr] = 0;
+                wg_fence();
+                const uint32_t ne = __shfl(nev, (int)r, 64);
+                for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, J.evbuf[(size_t)r * ECNE_EVCAP + e]);
+            }
+            *out_tail = qq.tail;
+            return c;
+        }
+        // expansion: my events, in emission order; long fan-out lists are shared out across the lanes afterwards
+        auto cand1 = [&](uint32_t t, uint32_t j, uint32_t a) {
+            const uint32_t st = J.inq[t];
+            const bool elig = st == 0 || (st >= 2 && st - 2 <= a);
+            J.cand[j] = t | (elig ? 0x80000000u : 0u);
+            if (elig && ld_agent(&J.best[t]) > j) atomicMin(&J.best[t], j);
+        };
+        uint32_t nlong = 0, lv = 0, lb = 0;      // at most one long-fan-out event per lane is deferred
+        {
+            uint32_t j = cbase;
+            for (uint32_t e = 0; e < nev; ++e) {
+                const uint32_t v = ev[e];
+                const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+                if (f1 - f0 > 64 && !nlong) { nlong = 1; lv = v; lb = j; }
+                else for (uint32_t k = f0; k < f1; ++k) cand1(J.fo_rows[k], j + (k - f0), rank);
+                j += f1 - f0;
+            }
+        }
+        for (uint64_t lm = __ballot(nlong != 0); lm; lm &= lm - 1) {
+            const int src = __ffsll((long long)lm) - 1;
+            const uint32_t v = __shfl(lv, src, 64), b0 = __shfl(lb, src, 64);
+            const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+            for (uint32_t k = f0 + lane; k < f1; k += 64) cand1(J.fo_rows[k], b0 + (k - f0), (uint32_t)src);
+        }
+        wg_fence();
+        // winners, in candidate order
+        for (uint32_t jb = 0; jb < M; jb += 64) {
+            const uint32_t j = jb + lane;
+            uint32_t t = 0;
+            bool win = false;
+            if (j < M) {
+                const uint32_t cw = J.cand[j];
+                t = cw & 0x7FFFFFFFu;
+                win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
+            }
+            const uint64_t wm = __ballot(win);
+            if (win) { J.queue[(new_tail + (uint32_t)__popcll(wm & lanes_below())) & J.qmask] = t; J.inq[t] = 1; }
+            new_tail += (uint32_t)__popcll(wm);
+        }
+        // (best[] is reset only now: every candidate above was judged against the same minima)
+        wg_fence();
+        for (uint32_t j = lane; j < M; j += 64) J.best[J.cand[j] & 0x7FFFFFFFu] = 0xFFFFFFFFu;
+        wg_fence();
+    }
+    // rows of the prefix that nobody re-queued are out of the queue now
+    if (mine && rank < c && J.inq[row] >= 2) J.inq[row] = 0;
+    wg_fence();
+    *out_tail = new_tail;
+    return c;
+}
+
+// The whole QUEUE phase (:805-1349) as the master workgroup sees it. q is kept identical in every thread.
+// A single-workgroup round examines up to ECNE_RPL * ECNE_WG queue entries; lane t owns the consecutive ranks
+// t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
+#define ECNE_RPL 4
+#ifndef ECNE_WGROW
+#define ECNE_WGROW 2
+#endif
+#ifndef ECNE_WMIN
+#define ECNE_WMIN 64
+#endif
+#ifndef ECNE_MULTI_MIN
+#define ECNE_MULTI_MIN 128    // queued rows from which a round runs on all workgroups of the job (measured optimum)
+#endif
+__device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
+                                    unsigned long long& steps, unsigned long long& nuniq,
+                                    unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
+    if (tid < 12) S.acc[tid] = 0;
+    for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+    if (tid == 0) { S.small_ovf = 0; big_reset(S); }
+    unsigned long long qt_last = wall_clock64();
+#ifdef ECNE_FINE_TICKS
+#define QTICK(slot) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); S.qt[slot] += t_ - qt_last; qt_last = t_; } } while (0)
+#else
+#define QTICK(slot) do { } while (0)
+#endif
+    LaneCtr C;
+    C.steps = C.nuniq = 0;
+    for (int i = 0; i < 8; ++i) C.hits[i] = 0;
+    uint32_t my_pops = 0, my_nnz = 0;
+    unsigned long long pops_total = pops;
+    uint32_t round = 0, burst = 0, next_burst = 16, window = ECNE_RPL * ECNE_WG;
+    uint32_t mwindow = 16384;        // window of multi-workgroup rounds (adaptive like `window`)
+    bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
+    __syncthreads();
+    while (q.head != q.tail) {
+        // the error word is polled every 8th round (a raised error only has to stop the solve soon)
+        if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
+        if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
+        const uint32_t avail = q.tail - q.head;
+        if (burst) {
+            // The last chunk round committed only a handful of rows (a dependency chain): pop the next
+            // `burst` rows strictly sequentially on wave 0 (cheaper per pop than a round), then look again.
+            if (w == 0) {
+                QState qq = q;
+                qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                unsigned long long st = 0, nu = 0, ht[16], pn = 0;
+                for (int i = 0; i < 16; ++i) ht[i] = 0;
+                uint32_t done = 0;
+                while (done < burst && qq.head != qq.tail && !J.ctr->error) {
+                    const uint32_t rr = J.queue[qq.head & J.qmask];
+                    qq.head++;
+                    if (lane == 0) J.inq[rr] = 0;
+                    wg_fence();
+                    ++done;
+                    pn += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
+                    if (!J.solved[rr]) exec_row(J, qq, rr, ht, st, nu);
+                }
+                if (lane == 0) {
+                    S.acc[0] += st; S.acc[1] += nu;
+                    for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
+                    S.acc[10] += done; S.acc[11] += pn;
+                    S.head = qq.head; S.tail = qq.tail; S.nbig = done;
+                }
+            }
+            __syncthreads();
+            q.head = S.head; q.tail = S.tail;
+            pops_total += S.nbig;
+            burst = 0;
+            __syncthreads();
+            QTICK(6);
+            continue;
+        }
+        // adaptive window: examining rows that end up behind the cut is wasted work, so the window
+        // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
+        const uint32_t n = avail < window ? avail : window;
+        if (n <= 64) {
+            // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
+            if (w == 0) {
+                uint32_t nt = q.tail;
+                const uint32_t cw = queue_round_wave(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &hits[15]);
+                if (lane == 0) { S.nbig = cw; S.tail = nt; }
+            }
+            __syncthreads();
+            const uint32_t cw = S.nbig, ntw = S.tail;
+            __syncthreads();
+            if (cw != 0xFFFFFFFFu) {
+                q.head += cw;
+                q.tail = ntw;
+                pops_total += cw;
+                hits[13]++;
+                if (cw < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+                if (cw == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+                else if (cw < n / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
+                else next_burst = 16;
+                QTICK(6);
+                continue;
+            }
+            // (the window starts with a live long row: the general path below takes this round)
+        }
+        const uint32_t rpl = (n + ECNE_WG - 1) / ECNE_WG;          // rows per lane this round
+        const uint32_t r0 = (uint32_t)tid * rpl;                    // my first rank
+        uint32_t row[ECNE_RPL], shape[ECNE_RPL], xv[ECNE_RPL];
+        uint32_t live = 0, noop = 0, noop_b = 0;                    // bit s = slot s
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
+            if (sl < rpl && r0 + sl < n) {
+                row[sl] = J.queue[(q.head + r0 + sl) & J.qmask];
+                const RowInfo ri = J.rinfo[row[sl]];
+                shape[sl] = ri.shape;
+                xv[sl] = ri.x;
+                if (!J.solved[row[sl]]) live |= 1u << sl;
+            }
+        }
+        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && !big_plain(shape[0])) ? 1u : 0u; }
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
+            if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
+        __syncthreads();
+        QTICK(0);
+        if (!S.fallback && J.nwg > 1 && avail >= ECNE_MULTI_MIN && window >= ECNE_MULTI_MIN) {
+            // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
+            const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+            uint32_t nm = avail < cap_n ? avail : cap_n;
+            if (nm > mwindow) nm = mwindow;
+            if (tid == 0) {
+                J.ctr->q_cmd[1] = q.head; J.ctr->q_cmd[2] = q.tail; J.ctr->q_cmd[3] = nm;
+                __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (job_barrier(J, s_err)) { helpers_released = true; break; }
+            uint32_t cm = 0, ntm = q.tail;
+            if (queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { helpers_released = true; break; }
+            q.head += cm;
+            q.tail = ntm;
+            pops_total += cm;
+            hits[13]++;
+            hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
+            hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
+            if (cm == nm) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
+            else if (cm < nm / 4) {
+                const uint32_t wn = 4 * cm;
+                if (wn >= 4096) mwindow = wn;
+                else { mwindow = 4096; window = wn < ECNE_WMIN ? ECNE_WMIN : (wn < ECNE_RPL * ECNE_WG ? wn : ECNE_RPL * ECNE_WG); }
+            }
+            QTICK(7);
+            continue;
+        }
+        if (S.fallback) {
+            // a big row at the queue head: popped alone. Wave 0 runs the wave-cooperative rules in emit
+            // mode; the whole workgroup then resolves its REQUEUE events in order.
+            const uint32_t brow = J.queue[q.head & J.qmask];
+            if (tid == 0) {
+                J.inq[brow] = 2;                       // being popped at rank 0
+                S.acc[10] += 1;
+                S.acc[11] += (J.rpA[brow + 1] - J.rpA[brow]) + (J.rpB[brow + 1] - J.rpB[brow]) + (J.rpC[brow + 1] - J.rpC[brow]);
+                S.nbig = 0;
+            }
+            __syncthreads();
+            const bool wgdone = J.solved[brow] || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig);
+            if (wgdone) {
+                // done by the whole workgroup (or an already solved row: the pop is all that happens)
+            } else if (w == 0) {
+                const uint32_t rr = brow;
+                QState qq;
+                qq.head = q.head + 1; qq.tail = q.tail; qq.evout = J.bigev; qq.nev = 0; qq.emit = 1;
+                unsigned long long st = 0, nu = 0, ht[16];
+                for (int i = 0; i < 16; ++i) ht[i] = 0;
+                exec_row(J, qq, rr, ht, st, nu);
+                if (lane == 0) {
+                    S.acc[0] += st; S.acc[1] += nu;
+                    for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
+                    S.nbig = qq.nev;
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t nt = resolve_pushes(J, S, J.bigev, false, S.nbig, (long long)q.head, 1, q.tail, &hits[15]);
+                if (tid == 0 && J.inq[brow] >= 2) J.inq[brow] = 0;
+                q.head += 1;
+                q.tail = nt;
+            }
+            pops_total++;
+            hits[14]++;
+            if (tid == 0) S.hasbig = 0;
+            __syncthreads();
+            QTICK(6);
+            continue;
+        }
+        uint32_t c;
+        // ---- small round (at most one row per lane): write-marks in the LDS hash table, every lane's
+        // access set cached in LDS between the two passes -- no device-memory atomics, one walk per row
+        bool small = n <= ECNE_WG && !S.hasbig;
+        uint32_t acnt = 0;
+        if (small) {
+            if ((uint32_t)tid < n) {
+                const uint32_t rank = (uint32_t)tid;
+                if (!(live & 1u)) { }                                     // solved row: the pop is all that happens
+                else if (shape[0] & SH_BIG) atomicMin(&S.cut, rank);   // (a long row of the R2..R6 shapes, rank > 0)
+                else {
+                    const RowInfo ri = J.rinfo[row[0]];
+                    bool nb = false;
+                    if (row_is_noop(J, row[0], ri, nb)) {
+                        noop |= 1u;
+                        if (nb) {
+                            noop_b |= 1u;
+                            for (uint32_t k = J.rpC[row[0]]; k < J.rpC[row[0] + 1]; ++k) {
+                                if (acnt < ECNE_ASET) S.aset[tid][acnt] = J.colC[k] | (2u << 28);
+                                ++acnt;
+                            }
+                        }
+                    } else {
+                        for_row_sets(J, row[0], shape[0], xv[0], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                            if (acnt < ECNE_ASET) S.aset[tid][acnt] = v | (rd << 28) | (wr << 30);
+                            ++acnt;
+                            if (wr & 1) hmark(S, v, 0, rank);
+                            if (wr & 2) hmark(S, v, 1, rank);
+                        });
+                    }
+                }
+            }
+            __syncthreads();
+            QTICK(1);
+            if (S.small_ovf) {   // (uniform) the table overflowed: wipe it and take the general path
+                __syncthreads();
+                for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+                if (tid == 0) { S.small_ovf = 0; S.cut = n; }
+                noop = noop_b = 0;
+                small = false;
+                __syncthreads();
+            }
+        }
+        if (small) {
+            // ---- check against the table. Lower rank than mine: I would read (or overwrite) what an earlier
+            // row writes -> blocked. Higher: that row would overwrite what I read -> the prefix is cut there.
+            if ((uint32_t)tid < n && (live & 1u) && !(shape[0] & SH_BIG)) {
+                const uint32_t rank = (uint32_t)tid;
+                bool blocked = false;
+                auto test = [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if ((rd | wr) & 1) {
+                        const uint32_t m = hlook(S, v, 0);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                    if ((rd | wr) & 2) {
+                        const uint32_t m = hlook(S, v, 1);
+                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                    }
+                };
+                if (noop & 1u) {
+                    if (noop_b & 1u) {
+                        if (acnt <= ECNE_ASET) { for (uint32_t i = 0; i < acnt; ++i) if (hlook(S, S.aset[tid][i] & 0x0FFFFFFFu, 1) < rank) blocked = true; }
+                        else for (uint32_t k = J.rpC[row[0]]; k < J.rpC[row[0] + 1]; ++k) if (hlook(S, J.colC[k], 1) < rank) blocked = true;
+                    }
+                } else if (acnt <= ECNE_ASET) {
+                    for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[tid][i]; test(e & 0x0FFFFFFFu, (e >> 28) & 3u, e >> 30); }
+                } else for_row_sets(J, row[0], shape[0], xv[0], test);
+                if (blocked) atomicMin(&S.cut, rank);
+            }
+            __syncthreads();
+            c = S.cut;   // >= 1: rank 0 is never blocked and not big
+            // ---- wipe the table; tag the rows being popped with their rank (see resolve_pushes)
+            for (uint32_t i = tid; i < ECNE_HSLOTS; i += ECNE_WG) { S.hkey[i] = 0; S.hrank[i] = 0xFFFFFFFFu; }
+            if ((uint32_t)tid < c) J.inq[row[0]] = (uint16_t)(tid + 2);
+            __syncthreads();
+            QTICK(2);
+        } else {
+            // ---- mark
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl || r0 + sl >= n) continue;
+                const uint32_t rank = r0 + sl;
+                if (!(live & (1u << sl))) continue;
+                if (shape[sl] & SH_BIG) {
+                    // a plain long row rides along (marked / checked / executed by the whole workgroup, below);
+                    // any other long row ends the prefix and is popped alone
+                    if (!big_plain(shape[sl]) || !big_register(S, row[sl], rank)) atomicMin(&S.cut, rank);
+                    continue;
+                }
+                const RowInfo ri = J.rinfo[row[sl]];
+                bool nb = false;
+                if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
+                // only WRITE sets are marked: the readers find write-after-read hazards themselves (below)
+                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                    if (wr & 1) atomicMin(&J.wmarkU[v], rank);
+                    if (wr & 2) atomicMin(&J.wmarkB[v], rank);
+                });
+            }
+            __syncthreads();
+            if (S.bl_any) { big_rows_mark(J, S); __syncthreads(); }
+            QTICK(1);
+            // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
+            // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
+                const uint32_t rank = r0 + sl;
+                bool blocked = false;
+                if (noop & (1u << sl)) {
+                    if (noop_b & (1u << sl))
+                        for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
+                            if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+                } else {
+                    // wmark holds the LOWEST rank that may write that state. Lower than mine: I would read
+                    // (or overwrite) what an earlier row writes -> I am blocked. Higher than mine: that row
+                    // would overwrite what I read -> it (and everything after it) is cut off.
+                    for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                        if ((rd | wr) & 1) {
+                            const uint32_t m = ld_agent(&J.wmarkU[v]);
+                            if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        }
+                        if ((rd | wr) & 2) {
+                            const uint32_t m = ld_agent(&J.wmarkB[v]);
+                            if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        }
+                    });
+                }
+                if (blocked) atomicMin(&S.cut, rank);
+            }
+            if (S.bl_any) big_rows_check(J, S);
+            __syncthreads();
+            c = S.cut;   // >= 1: rank 0 is never blocked and not big
+            if (S.bl_any) big_rows_unmark(J, S);
+            // ---- unmark; tag the rows being popped with their rank (in_queue bookkeeping, see resolve_pushes)
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl || r0 + sl >= n) continue;
+                if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
+                    for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
+                        if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+                        if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+                    });
+                if (r0 + sl < c) J.inq[row[sl]] = (uint16_t)(r0 + sl + 2);
+            }
+            __syncthreads();
+            QTICK(2);
+        }
+        // ---- execute the independent prefix, one lane per row (rpl rows per lane, in rank order)
+        uint32_t nev[ECNE_RPL], nev_tot = 0;
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+            nev[sl] = 0;
+            if (sl >= rpl || r0 + sl >= c) continue;
+            my_pops++;
+            my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
+            if (live & (1u << sl)) {
+                if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }   // the pop's only effect
+                else if (!(shape[sl] & SH_BIG)) exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+            }
+            nev_tot += nev[sl];
+        }
+        uint32_t bigsl = 0;          // slots of mine that hold a long row executed in this round
+        if (S.bl_any) {                // (uniform) the long rows of the prefix, by the whole workgroup
+            big_rows_exec(J, S, c, 0);
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
+                if (sl < rpl && r0 + sl < c && (shape[sl] & SH_BIG) && (live & (1u << sl))) {
+                    const int k = big_slot_of(S, r0 + sl);
+                    if (k >= 0) { nev[sl] = S.bl_nev[k]; nev_tot += nev[sl]; bigsl |= 1u << sl; }
+                }
+        }
+        QTICK(3);
+        // ---- REQUEUE resolution in sequential order: flatten the per-rank event lists, then resolve
+        uint32_t Nev;
+        {
+            const uint32_t eoff = wg_exclusive_scan(nev_tot, S.scan, &Nev);
+            uint32_t o = eoff;
+#pragma unroll
+            for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
+                if (sl >= rpl) continue;
+                if (bigsl & (1u << sl)) {   // a long row's events are copied by the whole workgroup, below
+                    S.bl_base[big_slot_of(S, r0 + sl)] = o;
+                    o += nev[sl];
+                    continue;
+                }
+                const uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
+                for (uint32_t e = 0; e < nev[sl]; ++e) { J.fvar[o] = ev[e]; J.frank[o] = r0 + sl; ++o; }
+            }
+            if (S.bl_any) {
+                __syncthreads();
+                for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+                    if (S.bl_rank[k] >= c) continue;
+                    const uint32_t* ev = big_ev(J, 0, k);
+                    for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) { J.fvar[S.bl_base[k] + e] = ev[e]; J.frank[S.bl_base[k] + e] = S.bl_rank[k]; }
+                }
+            }
+            __syncthreads();   // the flat list is read across lanes
+        }
+        QTICK(4);
+        const uint32_t new_tail = resolve_pushes(J, S, J.fvar, true, Nev, (long long)q.head, c, q.tail, &hits[15]);
+        QTICK(5);
+        // rows of the prefix that nobody re-queued are out of the queue now
+#pragma unroll
+        for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)
+            if (sl < rpl && r0 + sl < c && J.inq[row[sl]] >= 2) J.inq[row[sl]] = 0;
+        if (tid == 0) big_reset(S);
+        __syncthreads();
+        q.head += c;
+        q.tail = new_tail;
+        pops_total += c;
+        hits[13]++;
+        // adaptive: a short queue with a short independent prefix is a dependency chain -> sequential
+        // burst, doubling while it stays that way
+        if (c < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+        if (c == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+        else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
+        else next_burst = 16;
+    }
+    // ---- tell the helper workgroups (waiting at the command barrier) that the queue phase is over
+    if (J.nwg > 1 && !helpers_released) {
+        if (tid == 0) __hip_atomic_store(&J.ctr->q_cmd[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        job_barrier(J, s_err);
+    }
+    // ---- reduce the per-lane counters
+    __syncthreads();
+    if (C.steps) atomicAdd(&S.acc[0], (unsigned long long)C.steps);
+    if (C.nuniq) atomicAdd(&S.acc[1], (unsigned long long)C.nuniq);
+    for (int i = 0; i < 8; ++i)
+        if (C.hits[i]) atomicAdd(&S.acc[2 + i], (unsigned long long)C.hits[i]);
+    if (my_pops) atomicAdd(&S.acc[10], (unsigned long long)my_pops);
+    if (my_nnz) atomicAdd(&S.acc[11], (unsigned long long)my_nnz);
+    __syncthreads();
+    steps += S.acc[0];
+    nuniq += S.acc[1];
+    for (int i = 0; i < 8; ++i) hits[i] += S.acc[2 + i];
+    pops += S.acc[10];
+    pop_nnz += S.acc[11];
+    __syncthreads();
+}
+
+// Queue phase as seen by a helper workgroup: wait for the master's commands, join multi rounds.
+__device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, uint32_t wgrank, int* s_err) {
+    LaneCtr C;
+    C.steps = C.nuniq = 0;
+    for (int i = 0; i < 8; ++i) C.hits[i] = 0;
+    uint32_t my_pops = 0, my_nnz = 0;
+    if (threadIdx.x < 12) S.acc[threadIdx.x] = 0;   // long rows executed by this workgroup count here
+    if (threadIdx.x == 0) big_reset(S);
+    __syncthreads();
+    for (;;) {
+        if (job_barrier(J, s_err)) break;
+        if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
+        const uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
+        uint32_t c, nt;
+        if (queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) break;
+    }
+    Counters* ctr = J.ctr;
+    if (C.steps) atomicAdd(&ctr->q_acc[0], (unsigned long long)C.steps);
+    if (C.nuniq) atomicAdd(&ctr->q_acc[1], (unsigned long long)C.nuniq);
+    for (int i = 0; i < 8; ++i)
+        if (C.hits[i]) atomicAdd(&ctr->q_acc[2 + i], (unsigned long long)C.hits[i]);
+    if (my_pops) atomicAdd(&ctr->q_acc[10], (unsigned long long)my_pops);
+    if (my_nnz) atomicAdd(&ctr->q_acc[11], (unsigned long long)my_nnz);
+    __syncthreads();
+    if (threadIdx.x < 10 && S.acc[threadIdx.x]) atomicAdd(&ctr->q_acc[threadIdx.x], S.acc[threadIdx.x]);
+}
+
+}  // namespace ecne

@@ -1,0 +1,388 @@
+// rules_wave.hip.hpp — the queue cursor, REQUEUE and the wave-cooperative executor of one pop (rules R1..R8, :824-1348): sequential mode, bursts, long rows of the R2..R6 shapes.
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+#pragma once
+#include "dev_common.hip.hpp"
+
+namespace ecne {
+
+// ====================================================================================== solver
+struct QState {   // FIFO cursors, wave-uniform registers of the wave that drives the queue
+    uint32_t head, tail;
+    // "emit" mode: REQUEUE(v) appends v to evout[] instead of pushing; the pushes are resolved later,
+    // in the same order, by the whole workgroup (resolve_pushes)
+    uint32_t* evout;
+    uint32_t nev;
+    uint32_t emit;
+};
+
+__device__ __forceinline__ void raise(const Job& J, int code) { atomicCAS(&J.ctr->error, 0, code); }
+
+__device__ __forceinline__ void set_bounds(const Job& J, uint32_t v, const fp::u256& lb, const fp::u256& ub) {
+    st256(J.lb + 4ull * v, lb);
+    st256(J.ub + 4ull * v, ub);
+    uint8_t f = J.flags[v];
+    f = (uint8_t)((f & ~4u) | ((fp::is_zero(lb) && fp::is_one(ub)) ? 4u : 0u));
+    J.flags[v] = f;
+}
+
+// REQUEUE(v): for each row r of variable_to_indices[v], ascending: push r unless already queued.
+// Wave-cooperative; exactly the sequential order because the rows of one list are distinct.
+__device__ __noinline__ void requeue(const Job& J, QState& q, uint32_t v) {
+    const int lane = lane_id();
+    if (q.emit) {
+        if (lane == 0) q.evout[q.nev] = v;
+        q.nev++;
+        return;
+    }
+    const uint32_t beg = J.fo_ptr[v], end = J.fo_ptr[v + 1];
+    for (uint32_t base = beg; base < end; base += 64) {
+        uint32_t k = base + lane;
+        bool act = k < end;
+        uint32_t r = act ? J.fo_rows[k] : 0;
+        bool push = act && J.inq[r] == 0;
+        uint64_t m = __ballot(push);
+        if (push) {
+            uint32_t pos = q.tail + (uint32_t)__popcll(m & lanes_below());
+            J.queue[pos & J.qmask] = r;
+            J.inq[r] = 1;
+        }
+        q.tail += (uint32_t)__popcll(m);
+    }
+    wg_fence();
+}
+
+// make `v` unique + known (lane 0 writes), wave-uniform
+__device__ __forceinline__ void mark_unique(const Job& J, uint32_t v) {
+    if (lane_id() == 0) J.flags[v] |= 3;
+    wg_fence();
+}
+
+// walk C entries [c0,c1) in stored (= reference Set) order; every non-unique variable other than
+// `skip` becomes unique and is re-queued, in order. Returns how many.
+__device__ __noinline__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0, uint32_t c1, uint32_t skip) {
+    const int lane = lane_id();
+    uint32_t n = 0;
+    for (uint32_t base = c0; base < c1; base += 64) {
+        uint32_t k = base + lane;
+        bool act = k < c1;
+        uint32_t v = act ? J.colC[k] : 0;
+        bool todo = act && v != skip && !(J.flags[v] & 1);
+        uint64_t m = __ballot(todo);
+        if (!m) continue;
+        // REQUEUE never reads flags, so marking this chunk's variables first and re-queueing them
+        // afterwards, in order, is the reference's mark-one/requeue-one sequence
+        if (todo) J.flags[v] |= 3;
+        wg_fence();
+        n += (uint32_t)__popcll(m);
+        if (q.emit) {
+            if (todo) q.evout[q.nev + (uint32_t)__popcll(m & lanes_below())] = v;
+            q.nev += (uint32_t)__popcll(m);
+        } else {
+            while (m) {
+                int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                requeue(J, q, __shfl(v, src, 64));
+            }
+        }
+    }
+    return n;
+}
+
+// R7 (:1257-1272): entry k follows entry prev_k among the row's non-unique variables in sorted-|coefficient|
+// order. The link holds when |c_k| is a multiple of |c_prev| and the ratio exceeds the range of prev's variable.
+__device__ __noinline__ bool r7_link_fails(const Job& J, uint32_t k, uint32_t prev_k, bool negated) {
+    fp::u256 cn = ld256(J.coefC + 4ull * k), cc = ld256(J.coefC + 4ull * prev_k);
+    if (negated) { cn = fp::neg(cn); cc = fp::neg(cc); }
+    cn = r7_abs(cn); cc = r7_abs(cc);
+    fp::u256 qq, rem;
+    fp::divmod(cn, cc, qq, rem);
+    if (!fp::is_zero(rem)) return true;
+    const uint32_t pv = J.colC[prev_k];
+    const fp::u256 ub = ld256(J.ub + 4ull * pv), lb = ld256(J.lb + 4ull * pv);
+    if (fp::cmp(ub, lb) >= 0) {
+        fp::u256 diff;
+        fp::sub_raw(diff, ub, lb);
+        if (fp::cmp(qq, diff) <= 0) return true;
+    }
+    return false;
+}
+// R7's closing test (:1274): |c_last| * (ub(last) + 1) <= p
+__device__ __noinline__ bool r7_top_fits(const Job& J, uint32_t last_k, bool negated) {
+    const uint32_t lv = J.colC[last_k];
+    fp::u256 cl = ld256(J.coefC + 4ull * last_k);
+    if (negated) cl = fp::neg(cl);
+    cl = r7_abs(cl);
+    fp::u256 ub1;
+    fp::add_raw(ub1, ld256(J.ub + 4ull * lv), fp::make(1));
+    return !fp::mul_gt_p(cl, ub1);
+}
+
+// ---- one queue pop: rules R1..R8 on row `row`, in the reference's order (:824-1348)
+__device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
+                         unsigned long long& steps, unsigned long long& nuniq) {
+    const int lane = lane_id();
+    const RowInfo ri = J.rinfo[row];
+    const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1];
+    const uint32_t b0 = J.rpB[row], b1 = J.rpB[row + 1];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t shape = ri.shape;
+
+    // C is walked once: the R1 pass also gathers the statistics R7 / R8 need,
+    // valid as long as no rule in between changes the state (R1 / R3..R6 firing invalidates them).
+    const bool fuse = true;
+    bool st_valid = false, st_notknown = false, st_badgroup = false;
+    uint32_t st_cnt = 0;
+    int st_group = -2;
+    // R1 check_unique (:827-873)
+    {
+        bool nu = false;
+        for (uint32_t k = a0 + lane; k < a1; k += 64) nu |= !(J.flags[J.colA[k]] & 1);
+        for (uint32_t k = b0 + lane; k < b1; k += 64) nu |= !(J.flags[J.colB[k]] & 1);
+        if (!__ballot(nu)) {
+            uint32_t cnt = 0, u = 0;
+            for (uint32_t base = c0; base < c1; base += 64) {
+                uint32_t k = base + lane;
+                bool act = k < c1;
+                uint32_t v = act ? J.colC[k] : 0;
+                const uint8_t f = act ? J.flags[v] : 1;
+                bool x = act && !(f & 1);
+                uint64_t m = __ballot(x);
+                if (m && cnt == 0) u = __shfl(v, __ffsll((long long)m) - 1, 64);
+                cnt += (uint32_t)__popcll(m);
+                if (fuse && m) {
+                    // the same walk also collects what R7 and R8 ask of C's non-unique variables
+                    if (x && !(f & 2)) st_notknown = true;
+                    int a = x ? J.abz[v] : -1;
+                    if (st_group == -2) st_group = __shfl(a, __ffsll((long long)m) - 1, 64);
+                    if (x && (a == -1 || a != st_group)) st_badgroup = true;
+                }
+            }
+            st_cnt = cnt;
+            st_valid = fuse;
+            if (cnt == 1) {
+                mark_unique(J, u);
+                nuniq++; steps++; hits[0]++;
+                requeue(J, q, u);
+                st_valid = false;
+            }
+        }
+    }
+    const unsigned long long steps_at_r1 = steps, nuniq_at_r1 = nuniq;
+    // R2 check_quadratic (:875-942)
+    if (shape & SH_C_EMPTY) {
+        if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
+        if (shape & SH_R2) {
+            const uint32_t x = ri.x;
+            if (!(J.flags[x] & 2)) {
+                if (shape & SH_R2_DIV0) { raise(J, K_EDIVZERO); return; }
+                if (lane == 0) {
+                    // make_values: is_known, values; abz reset by the constructor (:158)
+                    st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));
+                    st256(J.values + 8ull * x + 4, ld256(J.vals + 4ull * (ri.validx + 1)));
+                    J.nvalues[x] = 2;
+                    J.flags[x] |= 2;
+                    J.abz[x] = -1;
+                    if (shape & SH_R2_IS01) set_bounds(J, x, fp::make(0), fp::make(1));   // make_bounds (:923-927)
+                    J.solved[row] = 1;
+                }
+                wg_fence();
+                requeue(J, q, x);
+                steps++; hits[1]++;
+            }
+        }
+    }
+    if (shape & SH_HAS_AB) return;   // (:944-946)
+    const uint32_t l = c1 - c0;
+
+    // R3 check_linear (:949-988)
+    if (shape & SH_R3) {
+        const uint32_t x = ri.x;
+        const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
+        bool new_info = false;
+        bool same = J.nvalues[x] == 1 && fp::eq(ld256(J.values + 8ull * x), tv);
+        uint8_t f = J.flags[x];
+        if (!same) { steps++; hits[2]++; new_info = true; }
+        if (!(f & 1)) { nuniq++; new_info = true; }
+        if (lane == 0) {
+            if (!same) { st256(J.values + 8ull * x, tv); J.nvalues[x] = 1; }
+            J.flags[x] = (uint8_t)(f | 3);
+            set_bounds(J, x, tv, tv);
+        }
+        wg_fence();
+        if (new_info) requeue(J, q, x);
+    }
+    // R4 checkBinary (:991-1076)
+    if ((shape & (SH_R4_T | SH_R4_T2)) && l > 0) {
+        uint32_t new_key;
+        if ((shape & SH_R4_T) && (shape & SH_R4_T2)) {   // l == 2: the row is negated on every visit
+            uint8_t o = (uint8_t)(J.flip3[row] ^ 1);
+            if (lane == 0) J.flip3[row] = o;
+            new_key = o ? ri.kneg : ri.kpos;
+        } else if (shape & SH_R4_T2) {
+            new_key = ri.kneg;   // negated once; the -1 entry is the 1 entry from then on
+        } else {
+            new_key = ri.kpos;
+        }
+        bool bad = false;   // every other variable needs bounds exactly [0,1] (:1020-1029)
+        for (uint32_t k = c0 + lane; k < c1; k += 64) {
+            uint32_t v = J.colC[k];
+            if (v != new_key && !(J.flags[v] & 4)) bad = true;
+        }
+        if (!__ballot(bad)) {
+            const fp::u256 fub = ld256(J.vals + 4ull * (ri.validx + 1));
+            const fp::u256 nlb = ld256(J.lb + 4ull * new_key), nub = ld256(J.ub + 4ull * new_key);
+            if (!(fp::is_zero(nlb) && fp::eq(nub, fub))) {
+                bool gt = false;   // integer compare ub.d > 2^(l-1) - 1 (:1035)
+                if (l - 1 < 254) {
+                    fp::u256 ip = fp::make(0);
+                    ip.w[(l - 1) >> 6] = 1ull << ((l - 1) & 63);
+                    fp::u256 im1;
+                    fp::sub_raw(im1, ip, fp::make(1));
+                    gt = fp::cmp(nub, im1) > 0;
+                }
+                if (gt) {
+                    if (lane == 0) { set_bounds(J, new_key, fp::make(0), fub); J.flags[new_key] |= 2; }
+                    wg_fence();
+                    steps++; hits[3]++;
+                    requeue(J, q, new_key);
+                }
+            }
+            if (J.flags[new_key] & 1) {   // (:1049-1067)
+                uint32_t n = uniq_range_and_requeue(J, q, c0, c1, new_key);
+                nuniq += n; steps += n; hits[3] += n;
+            }
+        }
+    }
+    // R5 checkpropagateBounds (:1078-1146) and R6 checkOnePropagateBounds (:1148-1232)
+    if (shape & (SH_R5 | SH_R6)) {
+        const bool is6 = (shape & SH_R6) != 0;
+        const uint32_t k1 = ri.k1, k2 = ri.k2;
+        fp::u256 lb1 = ld256(J.lb + 4ull * k1), ub1 = ld256(J.ub + 4ull * k1);
+        fp::u256 lb2 = ld256(J.lb + 4ull * k2), ub2 = ld256(J.ub + 4ull * k2);
+        uint8_t f1 = J.flags[k1], f2 = J.flags[k2];
+        bool ch1 = false, ch2 = false;
+        if (!fp::eq(ub2, ub1) || !fp::eq(lb2, lb1) || ((f1 ^ f2) & 1)) {
+            bool proceed = true;
+            if ((f1 ^ f2) & 1) {
+                // `!=` between a mutable struct and a fresh copy is identity, so both branches run.
+                // R5 writes key_1 twice (:1107-1108, sic); R6 writes key_2 (:1188-1189).
+                f1 |= 3;
+                if (is6) f2 |= 3;
+                nuniq += 2;
+                ch1 = ch2 = true;
+            }
+            fp::u256 mn = fp::cmp(ub1, ub2) <= 0 ? ub1 : ub2;
+            fp::u256 mx = fp::cmp(lb1, lb2) >= 0 ? lb1 : lb2;
+            if (is6 && (!fp::is_one(mn) || !fp::is_zero(mx))) proceed = false;   // (:1196-1199) returns before counting
+            bool w1 = false, w2 = false;
+            if (proceed) {
+                w1 = fp::cmp(ub1, mn) > 0 || fp::cmp(lb1, mx) < 0;
+                w2 = fp::cmp(ub2, mn) > 0 || fp::cmp(lb2, mx) < 0;
+            }
+            if (lane == 0) {
+                J.flags[k1] = f1;
+                J.flags[k2] = f2;
+                if (w1) {
+                    J.flags[k1] |= 2;
+                    set_bounds(J, k1, mx, mn);
+                    if (is6) { st256(J.values + 8ull * k1, mn); st256(J.values + 8ull * k1 + 4, mx); J.nvalues[k1] = 2; }
+                }
+                if (w2) {
+                    J.flags[k2] |= 2;
+                    set_bounds(J, k2, mx, mn);
+                    if (is6) { st256(J.values + 8ull * k2, mn); st256(J.values + 8ull * k2 + 4, mx); J.nvalues[k2] = 2; }
+                }
+            }
+            wg_fence();
+            if (proceed) {
+                ch1 |= w1; ch2 |= w2;
+                uint32_t nset = (k1 == k2) ? ((ch1 || ch2) ? 1u : 0u) : ((ch1 ? 1u : 0u) + (ch2 ? 1u : 0u));
+                steps += nset;
+                if (nset) hits[is6 ? 5 : 4]++;
+                // for j in Set(changed_vars): hash order of the (at most two) keys
+                uint32_t first = (shape & SH_R56_SWAP) ? k2 : k1, second = (shape & SH_R56_SWAP) ? k1 : k2;
+                bool cf = (shape & SH_R56_SWAP) ? ch2 : ch1, cs = (shape & SH_R56_SWAP) ? ch1 : ch2;
+                if (cf) requeue(J, q, first);
+                if (cs && second != first) requeue(J, q, second);
+            }
+        }
+    }
+    // R7 checkModularArithmetic (:1235-1298)
+    // (statistics from the R1 walk stay valid only if nothing fired since: R3..R6 always count a step
+    //  or a new unique variable when they change anything, except R4's flip byte which no rule reads)
+    if (st_valid && (steps != steps_at_r1 || nuniq != nuniq_at_r1)) st_valid = false;
+    if (l > 0) {
+        uint32_t nunk = 0;
+        bool notknown = false;
+        if (st_valid) { nunk = st_cnt; notknown = st_notknown; }
+        else
+        for (uint32_t base = c0; base < c1; base += 64) {
+            uint32_t k = base + lane;
+            bool act = k < c1;
+            uint8_t f = act ? J.flags[J.colC[k]] : 1;
+            uint64_t m = __ballot(act && !(f & 1));
+            nunk += (uint32_t)__popcll(m);
+            if (act && !(f & 1) && !(f & 2)) notknown = true;
+        }
+        if (nunk > 0 && !__ballot(notknown)) {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            bool fail = false;
+            // previous non-unique entry in sorted order, carried across chunks (wave-uniform)
+            uint32_t carry_k = 0xFFFFFFFFu;
+            for (uint32_t sb = 0; sb < l; sb += 64) {
+                uint32_t s = sb + lane;
+                bool act = s < l;
+                uint32_t k = act ? c0 + J.csort[c0 + s] : 0;
+                uint32_t v = act ? J.colC[k] : 0;
+                bool nu = act && !(J.flags[v] & 1);
+                uint64_t m = __ballot(nu);
+                uint64_t below = m & lanes_below();
+                // every lane executes the shuffle (uniform control flow); lanes without an in-chunk
+                // predecessor fall back to the carried one
+                const int psrc = below ? 63 - __clzll((long long)below) : 0;
+                const uint32_t pk = __shfl(k, psrc, 64);
+                const uint32_t prev_k = below ? pk : carry_k;
+                if (nu && prev_k != 0xFFFFFFFFu && r7_link_fails(J, k, prev_k, negated)) fail = true;
+                if (m) carry_k = __shfl(k, 63 - __clzll((long long)m), 64);
+                if (__ballot(fail)) { fail = true; break; }   // one broken link settles it: R7 does not fire
+            }
+            if (!__ballot(fail)) {
+                // coeffs[last] * (ub(last) + 1) <= p  (:1274)
+                if (r7_top_fits(J, carry_k, negated)) {
+                    steps += nunk; hits[6]++;
+                    uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
+                    nuniq += n;
+                }
+            }
+        }
+    }
+    // R8 checkAllButOneZeroGroup (:1304-1348)
+    if (l > 0) {
+        int group = -1;
+        bool bad = false;
+        uint32_t cnt = 0;
+        if (st_valid && steps == steps_at_r1 && nuniq == nuniq_at_r1) { cnt = st_cnt; bad = st_badgroup; }
+        else
+        for (uint32_t base = c0; base < c1; base += 64) {
+            uint32_t k = base + lane;
+            bool act = k < c1;
+            uint32_t v = act ? J.colC[k] : 0;
+            bool nu = act && !(J.flags[v] & 1);
+            int a = nu ? J.abz[v] : -1;
+            uint64_t m = __ballot(nu);
+            if (m) {
+                if (group == -1) group = __shfl(a, __ffsll((long long)m) - 1, 64);
+                if (nu && (a == -1 || a != group)) bad = true;
+                cnt += (uint32_t)__popcll(m);
+            }
+        }
+        // a first non-unique variable with abz == -1 leaves group == -1 and bad == true
+        if (cnt > 0 && !__ballot(bad)) {
+            hits[7]++;
+            uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
+            nuniq += n; steps += n;
+        }
+    }
+}
+
+}  // namespace ecne
