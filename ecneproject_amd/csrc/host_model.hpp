@@ -11,6 +11,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -78,6 +82,30 @@ struct Special {
     std::vector<int64_t> inputs, outputs;
 };
 
+// read-only view of a whole file (mmap; the 100+ MB constraint section is parsed in place)
+struct FileView {
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    bool ok = false;
+    explicit FileView(const char* path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (::fstat(fd, &st) == 0) {
+            size = (size_t)st.st_size;
+            if (size == 0) ok = true;
+            else {
+                void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { data = (const uint8_t*)m; ok = true; }
+            }
+        }
+        ::close(fd);
+    }
+    ~FileView() { if (data) ::munmap((void*)data, size); }
+    FileView(const FileView&) = delete;
+    FileView& operator=(const FileView&) = delete;
+};
+
 inline uint32_t rd32(const uint8_t* p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
@@ -87,20 +115,10 @@ inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)r
 // type 1..3 in any order, prime never compared, coefficient width fixed at 32 bytes, duplicate
 // wire ids "last wins" at the first occurrence's position, wire id == nWires accepted.
 inline int load_r1cs(const char* path, R1CSFile& out) {
-    std::vector<uint8_t> buf;
-    {
-        FILE* f = std::fopen(path, "rb");
-        if (!f) return K_EIO;
-        std::fseek(f, 0, SEEK_END);
-        long n = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        buf.resize((size_t)(n < 0 ? 0 : n));
-        size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
-        std::fclose(f);
-        if (got != buf.size()) return K_EIO;
-    }
-    const size_t N = buf.size();
-    const uint8_t* b = buf.data();
+    FileView fv(path);
+    if (!fv.ok) return K_EIO;
+    const size_t N = fv.size;
+    const uint8_t* b = fv.data;
     auto need = [&](size_t off, size_t len) { return off + len <= N; };
     if (!need(0, 12)) return K_EFORMAT;
     if (rd32(b + 4) != 1) return K_EFORMAT;
@@ -201,20 +219,10 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
 // included, coefficients reduced. Built on first use by reading the file again.
 inline int build_file_csr(R1CSFile& out) {
     if (out.csr_built) return K_OK;
-    std::vector<uint8_t> buf;
-    {
-        FILE* f = std::fopen(out.path.c_str(), "rb");
-        if (!f) return K_EIO;
-        std::fseek(f, 0, SEEK_END);
-        long n = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        buf.resize((size_t)(n < 0 ? 0 : n));
-        size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
-        std::fclose(f);
-        if (got != buf.size()) return K_EIO;
-    }
-    const size_t N = buf.size();
-    const uint8_t* b = buf.data();
+    FileView fv(out.path.c_str());
+    if (!fv.ok) return K_EIO;
+    const size_t N = fv.size;
+    const uint8_t* b = fv.data;
     auto need = [&](size_t off, size_t len) { return off + len <= N; };
     if (!need(0, 12)) return K_EFORMAT;
     size_t cur = 12, start2 = 0;
@@ -276,6 +284,13 @@ inline void part_values(const Rows& R, int p, size_t i, std::vector<fp::u256>& o
 inline uint64_t row_fingerprint(const Rows& R, size_t i, std::vector<fp::u256>& v) {   // v: scratch
     uint64_t h = 0x1234567;
     for (int p = 0; p < 3; ++p) {
+        // (most parts hold at most one non-zero value: nothing to sort, nothing to allocate)
+        const uint64_t k0 = R.ptr[p][i], k1 = R.ptr[p][i + 1];
+        uint64_t nzc = 0, last = 0;
+        for (uint64_t k = k0; k < k1 && nzc < 2; ++k)
+            if (!fp::is_zero(R.coef[p][k])) { ++nzc; last = k; }
+        if (nzc == 0) continue;
+        if (nzc == 1) { for (int w = 0; w < 4; ++w) h = mix64(h, R.coef[p][last].w[w]); continue; }
         part_values(R, p, i, v);
         for (auto& x : v)
             for (int w = 0; w < 4; ++w) h = mix64(h, x.w[w]);
