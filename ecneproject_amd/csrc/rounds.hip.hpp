@@ -504,6 +504,9 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 // A single-workgroup round examines up to ECNE_RPL * ECNE_WG queue entries; lane t owns the consecutive ranks
 // t*rpl .. t*rpl + rpl - 1, so that per-lane totals scanned once give rank-ordered offsets.
 #define ECNE_RPL 4
+#ifndef ECNE_BURST_C
+#define ECNE_BURST_C 8      // a round that commits fewer rows than this on a short queue switches to sequential bursts
+#endif
 #ifndef ECNE_WGROW
 #define ECNE_WGROW 2
 #endif
@@ -592,7 +595,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 q.tail = ntw;
                 pops_total += cw;
                 hits[13]++;
-                if (cw < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+                if (cw < ECNE_BURST_C && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
                 if (cw == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
                 else if (cw < n / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
                 else next_burst = 16;
@@ -903,7 +906,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         hits[13]++;
         // adaptive: a short queue with a short independent prefix is a dependency chain -> sequential
         // burst, doubling while it stays that way
-        if (c < 8 && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+        if (c < ECNE_BURST_C && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
         if (c == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
         else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
         else next_burst = 16;
