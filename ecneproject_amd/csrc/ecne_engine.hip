@@ -714,7 +714,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             r->generation = S.generation;
             ecne_summary& s = r->sum;
             std::memset(&s, 0, sizeof s);
-            s.status = c.error;
+            s.status = (c.err_key != ~0ull && (c.err_key & 0xFFu) != 0) ? -(int)(c.err_key & 0xFFu) : c.error;   // (the pop the sequential run dies on)
             s.unique_nontrivial = (int64_t)c.unique_nontrivial;
             s.n_nontrivial = (int64_t)c.n_nontrivial;
             s.unique_targets = (int64_t)c.unique_targets;

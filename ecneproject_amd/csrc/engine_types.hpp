@@ -69,6 +69,7 @@ struct Counters {   // one per job, device memory
     unsigned long long rule_hits[16];
     unsigned long long unique_nontrivial, n_nontrivial, unique_targets, pop_nnz;
     int error;          // first ecne_status raised on the device (0 = none)
+    unsigned long long err_key;   // lowest (queue position << 8 | -status) raised by a pop; all ones = none. Wins over `error`.
     unsigned int q_head, q_tail;
     unsigned int pad;
     unsigned long long phase_ticks[8];

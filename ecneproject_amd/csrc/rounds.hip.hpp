@@ -139,7 +139,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         if (live & (1u << sl)) {
             if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }
             else if (shape[sl] & SH_BIG) { bigsl |= 1u << sl; continue; }   // executed below by the whole workgroup
-            else exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+            else { C.rank = head + r0 + sl; exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C); }
         }
         uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
         for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
@@ -421,7 +421,7 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
     wg_fence();
     if (mine && rank < c && live) {
         if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }
-        else exec_row_lane(J, row, J.evbuf + (size_t)rank * ECNE_EVCAP, nev, C);
+        else { C.rank = head + rank; exec_row_lane(J, row, J.evbuf + (size_t)rank * ECNE_EVCAP, nev, C); }
     }
     wg_fence();
     // ---- REQUEUE resolution in sequential order (rank, emission index), see resolve_pushes
@@ -850,7 +850,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             my_nnz += (J.rpA[row[sl] + 1] - J.rpA[row[sl]]) + (J.rpB[row[sl] + 1] - J.rpB[row[sl]]) + (J.rpC[row[sl] + 1] - J.rpC[row[sl]]);
             if (live & (1u << sl)) {
                 if (noop & (1u << sl)) { if ((shape[sl] & SH_R4_T) && (shape[sl] & SH_R4_T2)) J.flip3[row[sl]] ^= 1; }   // the pop's only effect
-                else if (!(shape[sl] & SH_BIG)) exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C);
+                else if (!(shape[sl] & SH_BIG)) { C.rank = q.head + r0 + sl; exec_row_lane(J, row[sl], J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP, nev[sl], C); }
             }
             nev_tot += nev[sl];
         }

@@ -25,6 +25,7 @@ namespace ecne {
 
 struct LaneCtr {   // per-lane counter deltas of one queue phase (reduced at the end)
     uint32_t steps, nuniq, hits[8];
+    uint32_t rank;   // absolute queue position of the row being executed (orders the errors, see raise_ranked)
 };
 
 __device__ __forceinline__ uint32_t lane_uniq_range(const Job& J, uint32_t c0, uint32_t c1, uint32_t skip,
@@ -250,11 +251,11 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
     const uint32_t steps_at_r1 = C.steps, nuniq_at_r1 = C.nuniq;
     // R2 (:875-942)
     if (shape & SH_C_EMPTY) {
-        if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
+        if (shape & SH_R2_BOUNDSERR) { raise_ranked(J, C.rank, K_EBOUNDS); return; }
         if (shape & SH_R2) {
             const uint32_t x = ri.x;
             if (!(J.flags[x] & 2)) {
-                if (shape & SH_R2_DIV0) { raise(J, K_EDIVZERO); return; }
+                if (shape & SH_R2_DIV0) { raise_ranked(J, C.rank, K_EDIVZERO); return; }
                 st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));
                 st256(J.values + 8ull * x + 4, ld256(J.vals + 4ull * (ri.validx + 1)));
                 J.nvalues[x] = 2;

@@ -16,6 +16,14 @@ struct QState {   // FIFO cursors, wave-uniform registers of the wave that drive
 };
 
 __device__ __forceinline__ void raise(const Job& J, int code) { atomicCAS(&J.ctr->error, 0, code); }
+// An error raised by a queue pop. The reference stops at the FIRST pop that raises; rows of one parallel
+// prefix raise concurrently and the error word is only polled every few rounds, so besides setting it
+// (which stops the solve) every pop records (its absolute queue position, code) in a min-word: the lowest
+// position is the pop the sequential run would have died on. The host reports that code.
+__device__ __forceinline__ void raise_ranked(const Job& J, uint32_t queue_pos, int code) {
+    atomicMin(&J.ctr->err_key, ((unsigned long long)queue_pos << 8) | (unsigned long long)(-code));
+    raise(J, code);
+}
 
 __device__ __forceinline__ void set_bounds(const Job& J, uint32_t v, const fp::u256& lb, const fp::u256& ub) {
     st256(J.lb + 4ull * v, lb);
@@ -170,11 +178,11 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
     const unsigned long long steps_at_r1 = steps, nuniq_at_r1 = nuniq;
     // R2 check_quadratic (:875-942)
     if (shape & SH_C_EMPTY) {
-        if (shape & SH_R2_BOUNDSERR) { raise(J, K_EBOUNDS); return; }
+        if (shape & SH_R2_BOUNDSERR) { raise_ranked(J, q.head - 1, K_EBOUNDS); return; }   // (the row was popped just before)
         if (shape & SH_R2) {
             const uint32_t x = ri.x;
             if (!(J.flags[x] & 2)) {
-                if (shape & SH_R2_DIV0) { raise(J, K_EDIVZERO); return; }
+                if (shape & SH_R2_DIV0) { raise_ranked(J, q.head - 1, K_EDIVZERO); return; }
                 if (lane == 0) {
                     // make_values: is_known, values; abz reset by the constructor (:158)
                     st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));

@@ -111,3 +111,20 @@ def test_gpu_wide_fuzz_parity(wide_dir, force_nwg):
     systems = [E.System(E.R1CS(p)) for p in paths]
     for seed, (p, g) in enumerate(zip(paths, E.solve_batch(systems, force_nwg=force_nwg))):
         assert_bit_exact("wide fuzz seed %d" % seed, g, orc.run(p))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1239, 1272])
+def test_gpu_error_precedence_regression(tmp_path, seed):
+    """Two rows of one window raise different errors (BoundsError :916 / DivideError :919), the second one
+    a few rounds before the engine polls its error word: the status must be the one of the FIRST pop in
+    queue order, as in the sequential reference (found by tools/stress_fuzz.py)."""
+    import ecneproject_amd as E
+    p = str(tmp_path / ("%d.r1cs" % seed))
+    fuzz_r1cs.write(p, fuzz_r1cs.make(seed))
+    o = orc.run(p)
+    assert o.status in (-2, -3)
+    s = E.System(E.R1CS(p))
+    for nwg in (0, 2):
+        for mode in (0, 1):
+            assert E.solve_batch([s], force_nwg=nwg, queue_mode=mode)[0].status == o.status

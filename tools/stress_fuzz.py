@@ -1,0 +1,25 @@
+"""Developer aid (GPU box): one-off randomized stress beyond the seeds the test suite pins.
+python tools/stress_fuzz.py [first_seed] [count]   -- wide systems with long rows, several workgroup counts."""
+import os, sys, tempfile
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+import ecneproject_amd as E, fuzz_r1cs, orc
+from gpu_common import assert_bit_exact
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+d = tempfile.mkdtemp(prefix="ecne_stress_")
+paths = []
+for seed in range(first, first + count):
+    p = os.path.join(d, "%d.r1cs" % seed)
+    fuzz_r1cs.write(p, fuzz_r1cs.make_wide(seed) if seed % 3 else fuzz_r1cs.make(seed))
+    paths.append(p)
+oracles = [orc.run(p) for p in paths]
+systems = [E.System(E.R1CS(p)) for p in paths]
+for nwg in (0, 2, 5, 8):
+    res = []
+    for i in range(0, len(systems), 100):
+        res += E.solve_batch(systems[i:i + 100], force_nwg=nwg)
+    for p, g, o in zip(paths, res, oracles):
+        assert_bit_exact("%s nwg=%d" % (os.path.basename(p), nwg), g, o)
+    print("nwg", nwg, "ok:", len(res), "systems,", sum(o.status != 0 for o in oracles), "with error status")
