@@ -128,14 +128,15 @@ def make(seed, n_rows=None, n_vars=None, allow_errors=True):
     return dict(n_wires=n_vars - 1, n_out=n_out, n_pub=0, n_prv=n_in, rows=rows, witness=w)
 
 
-def make_wide(seed):
-    """A larger random system (100-400 variables, 150-700 small rows from make()) with LONG rows woven in --
+def make_wide(seed, scale=1):
+    """A larger random system (100-400 variables, 150-700 small rows from make(); `scale` multiplies both and
+    the number and length of the long rows) with LONG rows woven in --
     plain sums of 65-300 terms, decoder groups closed by a long sum (R8), mixed-radix sums over bit
     variables (R7), long binary decompositions (R4 shape: popped alone) -- over a mix of the base system's
     variables and fresh ones, all consistent with one witness. Exercises the engine's long-row paths
     (rows riding along in rounds, wavefront rounds, multi-workgroup rounds) in random surroundings."""
     rng = random.Random(1000003 * seed + 17)
-    base = make(seed + 5000, n_rows=rng.randint(150, 700), n_vars=rng.randint(100, 400), allow_errors=False)
+    base = make(seed + 5000, n_rows=scale * rng.randint(150, 700), n_vars=scale * rng.randint(100, 400), allow_errors=False)
     w = dict(base["witness"])
     rows = list(base["rows"])
     nv = base["n_wires"] + 1
@@ -155,9 +156,9 @@ def make_wide(seed):
         return b
 
     old = list(range(2, base["n_wires"] + 2))
-    for _ in range(rng.randint(2, 6)):
+    for _ in range(scale * rng.randint(2, 6)):
         kind = rng.random()
-        n = rng.randint(65, 300)
+        n = rng.randint(65, 300 if scale == 1 else 1100)
         if kind < 0.3:       # plain long sum, sometimes every addend pinned (R1 fires), sometimes not
             xs = [rng.choice(old) if rng.random() < 0.5 else fresh(rng.choice([0, 1, 5, 1 << 40])) for _ in range(n)]
             xs = list(dict.fromkeys(xs))
