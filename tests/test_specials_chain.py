@@ -60,3 +60,46 @@ def test_gpu_chain_parity(chain_files, force_nwg):
             assert len(s.specials()) == K
             g = E.solve_batch([s], force_nwg=force_nwg)[0]
             assert_bit_exact("chain K=%d rev=%s" % (K, rev), g, orc.run(p, [str(chain_files / "cube.r1cs")], ["Cube"]))
+
+
+# ---- the same for P5 (isZero pairs, :1492-1550): pair i is  a_i * z_i = 1 - y_i ;  a_i * y_i = 0  with
+# a_i = y_{i-1} (a_0 = the input). Every firing makes the next pair's A unique.
+def _write_iszero_chain(path, K, reverse):
+    # variables: 1 one, 2 = input, then y_0 .. y_{K-1}, then z_0 .. z_{K-1}
+    y = list(range(3, 3 + K))
+    z = list(range(3 + K, 3 + 2 * K))
+    a = [2] + y[:-1]
+    pairs = [[([(a[i], 1)], [(z[i], 1)], [(1, 1), (y[i], (-1) % P)]), ([(a[i], 1)], [(y[i], 1)], [])] for i in range(K)]
+    if reverse:
+        pairs.reverse()
+    r1cs_py.write(path, 2 * K + 1, 0, 1, 0, [r for pr in pairs for r in pr])
+
+
+@pytest.fixture(scope="module")
+def iszero_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("iszero")
+    for K in (5, 150):
+        for rev in (False, True):
+            _write_iszero_chain(str(d / ("iz_%d_%d.r1cs" % (K, rev))), K, rev)
+    return d
+
+
+@pytest.mark.parametrize("K,rev", [(5, False), (5, True), (150, False), (150, True)])
+def test_oracle_iszero_chain(iszero_files, K, rev):
+    o = orc.run(str(iszero_files / ("iz_%d_%d.r1cs" % (K, rev))))
+    assert o.status == 0
+    assert o.summary.rule_hits[12] == K                                  # P5 fired once per pair
+    assert o.unique[2:2 + K].all()                                       # every y_i
+    assert o.summary.outer_iterations == (K + 1 if rev else 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_nwg", [0, 2])
+def test_gpu_iszero_chain_parity(iszero_files, force_nwg):
+    import ecneproject_amd as E
+    from gpu_common import assert_bit_exact
+    for K in (5, 150):
+        for rev in (False, True):
+            p = str(iszero_files / ("iz_%d_%d.r1cs" % (K, rev)))
+            g = E.solve_batch([E.System(E.R1CS(p))], force_nwg=force_nwg)[0]
+            assert_bit_exact("iszero chain K=%d rev=%s" % (K, rev), g, orc.run(p))
