@@ -128,3 +128,40 @@ def test_gpu_error_precedence_regression(tmp_path, seed):
     for nwg in (0, 2):
         for mode in (0, 1):
             assert E.solve_batch([s], force_nwg=nwg, queue_mode=mode)[0].status == o.status
+
+
+def test_truncated_and_corrupted_files_fail_like_the_oracle(tmp_path):
+    """readR1CS on damaged input: the native reader and the oracle's reader agree on accept / reject
+    (ParseR1CS.jl:58,62,69 asserts; reading past the end)."""
+    import random
+    from ecneproject_amd import build
+    build.build()
+    import ecneproject_amd as E
+    rng = random.Random(5)
+    src = str(tmp_path / "good.r1cs")
+    fuzz_r1cs.write(src, fuzz_r1cs.make(3))
+    data = open(src, "rb").read()
+    n_rej = 0
+    for case in range(150):
+        d = bytearray(data)
+        if case % 3 == 0:
+            d = d[:rng.randrange(0, len(d))]                         # truncated
+        elif case % 3 == 1:
+            pos = rng.randrange(0, min(len(d), 200))                 # a header / early-section byte flipped
+            d[pos] ^= 1 << rng.randrange(8)
+        else:
+            pos = rng.randrange(0, len(d) - 4)                       # a count or id word overwritten
+            d[pos:pos + 4] = rng.choice([bytes([255, 255, 255, 127]), bytes(4), bytes([16, 0, 0, 0])])
+        p = str(tmp_path / ("bad%d.r1cs" % case))
+        open(p, "wb").write(bytes(d))
+        st_o, info = orc.read_info(p)
+        try:
+            f = E.R1CS(p)
+            st_n = 0
+        except E.EcneError as e:
+            st_n = e.status
+        assert (st_n == 0) == (st_o == 0), (case, st_n, st_o)
+        if st_n == 0:
+            assert list(f.info.nnz) == info["nnz"] and int(f.info.n_constraints) == info["nConstraints"], case
+        n_rej += st_n != 0
+    assert n_rej > 30
