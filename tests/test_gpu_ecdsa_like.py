@@ -62,3 +62,14 @@ def test_full_size_properties():
     if os.environ.get("ECNE_FULL_ORACLE") == "1":      # ~45 s of CPU
         o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
         assert_bit_exact("ecdsa_like(26,10)", g, o)
+
+
+@pytest.mark.parametrize("force_nwg", [0, 43])
+def test_mid_size_bit_exact(force_nwg):
+    """ecdsa_like(6, 10): 160 k reduced rows with the full-size 1 025-term rows, on the default and on the
+    bench's workgroup count -- the largest case the suite compares state by state (oracle ~2 s)."""
+    path = ecdsa_like.cached(6, 10)
+    s = build_system(None, *TRUSTED, path=path)
+    g = E.solve_batch([s], force_nwg=force_nwg)[0]
+    o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
+    assert_bit_exact("ecdsa_like(6,10) nwg=%d" % force_nwg, g, o)
