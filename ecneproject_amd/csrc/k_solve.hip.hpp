@@ -397,13 +397,19 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
             }
             if (job_barrier(J, &s_err)) break;
+            uint32_t my_fired = 0;
             for (uint32_t i = gtid; i < J.nP4; i += gstride) {
                 const uint32_t b = J.p4_b[i];
                 if ((J.flags[b] & 1) || ld_agent(&J.varmin[b]) != i || J.abz[b] != -1) continue;
                 J.abz[b] = (int32_t)(J.p4_s[i] & 0x7FFFFFFFu);
                 J.flags[b] |= 2;
                 J.fired[i] = 1;          // by list position; cleared again when the events are collected
-                atomicAdd(&ctr->p4_nfired, 1u);
+                ++my_fired;
+            }
+            {   // one device atomic per workgroup (the first sweep of a large circuit tags tens of thousands of rows)
+                uint32_t wg_fired;
+                wg_exclusive_scan(my_fired, s_scan, &wg_fired);
+                if (tid == 0 && wg_fired) atomicAdd(&ctr->p4_nfired, wg_fired);
             }
             if (master && tid == 0) ctr->q_cmd[2] = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
             if (job_barrier(J, &s_err)) break;

@@ -949,15 +949,17 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
         uint32_t c, nt;
         if (queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) break;
     }
+    // per-lane counters -> LDS -> ONE device atomic per counter and workgroup (22 000 lanes hitting twelve
+    // words of device memory serialise at the L2 for ~90 us per outer iteration otherwise)
     Counters* ctr = J.ctr;
-    if (C.steps) atomicAdd(&ctr->q_acc[0], (unsigned long long)C.steps);
-    if (C.nuniq) atomicAdd(&ctr->q_acc[1], (unsigned long long)C.nuniq);
+    if (C.steps) atomicAdd(&S.acc[0], (unsigned long long)C.steps);
+    if (C.nuniq) atomicAdd(&S.acc[1], (unsigned long long)C.nuniq);
     for (int i = 0; i < 8; ++i)
-        if (C.hits[i]) atomicAdd(&ctr->q_acc[2 + i], (unsigned long long)C.hits[i]);
-    if (my_pops) atomicAdd(&ctr->q_acc[10], (unsigned long long)my_pops);
-    if (my_nnz) atomicAdd(&ctr->q_acc[11], (unsigned long long)my_nnz);
+        if (C.hits[i]) atomicAdd(&S.acc[2 + i], (unsigned long long)C.hits[i]);
+    if (my_pops) atomicAdd(&S.acc[10], (unsigned long long)my_pops);
+    if (my_nnz) atomicAdd(&S.acc[11], (unsigned long long)my_nnz);
     __syncthreads();
-    if (threadIdx.x < 10 && S.acc[threadIdx.x]) atomicAdd(&ctr->q_acc[threadIdx.x], S.acc[threadIdx.x]);
+    if (threadIdx.x < 12 && S.acc[threadIdx.x]) atomicAdd(&ctr->q_acc[threadIdx.x], S.acc[threadIdx.x]);
 }
 
 }  // namespace ecne
