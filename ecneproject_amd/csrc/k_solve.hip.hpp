@@ -218,6 +218,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 tk[6]++;
                 // phase 1: evaluate rows >= f against the current state
                 // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
+                bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
                 for (uint32_t r4 = (f & ~3u) + 4u * gtid; r4 < nC; r4 += 4u * gstride) {
                     const uint32_t dead4 = *reinterpret_cast<const uint32_t*>(J.rdead + r4);   // padded to a multiple of 4
                     if (dead4 == 0x01010101u) continue;
@@ -237,10 +238,9 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                                 // p3_hot is raised only when this group could be complete with this member (k rows
                                 // counting the frozen ones): otherwise nobody has to look for trigger rows this pass
                                 const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
-                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k)
-                                    __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
                             }
-                            __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            my_any = true;
                             if (created) {   // remembered, so that only the slots in use are wiped afterwards
                                 const uint32_t pos = atomicAdd(&s_htn, 1u);
                                 if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                         }
                     }
                 }
+                if (my_any) __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (my_hot) __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
                 const bool any = ld_agent(&ctr->p3_any) != 0;
                 const bool hot = ld_agent(&ctr->p3_hot) != 0;
