@@ -85,7 +85,8 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     if (S.bl_any) big_rows_mark(J, S);
     if ((err = job_barrier(J, s_err))) return err;
     MTICK(0);
-    // ---- check
+    // ---- check (every lane keeps its own lowest cut; one LDS atomic per wavefront afterwards)
+    uint32_t mycut = 0xFFFFFFFFu;
 #pragma unroll
     for (uint32_t sl = 0; sl < 2; ++sl) {
         if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
@@ -99,16 +100,17 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
             for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
                     if ((rd | wr) & 1) {
                         const uint32_t m = ld_agent(&J.wmarkU[v]);
-                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
                     }
                     if ((rd | wr) & 2) {
                         const uint32_t m = ld_agent(&J.wmarkB[v]);
-                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
                     }
                 });
         }
-        if (blocked) atomicMin(&S.cut, rank);
+        if (blocked && rank < mycut) mycut = rank;
     }
+    { const uint32_t wm = wave_min(mycut); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.cut, wm); }
     if (S.bl_any) big_rows_check(J, S);
     // one global update per workgroup (thousands of lanes on one word would serialise)
     __syncthreads();
@@ -292,19 +294,6 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
 // without having touched anything when the window starts with a live long row (the caller's general path
 // takes it). Wave 0 only, all 64 lanes.
 #define ECNE_WSLOTS 1024
-__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t* total) {
-    uint32_t incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += y; }
-    *total = __shfl(incl, 63, 64);
-    return incl - x;
-}
-__device__ __forceinline__ uint32_t wave_min(uint32_t x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
-    return x;
-}
 __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n,
                                                   LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail,
                                                   unsigned long long* n_fallback) {
@@ -739,17 +728,18 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (small) {
             // ---- check against the table. Lower rank than mine: I would read (or overwrite) what an earlier
             // row writes -> blocked. Higher: that row would overwrite what I read -> the prefix is cut there.
+            uint32_t mycut = 0xFFFFFFFFu;   // (one LDS atomic per wavefront, below)
             if ((uint32_t)tid < n && (live & 1u) && !(shape[0] & SH_BIG)) {
                 const uint32_t rank = (uint32_t)tid;
                 bool blocked = false;
                 auto test = [&](uint32_t v, uint32_t rd, uint32_t wr) {
                     if ((rd | wr) & 1) {
                         const uint32_t m = hlook(S, v, 0);
-                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
                     }
                     if ((rd | wr) & 2) {
                         const uint32_t m = hlook(S, v, 1);
-                        if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                        if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
                     }
                 };
                 if (noop & 1u) {
@@ -760,8 +750,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 } else if (acnt <= ECNE_ASET) {
                     for (uint32_t i = 0; i < acnt; ++i) { const uint32_t e = S.aset[tid][i]; test(e & 0x0FFFFFFFu, (e >> 28) & 3u, e >> 30); }
                 } else for_row_sets(J, row[0], shape[0], xv[0], test);
-                if (blocked) atomicMin(&S.cut, rank);
+                if (blocked && rank < mycut) mycut = rank;
             }
+            { const uint32_t wm = wave_min(mycut); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.cut, wm); }
             __syncthreads();
             c = S.cut;   // >= 1: rank 0 is never blocked and not big
             // ---- wipe the table; tag the rows being popped with their rank (see resolve_pushes)
@@ -796,6 +787,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             QTICK(1);
             // ---- check: blocked if an earlier rank may write state I read, or reads/writes state I may write.
             // Marks are updated with device-scope atomics (performed at L2): read them past the L1.
+            uint32_t mycut = 0xFFFFFFFFu;   // (one LDS atomic per wavefront, below)
 #pragma unroll
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
                 if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
@@ -812,16 +804,17 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                     for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
                         if ((rd | wr) & 1) {
                             const uint32_t m = ld_agent(&J.wmarkU[v]);
-                            if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                            if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
                         }
                         if ((rd | wr) & 2) {
                             const uint32_t m = ld_agent(&J.wmarkB[v]);
-                            if (m < rank) blocked = true; else if (m > rank && m != 0xFFFFFFFFu) atomicMin(&S.cut, m);
+                            if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
                         }
                     });
                 }
-                if (blocked) atomicMin(&S.cut, rank);
+                if (blocked && rank < mycut) mycut = rank;
             }
+            { const uint32_t wm = wave_min(mycut); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.cut, wm); }
             if (S.bl_any) big_rows_check(J, S);
             __syncthreads();
             c = S.cut;   // >= 1: rank 0 is never blocked and not big
