@@ -76,10 +76,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         const RowInfo ri = J.rinfo[row[sl]];
         bool nb = false;
         if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
-        for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-            if (wr & 1) atomicMin(&J.wmarkU[v], rank);
-            if (wr & 2) atomicMin(&J.wmarkB[v], rank);
-        });
+        row_mark_global(J, row[sl], shape[sl], xv[sl], rank);
     }
     __syncthreads();
     if (S.bl_any) big_rows_mark(J, S);
@@ -93,20 +90,10 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         const uint32_t rank = r0 + sl;
         bool blocked = false;
         if (noop & (1u << sl)) {
-            if (noop_b & (1u << sl))
-                for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
-                    if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+            if (noop_b & (1u << sl)) blocked = row_noop_blocked_global(J, row[sl], rank);
         } else {
-            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                    if ((rd | wr) & 1) {
-                        const uint32_t m = ld_agent(&J.wmarkU[v]);
-                        if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
-                    }
-                    if ((rd | wr) & 2) {
-                        const uint32_t m = ld_agent(&J.wmarkB[v]);
-                        if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
-                    }
-                });
+            const uint32_t m = row_check_global(J, row[sl], shape[sl], xv[sl], rank);
+            if (m < mycut) mycut = m;
         }
         if (blocked && rank < mycut) mycut = rank;
     }
@@ -126,11 +113,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     for (uint32_t sl = 0; sl < 2; ++sl) {
         nev[sl] = 0;
         if (sl >= rpl || r0 + sl >= n) continue;
-        if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
-            for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
-                if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
-            });
+        if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl))) row_unmark_global(J, row[sl], shape[sl], xv[sl]);
         if (r0 + sl >= c) continue;
         // rank tags must fit inq's 16 bits: multi rounds tag with the rank's low part plus a flag that
         // the row is in the current prefix; the exact rank is recovered from prank[] (see below)
@@ -776,11 +759,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 const RowInfo ri = J.rinfo[row[sl]];
                 bool nb = false;
                 if (row_is_noop(J, row[sl], ri, nb)) { noop |= 1u << sl; if (nb) noop_b |= 1u << sl; continue; }
-                // only WRITE sets are marked: the readers find write-after-read hazards themselves (below)
-                for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                    if (wr & 1) atomicMin(&J.wmarkU[v], rank);
-                    if (wr & 2) atomicMin(&J.wmarkB[v], rank);
-                });
+                row_mark_global(J, row[sl], shape[sl], xv[sl], rank);
             }
             __syncthreads();
             if (S.bl_any) { big_rows_mark(J, S); __syncthreads(); }
@@ -794,23 +773,13 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 const uint32_t rank = r0 + sl;
                 bool blocked = false;
                 if (noop & (1u << sl)) {
-                    if (noop_b & (1u << sl))
-                        for (uint32_t k = J.rpC[row[sl]]; k < J.rpC[row[sl] + 1]; ++k)
-                            if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+                    if (noop_b & (1u << sl)) blocked = row_noop_blocked_global(J, row[sl], rank);
                 } else {
                     // wmark holds the LOWEST rank that may write that state. Lower than mine: I would read
                     // (or overwrite) what an earlier row writes -> I am blocked. Higher than mine: that row
                     // would overwrite what I read -> it (and everything after it) is cut off.
-                    for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                        if ((rd | wr) & 1) {
-                            const uint32_t m = ld_agent(&J.wmarkU[v]);
-                            if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
-                        }
-                        if ((rd | wr) & 2) {
-                            const uint32_t m = ld_agent(&J.wmarkB[v]);
-                            if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
-                        }
-                    });
+                    const uint32_t m = row_check_global(J, row[sl], shape[sl], xv[sl], rank);
+                    if (m < mycut) mycut = m;
                 }
                 if (blocked && rank < mycut) mycut = rank;
             }
@@ -823,11 +792,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #pragma unroll
             for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
                 if (sl >= rpl || r0 + sl >= n) continue;
-                if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl)))
-                    for_row_sets(J, row[sl], shape[sl], xv[sl], [&](uint32_t v, uint32_t rd, uint32_t wr) {
-                        if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
-                        if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
-                    });
+                if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl))) row_unmark_global(J, row[sl], shape[sl], xv[sl]);
                 if (r0 + sl < c) J.inq[row[sl]] = (uint16_t)(r0 + sl + 2);
             }
             __syncthreads();

@@ -187,6 +187,49 @@ __device__ __noinline__ bool row_is_noop(const Job& J, uint32_t row, const RowIn
     return true;
 }
 
+// The three walks of a round over one small row's access set, with the write-marks in device memory
+// (multi-workgroup rounds, wide single-workgroup rounds). Out of line on purpose: the access-set walk is
+// a few KB of code and a round calls it for up to four rows per lane in three passes -- inlined a dozen
+// times it made the queue loop several times larger than the instruction cache.
+__device__ __noinline__ void row_mark_global(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t rank) {
+    // only WRITE sets are marked: the readers find write-after-read hazards themselves (row_check_global)
+    for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+        if (wr & 1) atomicMin(&J.wmarkU[v], rank);
+        if (wr & 2) atomicMin(&J.wmarkB[v], rank);
+    });
+}
+// returns the lowest rank at which the prefix has to end because of this row: its own rank when an earlier
+// row may write what it reads or writes (blocked), else the lowest later rank that may overwrite what it
+// reads, else 0xFFFFFFFF. Marks are updated with device-scope atomics (performed at L2): read past the L1.
+__device__ __noinline__ uint32_t row_check_global(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t rank) {
+    bool blocked = false;
+    uint32_t mycut = 0xFFFFFFFFu;
+    for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+        if ((rd | wr) & 1) {
+            const uint32_t m = ld_agent(&J.wmarkU[v]);
+            if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
+        }
+        if ((rd | wr) & 2) {
+            const uint32_t m = ld_agent(&J.wmarkB[v]);
+            if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m;
+        }
+    });
+    return blocked ? rank : mycut;
+}
+__device__ __noinline__ void row_unmark_global(const Job& J, uint32_t row, uint32_t shape, uint32_t x) {
+    for_row_sets(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr) {
+        if (wr & 1) J.wmarkU[v] = 0xFFFFFFFFu;
+        if (wr & 2) J.wmarkB[v] = 0xFFFFFFFFu;
+    });
+}
+// a no-op row that looked at B-class state: blocked if an earlier row may write it
+__device__ __noinline__ bool row_noop_blocked_global(const Job& J, uint32_t row, uint32_t rank) {
+    bool blocked = false;
+    for (uint32_t k = J.rpC[row]; k < J.rpC[row + 1]; ++k)
+        if (ld_agent(&J.wmarkB[J.colC[k]]) < rank) blocked = true;
+    return blocked;
+}
+
 #define ECNE_HSLOTS 4096
 #define ECNE_ASET 6
 struct ChunkShared {   // LDS of the chunked queue phase
