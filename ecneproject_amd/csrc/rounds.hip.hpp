@@ -390,12 +390,11 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
         my_pops++;
         my_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
     }
-    wg_fence();
     if (mine && rank < c && live) {
         if (noop) { if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row] ^= 1; }
         else { C.rank = head + rank; exec_row_lane(J, row, J.evbuf + (size_t)rank * ECNE_EVCAP, nev, C); }
     }
-    wg_fence();
+    wg_fence();   // the rank tags (and the state changes) are visible to every lane before the pushes are resolved
     // ---- REQUEUE resolution in sequential order (rank, emission index), see resolve_pushes
     uint32_t new_tail = tail;
     uint32_t Nev;
@@ -460,8 +459,8 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
             if (win) { J.queue[(new_tail + (uint32_t)__popcll(wm & lanes_below())) & J.qmask] = t; J.inq[t] = 1; }
             new_tail += (uint32_t)__popcll(wm);
         }
-        // (best[] is reset only now: every candidate above was judged against the same minima)
-        wg_fence();
+        // (best[] is reset only now: every candidate above was judged against the same minima, and those
+        //  loads have all returned -- their values went into the ballots)
         for (uint32_t j = lane; j < M; j += 64) J.best[J.cand[j] & 0x7FFFFFFFu] = 0xFFFFFFFFu;
         wg_fence();
     }
