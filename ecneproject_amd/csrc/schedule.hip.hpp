@@ -244,7 +244,6 @@ struct ChunkShared {   // LDS of the chunked queue phase
     // memory, and every lane's access set kept here between the mark and the check pass
     uint32_t hkey[ECNE_HSLOTS], hrank[ECNE_HSLOTS];   // key = 1 + 2 * variable + class (0 = empty); lowest writer rank
     uint32_t aset[ECNE_WG][ECNE_ASET];                // variable | rd << 28 | wr << 30
-    uint32_t acnt[ECNE_WG];                           // entries cached; ECNE_ASET + 1 = too many, walk the row again
     uint32_t small_ovf;
     // long rows (> ECNE_SMALL_ROW entries) riding along in a round, at most ECNE_BIGK per workgroup: marked,
     // checked and executed by the whole workgroup, lanes across the row's entries
