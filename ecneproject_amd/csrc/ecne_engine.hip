@@ -358,6 +358,9 @@ static int upload_system(ecne_system& S, int device) {
     for (uint32_t r = 0; r < nC && bigrows.size() < ECNE_BIGTAB; ++r)
         if (L.rinfo[r].shape & SH_BIG) { bigrows.push_back(r); tbig[r] = (uint16_t)bigrows.size(); }
     size_t o_tbig = c.take(2ull * tbig.size()), o_bigrows = c.take(4ull * std::max<size_t>(bigrows.size(), 1));
+    std::vector<uint32_t> long_list;
+    for (uint32_t r = 0; r < nC; ++r) if (L.rinfo[r].shape & SH_BIG) long_list.push_back(r);
+    size_t o_long = c.take(4ull * std::max<size_t>(long_list.size(), 1));
     size_t o_p5r = c.take(4ull * std::max<size_t>(L.p5_rows.size(), 1)), o_p5y = c.take(4ull * std::max<size_t>(L.p5_y.size(), 1));
     const size_t static_end = c.off;
     size_t o_flags = c.take((size_t)nV + 1), o_abz = c.take(4ull * (nV + 1));
@@ -418,6 +421,7 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_cls, L.cls_list.data(), 4ull * L.cls_list.size()));
     HIP_TRY(up(o_tbig, tbig.data(), 2ull * tbig.size()));
     HIP_TRY(up(o_bigrows, bigrows.data(), 4ull * bigrows.size()));
+    HIP_TRY(up(o_long, long_list.data(), 4ull * long_list.size()));
     HIP_TRY(up(o_p5r, L.p5_rows.data(), 4ull * L.p5_rows.size()));
     HIP_TRY(up(o_p5y, L.p5_y.data(), 4ull * L.p5_y.size()));
     Job& J = S.dev.job;
@@ -452,6 +456,7 @@ static int upload_system(ecne_system& S, int device) {
     J.queue = (uint32_t*)(base + o_queue);
     J.varmin = (uint32_t*)(base + o_varmin);
     J.rdead = (uint8_t*)(base + o_rdead);
+    J.long_list = (const uint32_t*)(base + o_long); J.nLong = (uint32_t)long_list.size();
     J.tbig = (const uint16_t*)(base + o_tbig); J.bigrows = (const uint32_t*)(base + o_bigrows); J.nBigRows = (uint32_t)bigrows.size();
     J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);

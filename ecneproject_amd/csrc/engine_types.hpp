@@ -134,7 +134,9 @@ struct Job {
     const uint32_t* bigrows;
     uint32_t nBigRows;
     uint32_t* ht_list;         // group-table slots created in the current P3 sweep, one region per workgroup
-    uint8_t* rdead;            // row has no non-unique variable left (monotone): the sweeps skip it
+    uint8_t* rdead;            // bit 0: row has no non-unique variable left (monotone), the sweeps skip it; bit 1: long row
+    const uint32_t* long_list; // every row with more than ECNE_SMALL_ROW entries, ascending
+    uint32_t nLong;
     uint8_t* p3k;
     uint64_t *p3h, *p3h2;
     uint64_t *ht_key, *ht_key2;

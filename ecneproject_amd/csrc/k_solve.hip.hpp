@@ -50,6 +50,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
     if (master && tid == 0) { ctr->err_key = ~0ull; ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }
     job_barrier(J, &s_err);
+    for (uint32_t i = gtid; i < J.nLong; i += gstride) J.rdead[J.long_list[i]] = 2;   // bit 1: a long row (P3 evaluates it on a wavefront)
     for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
         uint32_t v = J.knowns[i];
         J.flags[v] = 3;
@@ -221,9 +222,9 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
                 for (uint32_t r4 = (f & ~3u) + 4u * gtid; r4 < nC; r4 += 4u * gstride) {
                     const uint32_t dead4 = *reinterpret_cast<const uint32_t*>(J.rdead + r4);   // padded to a multiple of 4
-                    if (dead4 == 0x01010101u) continue;
+                    if (((dead4 | (dead4 >> 1)) & 0x01010101u) == 0x01010101u) continue;       // all four dead or long
                     for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r) {
-                        if ((dead4 >> (8 * (r - r4))) & 1) continue;   // every variable unique already (p3k[r] stays 0)
+                        if ((dead4 >> (8 * (r - r4))) & 3) continue;   // dead: every variable unique already (p3k[r] stays 0); long: below
                         uint32_t k; uint64_t h, h2;
                         p3_eval(J, r, k, h, h2);
                         if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
@@ -242,6 +243,43 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                             }
                             my_any = true;
                             if (created) {   // remembered, so that only the slots in use are wiped afterwards
+                                const uint32_t pos = atomicAdd(&s_htn, 1u);
+                                if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                            }
+                        }
+                    }
+                }
+                // long rows: one WAVEFRONT per row, lanes across its entries (one lane walking a 1 025-term row made
+                // its whole workgroup -- and with it every workgroup of the job -- wait ~70 us per sweep)
+                for (uint32_t li = me.rank * ECNE_NWAVES + (uint32_t)w; li < J.nLong; li += J.nwg * ECNE_NWAVES) {
+                    const uint32_t r = J.long_list[li];
+                    if (r < f || (J.rdead[r] & 1)) continue;               // (wave-uniform)
+                    bool nuab = false;
+                    for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nuab |= !(J.flags[J.colA[e]] & 1);
+                    for (uint32_t e = J.rpB[r] + lane; e < J.rpB[r + 1]; e += 64) nuab |= !(J.flags[J.colB[e]] & 1);
+                    uint32_t k = 0; uint64_t h = 0, h2 = 0;
+                    for (uint32_t e = J.rpC[r] + lane; e < J.rpC[r + 1]; e += 64) {
+                        const uint32_t v = J.colC[e];
+                        if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
+                    }
+                    for (int d = 32; d >= 1; d >>= 1) { k += __shfl_xor(k, d, 64); h += __shfl_xor(h, d, 64); h2 += __shfl_xor(h2, d, 64); }
+                    const bool inelig = __ballot(nuab) != 0;
+                    h = mixA(h + k);
+                    if (lane == 0) {
+                        if (inelig) k = 0;
+                        else if (k == 0) J.rdead[r] |= 1;
+                        J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+                        if (k == 1) atomicMin(&ctr->p3_cand1, r);
+                        else if (k >= 2) {
+                            J.p3h[r] = h; J.p3h2[r] = h2;
+                            bool created = false;
+                            uint32_t s = ht_slot(J, h, h2, true, &created);
+                            if (s != 0xFFFFFFFFu) {
+                                const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
+                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
+                            }
+                            my_any = true;
+                            if (created) {
                                 const uint32_t pos = atomicAdd(&s_htn, 1u);
                                 if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
                             }
