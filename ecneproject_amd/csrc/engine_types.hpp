@@ -17,7 +17,9 @@
 
 namespace ecne {
 
+#ifndef ECNE_SMALL_ROW
 #define ECNE_SMALL_ROW 64   // rows with more entries than this are "long": handled by a whole workgroup
+#endif
 #ifndef ECNE_MAX_NWG
 #define ECNE_MAX_NWG 96      // workgroups one system can get (q_part[][128] and the scratch sizes follow it)
 #endif
