@@ -94,6 +94,7 @@ struct Counters {   // one per job, device memory
     unsigned int q_cmd[4];          // mode (0 = queue phase over, 1 = run one multi round), head, tail, n
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
     unsigned int q_part[2][128];
+    unsigned int q_blk[2][ECNE_MAX_NWG * 8];   // per-wavefront totals of the block-order scan (team_block_scan)
     unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 

@@ -7,8 +7,11 @@ namespace ecne {
 
 // ----------------------------------------------------------------- multi-workgroup queue round
 // Same round as in queue_phase_chunked, but executed by ALL workgroups of the job on a window of up
-// to nwg * 512 * 2 queue entries — for the thousand-row-wide frontiers of large circuits. Global
-// thread g owns ranks g*rpl .. g*rpl + rpl - 1. Cross-workgroup steps use job_barrier (6 per round)
+// to nwg * 512 * 2 queue entries — for the thousand-row-wide frontiers of large circuits. The ranks are
+// dealt out wavefront by wavefront: wave v of workgroup w owns the 64 * rpl ranks of block v * nwg + w, so
+// every workgroup gets low and high ranks alike (the rows that actually fire sit at the low ranks: with
+// one contiguous slice per workgroup the first workgroup worked five times longer than the others in the
+// execute / expand steps). Cross-workgroup steps use job_barrier (6 per round)
 // and two job-wide scans; everything a lane needs later (its rows, its events) it produced itself,
 // except cand[] / best[] / inq[] / wmark, which are read after a barrier. Returns nonzero on error.
 __device__ uint32_t team_exclusive_scan(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t buf,
@@ -22,6 +25,23 @@ __device__ uint32_t team_exclusive_scan(const Job& J, ChunkShared& S, uint32_t w
     uint32_t pre = 0, tot = 0;
     for (uint32_t i = 0; i < J.nwg; ++i) { const uint32_t v = S.bases[i]; if (i < wgrank) pre += v; tot += v; }
     __syncthreads();
+    *total = tot;
+    return pre + local;
+}
+
+// Job-wide exclusive scan in BLOCK order: wavefront v of workgroup w owns block b = v * nwg + w (64 lanes),
+// the scan runs over blocks 0, 1, 2, ... and inside a block over the lanes. Used where the ranks of a round
+// are dealt out to the workgroups wavefront by wavefront (queue_round_multi), so that the order of the
+// scan is the order of the ranks.
+__device__ uint32_t team_block_scan(const Job& J, uint32_t wgrank, uint32_t x, uint32_t buf, uint32_t* total, int* s_err, int* err_out) {
+    const uint32_t lane = (uint32_t)lane_id(), b = (uint32_t)wave_id() * J.nwg + wgrank, nblocks = J.nwg * ECNE_NWAVES;
+    uint32_t wtot;
+    const uint32_t local = wave_excl_scan(x, &wtot);
+    if (lane == 0) __hip_atomic_store(&J.ctr->q_blk[buf][b], wtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *err_out = job_barrier(J, s_err);
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t i = lane; i < nblocks; i += 64) { const uint32_t v = ld_agent(&J.ctr->q_blk[buf][i]); if (i < b) pre += v; tot += v; }
+    for (int d = 32; d >= 1; d >>= 1) { pre += __shfl_xor(pre, d, 64); tot += __shfl_xor(tot, d, 64); }
     *total = tot;
     return pre + local;
 }
@@ -40,7 +60,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     Counters* const ctr = J.ctr;
     const uint32_t T = J.nwg * ECNE_WG, g = wgrank * ECNE_WG + tid;
     const uint32_t rpl = (n + T - 1) / T;               // <= 2 by the caller's choice of n
-    const uint32_t r0 = g * rpl;
+    const uint32_t r0 = (((uint32_t)w * J.nwg + wgrank) * 64u + (uint32_t)lane) * rpl;   // block v * nwg + w, see above
     uint32_t row[2], shape[2], xv[2];
     uint32_t live = 0, noop = 0, noop_b = 0;
     int err;
@@ -165,7 +185,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
             }
     }
     uint32_t M;
-    const uint32_t cbase = team_exclusive_scan(J, S, wgrank, mycand, 0, &M, s_err, &err);
+    const uint32_t cbase = team_block_scan(J, wgrank, mycand, 0, &M, s_err, &err);   // candidates in rank order
     MTICK(2);
     if (err) return err;
     if (M > J.candcap) {
