@@ -16,7 +16,7 @@ per second (weak scaling).
 
 One JSON line on rank 0, with `roofline` (k_solve, HBM bound, algorithmic bytes B_alg of
 SURVEY.md §8d taken from the sequential oracle's pop/iteration counters) and `cpu_baseline`
-(the sequential CPU oracle timed on a bounded sample of the same workload).
+(the sequential CPU oracle timed on the same workload: ~17 s of CPU work on one core).
 """
 import argparse
 import json
@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--S", type=int, default=26, help="strides of ecdsa_like (26 = ECDSAPrivToPub(86,3))")
     ap.add_argument("--stride", type=int, default=10)
-    ap.add_argument("--cpu-sample-S", type=int, default=13, help="strides of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample-S", type=int, default=26, help="strides of the CPU-baseline sample (26 = the whole workload: ~13 s solve + ~4 s parse / abstraction on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queue-mode", type=int, default=0)
     return ap.parse_args()
