@@ -27,7 +27,7 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return SO
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-shared", "-fPIC",
            "-o", SO, os.path.join(CSRC, "ecne_engine.hip")]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -27,7 +27,8 @@
 using namespace ecne;
 
 struct ecne_r1cs {
-    R1CSFile f;
+    std::shared_ptr<R1CSFile> file = std::make_shared<R1CSFile>();   // shared with the systems made from it
+    R1CSFile& f = *file;
 };
 
 // Host image of the flat arrays (built once per system, uploaded once per device)
@@ -57,7 +58,12 @@ struct DeviceImage {
 };
 
 struct ecne_system {
-    Rows rows;                    // dictionary order, current (possibly reduced) rows
+    // dictionary order, current rows: the parsed file's own arrays until the first abstraction (no copy;
+    // `base` keeps them alive after ecne_r1cs_free), `reduced` afterwards
+    std::shared_ptr<const R1CSFile> base;
+    Rows reduced;
+    const Rows* cur = nullptr;
+    const Rows& rows() const { return *cur; }
     std::vector<Special> specials;
     std::vector<int64_t> knowns, targets;
     int64_t n_vars = 0, n_rows_main = 0;
@@ -89,7 +95,7 @@ struct ecne_result {
 // ------------------------------------------------------------------------------------ layout
 static void build_layout(ecne_system& S) {
     Layout& L = S.L;
-    const Rows& R = S.rows;
+    const Rows& R = S.rows();
     const size_t nC = R.n();
     L = Layout();
     L.nC = (uint32_t)nC;
@@ -587,7 +593,8 @@ void ecne_r1cs_free(ecne_r1cs* f) { delete f; }
 int ecne_system_from_r1cs(const ecne_r1cs* m, ecne_system** out) {
     if (!m || !out) return ECNE_EINVAL;
     ecne_system* s = new ecne_system();
-    s->rows = m->f.rows;
+    s->base = m->file;
+    s->cur = &s->base->rows;
     s->knowns = m->f.knowns;
     s->targets = m->f.outputs;
     s->n_vars = m->f.n_vars;
@@ -597,14 +604,25 @@ int ecne_system_from_r1cs(const ecne_r1cs* m, ecne_system** out) {
 }
 int ecne_abstract(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
     if (!sys || !trusted || !name) return ECNE_EINVAL;
+    Rows red;
+    const int rc = abstract_one(name, sys->rows(), trusted->f, sys->specials, red);
+    if (rc != K_OK) return rc;
     sys->laid_out = false;
-    return abstract_one(name, sys->rows, trusted->f, sys->specials);
+    if (sys->dev.arena) {   // an image uploaded for the old rows is stale now
+        (void)hipSetDevice(sys->dev.device);
+        (void)hipFree(sys->dev.arena);
+        sys->dev = DeviceImage();
+    }
+    sys->reduced = std::move(red);
+    sys->cur = &sys->reduced;
+    sys->base.reset();
+    return K_OK;
 }
 int ecne_system_info_get(const ecne_system* sys, ecne_system_info* o) {
     if (!sys || !o) return ECNE_EINVAL;
     ecne_system* s = const_cast<ecne_system*>(sys);
     if (!s->laid_out) build_layout(*s);
-    o->n_rows = (int64_t)sys->rows.n();
+    o->n_rows = (int64_t)sys->rows().n();
     o->n_rows_main = sys->n_rows_main;
     o->n_vars = sys->n_vars;
     o->n_specials = (int64_t)sys->specials.size();

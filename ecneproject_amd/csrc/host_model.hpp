@@ -8,15 +8,21 @@
 // Everything here is load-time data preparation; no propagation rule is evaluated on the host.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <map>
+#include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -39,25 +45,77 @@ enum Status : int {
     K_ECAPACITY = -10,  // an internal device table overflowed (never silently truncated)
 };
 
+// Host-side worker threads (parse, abstraction): ECNE_HOST_THREADS, default = the cores present, at most 32.
+// Results never depend on the thread count: every worker fills a range whose position was fixed beforehand.
+inline unsigned host_threads() {
+    static const unsigned n = [] {
+        const char* e = std::getenv("ECNE_HOST_THREADS");
+        long h = e ? std::atol(e) : (long)std::thread::hardware_concurrency();
+        return (unsigned)std::min<long>(std::max<long>(h, 1), 32);
+    }();
+    return n;
+}
+// f(chunk, worker) for every chunk in [0, n_chunks), chunks handed out dynamically
+template <class F>
+inline void for_chunks(size_t n_chunks, F&& f) {
+    const unsigned T = (unsigned)std::min<size_t>(host_threads(), n_chunks);
+    if (T <= 1) {
+        for (size_t c = 0; c < n_chunks; ++c) f(c, 0u);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&](unsigned w) {
+        for (size_t c; (c = next.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) f(c, w);
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(T - 1);
+    for (unsigned w = 1; w < T; ++w) pool.emplace_back(work, w);
+    work(0);
+    for (auto& t : pool) t.join();
+}
+inline unsigned for_chunks_workers(size_t n_chunks) { return (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_chunks)); }
+
+// std::allocator whose resize() leaves trivially-constructible elements uninitialised: the big row arrays are
+// sized once and then written (first touched) by the worker threads
+template <class T>
+struct RawAlloc {
+    typedef T value_type;
+    RawAlloc() = default;
+    template <class U> RawAlloc(const RawAlloc<U>&) {}
+    // big arrays: 2 MB-aligned and advised for transparent huge pages (a fresh 100+ MB array is otherwise
+    // dominated by 4 KB page faults the first time it is written)
+    static constexpr size_t HUGE_MIN = (size_t)8 << 20, HUGE_PAGE = (size_t)2 << 20;
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < HUGE_MIN) return static_cast<T*>(::operator new(bytes));
+        const size_t len = (bytes + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
+        void* p = std::aligned_alloc(HUGE_PAGE, len);
+        if (!p) throw std::bad_alloc();
+        (void)::madvise(p, len, MADV_HUGEPAGE);
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t n) {
+        if (n * sizeof(T) < HUGE_MIN) ::operator delete(p); else std::free(p);
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const RawAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const RawAlloc<U>&) const { return false; }
+};
+
 // One constraint system in "dictionary order": for every row part the entries appear in the
 // order the reference's DefaultDict would iterate them, explicit zero coefficients included
 // (an empty part is the single entry {1 => 0}, ParseR1CS.jl:113-115).
 struct Rows {
-    std::vector<uint64_t> ptr[3];     // size nC+1 each, offsets into var/coef
-    std::vector<uint32_t> var[3];     // 1-based variable id (= wire id + 1)
-    std::vector<fp::u256> coef[3];    // canonical residue
+    std::vector<uint64_t, RawAlloc<uint64_t>> ptr[3];     // size nC+1 each, offsets into var/coef
+    std::vector<uint32_t, RawAlloc<uint32_t>> var[3];     // 1-based variable id (= wire id + 1)
+    std::vector<fp::u256, RawAlloc<fp::u256>> coef[3];    // canonical residue
     size_t n() const { return ptr[0].empty() ? 0 : ptr[0].size() - 1; }
     void start() {
         for (int p = 0; p < 3; ++p) { ptr[p].assign(1, 0); var[p].clear(); coef[p].clear(); }
-    }
-    void append_row_from(const Rows& src, size_t i) {
-        for (int p = 0; p < 3; ++p) {
-            for (uint64_t k = src.ptr[p][i]; k < src.ptr[p][i + 1]; ++k) {
-                var[p].push_back(src.var[p][k]);
-                coef[p].push_back(src.coef[p][k]);
-            }
-            ptr[p].push_back(var[p].size());
-        }
     }
 };
 
@@ -146,11 +204,21 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
     out.n_labels = rd64(b + h + 16);
     out.n_cons = rd32(b + h + 24);
 
-    // pass 1 over the constraint section: term counts per part (bounds-checks the section, sizes the arrays)
+    // pass 1 over the constraint section (sequential: record lengths are only known by walking them): term
+    // counts per part, bounds check, and where every block of PARSE_BLOCK rows starts in the file and in the arrays
+    const size_t PARSE_BLOCK = 2048;
+    const size_t nblk = ((size_t)out.n_cons + PARSE_BLOCK - 1) / PARSE_BLOCK;
+    std::vector<size_t> blk_off(nblk + 1);
+    std::vector<uint64_t> blk_pos[3];
+    for (int p = 0; p < 3; ++p) blk_pos[p].resize(nblk + 1);
     uint64_t terms[3] = {0, 0, 0};
     {
         size_t c = start[2];
-        for (uint32_t r = 0; r < out.n_cons; ++r)
+        for (uint32_t r = 0; r < out.n_cons; ++r) {
+            if (r % PARSE_BLOCK == 0) {
+                blk_off[r / PARSE_BLOCK] = c;
+                for (int p = 0; p < 3; ++p) blk_pos[p][r / PARSE_BLOCK] = terms[p];
+            }
             for (int p = 0; p < 3; ++p) {
                 if (!need(c, 4)) return K_EFORMAT;
                 const uint32_t n = rd32(b + c);
@@ -159,51 +227,88 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
                 c += (size_t)n * 36;
                 terms[p] += n ? n : 1;   // an empty part is stored as {1 => 0}
             }
+        }
+        blk_off[nblk] = c;
+        for (int p = 0; p < 3; ++p) blk_pos[p][nblk] = terms[p];
     }
-    size_t c = start[2];
-    out.rows.start();
+    Rows& R = out.rows;
     for (int p = 0; p < 3; ++p) {
-        out.rows.ptr[p].reserve((size_t)out.n_cons + 1);
-        out.rows.var[p].reserve(terms[p]);
-        out.rows.coef[p].reserve(terms[p]);
+        R.ptr[p].resize((size_t)out.n_cons + 1);
+        R.ptr[p][0] = 0;
+        R.var[p].resize(terms[p]);
+        R.coef[p].resize(terms[p]);
     }
     out.path = path;
     out.csr_built = false;
-    jl::SlotTable tab;
-    std::vector<fp::u256> tmpc;
-    for (uint32_t r = 0; r < out.n_cons; ++r) {
-        for (int p = 0; p < 3; ++p) {
-            uint32_t n = rd32(b + c);
-            c += 4;
-            if (n == 0) {
-                out.rows.var[p].push_back(1);
-                out.rows.coef[p].push_back(fp::make(0));
-            } else if (n == 1) {   // one term: no dictionary order to reproduce
-                const uint32_t wire = rd32(b + c);
-                const fp::u256 v = fp::reduce(fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28)));
-                c += 36;
-                out.rows.var[p].push_back(wire + 1);
-                out.rows.coef[p].push_back(v);
-                if (!fp::is_zero(v)) out.nnz[p]++;
-            } else {
-                tab.reset();
-                tmpc.clear();
-                for (uint32_t k = 0; k < n; ++k) {
-                    uint32_t wire = rd32(b + c);
-                    fp::u256 v = fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28));
+    // pass 2, one block of rows per task: every block writes at the positions pass 1 assigned to it. A part
+    // that repeats a wire id comes out shorter than its term count ("last wins"); blocks where that
+    // happened are closed up afterwards.
+    std::vector<uint64_t> blk_len[3];
+    for (int p = 0; p < 3; ++p) blk_len[p].resize(nblk);
+    std::atomic<uint64_t> nnz_all[3];
+    for (int p = 0; p < 3; ++p) nnz_all[p].store(0);
+    for_chunks(nblk, [&](size_t blk, unsigned) {
+        jl::SlotTable tab;
+        std::vector<fp::u256> tmpc;
+        size_t c = blk_off[blk];
+        uint64_t pos[3] = {blk_pos[0][blk], blk_pos[1][blk], blk_pos[2][blk]}, nnz[3] = {0, 0, 0};
+        const size_t r0 = blk * PARSE_BLOCK, r1 = std::min<size_t>(r0 + PARSE_BLOCK, out.n_cons);
+        for (size_t r = r0; r < r1; ++r)
+            for (int p = 0; p < 3; ++p) {
+                const uint32_t n = rd32(b + c);
+                c += 4;
+                if (n == 0) {
+                    R.var[p][pos[p]] = 1;
+                    R.coef[p][pos[p]] = fp::make(0);
+                    ++pos[p];
+                } else if (n == 1) {   // one term: no dictionary order to reproduce
+                    const fp::u256 v = fp::reduce(fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28)));
+                    R.var[p][pos[p]] = rd32(b + c) + 1;
+                    R.coef[p][pos[p]] = v;
+                    ++pos[p];
                     c += 36;
-                    v = fp::reduce(v);
-                    bool ins;
-                    int64_t& slot = tab.upsert((int64_t)wire + 1, (int64_t)tmpc.size(), ins);
-                    if (ins) tmpc.push_back(v); else tmpc[(size_t)slot] = v;
+                    if (!fp::is_zero(v)) nnz[p]++;
+                } else {
+                    tab.reset();
+                    tmpc.clear();
+                    for (uint32_t k = 0; k < n; ++k) {
+                        const uint32_t wire = rd32(b + c);
+                        const fp::u256 v = fp::reduce(fp::make(rd64(b + c + 4), rd64(b + c + 12), rd64(b + c + 20), rd64(b + c + 28)));
+                        c += 36;
+                        bool ins;
+                        int64_t& slot = tab.upsert((int64_t)wire + 1, (int64_t)tmpc.size(), ins);
+                        if (ins) tmpc.push_back(v); else tmpc[(size_t)slot] = v;
+                    }
+                    tab.for_each([&](int64_t key, int64_t pay) {
+                        R.var[p][pos[p]] = (uint32_t)key;
+                        R.coef[p][pos[p]] = tmpc[(size_t)pay];
+                        ++pos[p];
+                        if (!fp::is_zero(tmpc[(size_t)pay])) nnz[p]++;
+                    });
                 }
-                tab.for_each([&](int64_t key, int64_t pay) {
-                    out.rows.var[p].push_back((uint32_t)key);
-                    out.rows.coef[p].push_back(tmpc[(size_t)pay]);
-                    if (!fp::is_zero(tmpc[(size_t)pay])) out.nnz[p]++;
-                });
+                R.ptr[p][r + 1] = pos[p];
             }
-            out.rows.ptr[p].push_back(out.rows.var[p].size());
+        for (int p = 0; p < 3; ++p) {
+            blk_len[p][blk] = pos[p] - blk_pos[p][blk];
+            nnz_all[p].fetch_add(nnz[p], std::memory_order_relaxed);
+        }
+    });
+    for (int p = 0; p < 3; ++p) {
+        out.nnz[p] = nnz_all[p].load();
+        uint64_t shift = 0;   // entries saved by repeated wire ids in the blocks before this one
+        for (size_t blk = 0; blk < nblk; ++blk) {
+            if (shift) {
+                const uint64_t from = blk_pos[p][blk], len = blk_len[p][blk];
+                std::memmove(R.var[p].data() + (from - shift), R.var[p].data() + from, len * sizeof(uint32_t));
+                std::memmove(R.coef[p].data() + (from - shift), R.coef[p].data() + from, len * sizeof(fp::u256));
+                const size_t r0 = blk * PARSE_BLOCK, r1 = std::min<size_t>(r0 + PARSE_BLOCK, out.n_cons);
+                for (size_t r = r0; r < r1; ++r) R.ptr[p][r + 1] -= shift;
+            }
+            shift += (blk_pos[p][blk + 1] - blk_pos[p][blk]) - blk_len[p][blk];
+        }
+        if (shift) {
+            R.var[p].resize(terms[p] - shift);
+            R.coef[p].resize(terms[p] - shift);
         }
     }
     out.knowns.assign(1, 1);
@@ -297,58 +402,83 @@ inline uint64_t row_fingerprint(const Rows& R, size_t i, std::vector<fp::u256>& 
     }
     return h;  // parts are NOT delimited: the reference hashes the concatenation (:231-232)
 }
-typedef std::vector<std::pair<int64_t, fp::u256>> Appear;
-inline bool appear_less(const Appear& x, const Appear& y) {
-    size_t n = std::min(x.size(), y.size());
-    for (size_t i = 0; i < n; ++i) {
-        if (x[i].first != y[i].first) return x[i].first < y[i].first;
-        int c = fp::cmp(x[i].second, y[i].second);
-        if (c) return c < 0;
-    }
-    return x.size() < y.size();
-}
-inline bool appear_eq(const Appear& x, const Appear& y) {
-    if (x.size() != y.size()) return false;
-    for (size_t i = 0; i < x.size(); ++i)
-        if (x[i].first != y[i].first || !fp::eq(x[i].second, y[i].second)) return false;
-    return true;
-}
+// Appearance signatures of the variables of one window: for every variable, in first-seen (dictionary) order,
+// the list of (part counter, coefficient) it occurs with. Flat storage: occurrences are appended as they come
+// and grouped per variable by finish() (a counting sort, so each list keeps its order) -- a window of 16 k
+// rows costs a handful of array growths instead of one small vector per variable.
 struct AppearMap {
-    jl::SlotTable tab;
-    std::vector<Appear> lists;   // lists[0 .. used): one per variable; the vectors are reused across clear()
+    jl::SlotTable tab;                       // variable -> list number
+    std::vector<uint32_t> occ_list;          // per occurrence, in arrival order
+    std::vector<int64_t> occ_where;
+    std::vector<const fp::u256*> occ_coef;
+    std::vector<uint32_t> start, slot;       // after finish(): list i = occurrences slot[start[i] .. start[i+1])
     size_t used = 0;
-    void clear() { tab.reset(); used = 0; }
-    void add(int64_t var, int64_t where, const fp::u256& c) {
+    void clear() {
+        tab.reset();
+        used = 0;
+        occ_list.clear(); occ_where.clear(); occ_coef.clear();
+    }
+    void add(int64_t var, int64_t where, const fp::u256* c) {
         bool ins;
         int64_t& s = tab.upsert(var, (int64_t)used, ins);
-        if (ins) {
-            if (used == lists.size()) lists.emplace_back(); else lists[used].clear();
-            ++used;
-        }
-        lists[(size_t)s].push_back({where, c});
+        if (ins) ++used;
+        occ_list.push_back((uint32_t)s);
+        occ_where.push_back(where);
+        occ_coef.push_back(c);
     }
-    // (variable, list index) sorted by list, stable w.r.t. table order
+    void finish() {
+        start.assign(used + 1, 0);
+        for (uint32_t l : occ_list) start[l + 1]++;
+        for (size_t i = 0; i < used; ++i) start[i + 1] += start[i];
+        slot.resize(occ_list.size());
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+        for (size_t o = 0; o < occ_list.size(); ++o) slot[fill[occ_list[o]]++] = (uint32_t)o;
+    }
+    size_t len(size_t l) const { return start[l + 1] - start[l]; }
+    int64_t where(size_t l, size_t i) const { return occ_where[slot[start[l] + i]]; }
+    const fp::u256& coef(size_t l, size_t i) const { return *occ_coef[slot[start[l] + i]]; }
+    // (variable, list number) sorted by list, stable w.r.t. table order
     std::vector<std::pair<int64_t, int64_t>> sorted() const {
         std::vector<std::pair<int64_t, int64_t>> v;
+        v.reserve(used);
         tab.for_each([&](int64_t key, int64_t pay) { v.push_back({key, pay}); });
         std::stable_sort(v.begin(), v.end(), [&](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
-            return appear_less(lists[(size_t)a.second], lists[(size_t)b.second]);
+            return compare(*this, (size_t)a.second, *this, (size_t)b.second) < 0;
         });
         return v;
+    }
+    // lexicographic order of two lists: by (counter, coefficient) pairs, a proper prefix first
+    static int compare(const AppearMap& X, size_t x, const AppearMap& Y, size_t y) {
+        const size_t nx = X.len(x), ny = Y.len(y), n = std::min(nx, ny);
+        for (size_t i = 0; i < n; ++i) {
+            const int64_t wx = X.where(x, i), wy = Y.where(y, i);
+            if (wx != wy) return wx < wy ? -1 : 1;
+            const int c = fp::cmp(X.coef(x, i), Y.coef(y, i));
+            if (c) return c;
+        }
+        return nx < ny ? -1 : nx > ny ? 1 : 0;
     }
 };
 }  // namespace detail
 
 // Replaces every (greedy, left to right, stuck-cursor) occurrence of `sub` in `rows` by a special
-// constraint; returns K_OK or K_EKEY.
-inline int abstract_one(const std::string& name, Rows& rows, const R1CSFile& sub, std::vector<Special>& specials) {
+// constraint: the reduced rows go to `red`, the new specials are appended. Returns K_OK or K_EKEY (then
+// `red` and `specials` are left as they were).  Fingerprints, the per-window variable matching and the
+// copy of the surviving rows run on the host worker threads; which windows match, and in which order,
+// does not depend on the thread count.
+inline int abstract_one(const std::string& name, const Rows& rows, const R1CSFile& sub, std::vector<Special>& specials, Rows& red) {
     using namespace detail;
     const size_t nC = rows.n(), nS = sub.rows.n();
+    const size_t FP_BLOCK = 8192;
     std::vector<size_t> cand;
-    if (nC + 1 >= nS + 1 && nC >= nS) {
+    if (nC >= nS) {
         std::vector<uint64_t> fb(nC), fs(nS);
+        for_chunks((nC + FP_BLOCK - 1) / FP_BLOCK, [&](size_t blk, unsigned) {
+            std::vector<fp::u256> scratch;
+            const size_t i1 = std::min(nC, (blk + 1) * FP_BLOCK);
+            for (size_t i = blk * FP_BLOCK; i < i1; ++i) fb[i] = row_fingerprint(rows, i, scratch);
+        });
         std::vector<fp::u256> scratch;
-        for (size_t i = 0; i < nC; ++i) fb[i] = row_fingerprint(rows, i, scratch);
         for (size_t i = 0; i < nS; ++i) fs[i] = row_fingerprint(sub.rows, i, scratch);
         for (size_t i = 0; i + nS <= nC; ++i) {
             bool m = true;
@@ -363,95 +493,126 @@ inline int abstract_one(const std::string& name, Rows& rows, const R1CSFile& sub
         for (size_t j = 0; j < nS; ++j)
             for (int p = 0; p < 3; ++p) {
                 for (uint64_t k = sub.rows.ptr[p][j]; k < sub.rows.ptr[p][j + 1]; ++k)
-                    if (!fp::is_zero(sub.rows.coef[p][k])) orig.add(sub.rows.var[p][k], counter, sub.rows.coef[p][k]);
+                    if (!fp::is_zero(sub.rows.coef[p][k])) orig.add(sub.rows.var[p][k], counter, &sub.rows.coef[p][k]);
                 ++counter;
             }
     }
+    orig.finish();
     const auto l2 = orig.sorted();
-    struct Match { size_t at; std::unordered_map<int64_t, int64_t> map; };
-    std::vector<Match> matches;
-    std::vector<fp::u256> va, vb;
     // the pattern's sorted coefficient lists, once (every candidate window is compared against them)
     std::vector<fp::u256> subvals;
     std::vector<size_t> subptr(1, 0);
-    if (!cand.empty())
+    if (!cand.empty()) {
+        std::vector<fp::u256> vb;
         for (size_t j = 0; j < nS; ++j)
             for (int p = 0; p < 3; ++p) {
                 part_values(sub.rows, p, j, vb);
                 subvals.insert(subvals.end(), vb.begin(), vb.end());
                 subptr.push_back(subvals.size());
             }
-    AppearMap cur;
-    for (size_t at : cand) {
-        cur.clear();
-        int64_t counter = 0;
-        bool ok = true;
-        for (size_t j = 0; j < nS && ok; ++j)
-            for (int p = 0; p < 3 && ok; ++p) {
-                ++counter;
-                part_values(rows, p, at + j, va);
-                const size_t s0 = subptr[j * 3 + (size_t)p], s1 = subptr[j * 3 + (size_t)p + 1];
-                if (va.size() != s1 - s0) { ok = false; break; }
-                for (size_t t = 0; t < va.size(); ++t)
-                    if (!fp::eq(va[t], subvals[s0 + t])) { ok = false; break; }
-                if (!ok) break;
-                for (uint64_t k = rows.ptr[p][at + j]; k < rows.ptr[p][at + j + 1]; ++k)
-                    if (!fp::is_zero(rows.coef[p][k])) cur.add(rows.var[p][k], counter, rows.coef[p][k]);
-            }
-        if (!ok) continue;
-        const auto l1 = cur.sorted();
-        if (l1.size() != l2.size()) continue;
-        for (size_t x = 0; x < l1.size() && ok; ++x)
-            if (!appear_eq(cur.lists[(size_t)l1[x].second], orig.lists[(size_t)l2[x].second])) ok = false;
-        if (!ok) continue;
-        Match m;
-        m.at = at;
-        for (size_t x = 0; x < l1.size(); ++x) m.map[l2[x].first] = l1[x].first;
-        matches.push_back(std::move(m));
     }
-    Rows red;
-    red.start();
-    for (int p = 0; p < 3; ++p) {
-        red.ptr[p].reserve(rows.ptr[p].size());
-        red.var[p].reserve(rows.var[p].size());
-        red.coef[p].reserve(rows.coef[p].size());
+    // one candidate window per task; image[c] = the window's variable for every pattern variable in l2 order
+    std::vector<std::vector<int64_t>> image(cand.size());
+    std::vector<uint8_t> matched(cand.size(), 0);
+    {
+        const unsigned W = for_chunks_workers(cand.size());
+        std::vector<AppearMap> curs(W);
+        std::vector<std::vector<fp::u256>> vas(W);
+        for_chunks(cand.size(), [&](size_t ci, unsigned w) {
+            AppearMap& cur = curs[w];
+            std::vector<fp::u256>& va = vas[w];
+            const size_t at = cand[ci];
+            cur.clear();
+            int64_t counter = 0;
+            for (size_t j = 0; j < nS; ++j)
+                for (int p = 0; p < 3; ++p) {
+                    ++counter;
+                    part_values(rows, p, at + j, va);
+                    const size_t s0 = subptr[j * 3 + (size_t)p], s1 = subptr[j * 3 + (size_t)p + 1];
+                    if (va.size() != s1 - s0) return;
+                    for (size_t t = 0; t < va.size(); ++t)
+                        if (!fp::eq(va[t], subvals[s0 + t])) return;
+                    for (uint64_t k = rows.ptr[p][at + j]; k < rows.ptr[p][at + j + 1]; ++k)
+                        if (!fp::is_zero(rows.coef[p][k])) cur.add(rows.var[p][k], counter, &rows.coef[p][k]);
+                }
+            cur.finish();
+            const auto l1 = cur.sorted();
+            if (l1.size() != l2.size()) return;
+            for (size_t x = 0; x < l1.size(); ++x)
+                if (AppearMap::compare(cur, (size_t)l1[x].second, orig, (size_t)l2[x].second) != 0) return;
+            image[ci].resize(l1.size());
+            for (size_t x = 0; x < l1.size(); ++x) image[ci][x] = l1[x].first;
+            matched[ci] = 1;
+        });
     }
-    // rows outside the matched windows are copied range by range
-    auto copy_range = [&](size_t a, size_t b) {   // rows [a, b)
-        for (int p = 0; p < 3; ++p) {
-            const uint64_t k0 = rows.ptr[p][a], k1 = rows.ptr[p][b];
-            const uint64_t shift = (uint64_t)red.var[p].size() - k0;
-            red.var[p].insert(red.var[p].end(), rows.var[p].begin() + (ptrdiff_t)k0, rows.var[p].begin() + (ptrdiff_t)k1);
-            red.coef[p].insert(red.coef[p].end(), rows.coef[p].begin() + (ptrdiff_t)k0, rows.coef[p].begin() + (ptrdiff_t)k1);
-            for (size_t r = a + 1; r <= b; ++r) red.ptr[p].push_back(rows.ptr[p][r] + shift);
-        }
-    };
+    // greedy left to right with the reference's stuck cursor (:368-388): a match that starts inside the
+    // previous window is never reached again, and neither is any later one. Rows outside the replaced
+    // windows survive as ranges [a, b).
+    std::vector<std::pair<size_t, size_t>> keep;
+    std::vector<Special> fresh;
+    std::unordered_map<int64_t, size_t> where;   // pattern variable -> position in l2 (later duplicates win, as in the map it replaces)
+    for (size_t x = 0; x < l2.size(); ++x) where[l2[x].first] = x;
     size_t i = 0;
-    for (size_t mi = 0; mi <= matches.size(); ++mi) {
-        // greedy left to right with the reference's stuck cursor (:368-388): a match that starts inside the
-        // previous window is never reached again, and neither is any later one
-        const size_t stop = mi < matches.size() ? matches[mi].at : nC;
-        if (stop < i) { copy_range(i, nC); i = nC; break; }
-        copy_range(i, stop);
+    for (size_t ci = 0; ci <= cand.size(); ++ci) {
+        if (ci < cand.size() && !matched[ci]) continue;
+        const size_t stop = ci < cand.size() ? cand[ci] : nC;
+        if (stop < i) { keep.push_back({i, nC}); i = nC; break; }
+        keep.push_back({i, stop});
         i = stop;
-        if (mi == matches.size()) break;
+        if (ci == cand.size()) break;
         Special sp;
         sp.name = name;
         for (int64_t x : sub.knowns)
             if (x != 1) {
-                auto it = matches[mi].map.find(x);
-                if (it == matches[mi].map.end()) return K_EKEY;
-                sp.inputs.push_back(it->second);
+                auto it = where.find(x);
+                if (it == where.end()) return K_EKEY;
+                sp.inputs.push_back(image[ci][it->second]);
             }
         for (int64_t x : sub.outputs) {
-            auto it = matches[mi].map.find(x);
-            if (it == matches[mi].map.end()) return K_EKEY;
-            sp.outputs.push_back(it->second);
+            auto it = where.find(x);
+            if (it == where.end()) return K_EKEY;
+            sp.outputs.push_back(image[ci][it->second]);
         }
-        specials.push_back(std::move(sp));
+        fresh.push_back(std::move(sp));
         i += nS;
     }
-    rows = std::move(red);
+    // lay the surviving ranges out back to back, then copy them in pieces on the worker threads
+    struct Piece { size_t a, b, row; uint64_t at[3]; };
+    const size_t COPY_BLOCK = 16384;
+    std::vector<Piece> pieces;
+    size_t nrow = 0;
+    uint64_t nterm[3] = {0, 0, 0};
+    for (auto& kb : keep)
+        for (size_t a = kb.first; a < kb.second; a += COPY_BLOCK) {
+            Piece pc;
+            pc.a = a;
+            pc.b = std::min(kb.second, a + COPY_BLOCK);
+            pc.row = nrow;
+            for (int p = 0; p < 3; ++p) {
+                pc.at[p] = nterm[p];
+                nterm[p] += rows.ptr[p][pc.b] - rows.ptr[p][pc.a];
+            }
+            nrow += pc.b - pc.a;
+            pieces.push_back(pc);
+        }
+    for (int p = 0; p < 3; ++p) {
+        red.ptr[p].resize(nrow + 1);
+        red.ptr[p][0] = 0;
+        red.var[p].resize(nterm[p]);
+        red.coef[p].resize(nterm[p]);
+    }
+    for_chunks(pieces.size(), [&](size_t pi, unsigned) {
+        const Piece& pc = pieces[pi];
+        for (int p = 0; p < 3; ++p) {
+            const uint64_t k0 = rows.ptr[p][pc.a], k1 = rows.ptr[p][pc.b];
+            if (k1 > k0) {
+                std::memcpy(red.var[p].data() + pc.at[p], rows.var[p].data() + k0, (k1 - k0) * sizeof(uint32_t));
+                std::memcpy(red.coef[p].data() + pc.at[p], rows.coef[p].data() + k0, (k1 - k0) * sizeof(fp::u256));
+            }
+            for (size_t r = pc.a; r < pc.b; ++r) red.ptr[p][pc.row + (r - pc.a) + 1] = rows.ptr[p][r + 1] - k0 + pc.at[p];
+        }
+    });
+    for (auto& sp : fresh) specials.push_back(std::move(sp));
     return K_OK;
 }
 

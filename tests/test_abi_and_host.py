@@ -142,3 +142,36 @@ def test_field_sqrt_utility(E):
         assert bool(ok) == is_res
         if ok:
             assert orc.limbs_to_int(r) ** 2 % P == a
+
+
+_DIGEST_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import ecneproject_amd as E, fixtures, ecdsa_like
+s = E.System(E.R1CS(ecdsa_like.cached(4, 10)))
+h = hashlib.sha256()
+for stage in range(2):
+    for part in range(3):
+        for a in s.rows(part):
+            h.update(a.tobytes())
+    h.update(repr(s.specials()).encode())
+    if stage == 0:
+        s.abstract(E.R1CS(fixtures.path("secp256k1.r1cs")), "Secp256k1AddUnequal")
+print(h.hexdigest(), len(s), len(s.specials()))
+"""
+
+
+def test_host_worker_threads_do_not_change_results():
+    """reader, abstraction and copy run on ECNE_HOST_THREADS workers; rows, their order and the specials of
+    ecdsa_like(4) (168 k rows, three Secp256k1AddUnequal instances) are the same with 1, 3 and 8 of them"""
+    import subprocess
+    import sys
+    from ecneproject_amd import build
+    build.build()
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for n in ("1", "3", "8"):
+        env = dict(os.environ, ECNE_HOST_THREADS=n)
+        outs.append(subprocess.check_output([sys.executable, "-c", _DIGEST_SCRIPT, os.path.dirname(here), here], env=env, timeout=600).decode().split())
+    assert outs[0] == outs[1] == outs[2], outs
+    assert int(outs[0][2]) == 3

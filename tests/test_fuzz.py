@@ -165,3 +165,62 @@ def test_truncated_and_corrupted_files_fail_like_the_oracle(tmp_path):
             assert list(f.info.nnz) == info["nnz"] and int(f.info.n_constraints) == info["nConstraints"], case
         n_rej += st_n != 0
     assert n_rej > 30
+
+
+def _many_block_rows(n_rows, n_vars, seed):
+    """rows for a file that spans several of the reader's row blocks: parts of 0-6 terms, every ~8th part
+    repeating a wire id (so blocks come out shorter than their term count), explicit zeros, values >= p"""
+    import random
+    rng = random.Random(seed)
+    rows = []
+    for _ in range(n_rows):
+        parts = []
+        for _p in range(3):
+            n = rng.choice([0, 1, 1, 2, 3, 4, 6])
+            terms = [(rng.randint(1, n_vars), rng.choice([0, 1, 2, orc.P - 1, orc.P + 3, rng.getrandbits(250)])) for _ in range(n)]
+            if n >= 2 and rng.random() < 0.12:
+                terms[rng.randrange(1, n)] = (terms[0][0], rng.choice([0, 5, 7]))     # repeated wire id: last value wins
+            parts.append(terms)
+        rows.append(tuple(parts))
+    return rows
+
+
+def _expected_part(terms):
+    """the reference's nonzeroKeys order of one part: file order -> Dict (last value wins) -> Set of the
+    non-zero keys (ParseR1CS.jl:108-115, R1CSConstraintSolver.jl:26-34)"""
+    val = {}
+    for v, c in terms:
+        val[v] = c % orc.P
+    keys = list(dict.fromkeys(v for v, _ in terms))
+    in_dict = orc.julia_order(keys, 2) if len(keys) > 1 else keys
+    nz = [k for k in in_dict if val[k] != 0]
+    nz = orc.julia_order(nz, 0) if len(nz) > 1 else nz
+    return [(k, val[k]) for k in nz]
+
+
+def test_reader_row_blocks_with_repeated_wire_ids(tmp_path):
+    """the reader fills blocks of 2048 rows on worker threads at positions fixed by a first pass; a block whose
+    parts repeat wire ids is closed up afterwards. Every row of a 7 000-row file against the dictionary model."""
+    from ecneproject_amd import build
+    build.build()
+    import ecneproject_amd as E
+    n_vars = 400
+    rows = _many_block_rows(7000, n_vars, 4242)
+    p = str(tmp_path / "blocks.r1cs")
+    fuzz_r1cs.write_raw(p, n_vars - 1, 1, 1, n_vars - 3, rows)
+    f = E.R1CS(p)
+    st, d = orc.read_info(p)
+    assert st == 0 and list(f.info.nnz) == d["nnz"]
+    s = E.System(f)
+    for part in range(3):
+        rp, col, cf = s.rows(part)
+        assert len(rp) == len(rows) + 1
+        for i, r in enumerate(rows):
+            want = _expected_part(r[part])
+            got = [(int(col[k]), orc.limbs_to_int(cf[k])) for k in range(rp[i], rp[i + 1])]
+            assert got == want, (part, i)
+    # the file-order CSR view (duplicates kept, zeros dropped) is built from the file, not from the blocks
+    for part in range(3):
+        rp, col, cf = f.csr(part)
+        assert int(rp[-1]) == sum(1 for r in rows for v, c in r[part] if c % orc.P)
+
