@@ -34,11 +34,13 @@ struct ecne_r1cs {
 // Host image of the flat arrays (built once per system, uploaded once per device)
 struct Layout {
     uint32_t nC = 0, nV = 0;
-    std::vector<uint32_t> rp[3], col[3];
-    std::vector<uint64_t> coef[3];
-    std::vector<RowInfo> rinfo;
+    // (the big ones are sized once and filled by the host worker threads: no zero fill, huge-page advised)
+    std::vector<uint32_t, RawAlloc<uint32_t>> rp[3], col[3];
+    std::vector<uint64_t, RawAlloc<uint64_t>> coef[3];
+    std::vector<RowInfo, RawAlloc<RowInfo>> rinfo;
     uint32_t n_vals = 0;
-    std::vector<uint32_t> fo_ptr, fo_rows;
+    std::vector<uint32_t> fo_ptr;
+    std::vector<uint32_t, RawAlloc<uint32_t>> fo_rows;
     std::vector<uint32_t> sp_in_ptr, sp_in, sp_out_ptr, sp_out;
     std::vector<uint8_t> sp_kind;
     std::vector<uint32_t> knowns, targets;
@@ -100,11 +102,29 @@ static void build_layout(ecne_system& S) {
     L = Layout();
     L.nC = (uint32_t)nC;
     L.nV = (uint32_t)S.n_vars;
+    const size_t BLK = 4096, nblk = (nC + BLK - 1) / BLK;
+    const unsigned W = for_chunks_workers(std::max<size_t>(nblk, 1));
     // a special or a row may mention a variable above nWires+1 only in malformed input; size state
-    // arrays for the largest id seen so that indexing stays in bounds
+    // arrays for the largest id seen so that indexing stays in bounds. Same pass: non-zero terms per
+    // block and part, i.e. where every block of rows starts in the flat arrays.
+    std::vector<uint32_t> wmax(W, L.nV);
+    std::vector<uint64_t> blk_pos[3];
+    for (int p = 0; p < 3; ++p) blk_pos[p].assign(nblk + 1, 0);
+    for_chunks(nblk, [&](size_t blk, unsigned w) {
+        const size_t i0 = blk * BLK, i1 = std::min(nC, i0 + BLK);
+        uint32_t mx = wmax[w];
+        for (int p = 0; p < 3; ++p) {
+            uint64_t nz = 0;
+            for (uint64_t k = R.ptr[p][i0]; k < R.ptr[p][i1]; ++k) {
+                mx = std::max(mx, R.var[p][k]);
+                nz += !fp::is_zero(R.coef[p][k]);
+            }
+            blk_pos[p][blk + 1] = nz;
+        }
+        wmax[w] = mx;
+    });
     uint32_t maxv = L.nV;
-    for (int p = 0; p < 3; ++p)
-        for (uint32_t v : R.var[p]) maxv = std::max(maxv, v);
+    for (uint32_t m : wmax) maxv = std::max(maxv, m);
     for (auto& sp : S.specials) {
         for (int64_t v : sp.inputs) maxv = std::max<uint32_t>(maxv, (uint32_t)v);
         for (int64_t v : sp.outputs) maxv = std::max<uint32_t>(maxv, (uint32_t)v);
@@ -112,22 +132,29 @@ static void build_layout(ecne_system& S) {
     const uint32_t nVall = maxv;   // arrays hold ids 0..nVall
     L.nV = nVall;
     for (int p = 0; p < 3; ++p) {
-        L.rp[p].assign(1, 0); L.col[p].clear(); L.coef[p].clear();
-        L.rp[p].reserve(nC + 1); L.col[p].reserve(R.var[p].size()); L.coef[p].reserve(4 * R.var[p].size());
+        for (size_t blk = 0; blk < nblk; ++blk) blk_pos[p][blk + 1] += blk_pos[p][blk];
+        L.nnz[p] = blk_pos[p][nblk];
+        L.rp[p].resize(nC + 1);
+        L.rp[p][0] = 0;
+        L.col[p].resize(L.nnz[p]);
+        L.coef[p].resize(4 * L.nnz[p]);
     }
-    L.rinfo.assign(nC, RowInfo());
+    L.rinfo.resize(nC);
     L.nontrivial.assign((size_t)nVall + 1, 0);
-    std::vector<uint32_t> deg((size_t)nVall + 2, 0);
+    std::vector<uint8_t> a_equal_next(nC, 0);
+    std::vector<std::vector<uint32_t>> blk_p4(nblk), blk_cls(nblk);
+    std::vector<uint32_t> blk_vals(nblk + 1, 0);   // rows of the block that own a pair of value slots
 
     const fp::u256 ONE = fp::make(1), PM1 = fp::pminus1();
-    jl::SlotTable set;
     struct E { uint32_t v; fp::u256 c; };
+    // per-row pass, one block of rows per task (every row writes its own slice of the flat arrays)
+    for_chunks(nblk, [&](size_t blk, unsigned) {
+    jl::SlotTable set;
     std::vector<E> nz[3], tmp;
-    std::vector<uint32_t> zeros_c;   // unused beyond counting
-    std::vector<uint8_t> a_equal_next(nC, 0);
-    std::vector<uint32_t> seen_stamp((size_t)nVall + 1, 0xFFFFFFFFu);
-
-    for (size_t i = 0; i < nC; ++i) {
+    uint64_t pos[3] = {blk_pos[0][blk], blk_pos[1][blk], blk_pos[2][blk]};
+    uint32_t vals_here = 0;
+    const size_t i0 = blk * BLK, i1 = std::min(nC, i0 + BLK);
+    for (size_t i = i0; i < i1; ++i) {
         RowInfo ri;
         std::memset(&ri, 0, sizeof ri);
         ri.validx = 0xFFFFFFFFu;
@@ -150,13 +177,12 @@ static void build_layout(ecne_system& S) {
                 set.for_each([&](int64_t, int64_t pay) { nz[p].push_back(tmp[(size_t)pay]); });
             }
             for (auto& e : nz[p]) {
-                L.col[p].push_back(e.v);
-                for (int w = 0; w < 4; ++w) L.coef[p].push_back(e.c.w[w]);
-                L.nontrivial[e.v] = 1;
-                if (seen_stamp[e.v] != (uint32_t)i) { seen_stamp[e.v] = (uint32_t)i; deg[e.v]++; }
+                L.col[p][pos[p]] = e.v;
+                for (int w = 0; w < 4; ++w) L.coef[p][4 * pos[p] + w] = e.c.w[w];
+                ++pos[p];
+                __atomic_store_n(&L.nontrivial[e.v], (uint8_t)1, __ATOMIC_RELAXED);   // same value from every worker
             }
-            L.rp[p].push_back((uint32_t)L.col[p].size());
-            L.nnz[p] += nz[p].size();
+            L.rp[p][i + 1] = (uint32_t)pos[p];
         }
         const size_t nA = nz[0].size(), nB = nz[1].size(), nCc = nz[2].size();
         ri.lenC = (uint32_t)nCc;
@@ -192,7 +218,7 @@ static void build_layout(ecne_system& S) {
                     if (e.v != 1) { slope_index = e.v; have = true; }   // last one wins (:1462-1465)
                 ri.kneg = slope_index;
                 if (!have) ri.shape |= SH_P4_DIV0;
-                L.p4_list.push_back((uint32_t)i);
+                blk_p4[blk].push_back((uint32_t)i);
             }
         }
         if (!(ri.shape & SH_HAS_AB) && nCc > 0) {
@@ -233,11 +259,11 @@ static void build_layout(ecne_system& S) {
             }
         }
         if ((ri.shape & SH_R2) || (!(ri.shape & SH_HAS_AB) && nCc > 0)) {
-            ri.validx = L.n_vals;
-            L.n_vals += 2;
+            ri.validx = 2 * vals_here;   // relative to the block; rebased below
+            ++vals_here;
         }
         L.rinfo[i] = ri;
-        if (nCc > 8) L.cls_list.push_back((uint32_t)i);
+        if (nCc > 8) blk_cls[blk].push_back((uint32_t)i);
         // A-map equality with the next row, zeros included (:1512)
         if (i + 1 < nC) {
             const uint64_t x0 = R.ptr[0][i], x1 = R.ptr[0][i + 1], y0 = R.ptr[0][i + 1], y1 = R.ptr[0][i + 2];
@@ -251,34 +277,78 @@ static void build_layout(ecne_system& S) {
             a_equal_next[i] = eq;
         }
     }
-    // P5 static candidates (:1492-1536)
-    for (size_t i = 0; i + 1 < nC; ++i) {
-        const uint32_t nc_next = L.rp[2][i + 2] - L.rp[2][i + 1];
-        const uint32_t nb_next = L.rp[1][i + 2] - L.rp[1][i + 1];
-        const uint32_t nc_this = L.rp[2][i + 1] - L.rp[2][i];
-        if (nc_next != 0 || nb_next != 1 || nc_this != 2 || !a_equal_next[i]) continue;
-        const uint32_t y = L.col[1][L.rp[1][i + 1]];
-        if (y == 1) continue;
-        bool bad = false;
-        for (uint32_t k = L.rp[2][i]; k < L.rp[2][i + 1]; ++k)
-            if (L.col[2][k] != 1 && L.col[2][k] != y) bad = true;
-        if (bad) continue;
-        L.p5_rows.push_back((uint32_t)i);
-        L.p5_y.push_back(y);
+    blk_vals[blk + 1] = vals_here;
+    });
+    // value slots are numbered in row order; the per-block lists are joined in block order
+    for (size_t blk = 0; blk < nblk; ++blk) blk_vals[blk + 1] += blk_vals[blk];
+    L.n_vals = 2 * blk_vals[nblk];
+    for_chunks(nblk, [&](size_t blk, unsigned) {
+        const uint32_t base = 2 * blk_vals[blk];
+        const size_t i0 = blk * BLK, i1 = std::min(nC, i0 + BLK);
+        if (base)
+            for (size_t i = i0; i < i1; ++i)
+                if (L.rinfo[i].validx != 0xFFFFFFFFu) L.rinfo[i].validx += base;
+    });
+    for (size_t blk = 0; blk < nblk; ++blk) {
+        L.p4_list.insert(L.p4_list.end(), blk_p4[blk].begin(), blk_p4[blk].end());
+        L.cls_list.insert(L.cls_list.end(), blk_cls[blk].begin(), blk_cls[blk].end());
     }
-    // variable_to_indices (:628-633): ascending rows per variable
-    L.fo_ptr.assign((size_t)nVall + 2, 0);
-    for (uint32_t v = 0; v <= nVall; ++v) L.fo_ptr[v + 1] = L.fo_ptr[v] + deg[v];
-    L.fo_rows.assign(L.fo_ptr[nVall + 1], 0);
+    // P5 static candidates (:1492-1536)
     {
-        std::vector<uint32_t> fill(L.fo_ptr.begin(), L.fo_ptr.end() - 1);
-        std::fill(seen_stamp.begin(), seen_stamp.end(), 0xFFFFFFFFu);
-        for (size_t i = 0; i < nC; ++i)
-            for (int p = 0; p < 3; ++p)
-                for (uint32_t k = L.rp[p][i]; k < L.rp[p][i + 1]; ++k) {
-                    uint32_t v = L.col[p][k];
-                    if (seen_stamp[v] != (uint32_t)i) { seen_stamp[v] = (uint32_t)i; L.fo_rows[fill[v]++] = (uint32_t)i; }
-                }
+        std::vector<std::vector<uint32_t>> blk_rows(nblk), blk_y(nblk);
+        for_chunks(nblk, [&](size_t blk, unsigned) {
+            const size_t i0 = blk * BLK, i1 = std::min(nC, i0 + BLK);
+            for (size_t i = i0; i < i1 && i + 1 < nC; ++i) {
+                const uint32_t nc_next = L.rp[2][i + 2] - L.rp[2][i + 1];
+                const uint32_t nb_next = L.rp[1][i + 2] - L.rp[1][i + 1];
+                const uint32_t nc_this = L.rp[2][i + 1] - L.rp[2][i];
+                if (nc_next != 0 || nb_next != 1 || nc_this != 2 || !a_equal_next[i]) continue;
+                const uint32_t y = L.col[1][L.rp[1][i + 1]];
+                if (y == 1) continue;
+                bool bad = false;
+                for (uint32_t k = L.rp[2][i]; k < L.rp[2][i + 1]; ++k)
+                    if (L.col[2][k] != 1 && L.col[2][k] != y) bad = true;
+                if (bad) continue;
+                blk_rows[blk].push_back((uint32_t)i);
+                blk_y[blk].push_back(y);
+            }
+        });
+        for (size_t blk = 0; blk < nblk; ++blk) {
+            L.p5_rows.insert(L.p5_rows.end(), blk_rows[blk].begin(), blk_rows[blk].end());
+            L.p5_y.insert(L.p5_y.end(), blk_y[blk].begin(), blk_y[blk].end());
+        }
+    }
+    // variable_to_indices (:628-633): ascending rows per variable. Every task owns a range of variable ids
+    // and walks all rows for it (count, then fill), so each list comes out in row order whatever the
+    // number of workers; the walk is a linear read of the column arrays.
+    {
+        const size_t nvar = (size_t)nVall + 1;
+        const size_t nrange = std::min<size_t>(W, nvar);
+        const size_t per = (nvar + nrange - 1) / nrange;
+        std::vector<uint32_t> deg(nvar + 1, 0), last(nvar, 0xFFFFFFFFu);
+        auto walk = [&](size_t rg, bool fill, std::vector<uint32_t>& cursor) {
+            const uint32_t v0 = (uint32_t)(rg * per), v1 = (uint32_t)std::min(nvar, (rg + 1) * per);
+            for (size_t i = 0; i < nC; ++i)
+                for (int p = 0; p < 3; ++p)
+                    for (uint32_t k = L.rp[p][i]; k < L.rp[p][i + 1]; ++k) {
+                        const uint32_t v = L.col[p][k];
+                        if (v < v0 || v >= v1) continue;
+                        if (!fill) {
+                            if (last[v] != (uint32_t)i) { last[v] = (uint32_t)i; deg[v + 1]++; }
+                        } else if (last[v] != (uint32_t)i) {
+                            last[v] = (uint32_t)i;
+                            L.fo_rows[cursor[v]++] = (uint32_t)i;
+                        }
+                    }
+        };
+        std::vector<uint32_t> none;
+        for_chunks(nrange, [&](size_t rg, unsigned) { walk(rg, false, none); });
+        L.fo_ptr.assign(nvar + 1, 0);
+        for (size_t v = 0; v < nvar; ++v) L.fo_ptr[v + 1] = L.fo_ptr[v] + deg[v + 1];
+        L.fo_rows.resize(L.fo_ptr[nvar]);
+        std::vector<uint32_t> cursor(L.fo_ptr.begin(), L.fo_ptr.end() - 1);
+        std::fill(last.begin(), last.end(), 0xFFFFFFFFu);
+        for_chunks(nrange, [&](size_t rg, unsigned) { walk(rg, true, cursor); });
     }
     // specials, I/O lists, nontrivial set (:600-618)
     L.sp_in_ptr.assign(1, 0);

@@ -11,9 +11,10 @@ m = E.R1CS(p); t.append(time.perf_counter())
 tr = E.R1CS(fixtures.path("secp256k1.r1cs")); t.append(time.perf_counter())
 s = E.System(m); t.append(time.perf_counter())
 s.abstract(tr, "Secp256k1AddUnequal"); t.append(time.perf_counter())
+s.info; t.append(time.perf_counter())
 r = E.solve_batch([s], fetch_states=False)[0]; t.append(time.perf_counter())
 r2 = E.solve_batch([s], fetch_states=False)[0]; t.append(time.perf_counter())
-names = ["parse main", "parse trusted", "system from r1cs", "abstraction", "first solve (layout + upload + classify + solve)", "second solve"]
+names = ["parse main", "parse trusted", "system from r1cs", "abstraction", "layout (flat arrays, host)", "first solve (upload + classify + solve)", "second solve"]
 for n, a, b in zip(names, t, t[1:]):
     print("%-55s %8.1f ms" % (n, (b - a) * 1e3))
-print("file MB %.1f rows %d -> %d, verdict %s, kernel %.1f ms, end to end %.1f ms" % (os.path.getsize(p) / 1e6, len(m), len(s), r.function_good, r2.summary.device_ms, (t[5] - t[0]) * 1e3))
+print("file MB %.1f rows %d -> %d, verdict %s, kernel %.1f ms, end to end %.1f ms" % (os.path.getsize(p) / 1e6, len(m), len(s), r.function_good, r2.summary.device_ms, (t[6] - t[0]) * 1e3))
