@@ -55,7 +55,9 @@ typedef struct ecne_info {
     int64_t n_vars;    /* nWires + 1 (ParseR1CS.jl:123) */
 } ecne_info;
 
-/* readR1CS — ParseR1CS.jl:50-124 */
+/* readR1CS — ParseR1CS.jl:50-124. Host-side work (this call, ecne_abstract, the one-time flat-array layout of a
+ * system) runs on worker threads: ECNE_HOST_THREADS in the environment, default = the cores present, at most
+ * 32; results do not depend on the count. */
 int ecne_r1cs_load(const char* path, ecne_r1cs** out);
 int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* out);
 /* CSR view of one part (0 = A, 1 = B, 2 = C) in file order, non-zero terms only; borrowed pointers,
