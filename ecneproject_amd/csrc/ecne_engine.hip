@@ -769,7 +769,11 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
         }
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
-        hipEvent_t e0, e1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        struct EventPair {   // destroyed on every way out of the block
+            hipEvent_t &a, &b;
+            ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+        } events{e0, e1};
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         (void)hipEventRecord(e0, stream);
         {
@@ -794,8 +798,6 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
         }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         for (size_t i = 0; i < n; ++i) {
             ecne_system& S = *sys[i];
             const Layout& L = S.L;
