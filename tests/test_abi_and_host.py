@@ -126,6 +126,12 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(root, fn), errors="ignore").read()
                 assert "libecne_oracle" not in txt and "import orc" not in txt and "oracle/" not in txt.replace("test oracle (oracle/jldict.hpp)", ""), fn
+    # the developer aids under tools/ are not checkers either (the ones that are live in tests/tools/)
+    for root, _d, files in os.walk(os.path.join(ROOT, "tools")):
+        for fn in files:
+            if fn.endswith((".py", ".sh", ".hip", ".cpp")):
+                txt = open(os.path.join(root, fn), errors="ignore").read()
+                assert "libecne_oracle" not in txt and "import orc" not in txt and "orc." not in txt, fn
 
 
 def test_field_sqrt_utility(E):

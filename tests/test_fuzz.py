@@ -118,7 +118,7 @@ def test_gpu_wide_fuzz_parity(wide_dir, force_nwg):
 def test_gpu_error_precedence_regression(tmp_path, seed):
     """Two rows of one window raise different errors (BoundsError :916 / DivideError :919), the second one
     a few rounds before the engine polls its error word: the status must be the one of the FIRST pop in
-    queue order, as in the sequential reference (found by tools/stress_fuzz.py)."""
+    queue order, as in the sequential reference (found by tests/tools/stress_fuzz.py)."""
     import ecneproject_amd as E
     p = str(tmp_path / ("%d.r1cs" % seed))
     fuzz_r1cs.write(p, fuzz_r1cs.make(seed))

@@ -1,9 +1,9 @@
 """Developer aid (GPU box): bit-exact comparison of the HIP engine with the sequential oracle on a
 scale-out ecdsa_like(S) (state of every variable, counts, pops, per-rule hits).  The oracle needs
-~25 s for S = 26 and ~7 min for S = 104 on one core.   python tools/full_parity_scale.py [S]"""
+~25 s for S = 26 and ~7 min for S = 104 on one core.   python tests/tools/full_parity_scale.py [S]"""
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, os.path.dirname(HERE))
 import ecneproject_amd as E, ecdsa_like, fixtures, orc
 from gpu_common import assert_bit_exact, build_system
 

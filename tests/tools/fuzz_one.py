@@ -1,7 +1,7 @@
 """Developer aid (GPU box): one fuzz seed on the engine (default and sequential schedule) and on the oracle."""
 import os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, os.path.dirname(HERE))
 import ecneproject_amd as E, fuzz_r1cs, orc
 seed = int(sys.argv[1]); wide = len(sys.argv) > 2 and sys.argv[2] == "wide"
 p = "/tmp/fuzz_%d.r1cs" % seed

@@ -1,12 +1,12 @@
 """Developer aid: run fixtures on the GPU engine and on the oracle, print first differences.
-Usage (on the GPU box): python tools/gpu_parity_debug.py [substring ...]"""
+Usage (on the GPU box): python tests/tools/gpu_parity_debug.py [substring ...]"""
 import os
 import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
-sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import numpy as np  # noqa: E402
 
 import ecneproject_amd as E  # noqa: E402

@@ -1,9 +1,9 @@
 """Developer aid (GPU box): one-off randomized stress beyond the seeds the test suite pins.
-python tools/stress_fuzz.py [first_seed] [count] [scale]   -- wide systems with long rows (scale > 1: thousands of
+python tests/tools/stress_fuzz.py [first_seed] [count] [scale]   -- wide systems with long rows (scale > 1: thousands of
 rows, long rows up to 1 100 terms), several workgroup counts."""
 import os, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, os.path.dirname(HERE))
 import ecneproject_amd as E, fuzz_r1cs, orc
 from gpu_common import assert_bit_exact
 

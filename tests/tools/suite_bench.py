@@ -1,15 +1,15 @@
 """BASELINE.json config 4: the 67 ecne_circomlib_tests/*.r1cs files, sharded file-per-GPU.
 
-One GPU:   python tools/suite_bench.py [reps]
+One GPU:   python tests/tools/suite_bench.py [reps]
 N GPUs:    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-               --master-port 29511 tools/suite_bench.py [reps]
+               --master-port 29511 tests/tools/suite_bench.py [reps]
 Every rank takes its share of the files (longest-processing-time-first packing by non-zero count,
 ecneproject_amd/sharding.py), solves it as ONE batch launch on its GPU (one workgroup(-group) per
 file) and the ranks meet in a single RCCL all-reduce (MIN) of the 4-byte verdict word. Rank 0 prints
 the suite's wall time (max over ranks) next to the sequential oracle run file by file on one core."""
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, os.path.dirname(HERE))
 import torch
 import torch.distributed as dist
 import ecneproject_amd as E, fixtures, orc
