@@ -91,7 +91,7 @@ struct Counters {   // one per job, device memory
     unsigned int p3_hot;   // some k >= 2 group could be complete in this pass (else nobody looks at the table)
     unsigned int p4_nfired, setup_tail;
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
-    unsigned int q_cmd[4];          // mode (0 = queue phase over, 1 = run one multi round), head, tail, n
+    unsigned int q_cmd[8];          // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
     unsigned int q_part[2][128];
     unsigned int q_blk[2][ECNE_MAX_NWG * 8];   // per-wavefront totals of the block-order scan (team_block_scan)

@@ -507,6 +507,39 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #ifndef ECNE_MULTI_MIN
 #define ECNE_MULTI_MIN 128    // queued rows from which a round runs on all workgroups of the job (measured optimum)
 #endif
+// ---- chained multi-workgroup rounds
+// After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
+// decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
+// for itself: the master skips its command (one job barrier and the loads of its own window per round), the
+// helpers go straight into the next round. Both sides run the two functions below on the same inputs; the
+// state they read (queue head entry, its shape, its solved flag) was published by the round's last barrier and
+// nobody writes between rounds. A chain ends after ECNE_CHAIN_MAX rounds so that the master's error / pop-cap
+// polling keeps its cadence.
+#ifndef ECNE_CHAIN_MAX
+#define ECNE_CHAIN_MAX 32
+#endif
+__device__ __forceinline__ void multi_window_update(uint32_t cm, uint32_t nm, uint32_t cap_n, uint32_t& mwindow, uint32_t& window) {
+    if (cm == nm) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
+    else if (cm < nm / 4) {
+        const uint32_t wn = 4 * cm;
+        if (wn >= 4096) mwindow = wn;
+        else { mwindow = 4096; window = wn < ECNE_WMIN ? ECNE_WMIN : (wn < ECNE_RPL * ECNE_WG ? wn : ECNE_RPL * ECNE_WG); }
+    }
+}
+// rows of the next chained round, 0 = back to the master's own loop (same tests as at its top)
+__device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head, uint32_t tail, uint32_t window, uint32_t mwindow) {
+    const uint32_t avail = tail - head;
+    const uint32_t n = avail < window ? avail : window;
+    if (n <= 64 || avail < ECNE_MULTI_MIN || window < ECNE_MULTI_MIN) return 0;
+    const uint32_t row0 = J.queue[head & J.qmask];
+    const uint32_t shape0 = J.rinfo[row0].shape;
+    if ((shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0)) return 0;   // a long row that is popped alone
+    const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+    uint32_t nm = avail < cap_n ? avail : cap_n;
+    if (nm > mwindow) nm = mwindow;
+    return nm;
+}
+
 __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
                                     unsigned long long& steps, unsigned long long& nuniq,
                                     unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
@@ -623,23 +656,25 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (nm > mwindow) nm = mwindow;
             if (tid == 0) {
                 J.ctr->q_cmd[1] = q.head; J.ctr->q_cmd[2] = q.tail; J.ctr->q_cmd[3] = nm;
+                J.ctr->q_cmd[4] = window; J.ctr->q_cmd[5] = mwindow;
                 __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (job_barrier(J, s_err)) { helpers_released = true; break; }
-            uint32_t cm = 0, ntm = q.tail;
-            if (queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { helpers_released = true; break; }
-            q.head += cm;
-            q.tail = ntm;
-            pops_total += cm;
-            hits[13]++;
-            hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
-            hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
-            if (cm == nm) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
-            else if (cm < nm / 4) {
-                const uint32_t wn = 4 * cm;
-                if (wn >= 4096) mwindow = wn;
-                else { mwindow = 4096; window = wn < ECNE_WMIN ? ECNE_WMIN : (wn < ECNE_RPL * ECNE_WG ? wn : ECNE_RPL * ECNE_WG); }
+            bool failed = false;
+            for (uint32_t chain = 1;; ++chain) {       // chained rounds, see multi_chain_next
+                uint32_t cm = 0, ntm = q.tail;
+                if (queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { failed = true; break; }
+                q.head += cm;
+                q.tail = ntm;
+                pops_total += cm;
+                hits[13]++;
+                hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
+                hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
+                multi_window_update(cm, nm, cap_n, mwindow, window);
+                nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow) : 0;
+                if (!nm) break;
             }
+            if (failed) { helpers_released = true; break; }
             QTICK(7);
             continue;
         }
@@ -922,9 +957,20 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
     for (;;) {
         if (job_barrier(J, s_err)) break;
         if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
-        const uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
-        uint32_t c, nt;
-        if (queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) break;
+        uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
+        uint32_t window = ld_agent(&J.ctr->q_cmd[4]), mwindow = ld_agent(&J.ctr->q_cmd[5]);
+        const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+        bool failed = false;
+        for (uint32_t chain = 1;; ++chain) {           // the master's chain, derived here (see multi_chain_next)
+            uint32_t c = 0, nt = tail;
+            if (queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) { failed = true; break; }
+            head += c;
+            tail = nt;
+            multi_window_update(c, n, cap_n, mwindow, window);
+            n = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, head, tail, window, mwindow) : 0;
+            if (!n) break;
+        }
+        if (failed) break;
     }
     // per-lane counters -> LDS -> ONE device atomic per counter and workgroup (22 000 lanes hitting twelve
     // words of device memory serialise at the L2 for ~90 us per outer iteration otherwise)
