@@ -114,8 +114,10 @@ class R1CS:
         n = len(self)
         rowptr = np.ctypeslib.as_array(rp, (n + 1,)).copy()
         nnz = int(rowptr[-1])
-        c = np.ctypeslib.as_array(col, (max(nnz, 1),))[:nnz].copy()
-        v = np.ctypeslib.as_array(cf, (max(nnz, 1) * 4,))[:nnz * 4].reshape(nnz, 4).copy()
+        if nnz == 0:      # a part without a single non-zero term: the library may hand out null arrays
+            return rowptr, np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64)
+        c = np.ctypeslib.as_array(col, (nnz,)).copy()
+        v = np.ctypeslib.as_array(cf, (nnz * 4,)).reshape(nnz, 4).copy()
         return rowptr, c, v
 
 
@@ -164,8 +166,10 @@ class System:
         n = len(self)
         rowptr = np.ctypeslib.as_array(rp, (n + 1,)).copy()
         nnz = int(rowptr[-1])
-        c = np.ctypeslib.as_array(col, (max(nnz, 1),))[:nnz].copy()
-        v = np.ctypeslib.as_array(cf, (max(nnz, 1) * 4,))[:nnz * 4].reshape(nnz, 4).copy()
+        if nnz == 0:      # a part without a single non-zero term: the library may hand out null arrays
+            return rowptr, np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64)
+        c = np.ctypeslib.as_array(col, (nnz,)).copy()
+        v = np.ctypeslib.as_array(cf, (nnz * 4,)).reshape(nnz, 4).copy()
         return rowptr, c, v
 
 

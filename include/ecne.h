@@ -61,7 +61,8 @@ typedef struct ecne_info {
 int ecne_r1cs_load(const char* path, ecne_r1cs** out);
 int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* out);
 /* CSR view of one part (0 = A, 1 = B, 2 = C) in file order, non-zero terms only; borrowed pointers,
- * valid until ecne_r1cs_free. coeff holds 4 limbs per term. */
+ * valid until ecne_r1cs_free. coeff holds 4 limbs per term. col / coeff may be NULL when the part has no
+ * non-zero term at all (rowptr[n] == 0); the same holds for ecne_system_rows. */
 int ecne_r1cs_csr(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col,
                   const uint64_t** coeff);
 /* known_variables = [1] ++ inputs, target_variables = outputs (ParseR1CS.jl:123) */
