@@ -28,7 +28,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return SO
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-shared", "-fPIC",
-           "-o", SO, os.path.join(CSRC, "ecne_engine.hip")]
+           "-o", SO, os.path.join(CSRC, "ecne_engine.hip")] + os.environ.get("ECNE_BUILD_FLAGS", "").split()   # e.g. -DECNE_POPPROF (developer builds)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -13,6 +13,9 @@ namespace ecne {
 #define ECNE_WG 512
 #define ECNE_NWAVES (ECNE_WG / 64)
 
+// dynamic LDS of k_solve: mutable state of single-workgroup jobs (k_solve "LDS residency", chain.hip.hpp)
+extern __shared__ __align__(16) unsigned char ecne_dyn_lds[];
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }

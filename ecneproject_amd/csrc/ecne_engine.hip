@@ -438,7 +438,31 @@ static int upload_system(ecne_system& S, int device) {
     for (uint32_t r = 0; r < nC; ++r) if (L.rinfo[r].shape & SH_BIG) long_list.push_back(r);
     size_t o_long = c.take(4ull * std::max<size_t>(long_list.size(), 1));
     size_t o_p5r = c.take(4ull * std::max<size_t>(L.p5_rows.size(), 1)), o_p5y = c.take(4ull * std::max<size_t>(L.p5_y.size(), 1));
-    const size_t static_end = c.off;
+    // chain executor tables (systems small enough for one workgroup): the row in one line, the fan-out inline
+    const bool chain = nC <= ECNE_CHAIN_ROWS;
+    std::vector<uint32_t> rec, foi;
+    if (chain) {
+        rec.assign(16ull * std::max<size_t>(nC, 1), 0);
+        for (uint32_t r = 0; r < nC; ++r) {
+            const uint32_t la = L.rp[0][r + 1] - L.rp[0][r], lb = L.rp[1][r + 1] - L.rp[1][r], lc = L.rp[2][r + 1] - L.rp[2][r];
+            if (la + lb + lc > 15) continue;
+            uint32_t* w = &rec[16ull * r];
+            w[0] = la | lb << 8 | lc << 16 | 1u << 24;
+            uint32_t k = 1;
+            for (int p = 0; p < 3; ++p)
+                for (uint32_t e = L.rp[p][r]; e < L.rp[p][r + 1]; ++e) w[k++] = L.col[p][e];
+        }
+        foi.assign(4ull * L.fo_ptr.size(), 0);
+        for (size_t v = 0; v + 1 < L.fo_ptr.size(); ++v) {
+            const uint32_t f0 = L.fo_ptr[v], n = L.fo_ptr[v + 1] - f0;
+            uint32_t* w = &foi[4 * v];
+            w[0] = n;
+            if (n <= 3) for (uint32_t i = 0; i < n; ++i) w[1 + i] = L.fo_rows[f0 + i];
+            else w[1] = f0;
+        }
+    }
+    size_t o_rec = c.take(4ull * std::max<size_t>(rec.size(), 4)), o_foi = c.take(4ull * std::max<size_t>(foi.size(), 4));
+    const size_t static_end = c.off;   // [o_rp[0], static_end): everything the solve only reads
     size_t o_flags = c.take((size_t)nV + 1), o_abz = c.take(4ull * (nV + 1));
     size_t o_lb = c.take(32ull * (nV + 1)), o_ub = c.take(32ull * (nV + 1));
     size_t o_nvalues = c.take((size_t)nV + 1), o_values = c.take(64ull * (nV + 1));
@@ -463,7 +487,6 @@ static int upload_system(ecne_system& S, int device) {
     const uint32_t bigstride = 2 * (maxrowC + 8);
     size_t o_bigpool = c.take(4ull * ECNE_MAX_NWG * ECNE_BIGK * bigstride);
     size_t o_ctr = c.take(sizeof(Counters));
-    (void)static_end;
     char* base = nullptr;
     HIP_TRY(hipMalloc((void**)&base, c.off));
     S.dev.arena = base;
@@ -500,6 +523,8 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_long, long_list.data(), 4ull * long_list.size()));
     HIP_TRY(up(o_p5r, L.p5_rows.data(), 4ull * L.p5_rows.size()));
     HIP_TRY(up(o_p5y, L.p5_y.data(), 4ull * L.p5_y.size()));
+    HIP_TRY(up(o_rec, rec.data(), 4ull * rec.size()));
+    HIP_TRY(up(o_foi, foi.data(), 4ull * foi.size()));
     Job& J = S.dev.job;
     std::memset(&J, 0, sizeof J);
     J.nC = nC; J.nV = nV; J.nSp = nSp;
@@ -546,6 +571,10 @@ static int upload_system(ecne_system& S, int device) {
     J.bigev = (uint32_t*)(base + o_bigev);
     J.bigpool = (uint32_t*)(base + o_bigpool); J.bigstride = bigstride;
     J.ctr = (Counters*)(base + o_ctr);
+    J.rec = chain ? (const uint32_t*)(base + o_rec) : nullptr;
+    J.foi = chain ? (const uint32_t*)(base + o_foi) : nullptr;
+    J.lds_flags_off = J.lds_inq_off = 0xFFFFFFFFu;
+    J.warm_bytes = (static_end - o_rp[0]) <= (7u << 19) ? (uint32_t)(static_end - o_rp[0]) : 0u;   // fits one XCD's 4 MB L2 beside the state
     S.dev.classified = false;
     return K_OK;
 }
@@ -763,10 +792,31 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) != hipSuccess || n_cu < 1) { rc = ECNE_ENODEVICE; break; }
         const uint32_t cap = (uint32_t)std::max(1, n_cu - 8);   // margin: never rely on the last CU being free
+        // dynamic LDS: whatever the CU has beyond k_solve's static tables (a workgroup owns its CU anyway);
+        // single-workgroup jobs keep their hot state there (k_solve, "LDS residency")
+        uint32_t dyn_lds = 0;
+        {
+            hipFuncAttributes fa;
+            int lds_max = 0;
+            if (hipFuncGetAttributes(&fa, (const void*)k_solve) == hipSuccess &&
+                hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, o.device) == hipSuccess &&
+                (size_t)lds_max > fa.sharedSizeBytes + 1024) {
+                dyn_lds = ((uint32_t)lds_max - (uint32_t)fa.sharedSizeBytes - 256u) & ~255u;
+                if (const char* e = getenv("ECNE_LDS_BYTES")) dyn_lds = std::min<uint32_t>(dyn_lds, (uint32_t)atoi(e));   // test hook
+                if (dyn_lds && hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess) dyn_lds = 0;
+            }
+            (void)hipGetLastError();
+        }
+        uint32_t single_wg_rows = ECNE_ROWS_PER_WG;
+        if (const char* e = getenv("ECNE_SINGLE_WG_ROWS")) single_wg_rows = (uint32_t)atoi(e);   // experiment hook
         for (size_t i = 0; i < n; ++i) {
             uint32_t want = (hj[i].nC + ECNE_ROWS_PER_WG - 1u) / ECNE_ROWS_PER_WG;
+            // a system whose flags and in_queue tags fit the LDS is solved by ONE workgroup (chain executor, chain.hip.hpp)
+            const bool lds_fits = hj[i].rec && ((size_t)hj[i].nV + 1 + 16) + (2ull * hj[i].nC + 16) <= dyn_lds;
+            if (hj[i].nC <= single_wg_rows || (lds_fits && !getenv("ECNE_SINGLE_WG_ROWS"))) want = 1;
             if (o.debug > 0) want = (uint32_t)o.debug;          // test hook: force the helper count
             hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
+            hj[i].lds_bytes = dyn_lds;
         }
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -789,7 +839,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
                     ++i;
                 }
                 if (hipMemcpyAsync(d_descs, descs.data(), sizeof(WgDesc) * descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) { fail = true; break; }
-                hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), 0, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
                 if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
             }
             (void)hipEventRecord(e1, stream);

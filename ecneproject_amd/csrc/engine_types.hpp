@@ -10,7 +10,10 @@
 //   rinfo[nC] RowInfo        static shape of the row = which propagation rules it can ever feed
 //   vals[...][4] u64         per-row constants: R2's two candidate values / R3's value, R4's bound
 //   fo_ptr[nV+2], fo_rows    variable -> ascending rows containing it (variable_to_indices, :628-633)
-// and the mutable solver state (SoA): flags u8 (bit0 unique, bit1 is_known, bit2 bounds==[0,1]),
+//   rec[nC][16] u32          systems one workgroup solves: the row's lengths + up to 15 variable ids in ONE 64-byte line
+//   foi[nV+2] 4 x u32        ... and per variable its fan-out inline (count + up to 3 rows, or count + offset into fo_rows)
+// and the mutable solver state (SoA): flags u8 (bit0 unique, bit1 is_known, bit2 bounds==[0,1], bit3 bounds neither
+// [0,1] nor the initial [0,p-1], bit4 carries a group tag i.e. abz != -1),
 // abz i32, lb/ub 4xu64, nvalues u8 + values 2x4xu64, per-row inq/solved/flip bytes, FIFO ring.
 #pragma once
 #include <stdint.h>
@@ -28,6 +31,9 @@ namespace ecne {
 #endif
 #ifndef ECNE_BIGK
 #define ECNE_BIGK 8         // long rows one workgroup takes along in one round
+#endif
+#ifndef ECNE_CHAIN_ROWS
+#define ECNE_CHAIN_ROWS 49152   // systems up to this many rows are solved by ONE workgroup with the chain executor (flags + in_queue tags in LDS)
 #endif
 #define ECNE_BIGTAB 2048    // big rows with an LDS slot for their push candidates (the rest use memory atomics directly)
 #define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
@@ -101,6 +107,8 @@ struct Counters {   // one per job, device memory
 struct Job {
     // sizes
     uint32_t nC, nV, nSp, nKnown, nTarget, nP4, nP5, qmask, htmask, secp_solve, queue_mode, hotcap;
+    uint32_t warm_bytes;     // bytes of static arrays (from rpA on) a single-workgroup job streams once to warm its XCD's L2; 0 = off
+    uint32_t lds_bytes;      // dynamic LDS of the launch: a single-workgroup job keeps as much of its mutable state there as fits (k_solve)
     uint32_t nwg, nBigCls;   // nBigCls: rows with more than 8 entries in C (classified one wavefront each)   // workgroups cooperating on this job (1 = the master alone)
     // static system
     const uint32_t *rpA, *rpB, *rpC;
@@ -110,6 +118,11 @@ struct Job {
     RowInfo* rinfo;
     uint64_t* vals;
     const uint32_t *fo_ptr, *fo_rows;
+    // chain executor (chain.hip.hpp), single-workgroup jobs only (else null): rec[16 * row] = lenA | lenB << 8 | lenC << 16 |
+    // 1 << 24 followed by the row's variable ids (A, B, C; stored order), word 0 = 0 for rows with more than 15 entries;
+    // foi[4 * v] = {n, r0, r1, r2} for n <= 3 rows of variable_to_indices[v], else {n, offset into fo_rows, 0, 0}
+    const uint32_t *rec, *foi;
+    uint32_t lds_flags_off, lds_inq_off;   // byte offsets of flags / inq in the dynamic LDS when resident there, else 0xFFFFFFFF (set by k_solve)
     const uint32_t *sp_in_ptr, *sp_in, *sp_out_ptr, *sp_out;
     const uint8_t* sp_kind;   // 1 = "BigMultModP", 2 = "BigLessThan", 0 = anything else (:751, :755)
     const uint32_t* k1_list;  // indices of the "BigMultModP" specials, ascending

@@ -24,7 +24,32 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     __syncthreads();
     const uint32_t nC = J.nC, nV = J.nV;
     const bool master = me.rank == 0;
+    const bool seq_mode = J.queue_mode == 1 || J.queue_mode == 2;   // strictly sequential pops: 1 = exec_row(), 2 = the chain executor where it applies
+    // ---------------- LDS residency. A job run by ONE workgroup keeps the two arrays every pop reads and writes
+    // -- the unique / is_known flag bytes and the in_queue tags -- in the CU's LDS when they fit the launch's
+    // dynamic LDS. The Job's pointers are generic (flat) pointers, so every rule, sweep and REQUEUE below works on
+    // either memory unchanged (an LDS access through a generic pointer costs what an L2 hit costs, 106 ns); the
+    // chain executor (chain.hip.hpp) reads them with ds_read (27 ns). The host reads the flags afterwards: they
+    // are copied back before the verdict count.
+    uint8_t* const g_flags = J.flags;
+    if (J.nwg == 1 && J.lds_bytes && tid == 0) {
+        uint32_t off = 0;
+        const uint32_t cap = J.lds_bytes;
+        auto take = [&](size_t bytes) -> unsigned char* {
+            const uint32_t b = ((uint32_t)bytes + 15u) & ~15u;
+            if (bytes > cap || off + b > cap) return nullptr;
+            unsigned char* p = ecne_dyn_lds + off;
+            off += b;
+            return p;
+        };
+        if (unsigned char* p = take((size_t)nV + 1)) { J.flags = (uint8_t*)p; J.lds_flags_off = (uint32_t)(p - ecne_dyn_lds); }
+        if (unsigned char* p = take(2ull * (nC ? nC : 1))) { J.inq = (uint16_t*)p; J.lds_inq_off = (uint32_t)(p - ecne_dyn_lds); }
+    }
+    __syncthreads();
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
+#ifdef ECNE_POPPROF
+    if (tid < 8) pop_prof().acc[tid] = 0;
+#endif
     const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
     Counters* const ctr = J.ctr;
     const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
@@ -105,6 +130,17 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         q.tail = total_pushes;
         (void)scan_err;
     }
+    // ---------------- L2 warm-up. A workgroup meets most rows of a small system exactly once per visit and, after
+    // a fresh upload or on another XCD than last time, every first touch of a row's descriptor, entries and
+    // fan-out lists would be a round trip beyond this XCD's L2 in the middle of a dependency chain. One
+    // streaming pass over the static arrays (a few MB at most, all 512 lanes) makes them L2 hits.
+    if (J.nwg == 1 && J.warm_bytes) {
+        const uint4* const w0 = (const uint4*)J.rpA;          // the static arrays are one contiguous carve, rpA first
+        const uint32_t nq = J.warm_bytes / 16;
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < nq; i += ECNE_WG) { const uint4 x = w0[i]; acc ^= x.x ^ x.y ^ x.z ^ x.w; }
+        if (acc == 0x9E3779B9u && nq == 0xFFFFFFFFu) s_u32[1] = acc;   // (keeps the loads alive)
+    }
     ECNE_TICK(0);
     unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
     unsigned long long hits[16];
@@ -164,18 +200,34 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                     }
                     if (J.ctr->error) break;
                 }
-                if (J.queue_mode == 1) {
-                    // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
+                if (J.queue_mode == 2 && chain_ok(J)) {
+#ifdef ECNE_POPPROF
+                    if (tid == 0) { pop_prof().last = wall_clock64(); }
+#endif
+                    // QUEUE, strictly sequential pops on the chain executor (chain.hip.hpp)
                     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
                     while (q.head != q.tail && !J.ctr->error) {
                         if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+                        chain_pops(J, q, 1u << 16, 0, hits, steps, nuniq, pops, pop_nnz);
+                    }
+                } else if (seq_mode) {
+                    // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
+                    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
+#ifdef ECNE_POPPROF
+                    if (tid == 0) { pop_prof().last = wall_clock64(); }
+#endif
+                    while (q.head != q.tail && !J.ctr->error) {
+                        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+                        ECNE_PT(7);
                         uint32_t row = J.queue[q.head & J.qmask];
                         q.head++;
                         if (lane == 0) J.inq[row] = 0;
                         wg_fence();
+                        ECNE_PT(0);
                         pops++;
                         pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
                         if (J.solved[row]) continue;
+                        ECNE_PT(1);
                         exec_row(J, q, row, hits, steps, nuniq);
                     }
                 }
@@ -184,11 +236,11 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
             __syncthreads();
             steps = s_steps;
             q = s_q;
-            if (J.queue_mode != 1 && wg_error(J, &s_err)) {
+            if (!seq_mode && wg_error(J, &s_err)) {
                 // P1/P2 raised: the queue phase is skipped, but the helpers are waiting at its command
                 // barrier — meet them there (they leave on the error snapshot)
                 if (J.nwg > 1) job_barrier(J, &s_err);
-            } else if (J.queue_mode != 1) {
+            } else if (!seq_mode) {
                 // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
                 unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
                 for (int i = 0; i < 16; ++i) ht2[i] = 0;
@@ -197,9 +249,9 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
             }
         }
-        else if (J.queue_mode != 1) queue_phase_helper(J, s_chunk, me.rank, &s_err);
+        else if (!seq_mode) queue_phase_helper(J, s_chunk, me.rank, &s_err);
         if (job_barrier(J, &s_err)) break;      // publishes the queue phase's state changes to the helpers
-        if (master && J.nwg > 1 && J.queue_mode != 1) {
+        if (master && J.nwg > 1 && !seq_mode) {
             // fold in what the helpers did during multi-workgroup rounds
             steps += ctr->q_acc[0];
             if (w == 0) {
@@ -442,7 +494,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 const uint32_t b = J.p4_b[i];
                 if ((J.flags[b] & 1) || ld_agent(&J.varmin[b]) != i || J.abz[b] != -1) continue;
                 J.abz[b] = (int32_t)(J.p4_s[i] & 0x7FFFFFFFu);
-                J.flags[b] |= 2;
+                J.flags[b] |= 2 | 16;    // is_known; bit 4: carries a group tag (abz != -1)
                 J.fired[i] = 1;          // by list position; cleared again when the events are collected
                 ++my_fired;
             }
@@ -621,6 +673,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
 
     // ---------------- verdict counts (:1558-1597), all workgroups
     job_barrier(J, &s_err);
+    if (J.flags != g_flags) for (uint32_t v = tid; v <= nV; v += ECNE_WG) g_flags[v] = J.flags[v];   // (LDS-resident flags: the host reads them back)
     uint32_t un = 0, nn = 0, ut = 0;
     for (uint32_t v = 1 + gtid; v <= nV; v += gstride) {
         if (J.nontrivial[v]) { nn++; if (J.flags[v] & 1) un++; }
@@ -648,6 +701,9 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 ECNE_TICK(5);
                 for (int i = 0; i < 8; ++i) ctr->phase_ticks[i] = tk[i];
                 for (int i = 0; i < 8; ++i) ctr->qticks[i] = s_chunk.qt[i];
+#ifdef ECNE_POPPROF
+                if (seq_mode) for (int i = 0; i < 8; ++i) ctr->qticks[i] = pop_prof().acc[i];
+#endif
                 for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
             }
         }

@@ -2,6 +2,7 @@
 // Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
 #pragma once
 #include "job_barrier.hip.hpp"
+#include "chain.hip.hpp"
 
 namespace ecne {
 
@@ -498,6 +499,9 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #ifndef ECNE_BURST_C
 #define ECNE_BURST_C 8      // a round that commits fewer rows than this on a short queue switches to sequential bursts
 #endif
+#ifndef ECNE_CHAIN_BURST_C
+#define ECNE_CHAIN_BURST_C 12
+#endif
 #ifndef ECNE_WGROW
 #define ECNE_WGROW 2
 #endif
@@ -560,6 +564,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     uint32_t my_pops = 0, my_nnz = 0;
     unsigned long long pops_total = pops;
     uint32_t round = 0, burst = 0, next_burst = 16, window = ECNE_RPL * ECNE_WG;
+    // With the chain executor a sequential pop costs about a fifth of exec_row()'s, so a round has to commit
+    // more rows to be worth its latency, whatever the queue length; bursts grow further while the chain lasts.
+    const bool chain = chain_ok(J);
+    const uint32_t burst_c = chain ? ECNE_CHAIN_BURST_C : ECNE_BURST_C, burst_avail = chain ? 0xFFFFFFFFu : 64u, burst_max = chain ? 4096u : 512u;
     uint32_t mwindow = 16384;        // window of multi-workgroup rounds (adaptive like `window`)
     bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
     __syncthreads();
@@ -577,6 +585,11 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 unsigned long long st = 0, nu = 0, ht[16], pn = 0;
                 for (int i = 0; i < 16; ++i) ht[i] = 0;
                 uint32_t done = 0;
+                if (chain_ok(J)) {      // flags / in_queue tags in LDS, rows in one line: the chain executor
+                    unsigned long long pp = 0;
+                    chain_pops(J, qq, burst, 0, ht, st, nu, pp, pn);
+                    done = (uint32_t)pp;
+                } else
                 while (done < burst && qq.head != qq.tail && !J.ctr->error) {
                     const uint32_t rr = J.queue[qq.head & J.qmask];
                     qq.head++;
@@ -619,7 +632,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 q.tail = ntw;
                 pops_total += cw;
                 hits[13]++;
-                if (cw < ECNE_BURST_C && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+                if (cw < burst_c && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
                 if (cw == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
                 else if (cw < n / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
                 else next_burst = 16;
@@ -918,7 +931,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         hits[13]++;
         // adaptive: a short queue with a short independent prefix is a dependency chain -> sequential
         // burst, doubling while it stays that way
-        if (c < ECNE_BURST_C && avail < 64) { burst = next_burst; if (next_burst < 512) next_burst *= 2; }
+        if (c < burst_c && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
         if (c == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
         else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
         else next_burst = 16;

@@ -115,7 +115,7 @@ __device__ __noinline__ void exec_xy_lane(const Job& J, uint32_t row, const RowI
     bool bdirty[2] = {false, false};
     auto set_b = [&](int i, const fp::u256& nlb, const fp::u256& nub) {   // set_bounds()
         lb[i] = nlb; ub[i] = nub; bdirty[i] = true;
-        f[i] = (uint8_t)((f[i] & ~4u) | ((fp::is_zero(nlb) && fp::is_one(nub)) ? 4u : 0u));
+        f[i] = (uint8_t)((f[i] & ~12u) | bounds_class_bits(nlb, nub));
     };
     // R1 (:827-873): no A / B; exactly one non-unique variable of C becomes unique
     {
@@ -259,7 +259,7 @@ __device__ __noinline__ void exec_row_lane(const Job& J, uint32_t row, uint32_t*
                 st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));
                 st256(J.values + 8ull * x + 4, ld256(J.vals + 4ull * (ri.validx + 1)));
                 J.nvalues[x] = 2;
-                J.flags[x] |= 2;
+                J.flags[x] = (uint8_t)((J.flags[x] | 2) & ~16u);   // is_known; the group tag is gone (bit 4)
                 J.abz[x] = -1;
                 if (shape & SH_R2_IS01) set_bounds(J, x, fp::make(0), fp::make(1));
                 J.solved[row] = 1;

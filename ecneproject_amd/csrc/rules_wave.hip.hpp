@@ -25,11 +25,22 @@ __device__ __forceinline__ void raise_ranked(const Job& J, uint32_t queue_pos, i
     raise(J, code);
 }
 
+// flag bit 4 (16): the variable carries a group tag, abz != -1 (set by P4 :1425-1483, cleared by R2's make_values).
+// flag bits 2 and 3 summarise a variable's bounds: 4 = exactly [0,1] (what R4 asks, :1020-1029), 0 = still the
+// initial [0, p-1], 8 = anything else -- so that the common x == y pop decides "equal bounds?" from the flag
+// bytes alone (chain.hip.hpp); lb / ub themselves are only read when a bound of the third kind is involved.
+__device__ __forceinline__ uint32_t bounds_class_bits(const fp::u256& lb, const fp::u256& ub) {
+    if (fp::is_zero(lb)) {
+        if (fp::is_one(ub)) return 4u;
+        if (fp::eq(ub, fp::pminus1())) return 0u;
+    }
+    return 8u;
+}
 __device__ __forceinline__ void set_bounds(const Job& J, uint32_t v, const fp::u256& lb, const fp::u256& ub) {
     st256(J.lb + 4ull * v, lb);
     st256(J.ub + 4ull * v, ub);
     uint8_t f = J.flags[v];
-    f = (uint8_t)((f & ~4u) | ((fp::is_zero(lb) && fp::is_one(ub)) ? 4u : 0u));
+    f = (uint8_t)((f & ~12u) | bounds_class_bits(lb, ub));
     J.flags[v] = f;
 }
 
@@ -125,6 +136,15 @@ __device__ __noinline__ bool r7_top_fits(const Job& J, uint32_t last_k, bool neg
     return !fp::mul_gt_p(cl, ub1);
 }
 
+#ifdef ECNE_POPPROF
+// developer aid: where the time of a strictly sequential pop goes (queue_mode 1), 100 MHz ticks per stage
+struct PopProf { unsigned long long last, acc[8]; };
+__device__ __forceinline__ PopProf& pop_prof() { __shared__ PopProf p; return p; }
+#define ECNE_PT(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) { PopProf& pp_ = pop_prof(); const unsigned long long t_ = wall_clock64(); pp_.acc[k] += t_ - pp_.last; pp_.last = t_; } } while (0)
+#else
+#define ECNE_PT(k) do { } while (0)
+#endif
+
 // ---- one queue pop: rules R1..R8 on row `row`, in the reference's order (:824-1348)
 __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
                          unsigned long long& steps, unsigned long long& nuniq) {
@@ -138,6 +158,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
     // C is walked once: the R1 pass also gathers the statistics R7 / R8 need,
     // valid as long as no rule in between changes the state (R1 / R3..R6 firing invalidates them).
     const bool fuse = true;
+    ECNE_PT(2);
     bool st_valid = false, st_notknown = false, st_badgroup = false;
     uint32_t st_cnt = 0;
     int st_group = -2;
@@ -146,6 +167,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
         bool nu = false;
         for (uint32_t k = a0 + lane; k < a1; k += 64) nu |= !(J.flags[J.colA[k]] & 1);
         for (uint32_t k = b0 + lane; k < b1; k += 64) nu |= !(J.flags[J.colB[k]] & 1);
+        ECNE_PT(3);
         if (!__ballot(nu)) {
             uint32_t cnt = 0, u = 0;
             for (uint32_t base = c0; base < c1; base += 64) {
@@ -167,11 +189,13 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
             }
             st_cnt = cnt;
             st_valid = fuse;
+            ECNE_PT(4);
             if (cnt == 1) {
                 mark_unique(J, u);
                 nuniq++; steps++; hits[0]++;
                 requeue(J, q, u);
                 st_valid = false;
+                ECNE_PT(5);
             }
         }
     }
@@ -188,7 +212,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
                     st256(J.values + 8ull * x, ld256(J.vals + 4ull * ri.validx));
                     st256(J.values + 8ull * x + 4, ld256(J.vals + 4ull * (ri.validx + 1)));
                     J.nvalues[x] = 2;
-                    J.flags[x] |= 2;
+                    J.flags[x] = (uint8_t)((J.flags[x] | 2) & ~16u);   // is_known; the group tag is gone (bit 4)
                     J.abz[x] = -1;
                     if (shape & SH_R2_IS01) set_bounds(J, x, fp::make(0), fp::make(1));   // make_bounds (:923-927)
                     J.solved[row] = 1;
@@ -199,6 +223,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
             }
         }
     }
+    ECNE_PT(6);
     if (shape & SH_HAS_AB) return;   // (:944-946)
     const uint32_t l = c1 - c0;
 
@@ -385,6 +410,76 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
             }
         }
         // a first non-unique variable with abz == -1 leaves group == -1 and bad == true
+        if (cnt > 0 && !__ballot(bad)) {
+            hits[7]++;
+            uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
+            nuniq += n; steps += n;
+        }
+    }
+}
+
+// R7 then R8 of one row from the state in memory (the closing part of exec_row() without statistics carried over
+// from R1): what the chain executor calls in the rare case one of the two could fire after its own fast rules.
+__device__ __noinline__ void exec_r78_wave(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
+                                           unsigned long long& steps, unsigned long long& nuniq) {
+    const int lane = lane_id();
+    const uint32_t shape = J.rinfo[row].shape;
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    const uint32_t l = c1 - c0;
+    if (l == 0) return;
+    {   // R7 (:1235-1298)
+        uint32_t nunk = 0;
+        bool notknown = false;
+        for (uint32_t base = c0; base < c1; base += 64) {
+            uint32_t k = base + lane;
+            bool act = k < c1;
+            uint8_t f = act ? J.flags[J.colC[k]] : 1;
+            uint64_t m = __ballot(act && !(f & 1));
+            nunk += (uint32_t)__popcll(m);
+            if (act && !(f & 1) && !(f & 2)) notknown = true;
+        }
+        if (nunk > 0 && !__ballot(notknown)) {
+            const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            bool fail = false;
+            uint32_t carry_k = 0xFFFFFFFFu;
+            for (uint32_t sb = 0; sb < l; sb += 64) {
+                uint32_t s = sb + lane;
+                bool act = s < l;
+                uint32_t k = act ? c0 + J.csort[c0 + s] : 0;
+                uint32_t v = act ? J.colC[k] : 0;
+                bool nu = act && !(J.flags[v] & 1);
+                uint64_t m = __ballot(nu);
+                uint64_t below = m & lanes_below();
+                const int psrc = below ? 63 - __clzll((long long)below) : 0;
+                const uint32_t pk = __shfl(k, psrc, 64);
+                const uint32_t prev_k = below ? pk : carry_k;
+                if (nu && prev_k != 0xFFFFFFFFu && r7_link_fails(J, k, prev_k, negated)) fail = true;
+                if (m) carry_k = __shfl(k, 63 - __clzll((long long)m), 64);
+                if (__ballot(fail)) { fail = true; break; }
+            }
+            if (!__ballot(fail) && r7_top_fits(J, carry_k, negated)) {
+                steps += nunk; hits[6]++;
+                nuniq += uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
+            }
+        }
+    }
+    {   // R8 (:1304-1348)
+        int group = -1;
+        bool bad = false;
+        uint32_t cnt = 0;
+        for (uint32_t base = c0; base < c1; base += 64) {
+            uint32_t k = base + lane;
+            bool act = k < c1;
+            uint32_t v = act ? J.colC[k] : 0;
+            bool nu = act && !(J.flags[v] & 1);
+            int a = nu ? J.abz[v] : -1;
+            uint64_t m = __ballot(nu);
+            if (m) {
+                if (group == -1) group = __shfl(a, __ffsll((long long)m) - 1, 64);
+                if (nu && (a == -1 || a != group)) bad = true;
+                cnt += (uint32_t)__popcll(m);
+            }
+        }
         if (cnt > 0 && !__ballot(bad)) {
             hits[7]++;
             uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
