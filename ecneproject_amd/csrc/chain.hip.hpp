@@ -46,12 +46,19 @@ __device__ __forceinline__ void chain_window_load(const ECNE_GLOBAL uint32_t* qu
     cq.win = (int32_t)(cq.tail - pos) > 0 ? queue[pos & qmask] : 0u;
 }
 
-// push row r (held by lane src_lane of r_vec... the caller passes it wave-uniform) at the tail
+// push row r (wave-uniform) at the tail. A position inside the register window is written to the ring only when the
+// window is handed back (chain_window_flush): a store per pop would sit in front of the next pop's loads (the memory
+// counter is in-order) and its acknowledgement takes as long as a load.
 __device__ __forceinline__ void chain_push(ECNE_GLOBAL uint32_t* queue, uint32_t qmask, ChainQ& cq, uint32_t r) {
     const uint32_t pos = cq.tail;
-    if (lane_id() == 0) queue[pos & qmask] = r;
-    if ((uint32_t)lane_id() == pos - cq.wbase) cq.win = r;      // (no lane matches when the position is beyond the window)
+    if (pos - cq.wbase < 64u) { if ((uint32_t)lane_id() == pos - cq.wbase) cq.win = r; }
+    else if (lane_id() == 0) queue[pos & qmask] = r;
     cq.tail = pos + 1;
+}
+// the unpopped part of the window goes to the ring (before anybody else reads or extends the queue)
+__device__ __forceinline__ void chain_window_flush(ECNE_GLOBAL uint32_t* queue, uint32_t qmask, const ChainQ& cq) {
+    const uint32_t pos = cq.wbase + (uint32_t)lane_id();
+    if ((int32_t)(pos - cq.head) >= 0 && (int32_t)(cq.tail - pos) > 0) queue[pos & qmask] = cq.win;
 }
 
 // REQUEUE(v) (:628-633 lists, `if !in_queue[r] push!`), v's inline fan-out given wave-uniform
@@ -72,7 +79,7 @@ __device__ __forceinline__ void chain_requeue(const ECNE_GLOBAL uint32_t* fo_row
         const uint64_t m = __ballot(push);
         if (!m) continue;
         const uint32_t pos = cq.tail + (uint32_t)__popcll(m & lanes_below());
-        if (push) { queue[pos & qmask] = r; inq[r] = 1; }
+        if (push) { inq[r] = 1; if (pos - cq.wbase >= 64u) queue[pos & qmask] = r; }
         // mirror into the register window: position p belongs to lane p - wbase
         for (uint64_t mm = m; mm; mm &= mm - 1) {
             const int src = __ffsll((long long)mm) - 1;
@@ -104,7 +111,10 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
     ECNE_GLOBAL uint32_t* const queue = (ECNE_GLOBAL uint32_t*)uni(J.queue);
     const uint32_t qmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.qmask);
     ECNE_GLOBAL uint8_t* const solved = (ECNE_GLOBAL uint8_t*)uni(J.solved);      // (solved / flip3 / queue stay in device memory, see k_solve)
-    ECNE_GLOBAL uint8_t* const flip3 = (ECNE_GLOBAL uint8_t*)uni(J.flip3);
+    // the orientation bytes of the x == y rows (R4, :1001-1011): in LDS when they fit, else device memory
+    const bool flip_lds = J.lds_flip_off != 0xFFFFFFFFu;
+    uint8_t* const flipL = (uint8_t*)(ecne_dyn_lds + (flip_lds ? J.lds_flip_off : 0u));
+    ECNE_GLOBAL uint8_t* const flipG = flip_lds ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flip3);
     // counters live in registers here (the by-reference ones are memory: one round trip per increment) and are
     // folded in before every call that takes the references and at the end
     uint32_t c_steps = 0, c_nuniq = 0, c_pops = 0, c_nnz = 0, c_h0 = 0, c_h1 = 0, c_h3 = 0, c_h4 = 0;
@@ -127,6 +137,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
     auto fetch_row = [&](uint32_t pos) {
         uint32_t i = pos - cq.wbase;
         if (i >= 64) {              // beyond the window: the next 64 entries (our own stores have to have landed)
+            chain_window_flush(queue, qmask, cq);
             wg_fence();
             chain_window_load(queue, qmask, cq);
             i = pos - cq.wbase;
@@ -137,10 +148,13 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
         if (lane < 16) pf_w = rec[16u * pf_row + (uint32_t)lane];
         else if (lane < 24) pf_w = rinfo[8u * pf_row + (uint32_t)(lane - 16)];
         pf_solved = solved[pf_row];
-        pf_flip = flip3[pf_row];
+        pf_flip = flip_lds ? flipL[pf_row] : flipG[pf_row];
     };
     while (cq.head != cq.tail && done < max_pops && !stop) {
         if (stop_avail && cq.tail - cq.head > stop_avail) break;
+#ifdef ECNE_AVAILHIST
+        if (threadIdx.x == 0) { const uint32_t a_ = cq.tail - cq.head; pop_prof().acc[a_ <= 1 ? 0 : a_ <= 2 ? 1 : a_ <= 4 ? 2 : a_ <= 8 ? 3 : a_ <= 16 ? 4 : a_ <= 64 ? 5 : a_ <= 512 ? 6 : 7]++; }
+#endif
         ECNE_PT(7);
         if (pf_pos != cq.head) fetch_row(cq.head);
         const uint32_t row = pf_row;
@@ -177,6 +191,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
             QState qq;
             qq.head = cq.head; qq.tail = cq.tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
             flush();
+            chain_window_flush(queue, qmask, cq);
             wg_fence();
             exec_row(J, qq, row, hits, steps, nuniq);
             wg_fence();
@@ -252,7 +267,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
             // R4 (:991-1076), l == 2: the row is negated on every visit, the pivot alternates
             {
                 const uint8_t o = (uint8_t)(flip_in ^ 1);
-                if (lane == 0) flip3[row] = o;
+                if (lane == 0) { if (flip_lds) flipL[row] = o; else flipG[row] = o; }
                 const uint32_t new_key = o ? kneg : kpos;
                 const bool n_is_a = new_key == k1;
                 uint8_t& fn = n_is_a ? fa : fb;
@@ -297,6 +312,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
                 QState qq;
                 qq.head = cq.head; qq.tail = cq.tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
                 flush();
+                chain_window_flush(queue, qmask, cq);
                 wg_fence();
                 exec_r78_wave(J, qq, row, hits, steps, nuniq);
                 wg_fence();
@@ -315,6 +331,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
                 QState qq;
                 qq.head = cq.head; qq.tail = cq.tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
                 flush();
+                chain_window_flush(queue, qmask, cq);
                 wg_fence();
                 exec_r78_wave(J, qq, row, hits, steps, nuniq);
                 wg_fence();
@@ -324,6 +341,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
         }
     }
     flush();
+    chain_window_flush(queue, qmask, cq);
     wg_fence();
     q.head = cq.head;
     q.tail = cq.tail;

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         };
         if (unsigned char* p = take((size_t)nV + 1)) { J.flags = (uint8_t*)p; J.lds_flags_off = (uint32_t)(p - ecne_dyn_lds); }
         if (unsigned char* p = take(2ull * (nC ? nC : 1))) { J.inq = (uint16_t*)p; J.lds_inq_off = (uint32_t)(p - ecne_dyn_lds); }
+        if (unsigned char* p = take(nC ? nC : 1)) { J.flip3 = (uint8_t*)p; J.lds_flip_off = (uint32_t)(p - ecne_dyn_lds); }
     }
     __syncthreads();
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }

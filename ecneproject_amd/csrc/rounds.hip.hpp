@@ -499,6 +499,9 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #ifndef ECNE_BURST_C
 #define ECNE_BURST_C 8      // a round that commits fewer rows than this on a short queue switches to sequential bursts
 #endif
+#ifndef ECNE_CHAIN_AVAIL
+#define ECNE_CHAIN_AVAIL 0      // queue length up to which the chain executor pops without trying a round first (measured: wave rounds win from 3-4 rows; 0 = off)
+#endif
 #ifndef ECNE_CHAIN_BURST_C
 #define ECNE_CHAIN_BURST_C 12
 #endif
@@ -576,6 +579,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
         if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
         const uint32_t avail = q.tail - q.head;
+        // chain executor: a short queue is popped sequentially right away (a round over a handful of rows costs more
+        // than their pops, ~0.8 us each), until the queue is empty or a frontier has built up again
+        uint32_t burst_stop = 0;
+        if (chain && !burst && avail <= ECNE_CHAIN_AVAIL) { burst = 1u << 20; burst_stop = 2 * ECNE_CHAIN_AVAIL; }
         if (burst) {
             // The last chunk round committed only a handful of rows (a dependency chain): pop the next
             // `burst` rows strictly sequentially on wave 0 (cheaper per pop than a round), then look again.
@@ -587,7 +594,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 uint32_t done = 0;
                 if (chain_ok(J)) {      // flags / in_queue tags in LDS, rows in one line: the chain executor
                     unsigned long long pp = 0;
-                    chain_pops(J, qq, burst, 0, ht, st, nu, pp, pn);
+                    chain_pops(J, qq, burst, burst_stop, ht, st, nu, pp, pn);
                     done = (uint32_t)pp;
                 } else
                 while (done < burst && qq.head != qq.tail && !J.ctr->error) {

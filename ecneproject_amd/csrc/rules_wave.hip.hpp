@@ -140,7 +140,11 @@ __device__ __noinline__ bool r7_top_fits(const Job& J, uint32_t last_k, bool neg
 // developer aid: where the time of a strictly sequential pop goes (queue_mode 1), 100 MHz ticks per stage
 struct PopProf { unsigned long long last, acc[8]; };
 __device__ __forceinline__ PopProf& pop_prof() { __shared__ PopProf p; return p; }
+#ifdef ECNE_AVAILHIST
+#define ECNE_PT(k) do { } while (0)
+#else
 #define ECNE_PT(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) { PopProf& pp_ = pop_prof(); const unsigned long long t_ = wall_clock64(); pp_.acc[k] += t_ - pp_.last; pp_.last = t_; } } while (0)
+#endif
 #else
 #define ECNE_PT(k) do { } while (0)
 #endif

@@ -1,0 +1,24 @@
+"""Developer aid (GPU box): one reference configuration (fixture + trusted functions), timing + schedule diagnostics.
+python tools/solve_case.py secp|withdraw|commit|<fixture relpath> [mode ...]"""
+import os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+import ecneproject_amd as E, fixtures
+CASES = {"secp": ("secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"]),
+         "withdraw": ("tornadocash_circuits/withdraw.r1cs", fixtures.PED, fixtures.PED_NAMES),
+         "commit": ("tornadocash_circuits/commitHasher.r1cs", fixtures.PED, fixtures.PED_NAMES)}
+rel, tr, nm = CASES.get(sys.argv[1], (sys.argv[1], [], []))
+fl = sorted([(n, E.R1CS(fixtures.path(t))) for t, n in zip(tr, nm)], key=lambda x: -len(x[1]))
+s = E.System(E.R1CS(fixtures.path(rel)))
+for n, f in fl:
+    s.abstract(f, n)
+for mode in ([int(m) for m in sys.argv[2:]] or [0]):
+    best = None
+    for rep in range(3):
+        r = E.solve_batch([s], secp_solve=True, fetch_states=False, queue_mode=mode)[0]
+        if best is None or r.summary.device_ms < best.summary.device_ms:
+            best = r
+    sm = best.summary
+    print(rel, "mode", mode, "rows", len(s), "status", best.status, "dev_ms %.3f" % sm.device_ms, "pops", sm.pops, "outer", sm.outer_iterations,
+          "rounds", sm.rule_hits[13], "alone", sm.rule_hits[14] & 0xFFFF, "\n   phases[setup,P1+P2+queue,P3,P4,P5,verdict]", [round(x, 3) for x in sm.phase_ms[:6]], "P3 passes", int(sm.phase_ms[6]),
+          "\n   queue[head,mark,check,exec,flatten,resolve,alone+bursts+wave,multi]", [round(x, 3) for x in sm.queue_ms[:8]], "\n   hits", list(sm.rule_hits[:13]))
