@@ -438,28 +438,38 @@ static int upload_system(ecne_system& S, int device) {
     for (uint32_t r = 0; r < nC; ++r) if (L.rinfo[r].shape & SH_BIG) long_list.push_back(r);
     size_t o_long = c.take(4ull * std::max<size_t>(long_list.size(), 1));
     size_t o_p5r = c.take(4ull * std::max<size_t>(L.p5_rows.size(), 1)), o_p5y = c.take(4ull * std::max<size_t>(L.p5_y.size(), 1));
-    // chain executor tables (systems small enough for one workgroup): the row in one line, the fan-out inline
-    const bool chain = nC <= ECNE_CHAIN_ROWS;
-    std::vector<uint32_t> rec, foi;
-    if (chain) {
-        rec.assign(16ull * std::max<size_t>(nC, 1), 0);
-        for (uint32_t r = 0; r < nC; ++r) {
-            const uint32_t la = L.rp[0][r + 1] - L.rp[0][r], lb = L.rp[1][r + 1] - L.rp[1][r], lc = L.rp[2][r + 1] - L.rp[2][r];
-            if (la + lb + lc > 15) continue;
-            uint32_t* w = &rec[16ull * r];
-            w[0] = la | lb << 8 | lc << 16 | 1u << 24;
-            uint32_t k = 1;
-            for (int p = 0; p < 3; ++p)
-                for (uint32_t e = L.rp[p][r]; e < L.rp[p][r + 1]; ++e) w[k++] = L.col[p][e];
-        }
-        foi.assign(4ull * L.fo_ptr.size(), 0);
-        for (size_t v = 0; v + 1 < L.fo_ptr.size(); ++v) {
-            const uint32_t f0 = L.fo_ptr[v], n = L.fo_ptr[v + 1] - f0;
-            uint32_t* w = &foi[4 * v];
-            w[0] = n;
-            if (n <= 3) for (uint32_t i = 0; i < n; ++i) w[1 + i] = L.fo_rows[f0 + i];
-            else w[1] = f0;
-        }
+    // row records and inline fan-out lists (chain executor, fast wavefront rounds): the row in one line, the fan-out inline
+    const bool chain = true;
+    std::vector<uint32_t, RawAlloc<uint32_t>> rec, foi;
+    {
+        rec.resize(16ull * std::max<size_t>(nC, 1));
+        const size_t RB = 8192, nrb = ((size_t)nC + RB - 1) / RB;
+        if (nC == 0) std::fill(rec.begin(), rec.end(), 0u);
+        for_chunks(nrb, [&](size_t blk, unsigned) {
+            for (uint32_t r = (uint32_t)(blk * RB); r < std::min<size_t>(nC, (blk + 1) * RB); ++r) {
+                const uint32_t la = L.rp[0][r + 1] - L.rp[0][r], lb = L.rp[1][r + 1] - L.rp[1][r], lc = L.rp[2][r + 1] - L.rp[2][r];
+                uint32_t* w = &rec[16ull * r];
+                std::memset(w, 0, 64);
+                if (la + lb + lc > 15) continue;
+                w[0] = la | lb << 8 | lc << 16 | 1u << 24;
+                uint32_t k = 1;
+                for (int p = 0; p < 3; ++p)
+                    for (uint32_t e = L.rp[p][r]; e < L.rp[p][r + 1]; ++e) w[k++] = L.col[p][e];
+            }
+        });
+        const size_t nvar = L.fo_ptr.size() - 1;
+        foi.resize(4ull * L.fo_ptr.size());
+        std::memset(&foi[4 * nvar], 0, 16);
+        const size_t nvb = (nvar + RB - 1) / RB;
+        for_chunks(nvb, [&](size_t blk, unsigned) {
+            for (size_t v = blk * RB; v < std::min(nvar, (blk + 1) * RB); ++v) {
+                const uint32_t f0 = L.fo_ptr[v], n = L.fo_ptr[v + 1] - f0;
+                uint32_t* w = &foi[4 * v];
+                w[0] = n; w[1] = w[2] = w[3] = 0;
+                if (n <= 3) for (uint32_t i = 0; i < n; ++i) w[1 + i] = L.fo_rows[f0 + i];
+                else w[1] = f0;
+            }
+        });
     }
     size_t o_rec = c.take(4ull * std::max<size_t>(rec.size(), 4)), o_foi = c.take(4ull * std::max<size_t>(foi.size(), 4));
     const size_t static_end = c.off;   // [o_rp[0], static_end): everything the solve only reads
@@ -573,7 +583,7 @@ static int upload_system(ecne_system& S, int device) {
     J.ctr = (Counters*)(base + o_ctr);
     J.rec = chain ? (const uint32_t*)(base + o_rec) : nullptr;
     J.foi = chain ? (const uint32_t*)(base + o_foi) : nullptr;
-    J.lds_flags_off = J.lds_inq_off = J.lds_flip_off = 0xFFFFFFFFu;
+    J.lds_flags_off = J.lds_inq_off = J.lds_flip_off = J.lds_w2_off = 0xFFFFFFFFu;
     J.warm_bytes = (static_end - o_rp[0]) <= (7u << 19) ? (uint32_t)(static_end - o_rp[0]) : 0u;   // fits one XCD's 4 MB L2 beside the state
     S.dev.classified = false;
     return K_OK;
@@ -812,7 +822,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
         for (size_t i = 0; i < n; ++i) {
             uint32_t want = (hj[i].nC + ECNE_ROWS_PER_WG - 1u) / ECNE_ROWS_PER_WG;
             // a system whose flags and in_queue tags fit the LDS is solved by ONE workgroup (chain executor, chain.hip.hpp)
-            const bool lds_fits = hj[i].rec && ((size_t)hj[i].nV + 1 + 16) + (2ull * hj[i].nC + 16) <= dyn_lds;
+            const bool lds_fits = hj[i].rec && hj[i].nC <= ECNE_CHAIN_ROWS && ((size_t)hj[i].nV + 1 + 16) + (2ull * hj[i].nC + 16) + 8192 <= dyn_lds;
             if (hj[i].nC <= single_wg_rows || (lds_fits && !getenv("ECNE_SINGLE_WG_ROWS"))) want = 1;
             if (o.debug > 0) want = (uint32_t)o.debug;          // test hook: force the helper count
             hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
@@ -877,6 +887,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             s.classify_ms = S.dev.classify_ms;
             for (int k = 0; k < 8; ++k) s.queue_ms[k] = (double)c.qticks[k] * 1e-5;
             for (int k = 0; k < 8; ++k) s.multi_ms[k] = (double)c.mticks[k] * 1e-5;
+            for (int k = 0; k < 16; ++k) s.sched[k] = (int64_t)c.sched[k];
             for (int k = 0; k < 8; ++k) s.phase_ms[k] = (k == 6) ? (double)c.phase_ticks[k] : (double)c.phase_ticks[k] * 1e-5;
             out[i] = r;
         }

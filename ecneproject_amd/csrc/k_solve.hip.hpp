@@ -32,9 +32,10 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     // chain executor (chain.hip.hpp) reads them with ds_read (27 ns). The host reads the flags afterwards: they
     // are copied back before the verdict count.
     uint8_t* const g_flags = J.flags;
-    if (J.nwg == 1 && J.lds_bytes && tid == 0) {
+    if (tid == 0) J.lds_w2_off = J.lds_bytes >= ECNE_W2_BYTES ? J.lds_bytes - ECNE_W2_BYTES : 0xFFFFFFFFu;   // tables of the fast wavefront round (top of the dynamic LDS)
+    if (J.nwg == 1 && J.lds_bytes > ECNE_W2_BYTES && tid == 0) {
         uint32_t off = 0;
-        const uint32_t cap = J.lds_bytes;
+        const uint32_t cap = J.lds_bytes - ECNE_W2_BYTES;
         auto take = [&](size_t bytes) -> unsigned char* {
             const uint32_t b = ((uint32_t)bytes + 15u) & ~15u;
             if (bytes > cap || off + b > cap) return nullptr;
@@ -47,7 +48,9 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         if (unsigned char* p = take(nC ? nC : 1)) { J.flip3 = (uint8_t*)p; J.lds_flip_off = (uint32_t)(p - ecne_dyn_lds); }
     }
     __syncthreads();
+    if (J.lds_w2_off != 0xFFFFFFFFu) w2_tables_init(J.lds_w2_off);
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
+    if (tid < 16) s_chunk.sd[tid] = 0;
 #ifdef ECNE_POPPROF
     if (tid < 8) pop_prof().acc[tid] = 0;
 #endif
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 if (seq_mode) for (int i = 0; i < 8; ++i) ctr->qticks[i] = pop_prof().acc[i];
 #endif
                 for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
+                for (int i = 0; i < 16; ++i) ctr->sched[i] = s_chunk.sd[i];
             }
         }
     }

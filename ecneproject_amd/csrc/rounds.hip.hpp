@@ -3,6 +3,7 @@
 #pragma once
 #include "job_barrier.hip.hpp"
 #include "chain.hip.hpp"
+#include "wave2.hip.hpp"
 
 namespace ecne {
 
@@ -514,6 +515,21 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #ifndef ECNE_MULTI_MIN
 #define ECNE_MULTI_MIN 128    // queued rows from which a round runs on all workgroups of the job (measured optimum)
 #endif
+#ifndef ECNE_V2_DECLINES
+#define ECNE_V2_DECLINES 4
+#endif
+#ifndef ECNE_V2_WINDOW
+#define ECNE_V2_WINDOW 1024
+#endif
+#ifndef ECNE_V2_AVAIL
+#define ECNE_V2_AVAIL 512     // ... when the fast wavefront round is available: it takes 64 rows in ~7 us, a multi-workgroup round costs ~55 us
+#endif
+// (the same value on every workgroup of the job: the chained rounds derive their schedule from it)
+__device__ __forceinline__ bool fast_wave_ok(const Job& J) { return J.rec != nullptr && J.lds_w2_off != 0xFFFFFFFFu; }
+__device__ __forceinline__ uint32_t multi_min(const Job& J) { return fast_wave_ok(J) ? ECNE_V2_AVAIL : ECNE_MULTI_MIN; }
+// the adaptive single-workgroup window has to have grown this far (rounds committing everything they looked at, doubling
+// it) before a round goes to all workgroups: with the fast round a multi-workgroup round pays from ~500 committed rows
+__device__ __forceinline__ uint32_t multi_window_min(const Job& J) { return fast_wave_ok(J) ? ECNE_V2_WINDOW : ECNE_MULTI_MIN; }
 // ---- chained multi-workgroup rounds
 // After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
 // decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
@@ -537,7 +553,7 @@ __device__ __forceinline__ void multi_window_update(uint32_t cm, uint32_t nm, ui
 __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head, uint32_t tail, uint32_t window, uint32_t mwindow) {
     const uint32_t avail = tail - head;
     const uint32_t n = avail < window ? avail : window;
-    if (n <= 64 || avail < ECNE_MULTI_MIN || window < ECNE_MULTI_MIN) return 0;
+    if (n <= 64 || avail < multi_min(J) || window < multi_window_min(J)) return 0;
     const uint32_t row0 = J.queue[head & J.qmask];
     const uint32_t shape0 = J.rinfo[row0].shape;
     if ((shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0)) return 0;   // a long row that is popped alone
@@ -570,6 +586,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     // With the chain executor a sequential pop costs about a fifth of exec_row()'s, so a round has to commit
     // more rows to be worth its latency, whatever the queue length; bursts grow further while the chain lasts.
     const bool chain = chain_ok(J);
+    const bool v2 = fast_wave_ok(J);
+    bool declined_wide = false;      // the fast wavefront round keeps declining the head row of a wide frontier
+    uint32_t declined_run = 0;
     const uint32_t burst_c = chain ? ECNE_CHAIN_BURST_C : ECNE_BURST_C, burst_avail = chain ? 0xFFFFFFFFu : 64u, burst_max = chain ? 4096u : 512u;
     uint32_t mwindow = 16384;        // window of multi-workgroup rounds (adaptive like `window`)
     bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
@@ -623,25 +642,53 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         }
         // adaptive window: examining rows that end up behind the cut is wasted work, so the window
         // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
-        const uint32_t n = avail < window ? avail : window;
-        if (n <= 64) {
+        uint32_t n = avail < window ? avail : window;
+        // with the fast wavefront round a frontier below the multi-workgroup threshold is taken 64 rows at a time
+        if (v2 && n > 64 && J.nwg > 1 && !declined_wide && (avail < multi_min(J) || window < multi_window_min(J))) n = 64;
+        if (n <= 64 && !declined_wide) {
             // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
             if (w == 0) {
-                uint32_t nt = q.tail;
-                const uint32_t cw = queue_round_wave(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &hits[15]);
-                if (lane == 0) { S.nbig = cw; S.tail = nt; }
+                uint32_t nt = q.tail, nx = n;
+                uint32_t cw = 0xFFFFFFFFu;
+                // the fast round on row records first; it declines (nothing touched) what it does not cover
+                if (v2)
+                    cw = chain ? queue_round_wave2<true>(J, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
+                               : queue_round_wave2<false>(J, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
+                const bool fast = cw < 0xFFFFFFFEu;
+                // declined at rank 0: a single-workgroup job (or a long row) takes the general wavefront round; the master of a
+                // multi-workgroup job pops that one row with the general executor (narrow level) or goes to a round on all
+                // workgroups (wide frontier), see below
+                if (cw == 0xFFFFFFFFu || (cw == 0xFFFFFFFEu && J.nwg == 1)) cw = queue_round_wave(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &hits[15]);
+                if (lane == 0) { S.nbig = cw; S.tail = nt; S.flag7 = fast ? 1u : 0u; S.bl_tmp[0] = nx; }
             }
             __syncthreads();
-            const uint32_t cw = S.nbig, ntw = S.tail;
+            const uint32_t cw = S.nbig, ntw = S.tail, nx = S.bl_tmp[0];   // nx: rows the round examined (the fast round may stop short of n)
             __syncthreads();
+            if (cw == 0xFFFFFFFEu) {     // the fast round declined the row at the head
+                // one sequential pop of that row, then look again -- unless the head of a wide frontier keeps being declined
+                // (thousands of constant rows, say): then all workgroups take it
+                if (avail >= multi_min(J) && ++declined_run >= ECNE_V2_DECLINES) { declined_wide = true; declined_run = 0; }
+                else burst = 1;
+                continue;
+            }
             if (cw != 0xFFFFFFFFu) {
+#ifdef ECNE_FINE_TICKS
+                if (tid == 0) {    // schedule diagnostics: fast / general wavefront rounds, rows, ticks
+                    const unsigned long long dt_ = wall_clock64() - qt_last;
+                    const int b_ = S.flag7 ? 0 : 3;
+                    S.sd[b_] += 1; S.sd[b_ + 1] += cw; S.sd[b_ + 2] += dt_;
+                }
+#endif
                 q.head += cw;
                 q.tail = ntw;
                 pops_total += cw;
                 hits[13]++;
-                if (cw < burst_c && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
-                if (cw == n) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
-                else if (cw < n / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
+                declined_run = 0;
+                // (single-workgroup jobs: a short prefix goes to the chain executor whatever stopped it -- rows the fast round
+                //  does not take are cheap there; the master of a large job only bursts on true dependency chains)
+                if (cw < burst_c && (chain || cw < nx) && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
+                if (cw == nx) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+                else if (cw < nx / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
                 else next_burst = 16;
                 QTICK(6);
                 continue;
@@ -663,13 +710,16 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 if (!J.solved[row[sl]]) live |= 1u << sl;
             }
         }
-        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && !big_plain(shape[0])) ? 1u : 0u; }
+        // a live long row at the head is popped alone when it cannot ride along in a round (R2..R6 shapes) -- or when the
+        // window is narrow anyway: a workgroup round for a handful of rows costs ten times the long row's own pop
+        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && (!big_plain(shape[0]) || n <= 64)) ? 1u : 0u; }
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
             if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
-        if (!S.fallback && J.nwg > 1 && avail >= ECNE_MULTI_MIN && window >= ECNE_MULTI_MIN) {
+        if (!S.fallback && J.nwg > 1 && avail >= multi_min(J) && (window >= multi_window_min(J) || declined_wide)) {
+            declined_wide = false;
             // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
             const uint32_t cap_n = J.nwg * ECNE_WG * 2;
             uint32_t nm = avail < cap_n ? avail : cap_n;
@@ -690,6 +740,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 hits[13]++;
                 hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
                 hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
+                if (tid == 0) S.sd[cm < 64 ? 13 : cm < 4096 ? 14 : 15] += 1;   // schedule diagnostics: multi rounds by rows committed
                 multi_window_update(cm, nm, cap_n, mwindow, window);
                 nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow) : 0;
                 if (!nm) break;

@@ -250,6 +250,7 @@ struct ChunkShared {   // LDS of the chunked queue phase
     uint32_t bl_n, bl_any, bl_rank[ECNE_BIGK], bl_row[ECNE_BIGK], bl_nev[ECNE_BIGK], bl_deg[ECNE_BIGK], bl_base[ECNE_BIGK];
     uint32_t bl_tmp[8];
     uint32_t hasbig;
+    unsigned long long sd[16];  // schedule diagnostics (ecne_summary.sched)
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)
     unsigned long long qt[8];   // diagnostics: 100 MHz ticks in head / mark / check+unmark / exec / flatten / resolve / big / n
 };

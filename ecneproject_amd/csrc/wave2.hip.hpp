@@ -1,0 +1,364 @@
+// wave2.hip.hpp — the fast wavefront round: a window of up to 64 queue entries, one lane per row, decided from the
+// one-line row records and the flag bytes alone, committed in queue order.
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+//
+// queue_round_wave() (rounds.hip.hpp) walks CSR rows three times per round (no-op test, access sets, execution),
+// keeps its REQUEUE candidates and their per-target minima in device memory and costs ~23 us per round on the master
+// of a large job -- about a hundred dependent memory round trips. The narrow dependency levels it serves are half of
+// the solve time of ecdsa_like(26) for 0.4 % of its pops. This round needs five:
+//   1. the window's rows (one coalesced load of the ring);
+//   2. per lane: the 64-byte record rec[row], its RowInfo, solved and orientation bytes;
+//   3. the flag bytes of the row's variables (all loads in flight together);
+//      -> every lane now DECIDES its pop in registers (what the four common shapes do is a function of the flag bytes:
+//         products R1, bit checks R2, x == y rows R1/R4/R5 through the bounds-class bits, plain sums R1) without
+//         writing anything; written variables are marked in an LDS table, every lane looks its read set up: a lane is
+//         blocked iff an EARLIER rank writes something it reads. The prefix below the first blocked rank is exactly
+//         what sequential pops would do (decide-then-commit: only true dependencies matter, later writers of what an
+//         earlier row reads commit after its decision was taken);
+//   4. inline fan-out lists foi[v] of the emitted REQUEUE events and the in_queue tags of their targets;
+//      -> candidates (rank, event, position) are numbered by a wave scan; a target is eligible iff it is not queued as of
+//         the candidate's rank (not queued at all, or itself popped at a rank <= the candidate's: LDS table of the
+//         prefix rows); the lowest eligible candidate per target wins (LDS table), winners are appended in candidate order;
+//   5. the stores' completion.
+// Anything else -- another shape, more than 15 entries, a bound that is neither [0,1] nor [0,p-1], R7 / R8 in reach,
+// an event with more than 3 target rows, errors -- ends the window in front of that row; at rank 0 the round declines
+// (nothing touched): 0xFFFFFFFE = pop that one row with the general executor, 0xFFFFFFFF = a long row (> 64 entries) for the
+// general round, which runs it on the whole workgroup.
+#pragma once
+#include "chain.hip.hpp"
+
+namespace ecne {
+
+// LDS tables of the round, at the top of the dynamic LDS (k_solve keeps the state of single-workgroup jobs below them):
+// key / value pairs, linear probing, never more than half full, wiped after every round.
+#define ECNE_W2_MARKS 256      // write marks: variable -> lowest writer rank (<= 64 rows x 2 written variables)
+#define ECNE_W2_ROWS 128       // rows of the prefix -> rank
+#define ECNE_W2_TGT 512        // push targets -> lowest eligible candidate index
+#define ECNE_W2_MAXCAND 256    // candidates one round resolves
+#define ECNE_W2_BYTES (8u * (ECNE_W2_MARKS + ECNE_W2_ROWS + ECNE_W2_TGT))
+
+struct W2Tab { uint32_t* key; uint32_t* val; uint32_t mask, shift; };
+__device__ __forceinline__ void w2_min(const W2Tab& t, uint32_t key, uint32_t v) {          // key != 0
+    uint32_t s = (key * 2654435761u) >> t.shift;
+    for (;;) {
+        const uint32_t k = atomicCAS(&t.key[s], 0u, key);
+        if (k == 0u || k == key) { atomicMin(&t.val[s], v); return; }
+        s = (s + 1) & t.mask;
+    }
+}
+__device__ __forceinline__ uint32_t w2_get(const W2Tab& t, uint32_t key) {
+    uint32_t s = (key * 2654435761u) >> t.shift;
+    for (;;) {
+        const uint32_t k = t.key[s];
+        if (k == key) return t.val[s];
+        if (k == 0u) return 0xFFFFFFFFu;
+        s = (s + 1) & t.mask;
+    }
+}
+// all threads of the workgroup, once per launch
+__device__ __forceinline__ void w2_tables_init(uint32_t w2_off) {
+    uint32_t* const base = (uint32_t*)(ecne_dyn_lds + w2_off);
+    const uint32_t nslots = ECNE_W2_MARKS + ECNE_W2_ROWS + ECNE_W2_TGT;
+    for (uint32_t i = threadIdx.x; i < nslots; i += ECNE_WG) { base[i] = 0u; base[nslots + i] = 0xFFFFFFFFu; }
+}
+
+template <bool LDS>
+__device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
+                                                   uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail, uint32_t* out_examined,
+                                                   unsigned long long* why) {
+    const int lane = lane_id();
+    const uint32_t rank = (uint32_t)lane;
+    auto uni = [](const void* p) -> uint64_t {
+        const uint64_t x = (uint64_t)p;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    };
+    const ECNE_GLOBAL u32x4* const rec = (const ECNE_GLOBAL u32x4*)uni(J.rec);
+    const ECNE_GLOBAL u32x4* const foi = (const ECNE_GLOBAL u32x4*)uni(J.foi);
+    const ECNE_GLOBAL u32x4* const rinfo = (const ECNE_GLOBAL u32x4*)uni(J.rinfo);
+    ECNE_GLOBAL uint32_t* const queue = (ECNE_GLOBAL uint32_t*)uni(J.queue);
+    const uint32_t qmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.qmask);
+    ECNE_GLOBAL uint8_t* const solved = (ECNE_GLOBAL uint8_t*)uni(J.solved);
+    // flags / in_queue tags / orientation bytes: LDS (single-workgroup job, resident) or device memory
+    uint8_t* const Fl = (uint8_t*)(ecne_dyn_lds + (LDS ? J.lds_flags_off : 0u));
+    uint16_t* const Ql = (uint16_t*)(ecne_dyn_lds + (LDS ? J.lds_inq_off : 0u));
+    ECNE_GLOBAL uint8_t* const Fg = LDS ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flags);
+    ECNE_GLOBAL uint16_t* const Qg = LDS ? (ECNE_GLOBAL uint16_t*)nullptr : (ECNE_GLOBAL uint16_t*)uni(J.inq);
+    const bool flip_lds = LDS && J.lds_flip_off != 0xFFFFFFFFu;
+    uint8_t* const flipL = (uint8_t*)(ecne_dyn_lds + (flip_lds ? J.lds_flip_off : 0u));
+    ECNE_GLOBAL uint8_t* const flipG = flip_lds ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flip3);
+    auto ldF = [&](uint32_t v) -> uint8_t { if constexpr (LDS) return Fl[v]; else return Fg[v]; };
+    auto stF = [&](uint32_t v, uint8_t f) { if constexpr (LDS) Fl[v] = f; else Fg[v] = f; };
+    auto ldQ = [&](uint32_t r) -> uint16_t { if constexpr (LDS) return Ql[r]; else return Qg[r]; };
+    auto stQ = [&](uint32_t r, uint16_t x) { if constexpr (LDS) Ql[r] = x; else Qg[r] = x; };
+    uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + J.lds_w2_off);
+    const uint32_t NS = ECNE_W2_MARKS + ECNE_W2_ROWS + ECNE_W2_TGT;
+    const W2Tab Tm = {tb, tb + NS, ECNE_W2_MARKS - 1, 32 - 8};
+    const W2Tab Tr = {tb + ECNE_W2_MARKS, tb + NS + ECNE_W2_MARKS, ECNE_W2_ROWS - 1, 32 - 7};
+    const W2Tab Tt = {tb + ECNE_W2_MARKS + ECNE_W2_ROWS, tb + NS + ECNE_W2_MARKS + ECNE_W2_ROWS, ECNE_W2_TGT - 1, 32 - 9};
+
+    // ---- 1, 2: my row
+    const bool mine = rank < n;
+    uint32_t row = 0;
+    if (mine) row = queue[(head + rank) & qmask];
+    u32x4 w4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ri4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint8_t is_solved = 0, flip_in = 0;
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[i] = rec[4u * row + (uint32_t)i];
+        ri4[0] = rinfo[2u * row]; ri4[1] = rinfo[2u * row + 1u];
+        is_solved = solved[row];
+        flip_in = flip_lds ? flipL[row] : flipG[row];
+    }
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[4 * i] = w4[i].x; w[4 * i + 1] = w4[i].y; w[4 * i + 2] = w4[i].z; w[4 * i + 3] = w4[i].w; }
+    const uint32_t shape = ri4[0].x, rx = ri4[0].y, kpos = ri4[0].z, kneg = ri4[0].w, k1 = ri4[1].x, k2 = ri4[1].y, validx = ri4[1].z;
+    const uint32_t nA = w[0] & 0xFFu, nB = (w[0] >> 8) & 0xFFu, nCc = (w[0] >> 16) & 0xFFu, nE = nA + nB + nCc;
+    const bool xy = (shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2);
+    const bool f1 = (shape & SH_HAS_AB) && !(shape & SH_C_EMPTY);
+    const bool f2 = (shape & SH_C_EMPTY) != 0;
+    const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+    const bool live = mine && !is_solved;
+    // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
+    bool slow = mine && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4))));
+    uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
+    // ---- 3: flag bytes
+    const bool walk = live && !slow && !xy && !f2;        // products and plain sums look at every entry
+    uint8_t fl[15];
+#pragma unroll
+    for (uint32_t e = 0; e < 15; ++e) fl[e] = (walk && e < nE) ? ldF(w[1 + e]) : (uint8_t)3;
+    uint8_t fa = 3, fb = 3, fx = 3;
+    if (live && !slow && xy) { fa = ldF(k1); fb = ldF(k2); }
+    if (live && !slow && f2 && (shape & SH_R2)) fx = ldF(rx);
+    // ---- the decision, in registers
+    uint32_t wva = 0, wvb = 0;            // variables whose flag byte (and maybe bounds) this pop changes
+    uint8_t wfa = 0, wfb = 0;
+    bool wa = false, wb = false, a01 = false, b01 = false, r2 = false, flip_w = false;
+    uint8_t flip_new = 0;
+    uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;
+    uint32_t d_steps = 0, d_nuniq = 0, d_h0 = 0, d_h1 = 0, d_h3 = 0, d_h4 = 0;
+    auto emit = [&](uint32_t v) {
+        if (nev == 0) ev[0] = v; else if (nev == 1) ev[1] = v; else if (nev == 2) ev[2] = v; else if (nev == 3) ev[3] = v; else ev[4] = v;
+        ++nev;
+    };
+    if (live && !slow) {
+        if (f2) {
+            // R2 check_quadratic (:875-942); errors are the general executor's business
+            if (shape & SH_R2_BOUNDSERR) { slow = true; reason = 2; }
+            else if ((shape & SH_R2) && !(fx & 2)) {
+                if (shape & SH_R2_DIV0) { slow = true; reason = 2; }
+                else {
+                    wva = rx; wa = true; r2 = true;
+                    wfa = (uint8_t)((fx | 2) & ~16u);
+                    if (shape & SH_R2_IS01) { wfa = (uint8_t)((wfa & ~12u) | 4u); a01 = true; }
+                    emit(rx);
+                    d_steps = 1; d_h1 = 1;
+                }
+            }
+        } else if (xy) {
+            if (((fa | fb) & 8u) || k1 == k2 || nE != 2) { slow = true; reason = 3; }
+            else {
+                const bool sw = (shape & SH_R56_SWAP) != 0;          // C order starts with k2
+                const uint8_t fa_in = fa, fb_in = fb;
+                // R1 (:827-873)
+                if (((fa ^ fb) & 1u)) {
+                    if (!(fa & 1)) { fa |= 3; emit(k1); } else { fb |= 3; emit(k2); }
+                    d_nuniq++; d_steps++; d_h0++;
+                }
+                // R4 (:991-1076), l == 2: the row is negated on every visit, the pivot alternates
+                {
+                    flip_new = (uint8_t)(flip_in ^ 1);
+                    flip_w = true;
+                    const uint32_t new_key = flip_new ? kneg : kpos;
+                    const bool n_is_a = new_key == k1;
+                    uint8_t fn = n_is_a ? fa : fb, fo_ = n_is_a ? fb : fa;
+                    if (fo_ & 4) {
+                        if (!(fn & 4)) {
+                            fn = (uint8_t)((fn & ~12u) | 4u | 2u);
+                            if (n_is_a) a01 = true; else b01 = true;
+                            d_steps++; d_h3++;
+                            emit(new_key);
+                        }
+                        if ((fn & 1) && !(fo_ & 1)) {
+                            fo_ |= 3;
+                            d_nuniq++; d_steps++; d_h3++;
+                            emit(n_is_a ? k2 : k1);
+                        }
+                    }
+                    if (n_is_a) { fa = fn; fb = fo_; } else { fb = fn; fa = fo_; }
+                }
+                // R5 (:1078-1146): bounds are [0,1] or [0,p-1] here, equal iff the class bits agree
+                if (((fa ^ fb) & 4u) || ((fa ^ fb) & 1u)) {
+                    bool cha = false, chb = false;
+                    if ((fa ^ fb) & 1u) { fa |= 3; d_nuniq += 2; cha = chb = true; }        // key_1 written twice (sic, :1107-1108)
+                    const bool na = ((fa ^ fb) & 4u) && !(fa & 4u), nb = ((fa ^ fb) & 4u) && !(fb & 4u);
+                    if (na) { fa = (uint8_t)((fa & ~12u) | 4u | 2u); a01 = true; }
+                    if (nb) { fb = (uint8_t)((fb & ~12u) | 4u | 2u); b01 = true; }
+                    cha |= na; chb |= nb;
+                    const uint32_t nset = (cha ? 1u : 0u) + (chb ? 1u : 0u);
+                    d_steps += nset;
+                    if (nset) d_h4++;
+                    if (sw) { if (chb) emit(k2); if (cha) emit(k1); }
+                    else { if (cha) emit(k1); if (chb) emit(k2); }
+                }
+                wva = k1; wfa = fa; wa = fa != fa_in || a01;
+                wvb = k2; wfb = fb; wb = fb != fb_in || b01;
+                // R7 / R8 (:1235-1348) in reach (see chain.hip.hpp): the general executor decides
+                const bool nua = !(fa & 1), nub = !(fb & 1);
+                if ((nua || nub) && !((nua && (fa & 18u) != 18u) || (nub && (fb & 18u) != 18u))) { slow = true; reason = 4; }
+            }
+        } else {
+            // products and plain sums: R1 (:827-873)
+            bool nuab = false, notknown = false;
+            uint32_t cnt = 0, u = 0;
+            uint8_t uf = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 15; ++e) {
+                if (e >= nE) continue;
+                const uint8_t f = fl[e];
+                if (e < nA + nB) nuab |= !(f & 1);
+                else if (!(f & 1)) { if (!cnt) { u = w[1 + e]; uf = f; } ++cnt; if (!(f & 2)) notknown = true; }
+            }
+            if (!nuab && cnt == 1) {
+                wva = u; wfa = (uint8_t)(uf | 3); wa = true;
+                emit(u);
+                d_nuniq = 1; d_steps = 1; d_h0 = 1;
+            } else if (f4 && cnt > 0 && !notknown) { slow = true; reason = 5; }       // R7 / R8 in reach
+        }
+    }
+    // ---- the window ends in front of the first row this round does not take
+    uint32_t cmax = n;
+    {
+        const uint64_t ms = __ballot(slow);
+        if (ms & 1ull) {                                        // nothing has been touched
+            if (lane == 0) why[reason] += 1;
+            return (rdlane(shape, 0) & SH_BIG) ? 0xFFFFFFFFu : 0xFFFFFFFEu;
+        }
+        if (ms) cmax = (uint32_t)(__ffsll((long long)ms) - 1);
+    }
+    const bool cand = mine && rank < cmax;
+    // ---- write marks, then every lane looks its read set up: blocked iff an earlier rank writes what it reads
+    if (cand && live) {
+        if (wa) w2_min(Tm, wva + 1u, rank);
+        if (wb) w2_min(Tm, wvb + 1u, rank);
+    }
+    lds_fence();
+    bool blocked = false;
+    if (cand && live) {
+        if (f2) { if (shape & SH_R2) blocked = w2_get(Tm, rx + 1u) < rank; }
+        else if (xy) blocked = w2_get(Tm, k1 + 1u) < rank || w2_get(Tm, k2 + 1u) < rank;
+        else {
+#pragma unroll
+            for (uint32_t e = 0; e < 15; ++e)
+                if (e < nE && (fl[e] & 3) != 3 && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
+        }
+    }
+    uint32_t c = cmax;
+    {
+        const uint64_t mb = __ballot(blocked);
+        if (mb) { const uint32_t fb_ = (uint32_t)(__ffsll((long long)mb) - 1); if (fb_ < c) c = fb_; }   // >= 1: rank 0 is never blocked
+    }
+    // ---- 4: fan-out of the events of the prefix; an event with more than three target rows ends the prefix in front of it
+    u32x4 fo[5] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint32_t ncand = 0;
+    bool bigev = false;
+    if (mine && rank < c && live) {
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) if (k < nev) fo[k] = foi[ev[k]];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) if (k < nev) { if (fo[k].x > 3u) bigev = true; else ncand += fo[k].x; }
+    }
+    {
+        const uint64_t mbig = __ballot(bigev);
+        if (mbig & 1ull) {                                      // rank 0: the general round takes it (only marks were written)
+            for (uint32_t i = (uint32_t)lane; i < ECNE_W2_MARKS; i += 64) { Tm.key[i] = 0u; Tm.val[i] = 0xFFFFFFFFu; }
+            lds_fence();
+            if (lane == 0) why[6] += 1;
+            return 0xFFFFFFFEu;
+        }
+        if (mbig) { const uint32_t f0 = (uint32_t)(__ffsll((long long)mbig) - 1); if (f0 < c) c = f0; }
+    }
+    if (rank >= c) ncand = 0;
+    uint32_t M;
+    uint32_t cbase = wave_excl_scan(ncand, &M);
+    if (M > ECNE_W2_MAXCAND) {       // (many events with full fan-out) keep the ranks whose candidates fit
+        const uint64_t over = __ballot(rank < c && cbase + ncand > ECNE_W2_MAXCAND);
+        const uint32_t f0 = (uint32_t)(__ffsll((long long)over) - 1);       // >= 1: one row has at most 15 candidates
+        if (f0 < c) c = f0;
+        if (rank >= c) ncand = 0;
+        cbase = wave_excl_scan(ncand, &M);
+    }
+    const bool in = mine && rank < c;
+    // ---- commit the prefix (ranks below c), every lane its own pop
+    if (in) {
+        my_pops++;
+        my_nnz += nE;
+        w2_min(Tr, row + 1u, rank);
+    }
+    if (in && live) {
+        if (wa) stF(wva, wfa);
+        if (wb) stF(wvb, wfb);
+        if (a01) { st256(J.lb + 4ull * wva, fp::make(0)); st256(J.ub + 4ull * wva, fp::make(1)); }
+        if (b01) { st256(J.lb + 4ull * wvb, fp::make(0)); st256(J.ub + 4ull * wvb, fp::make(1)); }
+        if (r2) {        // make_values (:921-927)
+            st256(J.values + 8ull * rx, ld256(J.vals + 4ull * validx));
+            st256(J.values + 8ull * rx + 4, ld256(J.vals + 4ull * (validx + 1)));
+            J.nvalues[rx] = 2;
+            J.abz[rx] = -1;
+            solved[row] = 1;
+        }
+        if (flip_w) { if (flip_lds) flipL[row] = flip_new; else flipG[row] = flip_new; }
+        C.steps += d_steps; C.nuniq += d_nuniq;
+        C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[3] += d_h3; C.hits[4] += d_h4;
+    }
+    lds_fence();
+    // ---- REQUEUE resolution in sequential order (rank, emission index, position in the variable's row list)
+    uint32_t new_tail = tail;
+    if (M) {
+        uint32_t tg[15], st[15];
+        bool el[15];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) {
+            const uint32_t nf = (in && live && k < nev) ? fo[k].x : 0u;
+            tg[3 * k] = fo[k].y; tg[3 * k + 1] = fo[k].z; tg[3 * k + 2] = fo[k].w;
+#pragma unroll
+            for (uint32_t p = 0; p < 3; ++p) { el[3 * k + p] = p < nf; st[3 * k + p] = el[3 * k + p] ? (uint32_t)ldQ(tg[3 * k + p]) : 1u; }
+        }
+        // eligible: not queued at all, or itself a row of the prefix popped at my rank or before
+        uint32_t j = cbase;
+        uint32_t jj[15];
+#pragma unroll
+        for (uint32_t i = 0; i < 15; ++i) {
+            jj[i] = j;
+            if (!el[i]) continue;
+            ++j;
+            const uint32_t rk = w2_get(Tr, tg[i] + 1u);
+            el[i] = rk != 0xFFFFFFFFu ? rk <= rank : st[i] == 0u;
+            if (el[i]) w2_min(Tt, tg[i] + 1u, jj[i]);
+        }
+        lds_fence();
+        uint32_t nwin = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 15; ++i) {
+            if (el[i]) el[i] = w2_get(Tt, tg[i] + 1u) == jj[i];
+            nwin += el[i] ? 1u : 0u;
+        }
+        uint32_t W;
+        uint32_t o = tail + wave_excl_scan(nwin, &W);
+#pragma unroll
+        for (uint32_t i = 0; i < 15; ++i)
+            if (el[i]) { queue[o & qmask] = tg[i]; stQ(tg[i], (uint16_t)1); ++o; }
+        new_tail = tail + W;
+    }
+    // rows of the prefix that nobody re-queued are out of the queue now
+    if (in && (M == 0 || w2_get(Tt, row + 1u) == 0xFFFFFFFFu)) stQ(row, (uint16_t)0);
+    lds_fence();
+    // ---- leave the tables clean
+    for (uint32_t i = (uint32_t)lane; i < NS; i += 64) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
+    wg_fence();
+    *out_tail = new_tail;
+    *out_examined = cmax;      // rows the round looked at: a prefix shorter than THIS is a dependency (the caller's window adapts to it)
+    return c;
+}
+
+}  // namespace ecne

@@ -114,6 +114,11 @@ typedef struct ecne_summary {
                                 long rows popped alone + sequential bursts + wavefront rounds, multi-workgroup rounds */
     double multi_ms[8];      /* multi-workgroup rounds: mark, check + cut, exec + scan, expand, count + scan, write */
     double phase_ms[8];      /* in-kernel wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; [6] = P3 rounds (count) */
+    int64_t sched[16];       /* schedule diagnostics (master workgroup): 0 fast wavefront rounds, 1 rows they committed, 2 their
+                                100 MHz ticks; 3..5 the same for general wavefront rounds; 6..12 why the fast round declined at
+                                rank 0: no record / long row, other shape, error row, bound of the third kind, R7/R8 in reach
+                                (x == y), R7/R8 in reach (sum), event with > 3 target rows (12); 13..15 multi-workgroup rounds that committed
+                                < 64, < 4096, more rows */
 } ecne_summary;
 
 /* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is

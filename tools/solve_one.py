@@ -16,4 +16,4 @@ for mode in ([int(m) for m in sys.argv[4:]] if len(sys.argv) > 4 else [0]):
     sm = r.summary
     print("mode", mode, "rows", len(s), "status", r.status, "good", r.function_good, "dev_ms %.2f" % sm.device_ms, "pops", sm.pops, "outer", sm.outer_iterations,
           "rounds", sm.rule_hits[13], "bigfb", sm.rule_hits[14] & 0xFFFF, "multi", sm.rule_hits[14] >> 16, "multi_rows", sm.rule_hits[15] >> 8, "candfb", sm.rule_hits[15] & 0xFF,
-          "phases", [round(x, 2) for x in sm.phase_ms[:8]], "queue", [round(x, 2) for x in sm.queue_ms[:8]], "multi[mark,check,exec+scan,expand,compact+scan,final]", [round(x, 2) for x in sm.multi_ms[:8]])
+          "phases", [round(x, 2) for x in sm.phase_ms[:8]], "queue", [round(x, 2) for x in sm.queue_ms[:8]], "multi[mark,check,exec+scan,expand,compact+scan,final]", [round(x, 2) for x in sm.multi_ms[:6]], "\n   wave rounds fast: n %d rows %d ms %.2f; general: n %d rows %d ms %.2f; declined[norec/long, shape, err, bound3, xy r78, sum r78, bigfan]" % (sm.sched[0], sm.sched[1], sm.sched[2] * 1e-5, sm.sched[3], sm.sched[4], sm.sched[5] * 1e-5), list(sm.sched[6:13]), "multi rounds by rows committed [<64, <4096, more]", list(sm.sched[13:16]))
