@@ -25,7 +25,7 @@ from ._lib import Info, Opts, Summary, SystemInfo
 
 __all__ = ["readR1CS", "SolveConstraintsSymbolic", "solveWithTrustedFunctions", "solve_batch",
            "R1CS", "System", "SolveResult", "EcneError", "BoundsError", "DivideError", "UndefVarError",
-           "device_count", "classify"]
+           "device_count", "classify", "set_host_threads"]
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -63,8 +63,12 @@ class NoDeviceError(EcneError, RuntimeError):
     status = -8
 
 
+class DeviceBusyError(EcneError, TimeoutError):
+    status = -11
+
+
 _EXC = {-1: FormatError, -2: BoundsError, -3: DivideError, -4: UndefVarError, -5: AbstractionKeyError,
-        -6: DetSizeError, -7: OSError, -8: NoDeviceError, -9: ValueError, -10: EcneError}
+        -6: DetSizeError, -7: OSError, -8: NoDeviceError, -9: ValueError, -10: EcneError, -11: DeviceBusyError}
 
 
 def _check(st, what=""):
@@ -76,6 +80,12 @@ def _check(st, what=""):
 
 def device_count():
     return _lib.lib().ecne_device_count()
+
+
+def set_host_threads(n=0):
+    """Opt in to host worker threads for parsing, abstraction and the flat-array layout (n <= 0: the cores present,
+    at most 32). The library works on the calling thread unless asked. Returns the count now in effect."""
+    return int(_lib.lib().ecne_set_host_threads(int(n)))
 
 
 class R1CS:
@@ -144,6 +154,27 @@ class System:
         i = SystemInfo()
         _check(_lib.lib().ecne_system_info_get(self._h, C.byref(i)))
         return i
+
+    def io(self):
+        """(known_variables, target_variables) the solve will be asked with"""
+        kn, tg = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+        nk, nt = C.c_size_t(), C.c_size_t()
+        _check(_lib.lib().ecne_system_io(self._h, C.byref(kn), C.byref(nk), C.byref(tg), C.byref(nt)))
+        return [kn[i] for i in range(nk.value)], [tg[i] for i in range(nt.value)]
+
+    def set_io(self, known_variables, target_variables):
+        kn = (C.c_int64 * max(len(known_variables), 1))(*known_variables)
+        tg = (C.c_int64 * max(len(target_variables), 1))(*target_variables)
+        _check(_lib.lib().ecne_system_set_io(self._h, kn, len(known_variables), tg, len(target_variables)), "set_io")
+
+    def set_specials(self, special_constraints):
+        """special_constraints: [(name, inputs, outputs), ...] as abstraction builds them (:388)"""
+        L = _lib.lib()
+        _check(L.ecne_system_clear_specials(self._h))
+        for name, ins, outs in special_constraints:
+            a = (C.c_int64 * max(len(ins), 1))(*ins)
+            b = (C.c_int64 * max(len(outs), 1))(*outs)
+            _check(L.ecne_system_add_special(self._h, name.encode(), a, len(ins), b, len(outs)), "add_special")
 
     def specials(self):
         out = []
@@ -270,22 +301,40 @@ def readR1CS(filename):
 last_result = None
 
 
-def SolveConstraintsSymbolic(constraints, special_constraints, known_variables, debug=False,
-                             target_variables=(), num_variables=-1, input_sym="default.sym",
+def SolveConstraintsSymbolic(constraints, special_constraints=None, known_variables=None, debug=False,
+                             target_variables=None, num_variables=-1, input_sym="default.sym",
                              secp_solve=False, device=0):
-    """R1CSConstraintSolver.jl:583-1646.  `constraints` is a System (rows after abstraction; its
-    special constraints and I/O lists travel inside the handle) or an R1CS (no special constraints)."""
+    """R1CSConstraintSolver.jl:583-1646.  `constraints` is a System (the rows after abstraction) or an R1CS.
+    `special_constraints`, `known_variables` and `target_variables` are the reference's arguments: when given they
+    REPLACE what the handle carries (the file's lists, the specials abstraction produced) before the solve, as a caller
+    who edits them expects; None keeps the handle's. `num_variables` has to be the handle's nVars (or -1): the state
+    arrays are sized by it (:681) and it cannot be changed after parsing."""
     global last_result
     system = constraints if isinstance(constraints, System) else System(constraints)
+    if num_variables not in (-1, None) and int(num_variables) != int(system.info.n_vars):
+        raise ValueError("num_variables=%d differs from the system's %d" % (num_variables, system.info.n_vars))
+    kn0, tg0 = system.io()
+    if known_variables is not None or target_variables is not None:
+        kn = list(known_variables) if known_variables is not None else kn0
+        tg = list(target_variables) if target_variables is not None else tg0
+        if kn != kn0 or tg != tg0:
+            system.set_io(kn, tg)
+    if special_constraints is not None:
+        sp = [(str(c[0]), [int(x) for x in c[1]], [int(x) for x in c[2]]) for c in special_constraints]
+        if sp != system.specials():
+            system.set_specials(sp)
     res = solve_batch([system], secp_solve=secp_solve, device=device)[0]
     last_result = res
     res.raise_for_status()
     s = res.summary
-    # the three lines the reference always prints (:1565-1571, :1586-1592, :1599)
+    # what the reference always prints (:1565-1571, :1586-1592) and its report (:1599-1643)
     print("Solved for %d variables out of %d total variables" % (s.unique_nontrivial, s.n_nontrivial))
     print("Solved for %d target variables out of %d total target variables" % (s.unique_targets, s.n_targets))
-    print("------ Bad Constraints ------")
-    print()
+    from . import report
+    sym = report.read_sym(input_sym) if input_sym and os.path.exists(input_sym) else None
+    if input_sym and input_sym != "default.sym" and sym is None:
+        raise FileNotFoundError(input_sym)                  # CSV.File(input_sym) (:1603) on a missing file
+    print(report.render(system, res, sym, debug=debug), end="")
     return res.function_good
 
 
@@ -311,7 +360,7 @@ def solveWithTrustedFunctions(input_r1cs, input_r1cs_name, trusted_r1cs=(), trus
         print(system.specials())
         return True
     print("time to prep inputs %d milliseconds" % int((time.time() - a) * 1000))   # :551
-    result = SolveConstraintsSymbolic(system, None, None, debug, (), -1, input_sym, secp_solve, device=device)
+    result = SolveConstraintsSymbolic(system, None, None, debug, None, -1, input_sym if input_sym else "", secp_solve, device=device)
     if result:
         if function_list:
             if printRes:

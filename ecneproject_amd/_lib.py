@@ -45,6 +45,7 @@ EXPORTS = [
     "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_states",
     "ecne_result_bad_rows", "ecne_result_free", "ecne_classify", "ecne_fp_selftest", "ecne_fp_sqrt",
     "ecne_device_count", "ecne_strerror", "ecne_version",
+    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order",
 ]
 
 _L = None
@@ -93,5 +94,11 @@ def lib():
     L.ecne_strerror.restype = C.c_char_p
     L.ecne_version.argtypes = []
     L.ecne_version.restype = C.c_char_p
+    L.ecne_set_host_threads.argtypes = [C.c_int]
+    L.ecne_system_set_io.argtypes = [vp, i64p, C.c_size_t, i64p, C.c_size_t]
+    L.ecne_system_clear_specials.argtypes = [vp]
+    L.ecne_system_add_special.argtypes = [vp, C.c_char_p, i64p, C.c_size_t, i64p, C.c_size_t]
+    L.ecne_system_report_order.argtypes = [vp, C.c_int64, C.POINTER(i64p), C.POINTER(C.c_size_t)]
+    L.ecne_system_io.argtypes = [vp, C.POINTER(i64p), C.POINTER(C.c_size_t), C.POINTER(i64p), C.POINTER(C.c_size_t)]
     _L = L
     return L

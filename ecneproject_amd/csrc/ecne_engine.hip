@@ -14,6 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -73,6 +76,7 @@ struct ecne_system {
     uint64_t generation = 0;   // bumped by every solve
     Layout L;
     DeviceImage dev;
+    std::vector<int64_t> order_buf;   // ecne_system_report_order
     ~ecne_system() {
         if (dev.arena) {
             (void)hipSetDevice(dev.device);
@@ -81,6 +85,7 @@ struct ecne_system {
     }
 };
 
+static void system_changed_rows(ecne_system* sys);
 struct ecne_result {
     ecne_summary sum;
     // per-variable state is downloaded from HBM on first request (ecne_result_states /
@@ -93,6 +98,62 @@ struct ecne_result {
     std::vector<int32_t> abz;
     std::vector<int64_t> bad_rows;
 };
+
+// Live systems: a result fetches its per-variable state lazily from its system's device image, so it has to know
+// whether that system still exists (ecne_system_free may come first).
+static std::mutex g_live_mu;
+static std::set<const ecne_system*>& live_systems() { static std::set<const ecne_system*> s; return s; }
+static bool system_is_live(const ecne_system* s) { std::lock_guard<std::mutex> g(g_live_mu); return live_systems().count(s) != 0; }
+
+// nothing throws across the C ABI
+template <class F>
+static int guarded(F&& f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return ECNE_ECAPACITY; }
+    catch (...) { return ECNE_EINVAL; }
+}
+
+// One multi-workgroup solve at a time per device inside this process: its workgroups meet at a hand-rolled barrier and
+// have to be resident together (two such launches on one device could each hold CUs the other one waits for).
+static std::mutex& device_launch_mutex(int device) { static std::mutex m[64]; return m[(unsigned)device & 63u]; }
+
+// launch scratch of the calling thread (job descriptors, workgroup table, events): kept between solves
+struct LaunchScratch {
+    int device = -1;
+    Job* d_jobs = nullptr; size_t jobs_cap = 0;
+    WgDesc* d_descs = nullptr; size_t descs_cap = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void release() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (d_jobs) (void)hipFree(d_jobs);
+        if (d_descs) (void)hipFree(d_descs);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        *this = LaunchScratch();
+    }
+    int prepare(int dev, size_t n_jobs, size_t n_descs) {
+        if (device != dev) release();
+        device = dev;
+        if (n_jobs > jobs_cap) {
+            if (d_jobs) (void)hipFree(d_jobs);
+            d_jobs = nullptr; jobs_cap = 0;
+            if (hipMalloc((void**)&d_jobs, sizeof(Job) * n_jobs) != hipSuccess) return K_ENODEVICE;
+            jobs_cap = n_jobs;
+        }
+        if (n_descs > descs_cap) {
+            if (d_descs) (void)hipFree(d_descs);
+            d_descs = nullptr; descs_cap = 0;
+            if (hipMalloc((void**)&d_descs, sizeof(WgDesc) * n_descs) != hipSuccess) return K_ENODEVICE;
+            descs_cap = n_descs;
+        }
+        if (!e0 && hipEventCreate(&e0) != hipSuccess) return K_ENODEVICE;
+        if (!e1 && hipEventCreate(&e1) != hipSuccess) return K_ENODEVICE;
+        return K_OK;
+    }
+    ~LaunchScratch() { /* (thread exit: the HIP runtime may already be gone; the few KB are left to process teardown) */ }
+};
+static LaunchScratch& launch_scratch() { static thread_local LaunchScratch s; return s; }
 
 // ------------------------------------------------------------------------------------ layout
 static void build_layout(ecne_system& S) {
@@ -619,7 +680,7 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
 // download the per-variable state of a finished solve (lazy; see ecne_result)
 static int fetch_states(ecne_result* r) {
     if (r->have_states) return K_OK;
-    if (!r->sys || r->sys->generation != r->generation || !r->sys->dev.arena) return K_EINVAL;
+    if (!r->sys || !system_is_live(r->sys) || r->sys->generation != r->generation || !r->sys->dev.arena) return K_EINVAL;
     ecne_system& S = *r->sys;
     const Layout& L = S.L;
     const Job& J = S.dev.job;
@@ -661,7 +722,7 @@ static int fetch_states(ecne_result* r) {
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
-int ecne_r1cs_load(const char* path, ecne_r1cs** out) {
+static int ecne_r1cs_load_impl(const char* path, ecne_r1cs** out) {
     if (!path || !out) return ECNE_EINVAL;
     ecne_r1cs* r = new ecne_r1cs();
     int st = load_r1cs(path, r->f);
@@ -678,7 +739,7 @@ int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* o) {
     o->n_vars = f->f.n_vars;
     return ECNE_OK;
 }
-int ecne_r1cs_csr(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
+static int ecne_r1cs_csr_impl(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
     if (!f || part < 0 || part > 2) return ECNE_EINVAL;
     if (!f->f.csr_built) {   // (a handle is used by one thread at a time, include/ecne.h)
         const int st = build_file_csr(const_cast<ecne_r1cs*>(f)->f);
@@ -699,7 +760,7 @@ int ecne_r1cs_io(const ecne_r1cs* f, const int64_t** known, size_t* nk, const in
 }
 void ecne_r1cs_free(ecne_r1cs* f) { delete f; }
 
-int ecne_system_from_r1cs(const ecne_r1cs* m, ecne_system** out) {
+static int ecne_system_from_r1cs_impl(const ecne_r1cs* m, ecne_system** out) {
     if (!m || !out) return ECNE_EINVAL;
     ecne_system* s = new ecne_system();
     s->base = m->file;
@@ -708,26 +769,22 @@ int ecne_system_from_r1cs(const ecne_r1cs* m, ecne_system** out) {
     s->targets = m->f.outputs;
     s->n_vars = m->f.n_vars;
     s->n_rows_main = (int64_t)m->f.rows.n();
+    { std::lock_guard<std::mutex> g(g_live_mu); live_systems().insert(s); }
     *out = s;
     return ECNE_OK;
 }
-int ecne_abstract(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
+static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
     if (!sys || !trusted || !name) return ECNE_EINVAL;
     Rows red;
     const int rc = abstract_one(name, sys->rows(), trusted->f, sys->specials, red);
     if (rc != K_OK) return rc;
-    sys->laid_out = false;
-    if (sys->dev.arena) {   // an image uploaded for the old rows is stale now
-        (void)hipSetDevice(sys->dev.device);
-        (void)hipFree(sys->dev.arena);
-        sys->dev = DeviceImage();
-    }
+    system_changed_rows(sys);   // layout and device image are stale, earlier results unreadable
     sys->reduced = std::move(red);
     sys->cur = &sys->reduced;
     sys->base.reset();
     return K_OK;
 }
-int ecne_system_info_get(const ecne_system* sys, ecne_system_info* o) {
+static int ecne_system_info_get_impl(const ecne_system* sys, ecne_system_info* o) {
     if (!sys || !o) return ECNE_EINVAL;
     ecne_system* s = const_cast<ecne_system*>(sys);
     if (!s->laid_out) build_layout(*s);
@@ -751,7 +808,7 @@ int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, 
     if (nout) *nout = sp.outputs.size();
     return ECNE_OK;
 }
-int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
+static int ecne_system_rows_impl(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
     if (!sys || part < 0 || part > 2) return ECNE_EINVAL;
     if (!sys->laid_out) build_layout(*sys);
     if (rowptr) *rowptr = sys->L.rp[part].data();
@@ -759,7 +816,11 @@ int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const 
     if (coeff) *coeff = sys->L.coef[part].data();
     return ECNE_OK;
 }
-void ecne_system_free(ecne_system* sys) { delete sys; }
+void ecne_system_free(ecne_system* sys) {
+    if (!sys) return;
+    { std::lock_guard<std::mutex> g(g_live_mu); live_systems().erase(sys); }
+    delete sys;
+}
 
 int ecne_device_count(void) {
     int n = 0;
@@ -767,7 +828,7 @@ int ecne_device_count(void) {
     return n;
 }
 
-int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out) {
+static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out) {
     if (!sys || !out || n == 0) return ECNE_EINVAL;
     for (size_t i = 0; i < n; ++i) out[i] = nullptr;
     ecne_opts o;
@@ -781,8 +842,13 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
         int st = upload_system(*sys[i], o.device);
         if (st != K_OK) return st;
     }
-    Job* d_jobs = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_jobs, sizeof(Job) * n));
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) != hipSuccess || n_cu < 1) return ECNE_ENODEVICE;
+    const uint32_t cap = (uint32_t)std::max(1, n_cu - 8);   // margin: never rely on the last CU being free
+    // job descriptors, workgroup table and the two events live in the calling thread's launch scratch (no allocation per solve)
+    LaunchScratch& scratch = launch_scratch();
+    { const int st = scratch.prepare(o.device, n, cap); if (st != K_OK) return st; }
+    Job* const d_jobs = scratch.d_jobs;
     std::vector<Job> hj(n);
     int rc = ECNE_OK;
     do {
@@ -799,9 +865,6 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
         // workgroups of one launch must be co-resident (they meet at a hand-rolled barrier), and
         // k_solve occupies a whole CU per workgroup (512 threads x 256 VGPRs), so a launch never
         // holds more workgroups than the device has CUs; a batch that needs more is split.
-        int n_cu = 0;
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) != hipSuccess || n_cu < 1) { rc = ECNE_ENODEVICE; break; }
-        const uint32_t cap = (uint32_t)std::max(1, n_cu - 8);   // margin: never rely on the last CU being free
         // dynamic LDS: whatever the CU has beyond k_solve's static tables (a workgroup owns its CU anyway);
         // single-workgroup jobs keep their hot state there (k_solve, "LDS residency")
         uint32_t dyn_lds = 0;
@@ -829,19 +892,18 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             hj[i].lds_bytes = dyn_lds;
         }
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        struct EventPair {   // destroyed on every way out of the block
-            hipEvent_t &a, &b;
-            ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-        } events{e0, e1};
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
-        (void)hipEventRecord(e0, stream);
+        const hipEvent_t e0 = scratch.e0, e1 = scratch.e1;
         {
+            // a launch that holds a multi-workgroup job must have the device to itself (its workgroups meet at a barrier)
+            bool any_multi = false;
+            for (size_t i = 0; i < n; ++i) any_multi |= hj[i].nwg > 1;
+            std::unique_lock<std::mutex> device_lock(device_launch_mutex(o.device), std::defer_lock);
+            if (any_multi || n > 1) device_lock.lock();
+            (void)hipEventRecord(e0, stream);
             std::vector<WgDesc> descs;
-            WgDesc* d_descs = nullptr;
+            WgDesc* const d_descs = scratch.d_descs;
             size_t i = 0;
             bool fail = false;
-            if (hipMalloc((void**)&d_descs, sizeof(WgDesc) * (size_t)cap) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
             while (i < n && !fail) {
                 descs.clear();
                 while (i < n && descs.size() + hj[i].nwg <= cap) {
@@ -853,8 +915,7 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
                 if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
             }
             (void)hipEventRecord(e1, stream);
-            if (fail || hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(d_descs); rc = ECNE_ENODEVICE; break; }
-            (void)hipFree(d_descs);
+            if (fail || hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
@@ -870,11 +931,18 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             ecne_summary& s = r->sum;
             std::memset(&s, 0, sizeof s);
             s.status = (c.err_key != ~0ull && (c.err_key & 0xFFu) != 0) ? -(int)(c.err_key & 0xFFu) : c.error;   // (the pop the sequential run dies on)
+            // ids above num_variables: variable_states[i] raises BoundsError in the setup loop over known_variables (:682-692),
+            // for a target at the verdict (:1579-1583) -- the first only if nothing else stopped the run earlier... it IS the first
+            bool known_oob = false, target_oob = false;
+            for (int64_t v : S.knowns) known_oob |= v > S.n_vars;
+            for (int64_t v : S.targets) target_oob |= v > S.n_vars;
+            if (known_oob) s.status = ECNE_EBOUNDS;
+            else if (target_oob && s.status == 0) s.status = ECNE_EBOUNDS;
             s.unique_nontrivial = (int64_t)c.unique_nontrivial;
             s.n_nontrivial = (int64_t)c.n_nontrivial;
             s.unique_targets = (int64_t)c.unique_targets;
             s.n_targets = (int64_t)S.targets.size();
-            s.function_good = (c.error == 0 && s.unique_targets == s.n_targets) ? 1 : 0;
+            s.function_good = (s.status == 0 && c.error == 0 && s.unique_targets == s.n_targets) ? 1 : 0;
             s.successful_steps = (int64_t)c.successful_steps;
             s.outer_iterations = (int64_t)c.outer_iterations;
             s.pops = (int64_t)c.pops;
@@ -892,7 +960,6 @@ int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_re
             out[i] = r;
         }
     } while (0);
-    (void)hipFree(d_jobs);
     if (rc != ECNE_OK)
         for (size_t i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
     return rc;
@@ -907,7 +974,7 @@ int ecne_result_summary(const ecne_result* r, ecne_summary* out) {
     *out = r->sum;
     return ECNE_OK;
 }
-int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
+static int ecne_result_states_impl(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
                        const int32_t** abz, const uint8_t** nvalues, const uint64_t** values) {
     if (!r) return ECNE_EINVAL;
     int st = fetch_states(const_cast<ecne_result*>(r));
@@ -920,7 +987,7 @@ int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64
     if (values) *values = r->values.data();
     return ECNE_OK;
 }
-int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n) {
+static int ecne_result_bad_rows_impl(const ecne_result* r, const int64_t** rows, size_t* n) {
     if (!r) return ECNE_EINVAL;
     int st = fetch_states(const_cast<ecne_result*>(r));
     if (st != K_OK) return st;
@@ -930,7 +997,7 @@ int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n) 
 }
 void ecne_result_free(ecne_result* r) { delete r; }
 
-int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, double* kernel_ms, uint64_t* bytes) {
+static int ecne_classify_impl(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, double* kernel_ms, uint64_t* bytes) {
     if (!sys) return ECNE_EINVAL;
     ecne_opts o;
     std::memset(&o, 0, sizeof o);
@@ -957,7 +1024,7 @@ int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, 
     return ECNE_OK;
 }
 
-int ecne_fp_selftest(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+static int ecne_fp_selftest_impl(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
     if (ecne_device_count() <= device) return ECNE_ENODEVICE;
     HIP_TRY(hipSetDevice(device));
     uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -980,6 +1047,113 @@ int ecne_fp_sqrt(const uint64_t* a, uint64_t* root) {
     return 1;
 }
 
+
+static void system_changed_rows(ecne_system* sys) {
+    sys->generation++;
+    sys->laid_out = false;
+    if (sys->dev.arena) {
+        (void)hipSetDevice(sys->dev.device);
+        (void)hipFree(sys->dev.arena);
+        sys->dev = DeviceImage();
+    }
+}
+// ---- entry points proper: nothing throws across the ABI (guarded)
+int ecne_r1cs_load(const char* path, ecne_r1cs** out) { return guarded([&] { return ecne_r1cs_load_impl(path, out); }); }
+int ecne_r1cs_csr(const ecne_r1cs* f, int part, const uint64_t** rowptr, const uint32_t** col, const uint64_t** coeff) { return guarded([&] { return ecne_r1cs_csr_impl(f, part, rowptr, col, coeff); }); }
+int ecne_system_from_r1cs(const ecne_r1cs* m, ecne_system** out) { return guarded([&] { return ecne_system_from_r1cs_impl(m, out); }); }
+int ecne_abstract(ecne_system* sys, const ecne_r1cs* trusted, const char* name) { return guarded([&] { return ecne_abstract_impl(sys, trusted, name); }); }
+int ecne_system_info_get(const ecne_system* sys, ecne_system_info* o) { return guarded([&] { return ecne_system_info_get_impl(sys, o); }); }
+int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff) { return guarded([&] { return ecne_system_rows_impl(sys, part, rowptr, col, coeff); }); }
+int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out) { return guarded([&] { return ecne_solve_batch_impl(sys, n, opts, out); }); }
+int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n) { return guarded([&] { return ecne_result_bad_rows_impl(r, rows, n); }); }
+int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, double* kernel_ms, uint64_t* bytes) { return guarded([&] { return ecne_classify_impl(sys, opts, shape_out, kernel_ms, bytes); }); }
+int ecne_fp_selftest(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return guarded([&] { return ecne_fp_selftest_impl(device, op, n, a, b, out); }); }
+int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
+                       const int32_t** abz, const uint8_t** nvalues, const uint64_t** values) {
+    return guarded([&] { return ecne_result_states_impl(r, flags, lb, ub, abz, nvalues, values); });
+}
+
+int ecne_set_host_threads(int n) { return (int)set_host_threads(n); }
+
+// getVariables(constraints[i]) (:36-56) in Set order: keys of a, b, c (dictionary order, non-zero values) pushed into one Set
+static void row_variables_in_set_order(const Rows& R, size_t i, jl::SlotTable& set, std::vector<int64_t>& out) {
+    set.reset();
+    bool ins;
+    for (int p = 0; p < 3; ++p)
+        for (uint64_t k = R.ptr[p][i]; k < R.ptr[p][i + 1]; ++k)
+            if (!fp::is_zero(R.coef[p][k])) set.upsert((int64_t)R.var[p][k], 0, ins);
+    set.for_each([&](int64_t key, int64_t) { out.push_back(key); });
+}
+int ecne_system_report_order(ecne_system* sys, int64_t row, const int64_t** vars, size_t* n) {
+    if (!sys || row < 0 || (uint64_t)row > sys->rows().n()) return ECNE_EINVAL;
+    return guarded([&] {
+        const Rows& R = sys->rows();
+        std::vector<int64_t>& out = sys->order_buf;
+        out.clear();
+        jl::SlotTable set;
+        if (row >= 1) row_variables_in_set_order(R, (size_t)row - 1, set, out);
+        else {
+            // l = [variables of every row ...; inputs and outputs of every special ...; targets ...]; Set(l) (:600-618):
+            // union!(Set(), l) reserves room for length(l) keys before it pushes them
+            std::vector<int64_t> l, one;
+            for (size_t i = 0; i < R.n(); ++i) { one.clear(); row_variables_in_set_order(R, i, set, one); l.insert(l.end(), one.begin(), one.end()); }
+            for (auto& sp : sys->specials) { l.insert(l.end(), sp.inputs.begin(), sp.inputs.end()); l.insert(l.end(), sp.outputs.begin(), sp.outputs.end()); }
+            l.insert(l.end(), sys->targets.begin(), sys->targets.end());
+            jl::SlotTable all;
+            all.reserve((int64_t)l.size());
+            bool ins;
+            for (int64_t v : l) all.upsert(v, 0, ins);
+            all.for_each([&](int64_t key, int64_t) { out.push_back(key); });
+        }
+        if (vars) *vars = out.data();
+        if (n) *n = out.size();
+        return (int)ECNE_OK;
+    });
+}
+
+// A change of what the solve is asked (I/O lists, special constraints, rows) makes results of earlier solves
+// unreadable (generation) and the flat layout / device image stale.
+static void system_changed(ecne_system* sys) { system_changed_rows(sys); }
+int ecne_system_set_io(ecne_system* sys, const int64_t* known, size_t nk, const int64_t* targets, size_t nt) {
+    if (!sys || (nk && !known) || (nt && !targets)) return ECNE_EINVAL;
+    return guarded([&] {
+        for (size_t i = 0; i < nk; ++i) if (known[i] < 1) return (int)ECNE_EBOUNDS;
+        for (size_t i = 0; i < nt; ++i) if (targets[i] < 1) return (int)ECNE_EBOUNDS;
+        sys->knowns.assign(known, known + nk);
+        sys->targets.assign(targets, targets + nt);
+        system_changed(sys);
+        return (int)ECNE_OK;
+    });
+}
+int ecne_system_clear_specials(ecne_system* sys) {
+    if (!sys) return ECNE_EINVAL;
+    sys->specials.clear();
+    system_changed(sys);
+    return ECNE_OK;
+}
+int ecne_system_add_special(ecne_system* sys, const char* name, const int64_t* inputs, size_t ni, const int64_t* outputs, size_t no) {
+    if (!sys || !name || (ni && !inputs) || (no && !outputs)) return ECNE_EINVAL;
+    return guarded([&] {
+        for (size_t i = 0; i < ni; ++i) if (inputs[i] < 1 || inputs[i] > 0x7FFFFFFFll) return (int)ECNE_EBOUNDS;
+        for (size_t i = 0; i < no; ++i) if (outputs[i] < 1 || outputs[i] > 0x7FFFFFFFll) return (int)ECNE_EBOUNDS;
+        Special sp;
+        sp.name = name;
+        sp.inputs.assign(inputs, inputs + ni);
+        sp.outputs.assign(outputs, outputs + no);
+        sys->specials.push_back(std::move(sp));
+        system_changed(sys);
+        return (int)ECNE_OK;
+    });
+}
+int ecne_system_io(const ecne_system* sys, const int64_t** known, size_t* nk, const int64_t** targets, size_t* nt) {
+    if (!sys) return ECNE_EINVAL;
+    if (known) *known = sys->knowns.data();
+    if (nk) *nk = sys->knowns.size();
+    if (targets) *targets = sys->targets.data();
+    if (nt) *nt = sys->targets.size();
+    return ECNE_OK;
+}
+
 const char* ecne_strerror(int st) {
     switch (st) {
         case ECNE_OK: return "ok";
@@ -992,7 +1166,8 @@ const char* ecne_strerror(int st) {
         case ECNE_EIO: return "cannot read file";
         case ECNE_ENODEVICE: return "no usable HIP device (the engine has no CPU fallback)";
         case ECNE_EINVAL: return "invalid argument";
-        case ECNE_ECAPACITY: return "internal device table overflow";
+        case ECNE_ECAPACITY: return "internal device table overflow (or out of memory)";
+        case ECNE_ETIMEOUT: return "the workgroups of the solve did not meet within 0.2 s: is another process using this device?";
         default: return "unknown status";
     }
 }

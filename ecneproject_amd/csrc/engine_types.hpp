@@ -37,6 +37,7 @@ namespace ecne {
 #endif
 #define ECNE_BIGTAB 2048    // big rows with an LDS slot for their push candidates (the rest use memory atomics directly)
 #define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
+static_assert(ECNE_EVCAP >= 5 + 3 * ECNE_SMALL_ROW, "a small row can emit 5 + 3 * ECNE_SMALL_ROW REQUEUE events");
 #define ECNE_CANDCAP 65536  // push candidates resolved in parallel per round; beyond: sequential fallback
 
 // RowInfo.shape bits. "static" = depends only on coefficients/structure, computed once.
@@ -93,6 +94,7 @@ struct Counters {   // one per job, device memory
     alignas(128) unsigned int xcd_count[8][32];   // per-XCD arrival counters, one cache line each
     unsigned int xcd_members[8];                  // workgroups of this job resident on each XCD
     unsigned int n_xcd_active, bar_ready;
+    unsigned int heartbeat;                       // bumped by the master while it works alone (bounds the barrier wait, job_barrier)
     alignas(128) unsigned int pad_after_barrier;
     unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;
     unsigned int p3_hot;   // some k >= 2 group could be complete in this pass (else nobody looks at the table)

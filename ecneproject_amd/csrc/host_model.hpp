@@ -43,17 +43,26 @@ enum Status : int {
     K_ENODEVICE = -8,   // no HIP device / HIP runtime error
     K_EINVAL = -9,
     K_ECAPACITY = -10,  // an internal device table overflowed (never silently truncated)
+    K_ETIMEOUT = -11,   // the workgroups of a job did not meet at their barrier in time (the device is shared)
 };
 
-// Host-side worker threads (parse, abstraction): ECNE_HOST_THREADS, default = the cores present, at most 32.
+// Host-side worker threads (parse, abstraction, layout): opt-in. The library works on the calling thread unless the
+// caller asks for workers (ecne_set_host_threads, or ECNE_HOST_THREADS in the environment); at most 32.
 // Results never depend on the thread count: every worker fills a range whose position was fixed beforehand.
-inline unsigned host_threads() {
-    static const unsigned n = [] {
+inline std::atomic<unsigned>& host_threads_setting() {
+    static std::atomic<unsigned> n{[] {
         const char* e = std::getenv("ECNE_HOST_THREADS");
-        long h = e ? std::atol(e) : (long)std::thread::hardware_concurrency();
+        long h = e ? std::atol(e) : 1;
+        if (e && h <= 0) h = (long)std::thread::hardware_concurrency();
         return (unsigned)std::min<long>(std::max<long>(h, 1), 32);
-    }();
+    }()};
     return n;
+}
+inline unsigned host_threads() { return host_threads_setting().load(std::memory_order_relaxed); }
+inline unsigned set_host_threads(int n) {
+    long h = n <= 0 ? (long)std::thread::hardware_concurrency() : n;
+    host_threads_setting().store((unsigned)std::min<long>(std::max<long>(h, 1), 32), std::memory_order_relaxed);
+    return host_threads();
 }
 // f(chunk, worker) for every chunk in [0, n_chunks), chunks handed out dynamically
 template <class F>
@@ -177,7 +186,7 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
     if (!fv.ok) return K_EIO;
     const size_t N = fv.size;
     const uint8_t* b = fv.data;
-    auto need = [&](size_t off, size_t len) { return off + len <= N; };
+    auto need = [&](size_t off, size_t len) { return len <= N && off <= N - len; };   // (no wrap-around)
     if (!need(0, 12)) return K_EFORMAT;
     if (rd32(b + 4) != 1) return K_EFORMAT;
     if (rd32(b + 8) != 3) return K_EFORMAT;
@@ -189,7 +198,9 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
         if (t < 1 || t > 3) return K_EFORMAT;
         start[t] = cur + 12;
         seen[t] = true;
-        cur += 12 + (size_t)rd64(b + cur + 4);
+        const uint64_t sz = rd64(b + cur + 4);
+        if (sz > ~(uint64_t)0 - cur - 12) return K_EFORMAT;      // a section size that would wrap the cursor around
+        cur += 12 + (size_t)sz;
     }
     if (!seen[1] || !seen[2]) return K_EFORMAT;
     size_t h = start[1];
@@ -328,13 +339,15 @@ inline int build_file_csr(R1CSFile& out) {
     if (!fv.ok) return K_EIO;
     const size_t N = fv.size;
     const uint8_t* b = fv.data;
-    auto need = [&](size_t off, size_t len) { return off + len <= N; };
+    auto need = [&](size_t off, size_t len) { return len <= N && off <= N - len; };   // (no wrap-around)
     if (!need(0, 12)) return K_EFORMAT;
     size_t cur = 12, start2 = 0;
     for (int s = 0; s < 3; ++s) {
         if (!need(cur, 12)) return K_EFORMAT;
         if (rd32(b + cur) == 2) start2 = cur + 12;
-        cur += 12 + (size_t)rd64(b + cur + 4);
+        const uint64_t sz = rd64(b + cur + 4);
+        if (sz > ~(uint64_t)0 - cur - 12) return K_EFORMAT;
+        cur += 12 + (size_t)sz;
     }
     if (!start2) return K_EFORMAT;
     size_t c = start2;

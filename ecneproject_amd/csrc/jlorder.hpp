@@ -83,6 +83,15 @@ class SlotTable {
             return pay_[idx];
         }
     }
+    // sizehint!(d, n) (base/dict.jl): room for n keys up front -- what union!(Set(), itr) does before it pushes,
+    // and it changes the slot order compared with growing step by step
+    void reserve(int64_t n) {
+        if (n < n_) n = n_;
+        const int64_t want = (3 * n + 1) / 2;
+        int64_t nsz = 16;
+        while (nsz < want) nsz <<= 1;
+        if (nsz > (int64_t)key_.size()) grow(nsz);      // (sizehint! never shrinks)
+    }
     bool contains(int64_t key) const { return locate(key) >= 0; }
     int64_t payload_of(int64_t key) const {
         int64_t i = locate(key);

@@ -13,7 +13,7 @@ namespace ecne {
 // arriving (writes back this XCD's dirty L2 lines) and agent-scope acquire after leaving (drops
 // stale L1/L2 lines) — per-XCD L2s are not coherent with each other on MI355X. The last arriver
 // snapshots the job's error word, so every workgroup leaves with the SAME view of it and takes the
-// same branch. Spins are bounded.
+// same branch. Waits are bounded (K_ETIMEOUT).
 __device__ __forceinline__ uint32_t my_xcc_id() {
     // HW_REG_XCC_ID (hwreg 20), bits [3:0]: which of the 8 XCDs this wave runs on
     return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
@@ -76,10 +76,21 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                     __hip_atomic_store(&c->bar_gen, ((g + 1u) << 1) | (e != 0 ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            // the wait is bounded by wall-clock time (0.2 s of the 100 MHz counter): the workgroups of a job are resident
+            // together unless something else occupies the device (include/ecne.h: one solver process per device)
+            // (helpers legitimately wait for as long as the master works alone -- a deep chain can take many milliseconds --
+            //  so the clock restarts whenever the master's heartbeat word has moved: the bound is on time WITHOUT progress)
             unsigned spins = 0, w;
+            unsigned long long t_wait0 = wall_clock64();
+            unsigned hb = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (((w = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 28)) { raise(J, K_ECAPACITY); w = 1; break; }
+                if ((++spins & 1023u) == 0) {
+                    const unsigned long long now = wall_clock64();
+                    const unsigned hb2 = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (hb2 != hb) { hb = hb2; t_wait0 = now; }
+                    else if (now - t_wait0 > 20000000ull) { raise(J, K_ETIMEOUT); w = 1; break; }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             b.gen = g + 1;

@@ -595,6 +595,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     __syncthreads();
     while (q.head != q.tail) {
         // the error word is polled every 8th round (a raised error only has to stop the solve soon)
+        if (tid == 0 && J.nwg > 1) __hip_atomic_store(&J.ctr->heartbeat, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "the master is alive"
         if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
         if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
         const uint32_t avail = q.tail - q.head;

@@ -54,26 +54,56 @@ def state_text(result, v):
     out.append("Bounds: None" if (lb == 0 and ub == P - 1) else "Bounds: [%d, %d]" % (lb, ub))
     n = int(result.nvalues[v - 1])
     if n:
-        out.append("All possible values: " + str(sorted(_int(result.values[v - 1][i]) for i in range(n))).replace("[", "BigInt[" if False else "["))
+        # println of a Vector{BigInt} carries the element type: "BigInt[0, 1]"
+        out.append("All possible values: BigInt" + str(sorted(_int(result.values[v - 1][i]) for i in range(n))))
     out.append("")
     return out
 
 
+def _order(system, row):
+    """variables in the order the reference's report walks them (ecne_system_report_order)"""
+    import ctypes as C
+    from . import _lib
+    ptr, n = C.POINTER(C.c_int64)(), C.c_size_t()
+    st = _lib.lib().ecne_system_report_order(system._h, int(row), C.byref(ptr), C.byref(n))
+    if st != 0:
+        raise ValueError("ecne_system_report_order: status %d" % st)
+    return [int(ptr[i]) for i in range(n.value)]
+
+
 def bad_constraints_report(system, result, sym_path):
-    """The lines between "------ Bad Constraints ------" and "------ All Variables ------"."""
-    names = read_sym(sym_path)
+    """The lines between "------ Bad Constraints ------" and "------ All Variables ------" (:1609-1632)."""
+    names = read_sym(sym_path) if isinstance(sym_path, str) else sym_path
     lines = []
-    rps = [system.rows(p) for p in range(3)]
     for row in result.bad_rows.tolist():
         lines.append("constraint #%d" % row)
         lines.append(equation_text(system, row, names))
-        seen = []
-        for rp, col, _cf in rps:                     # getVariables: a, then b, then c (Set order differs only in order)
-            for k in range(int(rp[row - 1]), int(rp[row])):
-                v = int(col[k])
-                if v != 1 and v not in seen:
-                    seen.append(v)
-        for v in seen:
+        for v in _order(system, row):                # for j in getVariables(constraints[i]) (:1625)
+            if v == 1:
+                continue
             lines.append(names[v - 2])
             lines.extend(state_text(result, v))
     return lines
+
+
+def all_variables_report(system, result, names):
+    """The lines after "------ All Variables ------" (:1633-1643): every non-trivial variable but the constant wire, in the
+    iteration order of the reference's Set."""
+    lines = []
+    for v in _order(system, 0):
+        if v == 1:
+            continue
+        lines.append(names[v - 2])
+        lines.extend(state_text(result, v))
+    return lines
+
+
+def render(system, result, names=None, debug=False):
+    """Everything SolveConstraintsSymbolic prints after its two count lines (:1599-1643). `names` = read_sym(input_sym), or
+    None when input_sym == "" (then only the header is printed, as in the reference)."""
+    out = ["------ Bad Constraints ------", ""]
+    if names is not None:
+        out += bad_constraints_report(system, result, names)
+        out += ["------ All Variables ------", ""]
+        out += all_variables_report(system, result, names)
+    return "\n".join(out) + "\n"

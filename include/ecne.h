@@ -16,8 +16,9 @@
  * readR1CS / SolveConstraintsSymbolic / solveWithTrustedFunctions signatures.
  *
  * Conventions: plain pointers and sizes only; every function returns 0 or a negative ecne_status;
- * nothing throws across the ABI; no global mutable state; a handle is used by one thread at a
- * time, different handles may be used concurrently. Variable ids are 1-based (wire id + 1, variable
+ * nothing throws across the ABI (allocation failures come back as ECNE_ECAPACITY); a handle is used by
+ * one thread at a time, different handles may be used concurrently. Process-wide state is limited to
+ * the host worker-thread count (ecne_set_host_threads) and per-thread launch scratch buffers. Variable ids are 1-based (wire id + 1, variable
  * 1 = the constant-one wire) exactly as in the reference. Field elements are 4 little-endian
  * uint64 limbs holding the canonical residue < p (BN254 scalar field).
  */
@@ -41,7 +42,9 @@ typedef enum ecne_status {
     ECNE_EIO = -7,
     ECNE_ENODEVICE = -8,  /* no usable HIP device: the engine never falls back to the CPU           */
     ECNE_EINVAL = -9,
-    ECNE_ECAPACITY = -10  /* internal device table overflow (reported, never silently truncated)    */
+    ECNE_ECAPACITY = -10, /* internal device table overflow (reported, never silently truncated)    */
+    ECNE_ETIMEOUT = -11   /* the workgroups of a solve did not meet at their barrier within 0.2 s: something else
+                             occupies the device (see ecne_solve: one solver process per device)          */
 } ecne_status;
 
 typedef struct ecne_r1cs ecne_r1cs;     /* a parsed .r1cs file                                   */
@@ -55,9 +58,13 @@ typedef struct ecne_info {
     int64_t n_vars;    /* nWires + 1 (ParseR1CS.jl:123) */
 } ecne_info;
 
-/* readR1CS — ParseR1CS.jl:50-124. Host-side work (this call, ecne_abstract, the one-time flat-array layout of a
- * system) runs on worker threads: ECNE_HOST_THREADS in the environment, default = the cores present, at most
- * 32; results do not depend on the count. */
+/* Host-side work (ecne_r1cs_load, ecne_abstract, the one-time flat-array layout of a system) runs on the
+ * CALLING thread unless the caller opts in to worker threads: ecne_set_host_threads(n) (n <= 0: the cores
+ * present, at most 32), or ECNE_HOST_THREADS=n in the environment. The library never spawns threads on its
+ * own. Results do not depend on the count. Returns the count now in effect. */
+int ecne_set_host_threads(int n);
+
+/* readR1CS — ParseR1CS.jl:50-124. */
 int ecne_r1cs_load(const char* path, ecne_r1cs** out);
 int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* out);
 /* CSR view of one part (0 = A, 1 = B, 2 = C) in file order, non-zero terms only; borrowed pointers,
@@ -88,6 +95,20 @@ int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, 
  * reference iterates nonzeroKeys(part) (a Julia Set): what printEquation (:431-456) walks when it
  * renders a constraint. Borrowed pointers, valid until the system is freed or abstracted again. */
 int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff);
+/* Iteration orders the text report walks (:1609-1643): row >= 1 -> the variables of constraint `row` in the order of
+ * getVariables(constraints[row]) (a Julia Set filled from the a, b, c dictionaries, :36-56); row == 0 -> all_nontrivial_vars
+ * (:600-618: every variable of every row, of the specials and the targets, as Set(l) iterates). Borrowed until the next
+ * call on this system. */
+int ecne_system_report_order(ecne_system* sys, int64_t row, const int64_t** vars, size_t* n);
+/* SolveConstraintsSymbolic takes its known / target lists and special constraints as ARGUMENTS (:583-592); a system
+ * made from a file starts with the file's lists (ParseR1CS.jl:123) and the specials abstraction produced. A caller
+ * that edits them says so here (ids 1-based; copied). Changing them invalidates the device image of the system. */
+int ecne_system_set_io(ecne_system* sys, const int64_t* known, size_t n_known, const int64_t* targets, size_t n_targets);
+int ecne_system_clear_specials(ecne_system* sys);
+int ecne_system_add_special(ecne_system* sys, const char* name, const int64_t* inputs, size_t n_inputs,
+                            const int64_t* outputs, size_t n_outputs);
+int ecne_system_io(const ecne_system* sys, const int64_t** known, size_t* n_known, const int64_t** targets, size_t* n_targets);
+/* Results made from this system stay readable (summary) but their per-variable state can no longer be fetched. */
 void ecne_system_free(ecne_system* sys);
 
 typedef struct ecne_opts {
@@ -122,11 +143,20 @@ typedef struct ecne_summary {
 } ecne_summary;
 
 /* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is
- * usable. ecne_solve_batch runs n independent systems in one launch (one workgroup per system). */
+ * usable. ecne_solve_batch runs n independent systems in one launch (one workgroup per system, more for large
+ * ones). The workgroups of a large system meet at a barrier of their own and therefore have to be resident on
+ * the device together: the library takes at most (CUs - 8) workgroups per launch and serialises its own launches
+ * per device inside the process, but it cannot see other processes -- run ONE solver process per device. A solve
+ * whose workgroups do not meet within 0.2 s returns ECNE_ETIMEOUT instead of hanging.
+ * Out-of-range ids (malformed input): a known id above n_vars raises ECNE_EBOUNDS as the reference's setup does
+ * (:682), a target id above n_vars at the verdict (:1580); a ROW that mentions an id above n_vars is solved with the
+ * state arrays widened (the reference raises BoundsError at the first rule that reads that state). */
 int ecne_solve(ecne_system* sys, const ecne_opts* opts, ecne_result** out);
 int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out);
 int ecne_result_summary(const ecne_result* r, ecne_summary* out);
-/* per-variable VariableState (:135-160), variable v at index v-1; borrowed, valid until free.
+/* per-variable VariableState (:135-160), variable v at index v-1; borrowed, valid until ecne_result_free. The state
+ * is downloaded on the first call: it must come before the system is solved again, abstracted, edited
+ * (ecne_system_set_io / _add_special) or freed -- afterwards ECNE_EINVAL.
  * flags bit0 = unique, bit1 = is_known; lb/ub: 4 limbs; nvalues in {0,1,2}; values: 2 x 4 limbs. */
 int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
                        const int32_t** abz, const uint8_t** nvalues, const uint64_t** values);

@@ -6,7 +6,7 @@
 #   solveWithTrustedFunctions(...)         (reference src/R1CSConstraintSolver.jl:502)
 # Same names, argument meaning, return values and exception types. All propagation work runs in
 # the HIP kernels; this file only marshals handles. Julia is not available in the build image, so
-# this shim has not been executed there; it mirrors ecneproject_amd/_lib.py (ctypes) call for call.
+# this shim has not been executed there; it mirrors ecneproject_amd/_lib.py + __init__.py + report.py (ctypes) call for call.
 module EcneHIP
 
 export readR1CS, SolveConstraintsSymbolic, solveWithTrustedFunctions, EcneSystem, EcneR1CS
@@ -22,6 +22,7 @@ struct EcneSummary
     successful_steps::Int64; outer_iterations::Int64; pops::Int64; num_unique::Int64
     rule_hits::NTuple{16,Int64}; n_rows::Int64; n_vars::Int64; pop_nnz::Int64
     device_ms::Float64; classify_ms::Float64; queue_ms::NTuple{8,Float64}; multi_ms::NTuple{8,Float64}; phase_ms::NTuple{8,Float64}
+    sched::NTuple{16,Int64}
 end
 struct EcneInfo
     field_size::UInt32; n_wires::UInt32; n_pub_out::UInt32; n_pub_in::UInt32; n_prv_in::UInt32
@@ -55,7 +56,80 @@ function check(st::Integer)
     st == -4 && throw(UndefVarError(:dsu))           # :762 without secp_solve
     st == -5 && throw(KeyError(msg))                 # abstraction's variable map (:381-382)
     st == -7 && throw(SystemError(msg))
-    error("ecne_hip: $msg (status $st)")
+    st == -10 && throw(OutOfMemoryError())
+    error("ecne_hip: $msg (status $st)")           # -6 group of > 10 unknowns, -8 no device, -9 invalid argument, -11 device busy
+end
+
+# ---- what the handle carries: I/O lists and special constraints (the reference passes them as arguments, :583-592)
+function system_io(sys::EcneSystem)
+    kn = Ref{Ptr{Int64}}(C_NULL); nk = Ref{Csize_t}(0); tg = Ref{Ptr{Int64}}(C_NULL); nt = Ref{Csize_t}(0)
+    check(ccall((:ecne_system_io, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Int64}}, Ref{Csize_t}, Ref{Ptr{Int64}}, Ref{Csize_t}), sys.h, kn, nk, tg, nt))
+    return copy(unsafe_wrap(Array, kn[], Int(nk[]))), copy(unsafe_wrap(Array, tg[], Int(nt[])))
+end
+function system_specials(sys::EcneSystem)
+    info = Ref{NTuple{9,Int64}}()            # ecne_system_info: n_rows, n_rows_main, n_vars, n_specials, n_known, n_targets, nnz[3]
+    check(ccall((:ecne_system_info_get, LIB), Cint, (Ptr{Cvoid}, Ref{NTuple{9,Int64}}), sys.h, info))
+    out = Any[]
+    for k in 0:info[][4]-1
+        name = Ref{Cstring}(C_NULL); ins = Ref{Ptr{Int64}}(C_NULL); ni = Ref{Csize_t}(0); outs = Ref{Ptr{Int64}}(C_NULL); no = Ref{Csize_t}(0)
+        check(ccall((:ecne_system_special, LIB), Cint, (Ptr{Cvoid}, Int64, Ref{Cstring}, Ref{Ptr{Int64}}, Ref{Csize_t}, Ref{Ptr{Int64}}, Ref{Csize_t}),
+                    sys.h, k, name, ins, ni, outs, no))
+        push!(out, (unsafe_string(name[]), copy(unsafe_wrap(Array, ins[], Int(ni[]))), copy(unsafe_wrap(Array, outs[], Int(no[])))))
+    end
+    return out, Int(info[][3])
+end
+function report_order(sys::EcneSystem, row::Integer)      # getVariables(constraints[row]) order; row == 0: all_nontrivial_vars
+    p = Ref{Ptr{Int64}}(C_NULL); n = Ref{Csize_t}(0)
+    check(ccall((:ecne_system_report_order, LIB), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Int64}}, Ref{Csize_t}), sys.h, row, p, n))
+    return copy(unsafe_wrap(Array, p[], Int(n[])))
+end
+
+const P_BJJ = BigInt(21888242871839275222246405745257275088548364400416034343698204186575808495617)
+limbs(p::Ptr{UInt64}, i) = sum(BigInt(unsafe_load(p, 4 * i + k)) << (64 * (k - 1)) for k in 1:4)      # element i (0-based), 4 LE limbs
+fix_number(x::BigInt) = x > P_BJJ - 1000000000000000000000000000100 ? x - P_BJJ : x                      # :421-428
+
+# the report of :1599-1643, from the ABI's data: bad rows, per-variable state, rows in printEquation's term order
+function print_report(sys::EcneSystem, res::Ptr{Cvoid}, input_sym::String)
+    println("------ Bad Constraints ------"); println()
+    input_sym == "" && return
+    names = String[String(split(l, ","; limit=4)[4]) for l in eachline(input_sym) if !isempty(l)]          # :1603-1607
+    fl = Ref{Ptr{UInt8}}(C_NULL); lb = Ref{Ptr{UInt64}}(C_NULL); ub = Ref{Ptr{UInt64}}(C_NULL)
+    abz = Ref{Ptr{Int32}}(C_NULL); nv = Ref{Ptr{UInt8}}(C_NULL); vals = Ref{Ptr{UInt64}}(C_NULL)
+    check(ccall((:ecne_result_states, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{UInt8}}, Ref{Ptr{UInt64}}, Ref{Ptr{UInt64}}, Ref{Ptr{Int32}}, Ref{Ptr{UInt8}}, Ref{Ptr{UInt64}}),
+                res, fl, lb, ub, abz, nv, vals))
+    function print_state(v)                                                                             # printState :397-419
+        println("Uniquely Determined: ", (unsafe_load(fl[], v) & 1) == 1)
+        l, u = limbs(lb[], v - 1), limbs(ub[], v - 1)
+        (l == 0 && u == P_BJJ - 1) ? println("Bounds: None") : println("Bounds: [", l, ", ", u, "]")
+        n = Int(unsafe_load(nv[], v))
+        n > 0 && println("All possible values: ", sort!(BigInt[limbs(vals[], 2 * (v - 1) + k) for k in 0:n-1]))
+        println()
+    end
+    rp = [Ref{Ptr{UInt32}}(C_NULL) for _ in 1:3]; col = [Ref{Ptr{UInt32}}(C_NULL) for _ in 1:3]; cf = [Ref{Ptr{UInt64}}(C_NULL) for _ in 1:3]
+    for p in 1:3
+        check(ccall((:ecne_system_rows, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{UInt32}}, Ref{Ptr{UInt32}}, Ref{Ptr{UInt64}}), sys.h, p - 1, rp[p], col[p], cf[p]))
+    end
+    function lin(p, row)                                                                                # get_lin :433-451
+        a, b = Int(unsafe_load(rp[p][], row)), Int(unsafe_load(rp[p][], row + 1))
+        a == b && return "0"
+        return "(" * join([string(fix_number(limbs(cf[p][], k))) * " * " * (unsafe_load(col[p][], k + 1) > 1 ? names[unsafe_load(col[p][], k + 1) - 1] : "1")
+                           for k in a:b-1], " + ") * ")"
+    end
+    rows = Ref{Ptr{Int64}}(C_NULL); nr = Ref{Csize_t}(0)
+    check(ccall((:ecne_result_bad_rows, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Int64}}, Ref{Csize_t}), res, rows, nr))
+    for i in unsafe_wrap(Array, rows[], Int(nr[]))
+        println("constraint #", i)
+        println(lin(1, i) * " * " * lin(2, i) * " = " * lin(3, i))
+        for j in report_order(sys, i)
+            j == 1 && continue
+            println(names[j-1]); print_state(j)
+        end
+    end
+    println("------ All Variables ------"); println()
+    for i in report_order(sys, 0)
+        i == 1 && continue
+        println(names[i-1]); print_state(i)
+    end
 end
 
 function readR1CS(filename::String)                  # -> (equations, known, outputs, nVars)
@@ -68,20 +142,43 @@ function readR1CS(filename::String)                  # -> (equations, known, out
     return f, copy(unsafe_wrap(Array, kn[], Int(nk[]))), copy(unsafe_wrap(Array, tg[], Int(nt[]))), Int64(info[].n_vars)
 end
 
-function SolveConstraintsSymbolic(constraints, special_constraints=Any[], known_variables=Int64[],
-                                  debug::Bool=false, target_variables=Int64[], num_variables::Int=-1,
+function SolveConstraintsSymbolic(constraints, special_constraints=nothing, known_variables=nothing,
+                                  debug::Bool=false, target_variables=nothing, num_variables::Int=-1,
                                   input_sym::String="default.sym", secp_solve::Bool=false; device::Int=0)
     sys = constraints isa EcneSystem ? constraints : EcneSystem(constraints)
+    # the reference takes these lists as arguments: what the caller passes REPLACES what the handle carries
+    # (the file's lists, the specials abstraction() produced); `nothing` keeps the handle's
+    sp0, nvars = system_specials(sys)
+    (num_variables == -1 || num_variables == nvars) || throw(ArgumentError("num_variables differs from the system's nVars"))
+    kn0, tg0 = system_io(sys)
+    kn = known_variables === nothing ? kn0 : Int64[known_variables...]
+    tg = target_variables === nothing ? tg0 : Int64[target_variables...]
+    if kn != kn0 || tg != tg0
+        check(ccall((:ecne_system_set_io, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Csize_t, Ptr{Int64}, Csize_t), sys.h, kn, length(kn), tg, length(tg)))
+    end
+    if special_constraints !== nothing
+        sp = Any[(String(c[1]), Int64[c[2]...], Int64[c[3]...]) for c in special_constraints]
+        if sp != sp0
+            check(ccall((:ecne_system_clear_specials, LIB), Cint, (Ptr{Cvoid},), sys.h))
+            for (name, ins, outs) in sp
+                check(ccall((:ecne_system_add_special, LIB), Cint, (Ptr{Cvoid}, Cstring, Ptr{Int64}, Csize_t, Ptr{Int64}, Csize_t),
+                            sys.h, name, ins, length(ins), outs, length(outs)))
+            end
+        end
+    end
     opts = Ref(EcneOpts(device, secp_solve, 0, 0, C_NULL))
     res = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:ecne_solve, LIB), Cint, (Ptr{Cvoid}, Ref{EcneOpts}, Ref{Ptr{Cvoid}}), sys.h, opts, res))
     s = Ref{EcneSummary}()
     check(ccall((:ecne_result_summary, LIB), Cint, (Ptr{Cvoid}, Ref{EcneSummary}), res[], s))
-    ccall((:ecne_result_free, LIB), Cvoid, (Ptr{Cvoid},), res[])
-    check(s[].status)
-    println("Solved for ", s[].unique_nontrivial, " variables out of ", s[].n_nontrivial, " total variables")           # :1565
-    println("Solved for ", s[].unique_targets, " target variables out of ", s[].n_targets, " total target variables")  # :1586
-    println("------ Bad Constraints ------"); println()
+    try
+        check(s[].status)
+        println("Solved for ", s[].unique_nontrivial, " variables out of ", s[].n_nontrivial, " total variables")           # :1565
+        println("Solved for ", s[].unique_targets, " target variables out of ", s[].n_targets, " total target variables")  # :1586
+        print_report(sys, res[], input_sym == "default.sym" && !isfile(input_sym) ? "" : input_sym)                        # :1599-1643
+    finally
+        ccall((:ecne_result_free, LIB), Cvoid, (Ptr{Cvoid},), res[])
+    end
     return s[].function_good == 1
 end
 
@@ -99,7 +196,7 @@ function solveWithTrustedFunctions(input_r1cs::String, input_r1cs_name::String;
         check(ccall((:ecne_abstract, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cstring), sys.h, f.h, name))
     end
     abstractionOnly && return true
-    result = SolveConstraintsSymbolic(sys, Any[], Int64[], debug, Int64[], -1, input_sym, secp_solve)
+    result = SolveConstraintsSymbolic(sys, nothing, nothing, debug, nothing, -1, input_sym, secp_solve)
     if result
         if !isempty(fl)
             printRes && throw(UndefVarError(:msg))                          # the reference's :556-559 behaviour
