@@ -39,7 +39,68 @@ def parse_args():
     ap.add_argument("--cpu-sample-S", type=int, default=26, help="strides of the CPU-baseline sample (26 = the whole workload: ~13 s solve + ~4 s parse / abstraction on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queue-mode", type=int, default=0)
+    ap.add_argument("--workload", choices=["ecdsa", "suite"], default="ecdsa",
+                    help="ecdsa = BASELINE.json config 5 (the metric's configuration); suite = config 4, the 67 circomlib files "
+                         "sharded file-per-GPU (ecneproject_amd/jobs.py)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host worker threads for parse / abstraction / layout (0 = the cores present, at most 32)")
     return ap.parse_args()
+
+
+def probe_julia():
+    """the reference itself can only be timed where Julia 1.7 and an instantiated Ecne checkout exist."""
+    import shutil
+    import subprocess
+    exe = shutil.which("julia")
+    if not exe:
+        return {"julia": None, "note": "julia not on PATH: the reference cannot be timed here; the baseline is the sequential C++ restatement"}
+    try:
+        v = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout.strip()
+    except Exception as e:      # noqa: BLE001
+        v = "error: %r" % (e,)
+    return {"julia": v, "note": "julia found; timing the reference needs an instantiated Ecne checkout (ECNE_REFERENCE_DIR), see julia/dump_unique.jl"}
+
+
+def run_suite(args, torch, dist, rank, local_rank, world):
+    """BASELINE.json config 4: the 67 ecne_circomlib_tests files, one batch launch per rank, one all-reduce of the verdict word."""
+    import ecneproject_amd as E
+    import fixtures
+    from ecneproject_amd import jobs as J
+    E.set_host_threads(args.host_threads)
+    rels = fixtures.circomlib_suite()
+    jl = [J.Job(fixtures.path(r), r) for r in rels]
+    runner = J.Runner(jl, rank, world, local_rank, dist if world > 1 else None)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(max(args.warmup, 1)):
+        res, ok = runner.run(stream=stream)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, ok = runner.run(stream=stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rows = torch.tensor([runner.rows_main], dtype=torch.int64, device="cuda")
+    good = torch.tensor([sum(int(r.function_good) for r in res)], dtype=torch.int64, device="cuda")
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.all_reduce(rows)
+        dist.all_reduce(good)
+    if rank == 0:
+        dev = max((r.summary.device_ms for r in res), default=0.0)
+        print(json.dumps({
+            "metric": "constraints resolved/sec (wall-clock to fixed point), circomlib suite",
+            "value": int(rows.item()) * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / max(args.steps, 1), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u64x4 (BN254 Fp limbs) + u8/u32 flags", "data": "reference fixtures (67 circom outputs)",
+            "config": {"workload": "ecne_circomlib_tests/*.r1cs (BASELINE.json config 4), sharded file-per-GPU, one batch launch per rank",
+                       "files": len(rels), "rows": int(rows.item()), "files_rank0": len(runner.mine), "verdicts_true": int(good.item()),
+                       "all_ran": bool(ok), "rank0_kernel_ms": dev,
+                       "note": "latency-bound: the batch takes as long as its longest dependency chain (EdDSAMiMCSponge)"}}))
 
 
 def main():
@@ -57,9 +118,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    if args.workload == "suite":
+        run_suite(args, torch, dist, rank, local_rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     import ecneproject_amd as E
     import ecdsa_like
     import fixtures
+    E.set_host_threads(args.host_threads)      # the caller opts in to host worker threads (include/ecne.h)
 
     # ---- build the workload (host side, untimed): generate, parse, abstract, lay out, upload, classify
     t0 = time.time()
@@ -128,6 +196,18 @@ def main():
                 t = json.load(f)
             traffic, traffic_src = t.get("k_solve_bytes_per_launch"), t.get("source")
         achieved = b_alg / (k_ms * 1e-3) / 1e9
+        # latency model: the solve is rounds x time per round; a round is one dependency level of the
+        # queue schedule (or a P-phase pass)
+        sd = list(s.sched)
+        n_multi = int(s.rule_hits[14]) >> 16
+        n_rounds = int(s.rule_hits[13])
+        q_ms = float(s.phase_ms[1])
+        multi_ms = float(s.queue_ms[7])
+        latency = {"rounds": n_rounds, "us_per_round": 1e3 * q_ms / max(n_rounds, 1),
+                   "multi_workgroup_rounds": n_multi, "us_per_multi_round": 1e3 * multi_ms / max(n_multi, 1),
+                   "fast_wavefront_rounds": sd[0], "rows_in_fast_rounds": sd[1], "us_per_fast_round": sd[2] * 1e-2 / max(sd[0], 1),
+                   "general_wavefront_rounds": sd[3], "outer_iterations": int(s.outer_iterations),
+                   "model": "t_solve ~ rounds x us_per_round + P-phases; %d levels at %.1f us" % (n_rounds, 1e3 * q_ms / max(n_rounds, 1))}
         out = {
             "metric": "constraints resolved/sec (wall-clock to fixed point), ecdsa-scale R1CS",
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,6 +224,8 @@ def main():
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6}},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
+                         "latency_model": latency,
                          "alg_bytes_per_launch": b_alg, "kernel_ms": k_ms,
                          "phase_ms": {k: round(v, 3) for k, v in zip(["setup", "queue", "P3", "P4", "P5", "verdict", "P3_rounds"], list(s.phase_ms)[:7])},
                          "queue_ms": {k: round(v, 3) for k, v in zip(["head", "mark", "check", "exec", "flatten", "resolve", "alone_bursts_wave_rounds", "multi_rounds"], list(s.queue_ms)[:8])},
@@ -160,7 +242,7 @@ def main():
                                              "(parse %.1f s and abstraction %.1f s excluded, as for the GPU)" %
                                              (args.cpu_sample_S, args.stride, o.summary.n_rows_main, o.summary.t_solve,
                                               o.summary.t_read, o.summary.t_abstract),
-                                   "host_cores_available": os.cpu_count()}
+                                   "host_cores_available": os.cpu_count(), "reference_probe": probe_julia()}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

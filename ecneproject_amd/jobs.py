@@ -1,0 +1,106 @@
+"""Batch front-end: a list of independent verification jobs (main .r1cs + trusted functions) run on the GPUs of one
+node. Stands in for the reference's drivers around the solver path -- the CLI loop of src/Ecne.jl:9-37 and the REST
+wrapper src/Server.jl:6-30 (whose call signature is stale) -- only as far as they feed SolveConstraintsSymbolic:
+a job queue, nothing else.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL; "gloo" in the CPU tests). Jobs shard at file
+granularity: longest-processing-time-first packing by non-zero count (sharding.assign), every rank solves its share as
+ONE batch launch (one workgroup(-group) per job, ecne_solve_batch) and the ranks meet in a single all-reduce (MIN) of the
+4-byte verdict word -- there is no data-path collective.
+
+    python -m ecneproject_amd.jobs jobs.json            # [{"r1cs": "...", "name": "...", "trusted": [["file", "Name"], ...], "secp_solve": false}, ...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m ecneproject_amd.jobs jobs.json
+"""
+import json
+import os
+import sys
+import time
+
+from . import sharding
+
+
+class Job:
+    def __init__(self, r1cs, name=None, trusted=(), secp_solve=False):
+        self.r1cs, self.name = r1cs, name or os.path.basename(r1cs)
+        self.trusted = [tuple(t) for t in trusted]           # (file, function name)
+        self.secp_solve = bool(secp_solve)
+
+    def build(self, E):
+        """readR1CS + the abstraction loop of solveWithTrustedFunctions (:513-544); returns (System, rows of the main file, nnz)"""
+        main = E.R1CS(self.r1cs)
+        fl = sorted(((n, E.R1CS(f)) for f, n in self.trusted), key=lambda x: -len(x[1]))      # :527
+        s = E.System(main)
+        for n, f in fl:
+            s.abstract(f, n)
+        return s, len(main), int(sum(main.info.nnz))
+
+
+def job_weights(E, jobs):
+    """non-zero count of every main file (header + one pass, on every rank: the packing must be the same everywhere)"""
+    return [int(sum(E.R1CS(j.r1cs).info.nnz)) + 1 for j in jobs]
+
+
+class Runner:
+    """Builds this rank's share of the jobs once (parse, abstraction, upload happen at the first run) and solves it as
+    batch launches. dist = torch.distributed or None (single process)."""
+
+    def __init__(self, jobs, rank=0, world=1, device=0, dist=None, weights=None, E=None):
+        if E is None:
+            import ecneproject_amd as E
+        self.E, self.jobs, self.rank, self.world, self.device, self.dist = E, list(jobs), rank, world, device, dist
+        self.weights = weights if weights is not None else job_weights(E, self.jobs)
+        self.mine = sharding.assign(self.weights, world)[rank]
+        self.systems, self.rows_main = [], 0
+        for i in self.mine:
+            s, n, _ = self.jobs[i].build(E)
+            self.systems.append(s)
+            self.rows_main += n
+        self.secp = [self.jobs[i].secp_solve for i in self.mine]
+
+    def run(self, stream=None, fetch_states=False, device_for_word="cuda"):
+        """one pass over this rank's jobs; returns (results of this rank, all verdicts good on every rank)"""
+        E = self.E
+        res = [None] * len(self.systems)
+        for flag in (False, True):                       # jobs that need secp_solve (:511) form their own launch
+            idx = [k for k, f in enumerate(self.secp) if f == flag]
+            if idx:
+                out = E.solve_batch([self.systems[k] for k in idx], secp_solve=flag, device=self.device, stream=stream,
+                                    fetch_states=fetch_states)
+                for k, r in zip(idx, out):
+                    res[k] = r
+        ok = all(r.status == 0 for r in res)
+        if self.dist is not None:
+            ok = sharding.allreduce_verdict(ok, self.dist, device=device_for_word)
+        return res, ok
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    import torch
+    import torch.distributed as dist
+    import ecneproject_amd as E
+    with open(argv[0]) as f:
+        jobs = [Job(j["r1cs"], j.get("name"), j.get("trusted", ()), j.get("secp_solve", False)) for j in json.load(f)]
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    r = Runner(jobs, rank, world, local, dist if world > 1 else None)
+    t = time.perf_counter()
+    res, ok = r.run(stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    for i, g in zip(r.mine, res):
+        print(json.dumps({"job": jobs[i].name, "rank": rank, "status": g.status, "sound": bool(g.function_good),
+                          "unique": int(g.summary.unique_nontrivial), "of": int(g.summary.n_nontrivial),
+                          "targets": "%d/%d" % (g.summary.unique_targets, g.summary.n_targets), "device_ms": round(g.summary.device_ms, 3)}))
+    if rank == 0:
+        print(json.dumps({"jobs": len(jobs), "n_gpus": world, "all_ran": ok, "wall_s": round(dt, 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -86,7 +86,7 @@ end
 
 const P_BJJ = BigInt(21888242871839275222246405745257275088548364400416034343698204186575808495617)
 limbs(p::Ptr{UInt64}, i) = sum(BigInt(unsafe_load(p, 4 * i + k)) << (64 * (k - 1)) for k in 1:4)      # element i (0-based), 4 LE limbs
-fix_number(x::BigInt) = x > P_BJJ - 1000000000000000000000000000100 ? x - P_BJJ : x                      # :421-428
+fix_number(x::BigInt) = x > P_BJJ - BigInt(1000000000000000000000000000000100) ? x - P_BJJ : x                      # :421-428
 
 # the report of :1599-1643, from the ABI's data: bad rows, per-variable state, rows in printEquation's term order
 function print_report(sys::EcneSystem, res::Ptr{Cvoid}, input_sym::String)

@@ -56,3 +56,61 @@ def test_assign_is_balanced_and_deterministic():
     loads = [sum(w[i] for i in part) for part in a]
     assert max(loads) - min(loads) <= 15
     assert a == sharding.assign(w, 3)
+
+
+RUNNER_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch, torch.distributed as dist
+import fixtures, orc
+import ecneproject_amd as E
+from ecneproject_amd import jobs as J
+
+
+class OracleEngine:
+    """stands in for the GPU solves (there is no GPU here): the product's reader / abstraction / job runner / sharding /
+    all-reduce run for real, only solve_batch is answered by the test oracle"""
+    R1CS, System = E.R1CS, E.System
+    paths = {}
+
+    @staticmethod
+    def solve_batch(systems, secp_solve=False, device=0, stream=None, fetch_states=False):
+        out = []
+        for s in systems:
+            o = orc.run(s.main.path, want_states=False)
+            out.append(type("R", (), {"status": o.status, "function_good": o.verdict, "summary": o.summary})())
+        return out
+
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rels = [r for r in fixtures.circomlib_suite() if "EdDSA" not in r]
+jl = [J.Job(fixtures.path(r), r) for r in rels]
+runner = J.Runner(jl, dist.get_rank(), dist.get_world_size(), 0, dist, E=OracleEngine)
+res, ok = runner.run(device_for_word="cpu")
+names = [jl[i].name for i in runner.mine]
+gathered = [None] * dist.get_world_size()
+dist.all_gather_object(gathered, (names, [bool(r.function_good) for r in res], runner.rows_main))
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps({"ok": bool(ok), "names": sum([g[0] for g in gathered], []), "verdicts": sum([g[1] for g in gathered], []),
+                                   "rows": [g[2] for g in gathered]}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_job_runner(tmp_path):
+    """ecneproject_amd.jobs.Runner on two gloo ranks: every job built (native reader) and run exactly once, rows and
+    verdicts add up, the all-reduced word says every job ran."""
+    import orc
+    script = tmp_path / "runner_worker.py"
+    script.write_text(RUNNER_WORKER % {"root": ROOT, "tests": HERE})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    rels = [r for r in fixtures.circomlib_suite() if "EdDSA" not in r]
+    assert sorted(res["names"]) == sorted(rels) and res["ok"] is True and min(res["rows"]) > 0
+    want = {r: orc.run(fixtures.path(r), want_states=False).verdict for r in rels}
+    assert dict(zip(res["names"], res["verdicts"])) == want

@@ -94,3 +94,51 @@ def test_documented_divergence_bits2point_strict():
     r = orc.run(fixtures.path("ecne_circomlib_tests/Bits2Point_Strict@pointbits.r1cs"))
     assert r.status == 0 and r.verdict is False
     assert r.counts()[2:] == (1, 2) and not r.unique[1]    # out[0] (the sqrt hint) stays unknown
+
+
+def test_bits2point_strict_hand_trace():
+    """Why examples/Bits2Point_Strict.jl:4 (`@assert ... == true`) cannot hold under the reference's own rules -- a hand
+    trace in the style of SURVEY.md Appendix E, every step checked against the file and against the oracle's state.
+
+    out[0] (variable 2) is the `<--` square-root hint of the point decompression. It occurs in exactly two rows, both
+    wirings:  #511  out[0] == v2061   and   #513  out[0] == v2319.
+      * v2061 occurs elsewhere only in #2066, BabyCheck's  (-v2061) * (v2061) = -v2063  (x2 = x*x): R1 (:827-873) wants
+        every variable of A and B unique -- v2061 itself. Circular; R2 needs C empty.
+      * v2319 occurs elsewhere only in #2323, the 255-term strict decomposition  v2319 = sum 2^i b_i  (i = 0..253):
+        R1 wants 254 of the 255 unique -- the bits are only `is_known` (their bit checks b*(b-1) = 0 give R2's two values,
+        :875-942, never uniqueness); R4 (:991-1076) would bound the pivot by 2^(l-1) - 1 = 2^254 - 1, but `ub.d >
+        2^(l-1) - 1` (:1035) is false for ub = p - 1 < 2^254, so the pivot never becomes is_known; R7 (:1235-1298) needs
+        every non-unique variable of the row is_known -- the pivot is not; R8 (:1304-1348) needs ONE group tag on all of them --
+        P4 (:1425-1483) tagged each bit with its own bit check's slope variable (254 different tags), the pivot has none.
+      * P3 (:1357-1417) groups rows by their unknown tuple and needs k rows for k unknowns: {2, 2061} and {2, 2319} are
+        one-row groups of size two. P5 (:1492-1550) has no isZero pair on these.
+    So the fixed point leaves out[0], v2061, v2319 and the 254 bits non-unique: 1 of 2 targets, verdict false."""
+    import r1cs_py
+    path = fixtures.path("ecne_circomlib_tests/Bits2Point_Strict@pointbits.r1cs")
+    hdr, rows = r1cs_py.parse_file(path)
+    P = r1cs_py.P
+    occ = {}
+    for i, parts in enumerate(rows):
+        for terms in parts:
+            for v, c in terms:
+                if c % P:
+                    occ.setdefault(v, set()).add(i + 1)
+    assert hdr["nPubOut"] == 2 and occ[2] == {511, 513}
+    assert rows[510] == [[], [], [(2061, P - 1), (2, 1)]] and rows[512] == [[], [], [(2, 1), (2319, P - 1)]]
+    assert occ[2061] == {511, 2066} and rows[2065] == [[(2061, P - 1)], [(2061, 1)], [(2063, P - 1)]]
+    assert occ[2319] == {513, 2323}
+    A, B, C = rows[2322]
+    assert not A and not B and len(C) == 255
+    coef = dict(C)
+    assert coef[2319] == 1 and sorted(c for v, c in C if v != 2319) == sorted((-pow(2, i, P)) % P for i in range(254))
+    assert (1 << 254) - 1 > P - 1                                  # R4's bound is no bound: the pivot stays un-known
+    bits = [v for v, c in C if v != 2319]
+    r = orc.run(path)
+    for v in (2, 2061, 2319):
+        assert not r.unique[v - 1] and not r.is_known[v - 1], v
+        assert orc.limbs_to_int(r.lb[v - 1]) == 0 and orc.limbs_to_int(r.ub[v - 1]) == P - 1 and r.abz[v - 1] == -1, v
+    assert all(r.is_known[v - 1] and not r.unique[v - 1] and r.nvalues[v - 1] == 2 for v in bits)
+    assert len({int(r.abz[v - 1]) for v in bits}) == 254 and -1 not in {int(r.abz[v - 1]) for v in bits}     # R8: no common tag
+    assert r.summary.rule_hits[7] == 0 and r.summary.rule_hits[10] == 0       # R8 and P3 never fired anywhere in this circuit
+    assert {511, 513, 2066, 2323} <= set(r.bad_rows.tolist())
+    assert r.unique[2] and r.counts()[2:] == (1, 2)                            # out[1] is determined, out[0] is not
