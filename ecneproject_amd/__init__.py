@@ -149,6 +149,13 @@ class System:
         """abstraction(name, rows, knowns_t, eqs_t, outs_t) (:237-395) applied in place."""
         _check(_lib.lib().ecne_abstract(self._h, trusted._h, name.encode()), "abstraction(%s)" % name)
 
+    @staticmethod
+    def last_abstract_stats():
+        """of the calling thread's last abstract(): dict(device, fingerprint_ms, scan_ms, bytes, upload_ms, candidates)"""
+        a = (C.c_double * 6)()
+        _check(_lib.lib().ecne_abstract_stats(a))
+        return dict(device=bool(a[0]), fingerprint_ms=a[1], scan_ms=a[2], bytes=a[3], upload_ms=a[4], candidates=int(a[5]))
+
     @property
     def info(self):
         i = SystemInfo()

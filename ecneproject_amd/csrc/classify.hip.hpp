@@ -17,6 +17,15 @@ __device__ __forceinline__ int ctz256(const fp::u256& a) {
     return 256;
 }
 
+// -num / den in the field. Almost every divisor a circuit presents is +-1 (bit checks b * (b - 1) = 0, constants
+// x = v): those need no inversion, and a lane that takes the binary-EGCD path (thousands of instructions) holds its
+// whole wavefront up.
+__device__ __forceinline__ fp::u256 neg_div(const fp::u256& num, const fp::u256& den) {
+    if (fp::is_one(den)) return fp::neg(num);
+    if (fp::is_one(fp::neg(den))) return num;
+    return fp::mul(fp::neg(num), fp::inv(den));
+}
+
 // One wavefront classifies one row. wave_scratch: 8 u32 of LDS per wave (256-bit exponent bitmap).
 __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch) {
     const int lane = lane_id();
@@ -39,7 +48,7 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
                 if (v == ri.x) slope = c;
                 else if (v == 1) icpt = c;
             }
-            val = fp::mul(fp::neg(icpt), fp::inv(slope));
+            val = neg_div(icpt, slope);
             st256(J.vals + 4ull * (ri.validx + lane), val);
         }
         fp::u256 v0 = shfl256(val, 0), v1 = shfl256(val, 1);
@@ -54,7 +63,7 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
                 if (v == 1) c1v = ld256(J.coefC + 4ull * k);
                 else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
             }
-            st256(J.vals + 4ull * ri.validx, fp::mul(fp::neg(c1v), fp::inv(cx)));
+            st256(J.vals + 4ull * ri.validx, neg_div(c1v, cx));
         }
         // ---- R4 pattern: multiset {1, -2^0..-2^(l-2)} (T) or its negation (T2)  (:999-1013)
         if (!(shape & SH_CZERO)) {
@@ -231,7 +240,7 @@ __device__ void classify_row_lane(const Job& J, uint32_t row) {
                 if (v == ri.x) slope = c;
                 else if (v == 1) icpt = c;
             }
-            val[part] = fp::mul(fp::neg(icpt), fp::inv(slope));
+            val[part] = neg_div(icpt, slope);
             st256(J.vals + 4ull * (ri.validx + part), val[part]);
         }
         if ((fp::is_zero(val[0]) && fp::is_one(val[1])) || (fp::is_one(val[0]) && fp::is_zero(val[1]))) shape |= SH_R2_IS01;
@@ -244,7 +253,7 @@ __device__ void classify_row_lane(const Job& J, uint32_t row) {
                 if (v == 1) c1v = ld256(J.coefC + 4ull * k);
                 else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
             }
-            st256(J.vals + 4ull * ri.validx, fp::mul(fp::neg(c1v), fp::inv(cx)));
+            st256(J.vals + 4ull * ri.validx, neg_div(c1v, cx));
         }
         fp::u256 key[ECNE_CLS_LANE];
         if (!(shape & SH_CZERO)) {

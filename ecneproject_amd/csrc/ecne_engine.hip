@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -773,10 +774,100 @@ static int ecne_system_from_r1cs_impl(const ecne_r1cs* m, ecne_system** out) {
     *out = s;
     return ECNE_OK;
 }
+// abstraction's candidate scan on the GPU (abstract.hip.hpp). Returns K_OK and the ascending candidate list, or an error
+// (the caller then scans on the host). stats: [0] fingerprint kernel ms (main file), [1] scan + candidate kernels ms,
+// [2] bytes the fingerprint kernel streamed, [3] upload ms
+struct AbstractStats { double fp_ms = 0, scan_ms = 0, bytes = 0, upload_ms = 0; int used_device = 0; size_t n_cand = 0; };
+static thread_local AbstractStats g_last_abstract;
+static int device_candidates(const Rows& rows, const Rows& sub, int device, std::vector<size_t>& cand) {
+    AbstractStats& st = g_last_abstract;
+    st = AbstractStats();
+    const uint64_t nC = rows.n(), nS = sub.n();
+    cand.clear();
+    if (nS == 0 || nC < nS) { st.used_device = 1; return K_OK; }
+    if (nC >= 0xFFFFFFF0ull) return K_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } };
+    auto upload = [&](const Rows& R, Buf* ptrb, Buf* coefb, AbsRows& A) -> int {
+        A.n = R.n();
+        for (int p = 0; p < 3; ++p) {
+            const size_t pb = 8ull * (A.n + 1), cb = 32ull * std::max<size_t>(R.coef[p].size(), 1);
+            HIP_TRY(hipMalloc(&ptrb[p].p, pb));
+            HIP_TRY(hipMalloc(&coefb[p].p, cb));
+            HIP_TRY(hipMemcpy(ptrb[p].p, R.ptr[p].data(), pb, hipMemcpyHostToDevice));
+            if (!R.coef[p].empty()) HIP_TRY(hipMemcpy(coefb[p].p, R.coef[p].data(), 32ull * R.coef[p].size(), hipMemcpyHostToDevice));
+            A.ptr[p] = (const uint64_t*)ptrb[p].p;
+            A.coef[p] = (const uint64_t*)coefb[p].p;
+            st.bytes += (&R == &rows) ? (double)(pb + 32ull * R.coef[p].size()) : 0.0;
+        }
+        return K_OK;
+    };
+    Buf mp[3], mc[3], sp[3], sc[3], bf, bfs, bP, btops, bcand, bn;
+    AbsRows M, S;
+    hipEvent_t e[4];
+    for (auto& x : e) HIP_TRY(hipEventCreate(&x));
+    struct Ev { hipEvent_t* e; ~Ev() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); } } ev{e};
+    const auto t_up = std::chrono::steady_clock::now();
+    { const int rc = upload(rows, mp, mc, M); if (rc != K_OK) return rc; }
+    { const int rc = upload(sub, sp, sc, S); if (rc != K_OK) return rc; }
+    st.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count();
+    const uint64_t nb = (nC + 1 + 1023) / 1024;
+    HIP_TRY(hipMalloc(&bf.p, 8ull * (nC + 1)));
+    HIP_TRY(hipMalloc(&bfs.p, 8ull * nS));
+    HIP_TRY(hipMalloc(&bP.p, 8ull * (nC + 1)));
+    HIP_TRY(hipMalloc(&btops.p, 8ull * nb));
+    HIP_TRY(hipMalloc(&bcand.p, 4ull * nC));
+    HIP_TRY(hipMalloc(&bn.p, 8));
+    HIP_TRY(hipMemset(bn.p, 0, 8));
+    HIP_TRY(hipMemset((char*)bf.p + 8ull * nC, 0, 8));
+    const unsigned g_rows = (unsigned)std::min<uint64_t>((nC + 255) / 256, 256 * 16), g_sub = (unsigned)std::min<uint64_t>((nS + 255) / 256, 256 * 16);
+    HIP_TRY(hipEventRecord(e[0], 0));
+    hipLaunchKernelGGL(k_abs_fingerprint, dim3(g_rows), dim3(256), 0, 0, M, (uint64_t*)bf.p);
+    HIP_TRY(hipEventRecord(e[1], 0));
+    hipLaunchKernelGGL(k_abs_fingerprint, dim3(g_sub), dim3(256), 0, 0, S, (uint64_t*)bfs.p);
+    // the pattern's value T = sum_j g_j r^j over its first nS - 1 rows (host: a few thousand terms)
+    std::vector<uint64_t> fs(nS);
+    HIP_TRY(hipMemcpy(fs.data(), bfs.p, 8ull * nS, hipMemcpyDeviceToHost));
+    uint64_t T = 0, w = 1;
+    for (uint64_t j = 0; j + 1 < nS; ++j) { T += fs[j] * w; w *= ECNE_ABS_R; }
+    HIP_TRY(hipEventRecord(e[2], 0));
+    hipLaunchKernelGGL(k_abs_weighted_scan, dim3((unsigned)nb), dim3(256), 0, 0, (const uint64_t*)bf.p, nC + 1, (uint64_t*)bP.p, (uint64_t*)btops.p);
+    hipLaunchKernelGGL(k_abs_scan_tops, dim3(1), dim3(256), 0, 0, (uint64_t*)btops.p, nb);
+    hipLaunchKernelGGL(k_abs_candidates, dim3(g_rows), dim3(256), 0, 0, (const uint64_t*)bP.p, (const uint64_t*)btops.p, nC, nS - 1, nS, T,
+                       (uint32_t*)bcand.p, (unsigned long long*)bn.p, nC);
+    HIP_TRY(hipEventRecord(e[3], 0));
+    HIP_TRY(hipEventSynchronize(e[3]));
+    HIP_TRY(hipGetLastError());
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, e[0], e[1]);
+    (void)hipEventElapsedTime(&b, e[2], e[3]);
+    st.fp_ms = a; st.scan_ms = b;
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, bn.p, 8, hipMemcpyDeviceToHost));
+    if (n > nC) return K_ECAPACITY;
+    std::vector<uint32_t> c32((size_t)n);
+    if (n) HIP_TRY(hipMemcpy(c32.data(), bcand.p, 4ull * n, hipMemcpyDeviceToHost));
+    std::sort(c32.begin(), c32.end());
+    cand.assign(c32.begin(), c32.end());
+    st.used_device = 1;
+    st.n_cand = cand.size();
+    return K_OK;
+}
+
 static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
     if (!sys || !trusted || !name) return ECNE_EINVAL;
     Rows red;
-    const int rc = abstract_one(name, sys->rows(), trusted->f, sys->specials, red);
+    // The candidate scan runs on the GPU for files worth the upload (ECNE_ABSTRACT_DEVICE=0 / 1 forces host / device);
+    // verification and replacement are the same host code either way, so the result does not depend on the choice.
+    std::vector<size_t> dcand;
+    bool have_dcand = false;
+    {
+        const char* e = getenv("ECNE_ABSTRACT_DEVICE");
+        const bool want = e ? atoi(e) != 0 : sys->rows().n() >= ECNE_ABSTRACT_DEVICE_ROWS;
+        g_last_abstract = AbstractStats();
+        if (want && ecne_device_count() > 0) have_dcand = device_candidates(sys->rows(), trusted->f.rows, 0, dcand) == K_OK;
+    }
+    const int rc = abstract_one(name, sys->rows(), trusted->f, sys->specials, red, have_dcand ? &dcand : nullptr);
     if (rc != K_OK) return rc;
     system_changed_rows(sys);   // layout and device image are stale, earlier results unreadable
     sys->reduced = std::move(red);
@@ -1074,6 +1165,12 @@ int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64
 }
 
 int ecne_set_host_threads(int n) { return (int)set_host_threads(n); }
+int ecne_abstract_stats(double* out6) {
+    if (!out6) return ECNE_EINVAL;
+    const AbstractStats& st = g_last_abstract;
+    out6[0] = st.used_device; out6[1] = st.fp_ms; out6[2] = st.scan_ms; out6[3] = st.bytes; out6[4] = st.upload_ms; out6[5] = (double)st.n_cand;
+    return ECNE_OK;
+}
 
 // getVariables(constraints[i]) (:36-56) in Set order: keys of a, b, c (dictionary order, non-zero values) pushed into one Set
 static void row_variables_in_set_order(const Rows& R, size_t i, jl::SlotTable& set, std::vector<int64_t>& out) {

@@ -35,6 +35,9 @@ namespace ecne {
 #ifndef ECNE_CHAIN_ROWS
 #define ECNE_CHAIN_ROWS 49152   // systems up to this many rows are solved by ONE workgroup with the chain executor (flags + in_queue tags in LDS)
 #endif
+#ifndef ECNE_ABSTRACT_DEVICE_ROWS
+#define ECNE_ABSTRACT_DEVICE_ROWS 100000   // main files from this many rows on: abstraction's candidate scan runs on the GPU
+#endif
 #define ECNE_BIGTAB 2048    // big rows with an LDS slot for their push candidates (the rest use memory atomics directly)
 #define ECNE_EVCAP 200      // REQUEUE events one small row can emit: 5 + 3 * ECNE_SMALL_ROW, rounded up
 static_assert(ECNE_EVCAP >= 5 + 3 * ECNE_SMALL_ROW, "a small row can emit 5 + 3 * ECNE_SMALL_ROW REQUEUE events");

@@ -479,12 +479,16 @@ struct AppearMap {
 // `red` and `specials` are left as they were).  Fingerprints, the per-window variable matching and the
 // copy of the surviving rows run on the host worker threads; which windows match, and in which order,
 // does not depend on the thread count.
-inline int abstract_one(const std::string& name, const Rows& rows, const R1CSFile& sub, std::vector<Special>& specials, Rows& red) {
+// device_cand: candidate window starts found on the GPU (abstract.hip.hpp), ascending -- a superset of the occurrences, like
+// the host scan's; null = scan here.
+inline int abstract_one(const std::string& name, const Rows& rows, const R1CSFile& sub, std::vector<Special>& specials, Rows& red,
+                        const std::vector<size_t>* device_cand = nullptr) {
     using namespace detail;
     const size_t nC = rows.n(), nS = sub.rows.n();
     const size_t FP_BLOCK = 8192;
     std::vector<size_t> cand;
-    if (nC >= nS) {
+    if (device_cand) cand = *device_cand;
+    else if (nC >= nS) {
         std::vector<uint64_t> fb(nC), fs(nS);
         for_chunks((nC + FP_BLOCK - 1) / FP_BLOCK, [&](size_t blk, unsigned) {
             std::vector<fp::u256> scratch;

@@ -15,10 +15,13 @@
 //                     worklist in HBM/L2, rules R1-R8, batch phases P1-P5, verdict counts.  All
 //                     ordering-sensitive steps follow the reference's sequential order exactly (see
 //                     DESIGN.md "Schedule").
+//   k_abs_*           abstraction's O(rows) part (reference :237-395): row fingerprints, a weighted prefix scan and the
+//                     window-candidate test (abstract.hip.hpp); verification and the greedy replacement stay on the host.
 //   k_fp_selftest     field-arithmetic known-answer vectors on the device.
 #pragma once
 #include "k_solve.hip.hpp"
 #include "classify.hip.hpp"
+#include "abstract.hip.hpp"
 
 namespace ecne {
 

@@ -81,6 +81,12 @@ void ecne_r1cs_free(ecne_r1cs* f);
  * The caller passes trusted functions in the reference's order (already sorted long -> short, :527). */
 int ecne_system_from_r1cs(const ecne_r1cs* main_file, ecne_system** out);
 int ecne_abstract(ecne_system* sys, const ecne_r1cs* trusted, const char* name);
+/* abstraction's O(rows) part -- row fingerprints and the window-candidate scan (:228-270) -- runs on HIP device 0 for main
+ * files of 100 000 rows and more (ECNE_ABSTRACT_DEVICE=0 / 1 in the environment forces host / device); verification (:272-351)
+ * and the greedy replacement (:368-388) are host code either way, the result does not depend on the choice. Statistics of the
+ * calling thread's last ecne_abstract: out6 = {ran on the device (0/1), fingerprint kernel ms, scan + candidate kernels ms,
+ * bytes the fingerprint kernel streamed, upload ms, candidate windows}. */
+int ecne_abstract_stats(double* out6);
 typedef struct ecne_system_info {
     int64_t n_rows;      /* rows handed to the solver (after abstraction) */
     int64_t n_rows_main; /* rows of the main file as read                 */
