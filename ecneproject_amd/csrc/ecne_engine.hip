@@ -645,7 +645,7 @@ static int upload_system(ecne_system& S, int device) {
     J.ctr = (Counters*)(base + o_ctr);
     J.rec = chain ? (const uint32_t*)(base + o_rec) : nullptr;
     J.foi = chain ? (const uint32_t*)(base + o_foi) : nullptr;
-    J.lds_flags_off = J.lds_inq_off = J.lds_flip_off = J.lds_w2_off = 0xFFFFFFFFu;
+    J.lds_flags_off = J.lds_inq_off = J.lds_flip_off = J.lds_w2_off = J.lds_w2b_off = 0xFFFFFFFFu;
     J.warm_bytes = (static_end - o_rp[0]) <= (7u << 19) ? (uint32_t)(static_end - o_rp[0]) : 0u;   // fits one XCD's 4 MB L2 beside the state
     S.dev.classified = false;
     return K_OK;

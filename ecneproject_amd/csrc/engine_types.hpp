@@ -128,7 +128,7 @@ struct Job {
     // 1 << 24 followed by the row's variable ids (A, B, C; stored order), word 0 = 0 for rows with more than 15 entries;
     // foi[4 * v] = {n, r0, r1, r2} for n <= 3 rows of variable_to_indices[v], else {n, offset into fo_rows, 0, 0}
     const uint32_t *rec, *foi;
-    uint32_t lds_w2_off;   // byte offset of the fast wavefront round's tables (wave2.hip.hpp) in the dynamic LDS, or 0xFFFFFFFF
+    uint32_t lds_w2_off, lds_w2b_off;   // byte offsets of the fast wavefront / workgroup round's tables (wave2.hip.hpp) in the dynamic LDS, or 0xFFFFFFFF
     uint32_t lds_flags_off, lds_inq_off, lds_flip_off;   // byte offsets of flags / inq / flip3 in the dynamic LDS when resident there, else 0xFFFFFFFF (set by k_solve)
     const uint32_t *sp_in_ptr, *sp_in, *sp_out_ptr, *sp_out;
     const uint8_t* sp_kind;   // 1 = "BigMultModP", 2 = "BigLessThan", 0 = anything else (:751, :755)

@@ -32,23 +32,30 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
     // chain executor (chain.hip.hpp) reads them with ds_read (27 ns). The host reads the flags afterwards: they
     // are copied back before the verdict count.
     uint8_t* const g_flags = J.flags;
-    if (tid == 0) J.lds_w2_off = J.lds_bytes >= ECNE_W2_BYTES ? J.lds_bytes - ECNE_W2_BYTES : 0xFFFFFFFFu;   // tables of the fast wavefront round (top of the dynamic LDS)
-    if (J.nwg == 1 && J.lds_bytes > ECNE_W2_BYTES && tid == 0) {
+    // dynamic LDS, from the top: tables of the fast wavefront round (always, 7 KB), below them those of the fast workgroup
+    // round (56 KB) when there is room -- always on a multi-workgroup job, on a single-workgroup job after its state
+    if (tid == 0) {
+        J.lds_w2_off = J.lds_bytes >= ECNE_W2_BYTES ? J.lds_bytes - ECNE_W2_BYTES : 0xFFFFFFFFu;
+        J.lds_w2b_off = 0xFFFFFFFFu;
         uint32_t off = 0;
-        const uint32_t cap = J.lds_bytes - ECNE_W2_BYTES;
-        auto take = [&](size_t bytes) -> unsigned char* {
-            const uint32_t b = ((uint32_t)bytes + 15u) & ~15u;
-            if (bytes > cap || off + b > cap) return nullptr;
-            unsigned char* p = ecne_dyn_lds + off;
-            off += b;
-            return p;
-        };
-        if (unsigned char* p = take((size_t)nV + 1)) { J.flags = (uint8_t*)p; J.lds_flags_off = (uint32_t)(p - ecne_dyn_lds); }
-        if (unsigned char* p = take(2ull * (nC ? nC : 1))) { J.inq = (uint16_t*)p; J.lds_inq_off = (uint32_t)(p - ecne_dyn_lds); }
-        if (unsigned char* p = take(nC ? nC : 1)) { J.flip3 = (uint8_t*)p; J.lds_flip_off = (uint32_t)(p - ecne_dyn_lds); }
+        const uint32_t cap = J.lds_bytes > ECNE_W2_BYTES ? J.lds_bytes - ECNE_W2_BYTES : 0u;
+        if (J.nwg == 1 && cap) {
+            auto take = [&](size_t bytes) -> unsigned char* {
+                const uint32_t b = ((uint32_t)bytes + 15u) & ~15u;
+                if (bytes > cap || off + b > cap) return nullptr;
+                unsigned char* p = ecne_dyn_lds + off;
+                off += b;
+                return p;
+            };
+            if (unsigned char* p = take((size_t)nV + 1)) { J.flags = (uint8_t*)p; J.lds_flags_off = (uint32_t)(p - ecne_dyn_lds); }
+            if (unsigned char* p = take(2ull * (nC ? nC : 1))) { J.inq = (uint16_t*)p; J.lds_inq_off = (uint32_t)(p - ecne_dyn_lds); }
+            if (unsigned char* p = take(nC ? nC : 1)) { J.flip3 = (uint8_t*)p; J.lds_flip_off = (uint32_t)(p - ecne_dyn_lds); }
+        }
+        if (cap >= off + ECNE_W2_BYTES_BIG) J.lds_w2b_off = cap - ECNE_W2_BYTES_BIG;
     }
     __syncthreads();
-    if (J.lds_w2_off != 0xFFFFFFFFu) w2_tables_init(J.lds_w2_off);
+    if (J.lds_w2_off != 0xFFFFFFFFu) w2_tables_init(J.lds_w2_off, false);
+    if (J.lds_w2b_off != 0xFFFFFFFFu) w2_tables_init(J.lds_w2b_off, true);
     if (tid < 8) { s_chunk.qt[tid] = 0; s_chunk.mt[tid] = 0; }
     if (tid < 16) s_chunk.sd[tid] = 0;
 #ifdef ECNE_POPPROF

@@ -519,17 +519,27 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #define ECNE_V2_DECLINES 4
 #endif
 #ifndef ECNE_V2_WINDOW
-#define ECNE_V2_WINDOW 1024
+#define ECNE_V2_WINDOW 128      // rows committed in a row without a dependency cut before a round goes to all workgroups (measured: 128 / 256 / 1024 -> 27.3 / 28.9 / 29.5 ms)
+#endif
+#ifndef ECNE_V2WG_AVAIL
+#define ECNE_V2WG_AVAIL 2048     // ... and with the fast WORKGROUP round (512 rows in ~13 us) from this many queued rows
+#endif
+#ifndef ECNE_V2WG_WINDOW
+#define ECNE_V2WG_WINDOW 2048
 #endif
 #ifndef ECNE_V2_AVAIL
-#define ECNE_V2_AVAIL 512     // ... when the fast wavefront round is available: it takes 64 rows in ~7 us, a multi-workgroup round costs ~55 us
+#define ECNE_V2_AVAIL 256     // ... when the fast wavefront round is available: it takes 64 rows in ~9 us, a multi-workgroup round costs ~55 us
 #endif
 // (the same value on every workgroup of the job: the chained rounds derive their schedule from it)
 __device__ __forceinline__ bool fast_wave_ok(const Job& J) { return J.rec != nullptr && J.lds_w2_off != 0xFFFFFFFFu; }
-__device__ __forceinline__ uint32_t multi_min(const Job& J) { return fast_wave_ok(J) ? ECNE_V2_AVAIL : ECNE_MULTI_MIN; }
+#ifndef ECNE_V2WG
+#define ECNE_V2WG 0      // the fast round on the whole workgroup (512 rows, wave2.hip.hpp WG = true): bit-exact, but measured slower than
+#endif                   // wavefront rounds + multi-workgroup rounds on every workload (ecdsa_like(26) 29.7 vs 27.3 ms, secp256k1 9.4 vs 8.4 ms): off
+__device__ __forceinline__ bool fast_wg_ok(const Job& J) { return ECNE_V2WG && J.rec != nullptr && J.lds_w2b_off != 0xFFFFFFFFu; }
+__device__ __forceinline__ uint32_t multi_min(const Job& J) { return fast_wg_ok(J) ? ECNE_V2WG_AVAIL : fast_wave_ok(J) ? ECNE_V2_AVAIL : ECNE_MULTI_MIN; }
 // the adaptive single-workgroup window has to have grown this far (rounds committing everything they looked at, doubling
 // it) before a round goes to all workgroups: with the fast round a multi-workgroup round pays from ~500 committed rows
-__device__ __forceinline__ uint32_t multi_window_min(const Job& J) { return fast_wave_ok(J) ? ECNE_V2_WINDOW : ECNE_MULTI_MIN; }
+__device__ __forceinline__ uint32_t multi_window_min(const Job& J) { return fast_wg_ok(J) ? ECNE_V2WG_WINDOW : fast_wave_ok(J) ? ECNE_V2_WINDOW : ECNE_MULTI_MIN; }
 // ---- chained multi-workgroup rounds
 // After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
 // decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
@@ -550,7 +560,11 @@ __device__ __forceinline__ void multi_window_update(uint32_t cm, uint32_t nm, ui
     }
 }
 // rows of the next chained round, 0 = back to the master's own loop (same tests as at its top)
-__device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head, uint32_t tail, uint32_t window, uint32_t mwindow) {
+__device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head, uint32_t tail, uint32_t window, uint32_t mwindow,
+                                                     uint32_t c_last, uint32_t n_last) {
+    // with the fast rounds at hand, a round that a dependency cut short of ECNE_V2WG_WINDOW rows hands the frontier back to them
+    // (the next prefix is likely short as well, and they find that out for a fifth of the price)
+    if (fast_wave_ok(J) && c_last != n_last && c_last < ECNE_V2WG_WINDOW) return 0;
     const uint32_t avail = tail - head;
     const uint32_t n = avail < window ? avail : window;
     if (n <= 64 || avail < multi_min(J) || window < multi_window_min(J)) return 0;
@@ -587,6 +601,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     // more rows to be worth its latency, whatever the queue length; bursts grow further while the chain lasts.
     const bool chain = chain_ok(J);
     const bool v2 = fast_wave_ok(J);
+    const bool v2wg = v2 && fast_wg_ok(J);
+    uint32_t streak = 0;             // rows committed in a row without a dependency cutting a round short (evidence for a wide independent frontier)
     bool declined_wide = false;      // the fast wavefront round keeps declining the head row of a wide frontier
     uint32_t declined_run = 0;
     const uint32_t burst_c = chain ? ECNE_CHAIN_BURST_C : ECNE_BURST_C, burst_avail = chain ? 0xFFFFFFFFu : 64u, burst_max = chain ? 4096u : 512u;
@@ -645,7 +661,11 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
         uint32_t n = avail < window ? avail : window;
         // with the fast wavefront round a frontier below the multi-workgroup threshold is taken 64 rows at a time
-        if (v2 && n > 64 && J.nwg > 1 && !declined_wide && (avail < multi_min(J) || window < multi_window_min(J))) n = 64;
+        if (v2 && J.nwg > 1 && !declined_wide && (avail < multi_min(J) || streak < multi_window_min(J))) {
+            const uint32_t cap_ = v2wg ? (uint32_t)ECNE_WG : 64u;        // below the multi-workgroup threshold the fast rounds take the frontier
+            n = avail < cap_ ? avail : cap_;
+        }
+        if (v2wg && J.nwg == 1 && n > ECNE_WG) n = ECNE_WG;
         if (n <= 64 && !declined_wide) {
             // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
             if (w == 0) {
@@ -653,8 +673,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 uint32_t cw = 0xFFFFFFFFu;
                 // the fast round on row records first; it declines (nothing touched) what it does not cover
                 if (v2)
-                    cw = chain ? queue_round_wave2<true>(J, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
-                               : queue_round_wave2<false>(J, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
+                    cw = chain ? queue_round_fast<true, false>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
+                               : queue_round_fast<false, false>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
                 const bool fast = cw < 0xFFFFFFFEu;
                 // declined at rank 0: a single-workgroup job (or a long row) takes the general wavefront round; the master of a
                 // multi-workgroup job pops that one row with the general executor (narrow level) or goes to a round on all
@@ -685,6 +705,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 pops_total += cw;
                 hits[13]++;
                 declined_run = 0;
+                streak = cw == nx ? streak + cw : 0;
                 // (single-workgroup jobs: a short prefix goes to the chain executor whatever stopped it -- rows the fast round
                 //  does not take are cheap there; the master of a large job only bursts on true dependency chains)
                 if (cw < burst_c && (chain || cw < nx) && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
@@ -695,6 +716,37 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 continue;
             }
             // (the window starts with a live long row: the general path below takes this round)
+        }
+        if (v2wg && n > 64 && n <= ECNE_WG && !declined_wide) {
+            // ---- a medium frontier: the fast round on the whole workgroup (one row per thread), see wave2.hip.hpp
+            uint32_t nt = q.tail, nx = n;
+            const uint32_t cw = chain ? queue_round_fast<true, true>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
+                                      : queue_round_fast<false, true>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
+            if (cw == 0xFFFFFFFEu) {
+                if (J.nwg > 1) {
+                    if (avail >= multi_min(J) && ++declined_run >= ECNE_V2_DECLINES) { declined_wide = true; declined_run = 0; }
+                    else burst = 1;
+                } else burst = chain ? next_burst : 1;
+                continue;
+            }
+            if (cw != 0xFFFFFFFFu) {
+#ifdef ECNE_FINE_TICKS
+                if (tid == 0) { const unsigned long long dt_ = wall_clock64() - qt_last; S.sd[0] += 1; S.sd[1] += cw; S.sd[2] += dt_; }
+#endif
+                q.head += cw;
+                q.tail = nt;
+                pops_total += cw;
+                hits[13]++;
+                declined_run = 0;
+                streak = cw == nx ? streak + cw : 0;
+                if (cw < burst_c && (chain || cw < nx) && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
+                if (cw == nx) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+                else if (cw < nx / 4) { uint32_t wn = 4 * cw; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
+                else next_burst = 16;
+                QTICK(6);
+                continue;
+            }
+            // (a long row at the head: the general path below pops it alone)
         }
         const uint32_t rpl = (n + ECNE_WG - 1) / ECNE_WG;          // rows per lane this round
         const uint32_t r0 = (uint32_t)tid * rpl;                    // my first rank
@@ -713,13 +765,13 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         }
         // a live long row at the head is popped alone when it cannot ride along in a round (R2..R6 shapes) -- or when the
         // window is narrow anyway: a workgroup round for a handful of rows costs ten times the long row's own pop
-        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && (!big_plain(shape[0]) || n <= 64)) ? 1u : 0u; }
+        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && (!big_plain(shape[0]) || n <= (v2wg ? (uint32_t)ECNE_WG : 64u))) ? 1u : 0u; }
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
             if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
-        if (!S.fallback && J.nwg > 1 && avail >= multi_min(J) && (window >= multi_window_min(J) || declined_wide)) {
+        if (!S.fallback && J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= multi_window_min(J) : window >= multi_window_min(J)) || declined_wide)) {
             declined_wide = false;
             // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
             const uint32_t cap_n = J.nwg * ECNE_WG * 2;
@@ -742,8 +794,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
                 hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
                 if (tid == 0) S.sd[cm < 64 ? 13 : cm < 4096 ? 14 : 15] += 1;   // schedule diagnostics: multi rounds by rows committed
+                streak = cm == nm ? streak + cm : 0;
                 multi_window_update(cm, nm, cap_n, mwindow, window);
-                nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow) : 0;
+                nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow, cm, nm) : 0;
                 if (!nm) break;
             }
             if (failed) { helpers_released = true; break; }
@@ -1039,7 +1092,7 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
             head += c;
             tail = nt;
             multi_window_update(c, n, cap_n, mwindow, window);
-            n = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, head, tail, window, mwindow) : 0;
+            n = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, head, tail, window, mwindow, c, n) : 0;
             if (!n) break;
         }
         if (failed) break;

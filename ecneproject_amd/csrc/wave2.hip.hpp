@@ -31,11 +31,16 @@ namespace ecne {
 
 // LDS tables of the round, at the top of the dynamic LDS (k_solve keeps the state of single-workgroup jobs below them):
 // key / value pairs, linear probing, never more than half full, wiped after every round.
-#define ECNE_W2_MARKS 256      // write marks: variable -> lowest writer rank (<= 64 rows x 2 written variables)
-#define ECNE_W2_ROWS 128       // rows of the prefix -> rank
-#define ECNE_W2_TGT 512        // push targets -> lowest eligible candidate index
-#define ECNE_W2_MAXCAND 256    // candidates one round resolves
-#define ECNE_W2_BYTES (8u * (ECNE_W2_MARKS + ECNE_W2_ROWS + ECNE_W2_TGT))
+// Two sizes: the wavefront round (64 rows) and the workgroup round (512 rows, all eight wavefronts of the master); the
+// second one is used when the dynamic LDS has room for its tables (always on the master of a multi-workgroup job, on a
+// single-workgroup job when its LDS-resident state leaves 56 KB).
+#define ECNE_W2_LOG_MARKS 8    // write marks: variable -> lowest writer rank (<= 64 rows x 2 written variables); x8 in the workgroup round
+#define ECNE_W2_LOG_ROWS 7     // rows of the prefix -> rank
+#define ECNE_W2_LOG_TGT 9      // push targets -> lowest eligible candidate index
+#define ECNE_W2_MAXCAND 256    // candidates one wavefront round resolves (x8 in the workgroup round)
+#define ECNE_W2_SLOTS(big) (((1u << ECNE_W2_LOG_MARKS) + (1u << ECNE_W2_LOG_ROWS) + (1u << ECNE_W2_LOG_TGT)) << ((big) ? 3 : 0))
+#define ECNE_W2_BYTES (8u * ECNE_W2_SLOTS(0))
+#define ECNE_W2_BYTES_BIG (8u * ECNE_W2_SLOTS(1))
 
 struct W2Tab { uint32_t* key; uint32_t* val; uint32_t mask, shift; };
 __device__ __forceinline__ void w2_min(const W2Tab& t, uint32_t key, uint32_t v) {          // key != 0
@@ -56,18 +61,39 @@ __device__ __forceinline__ uint32_t w2_get(const W2Tab& t, uint32_t key) {
     }
 }
 // all threads of the workgroup, once per launch
-__device__ __forceinline__ void w2_tables_init(uint32_t w2_off) {
+__device__ __forceinline__ void w2_tables_init(uint32_t w2_off, bool big) {
     uint32_t* const base = (uint32_t*)(ecne_dyn_lds + w2_off);
-    const uint32_t nslots = ECNE_W2_MARKS + ECNE_W2_ROWS + ECNE_W2_TGT;
+    const uint32_t nslots = ECNE_W2_SLOTS(big);
     for (uint32_t i = threadIdx.x; i < nslots; i += ECNE_WG) { base[i] = 0u; base[nslots + i] = 0xFFFFFFFFu; }
 }
 
-template <bool LDS>
-__device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
-                                                   uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail, uint32_t* out_examined,
-                                                   unsigned long long* why) {
+// WG = false: wavefront 0 alone, up to 64 rows. WG = true: ALL threads of the workgroup, up to ECNE_WG rows (rank = thread),
+// the wave-level votes and scans become workgroup-level ones through LDS; the return values are uniform across the workgroup.
+template <bool LDS, bool WG>
+__device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
+                                                  uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail, uint32_t* out_examined,
+                                                  unsigned long long* why) {
     const int lane = lane_id();
-    const uint32_t rank = (uint32_t)lane;
+    const uint32_t rank = WG ? (uint32_t)threadIdx.x : (uint32_t)lane;
+    const uint32_t NT = WG ? (uint32_t)ECNE_WG : 64u;          // threads taking part
+    __shared__ uint32_t s_red[8];                              // workgroup votes: lowest rank with a property (slots 0..3), rank 0's shape (4)
+    if (WG) { if (threadIdx.x < 8) s_red[threadIdx.x] = 0xFFFFFFFFu; __syncthreads(); }
+    auto sync = [&]() { if constexpr (WG) __syncthreads(); else lds_fence(); };
+    // lowest rank for which p holds (0xFFFFFFFF: none); slot: a vote of its own per call site
+    auto first_rank = [&](bool p, int slot) -> uint32_t {
+        const uint64_t m = __ballot(p);
+        if constexpr (!WG) { (void)slot; return m ? (uint32_t)(__ffsll((long long)m) - 1) : 0xFFFFFFFFu; }
+        else {
+            if (m && lane == 0) atomicMin(&s_red[slot], (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
+            __syncthreads();
+            return s_red[slot];
+        }
+    };
+    auto excl_scan = [&](uint32_t x, uint32_t* tot) -> uint32_t {
+        if constexpr (WG) return wg_exclusive_scan(x, S.scan, tot); else return wave_excl_scan(x, tot);
+    };
+    const bool big = WG;
+    const uint32_t MAXC = ECNE_W2_MAXCAND << (big ? 3 : 0);
     auto uni = [](const void* p) -> uint64_t {
         const uint64_t x = (uint64_t)p;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
@@ -90,11 +116,12 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
     auto stF = [&](uint32_t v, uint8_t f) { if constexpr (LDS) Fl[v] = f; else Fg[v] = f; };
     auto ldQ = [&](uint32_t r) -> uint16_t { if constexpr (LDS) return Ql[r]; else return Qg[r]; };
     auto stQ = [&](uint32_t r, uint16_t x) { if constexpr (LDS) Ql[r] = x; else Qg[r] = x; };
-    uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + J.lds_w2_off);
-    const uint32_t NS = ECNE_W2_MARKS + ECNE_W2_ROWS + ECNE_W2_TGT;
-    const W2Tab Tm = {tb, tb + NS, ECNE_W2_MARKS - 1, 32 - 8};
-    const W2Tab Tr = {tb + ECNE_W2_MARKS, tb + NS + ECNE_W2_MARKS, ECNE_W2_ROWS - 1, 32 - 7};
-    const W2Tab Tt = {tb + ECNE_W2_MARKS + ECNE_W2_ROWS, tb + NS + ECNE_W2_MARKS + ECNE_W2_ROWS, ECNE_W2_TGT - 1, 32 - 9};
+    uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + (WG ? J.lds_w2b_off : J.lds_w2_off));      // the two rounds have tables of their own
+    const uint32_t LM = ECNE_W2_LOG_MARKS + (big ? 3 : 0), LR = ECNE_W2_LOG_ROWS + (big ? 3 : 0), LT = ECNE_W2_LOG_TGT + (big ? 3 : 0);
+    const uint32_t NS = ECNE_W2_SLOTS(big), NMARK = 1u << LM, NROW = 1u << LR;
+    const W2Tab Tm = {tb, tb + NS, NMARK - 1, 32 - LM};
+    const W2Tab Tr = {tb + NMARK, tb + NS + NMARK, NROW - 1, 32 - LR};
+    const W2Tab Tt = {tb + NMARK + NROW, tb + NS + NMARK + NROW, (1u << LT) - 1, 32 - LT};
 
     // ---- 1, 2: my row
     const bool mine = rank < n;
@@ -113,14 +140,27 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) { w[4 * i] = w4[i].x; w[4 * i + 1] = w4[i].y; w[4 * i + 2] = w4[i].z; w[4 * i + 3] = w4[i].w; }
     const uint32_t shape = ri4[0].x, rx = ri4[0].y, kpos = ri4[0].z, kneg = ri4[0].w, k1 = ri4[1].x, k2 = ri4[1].y, validx = ri4[1].z;
-    const uint32_t nA = w[0] & 0xFFu, nB = (w[0] >> 8) & 0xFFu, nCc = (w[0] >> 16) & 0xFFu, nE = nA + nB + nCc;
+    uint32_t nA = w[0] & 0xFFu, nB = (w[0] >> 8) & 0xFFu, nCc = (w[0] >> 16) & 0xFFu, nE = nA + nB + nCc;
+    const uint32_t lenC = ri4[1].w;
     const bool xy = (shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2);
     const bool f1 = (shape & SH_HAS_AB) && !(shape & SH_C_EMPTY);
     const bool f2 = (shape & SH_C_EMPTY) != 0;
     const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
     const bool live = mine && !is_solved;
     // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
-    bool slow = mine && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4))));
+    // A long plain sum (no record: more than 15 terms, up to the 1 025 of a decoder) is re-queued by each of its terms and
+    // nearly all of those pops do nothing: two of its variables non-unique, one of them not is_known -- R1 wants exactly
+    // one, R7 wants all of them known, R8 all of them tagged. The lane looks at the first 8 terms; if they show that, the
+    // pop is settled here (reading exactly those variables), anything else goes to the general executor.
+    const bool bigsum = live && (w[0] >> 24) == 0 && f4 && lenC > 15;
+    if (bigsum) {
+        const ECNE_GLOBAL uint32_t* const colC = as_global(J.colC);
+        const uint32_t c0 = as_global(J.rpC)[row];
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
+        nA = 0; nB = 0; nCc = 8; nE = 8;
+    }
+    bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4))));
     uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
     // ---- 3: flag bytes
     const bool walk = live && !slow && !xy && !f2;        // products and plain sums look at every entry
@@ -134,6 +174,8 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
     uint32_t wva = 0, wvb = 0;            // variables whose flag byte (and maybe bounds) this pop changes
     uint8_t wfa = 0, wfb = 0;
     bool wa = false, wb = false, a01 = false, b01 = false, r2 = false, flip_w = false;
+    bool xa_w = false, xb_w = false;                 // x == y rows decided on the limbs: new bounds of k1 / k2
+    fp::u256 xlb0 = fp::make(0), xub0 = fp::make(0), xlb1 = fp::make(0), xub1 = fp::make(0);
     uint8_t flip_new = 0;
     uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;
     uint32_t d_steps = 0, d_nuniq = 0, d_h0 = 0, d_h1 = 0, d_h3 = 0, d_h4 = 0;
@@ -154,6 +196,66 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
                     emit(rx);
                     d_steps = 1; d_h1 = 1;
                 }
+            }
+        } else if (xy && ((fa | fb) & 8u) && k1 != k2 && nE == 2) {
+            // x == y with a bound that is neither [0,1] nor [0,p-1] (a constant wired on, say): the same three rules on the
+            // limbs themselves, statement for statement exec_xy_lane() (rules_lane.hip.hpp)
+            const bool sw = (shape & SH_R56_SWAP) != 0;
+            const uint8_t fa_in = fa, fb_in = fb;
+            fp::u256 lb0 = (fa & 8u) ? ld256(J.lb + 4ull * k1) : fp::make(0), ub0 = (fa & 8u) ? ld256(J.ub + 4ull * k1) : ((fa & 4u) ? fp::make(1) : fp::pminus1());
+            fp::u256 lb1 = (fb & 8u) ? ld256(J.lb + 4ull * k2) : fp::make(0), ub1 = (fb & 8u) ? ld256(J.ub + 4ull * k2) : ((fb & 4u) ? fp::make(1) : fp::pminus1());
+            if (((fa ^ fb) & 1u)) {                               // R1
+                if (!(fa & 1)) { fa |= 3; emit(k1); } else { fb |= 3; emit(k2); }
+                d_nuniq++; d_steps++; d_h0++;
+            }
+            {                                                     // R4, l == 2
+                flip_new = (uint8_t)(flip_in ^ 1);
+                flip_w = true;
+                const uint32_t new_key = flip_new ? kneg : kpos;
+                const bool n_is_a = new_key == k1;
+                uint8_t fn = n_is_a ? fa : fb, fo_ = n_is_a ? fb : fa;
+                const fp::u256 lbn = n_is_a ? lb0 : lb1, ubn = n_is_a ? ub0 : ub1;
+                if (fo_ & 4) {
+                    if (!(fp::is_zero(lbn) && fp::is_one(ubn)) && fp::cmp(ubn, fp::make(1)) > 0) {
+                        if (n_is_a) { lb0 = fp::make(0); ub0 = fp::make(1); xa_w = true; } else { lb1 = fp::make(0); ub1 = fp::make(1); xb_w = true; }
+                        fn = (uint8_t)((fn & ~12u) | 4u | 2u);
+                        d_steps++; d_h3++;
+                        emit(new_key);
+                    }
+                    if ((fn & 1) && !(fo_ & 1)) {
+                        fo_ |= 3;
+                        d_nuniq++; d_steps++; d_h3++;
+                        emit(n_is_a ? k2 : k1);
+                    }
+                }
+                if (n_is_a) { fa = fn; fb = fo_; } else { fb = fn; fa = fo_; }
+            }
+            if (!fp::eq(ub1, ub0) || !fp::eq(lb1, lb0) || ((fa ^ fb) & 1u)) {      // R5
+                bool cha = false, chb = false;
+                if ((fa ^ fb) & 1u) { fa |= 3; d_nuniq += 2; cha = chb = true; }
+                const fp::u256 mn = fp::cmp(ub0, ub1) <= 0 ? ub0 : ub1;
+                const fp::u256 mx = fp::cmp(lb0, lb1) >= 0 ? lb0 : lb1;
+                const bool na = fp::cmp(ub0, mn) > 0 || fp::cmp(lb0, mx) < 0, nb = fp::cmp(ub1, mn) > 0 || fp::cmp(lb1, mx) < 0;
+                if (na) { lb0 = mx; ub0 = mn; xa_w = true; fa = (uint8_t)((fa & ~12u) | bounds_class_bits(mx, mn) | 2u); }
+                if (nb) { lb1 = mx; ub1 = mn; xb_w = true; fb = (uint8_t)((fb & ~12u) | bounds_class_bits(mx, mn) | 2u); }
+                cha |= na; chb |= nb;
+                const uint32_t nset = (cha ? 1u : 0u) + (chb ? 1u : 0u);
+                d_steps += nset;
+                if (nset) d_h4++;
+                if (sw) { if (chb) emit(k2); if (cha) emit(k1); }
+                else { if (cha) emit(k1); if (chb) emit(k2); }
+            }
+            xlb0 = lb0; xub0 = ub0; xlb1 = lb1; xub1 = ub1;
+            wva = k1; wfa = fa; wa = fa != fa_in || xa_w;
+            wvb = k2; wfb = fb; wb = fb != fb_in || xb_w;
+            // R7 / R8 in reach? R7 with two non-unique, known variables and coefficients +-1 fires iff the first one (C order)
+            // has ub <= lb (:1267-1269); R8 needs a group tag on every non-unique variable
+            const bool nua = !(fa & 1), nub = !(fb & 1);
+            if ((nua || nub) && !((nua && !(fa & 2)) || (nub && !(fb & 2)))) {
+                const bool tagged = !((nua && !(fa & 16)) || (nub && !(fb & 16)));
+                const bool first_is_a = !sw;
+                const bool r7 = nua && nub && (first_is_a ? fp::cmp(ub0, lb0) <= 0 : fp::cmp(ub1, lb1) <= 0);
+                if (tagged || r7) { slow = true; reason = 4; }
             }
         } else if (xy) {
             if (((fa | fb) & 8u) || k1 == k2 || nE != 2) { slow = true; reason = 3; }
@@ -219,7 +321,8 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
                 if (e < nA + nB) nuab |= !(f & 1);
                 else if (!(f & 1)) { if (!cnt) { u = w[1 + e]; uf = f; } ++cnt; if (!(f & 2)) notknown = true; }
             }
-            if (!nuab && cnt == 1) {
+            if (bigsum) { if (!(cnt >= 2 && notknown)) { slow = true; reason = 0; } }
+            else if (!nuab && cnt == 1) {
                 wva = u; wfa = (uint8_t)(uf | 3); wa = true;
                 emit(u);
                 d_nuniq = 1; d_steps = 1; d_h0 = 1;
@@ -229,12 +332,14 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
     // ---- the window ends in front of the first row this round does not take
     uint32_t cmax = n;
     {
-        const uint64_t ms = __ballot(slow);
-        if (ms & 1ull) {                                        // nothing has been touched
-            if (lane == 0) why[reason] += 1;
-            return (rdlane(shape, 0) & SH_BIG) ? 0xFFFFFFFFu : 0xFFFFFFFEu;
+        if (WG && threadIdx.x == 0) s_red[4] = shape;
+        const uint32_t fs_ = first_rank(slow, 0);
+        if (fs_ == 0) {                                         // nothing has been touched
+            if (rank == 0) why[reason] += 1;
+            const uint32_t shape0 = WG ? s_red[4] : rdlane(shape, 0);
+            return (shape0 & SH_BIG) ? 0xFFFFFFFFu : 0xFFFFFFFEu;
         }
-        if (ms) cmax = (uint32_t)(__ffsll((long long)ms) - 1);
+        if (fs_ < cmax) cmax = fs_;
     }
     const bool cand = mine && rank < cmax;
     // ---- write marks, then every lane looks its read set up: blocked iff an earlier rank writes what it reads
@@ -242,7 +347,7 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
         if (wa) w2_min(Tm, wva + 1u, rank);
         if (wb) w2_min(Tm, wvb + 1u, rank);
     }
-    lds_fence();
+    sync();
     bool blocked = false;
     if (cand && live) {
         if (f2) { if (shape & SH_R2) blocked = w2_get(Tm, rx + 1u) < rank; }
@@ -254,10 +359,7 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
         }
     }
     uint32_t c = cmax;
-    {
-        const uint64_t mb = __ballot(blocked);
-        if (mb) { const uint32_t fb_ = (uint32_t)(__ffsll((long long)mb) - 1); if (fb_ < c) c = fb_; }   // >= 1: rank 0 is never blocked
-    }
+    { const uint32_t fb_ = first_rank(blocked, 1); if (fb_ < c) c = fb_; }      // >= 1: rank 0 is never blocked
     // ---- 4: fan-out of the events of the prefix; an event with more than three target rows ends the prefix in front of it
     u32x4 fo[5] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     uint32_t ncand = 0;
@@ -269,30 +371,29 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
         for (uint32_t k = 0; k < 5; ++k) if (k < nev) { if (fo[k].x > 3u) bigev = true; else ncand += fo[k].x; }
     }
     {
-        const uint64_t mbig = __ballot(bigev);
-        if (mbig & 1ull) {                                      // rank 0: the general round takes it (only marks were written)
-            for (uint32_t i = (uint32_t)lane; i < ECNE_W2_MARKS; i += 64) { Tm.key[i] = 0u; Tm.val[i] = 0xFFFFFFFFu; }
-            lds_fence();
-            if (lane == 0) why[6] += 1;
+        const uint32_t f0 = first_rank(bigev, 2);
+        if (f0 == 0) {                                          // rank 0: the general executor takes it (only marks were written)
+            for (uint32_t i = rank; i < NMARK; i += NT) { Tm.key[i] = 0u; Tm.val[i] = 0xFFFFFFFFu; }
+            sync();
+            if (rank == 0) why[6] += 1;
             return 0xFFFFFFFEu;
         }
-        if (mbig) { const uint32_t f0 = (uint32_t)(__ffsll((long long)mbig) - 1); if (f0 < c) c = f0; }
+        if (f0 < c) c = f0;
     }
     if (rank >= c) ncand = 0;
     uint32_t M;
-    uint32_t cbase = wave_excl_scan(ncand, &M);
-    if (M > ECNE_W2_MAXCAND) {       // (many events with full fan-out) keep the ranks whose candidates fit
-        const uint64_t over = __ballot(rank < c && cbase + ncand > ECNE_W2_MAXCAND);
-        const uint32_t f0 = (uint32_t)(__ffsll((long long)over) - 1);       // >= 1: one row has at most 15 candidates
+    uint32_t cbase = excl_scan(ncand, &M);
+    if (M > MAXC) {       // (many events with full fan-out) keep the ranks whose candidates fit
+        const uint32_t f0 = first_rank(rank < c && cbase + ncand > MAXC, 3);       // >= 1: one row has at most 15 candidates
         if (f0 < c) c = f0;
         if (rank >= c) ncand = 0;
-        cbase = wave_excl_scan(ncand, &M);
+        cbase = excl_scan(ncand, &M);
     }
     const bool in = mine && rank < c;
     // ---- commit the prefix (ranks below c), every lane its own pop
     if (in) {
         my_pops++;
-        my_nnz += nE;
+        my_nnz += bigsum ? lenC : nE;
         w2_min(Tr, row + 1u, rank);
     }
     if (in && live) {
@@ -300,6 +401,8 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
         if (wb) stF(wvb, wfb);
         if (a01) { st256(J.lb + 4ull * wva, fp::make(0)); st256(J.ub + 4ull * wva, fp::make(1)); }
         if (b01) { st256(J.lb + 4ull * wvb, fp::make(0)); st256(J.ub + 4ull * wvb, fp::make(1)); }
+        if (xa_w) { st256(J.lb + 4ull * wva, xlb0); st256(J.ub + 4ull * wva, xub0); }
+        if (xb_w) { st256(J.lb + 4ull * wvb, xlb1); st256(J.ub + 4ull * wvb, xub1); }
         if (r2) {        // make_values (:921-927)
             st256(J.values + 8ull * rx, ld256(J.vals + 4ull * validx));
             st256(J.values + 8ull * rx + 4, ld256(J.vals + 4ull * (validx + 1)));
@@ -311,7 +414,7 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
         C.steps += d_steps; C.nuniq += d_nuniq;
         C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[3] += d_h3; C.hits[4] += d_h4;
     }
-    lds_fence();
+    sync();
     // ---- REQUEUE resolution in sequential order (rank, emission index, position in the variable's row list)
     uint32_t new_tail = tail;
     if (M) {
@@ -336,7 +439,7 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
             el[i] = rk != 0xFFFFFFFFu ? rk <= rank : st[i] == 0u;
             if (el[i]) w2_min(Tt, tg[i] + 1u, jj[i]);
         }
-        lds_fence();
+        sync();
         uint32_t nwin = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 15; ++i) {
@@ -344,7 +447,7 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
             nwin += el[i] ? 1u : 0u;
         }
         uint32_t W;
-        uint32_t o = tail + wave_excl_scan(nwin, &W);
+        uint32_t o = tail + excl_scan(nwin, &W);
 #pragma unroll
         for (uint32_t i = 0; i < 15; ++i)
             if (el[i]) { queue[o & qmask] = tg[i]; stQ(tg[i], (uint16_t)1); ++o; }
@@ -352,10 +455,11 @@ __device__ __noinline__ uint32_t queue_round_wave2(const Job& J, uint32_t head, 
     }
     // rows of the prefix that nobody re-queued are out of the queue now
     if (in && (M == 0 || w2_get(Tt, row + 1u) == 0xFFFFFFFFu)) stQ(row, (uint16_t)0);
-    lds_fence();
+    sync();
     // ---- leave the tables clean
-    for (uint32_t i = (uint32_t)lane; i < NS; i += 64) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
+    for (uint32_t i = rank; i < NS; i += NT) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
     wg_fence();
+    if (WG) __syncthreads();
     *out_tail = new_tail;
     *out_examined = cmax;      // rows the round looked at: a prefix shorter than THIS is a dependency (the caller's window adapts to it)
     return c;
