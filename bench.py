@@ -141,6 +141,7 @@ def main():
     system = E.System(main_file)
     system.abstract(trusted, "Secp256k1AddUnequal")
     t_abstract = time.time() - t0
+    abstract_stats = E.System.last_abstract_stats()
     n_main = len(main_file)
     info = system.info
     stream = torch.cuda.current_stream().cuda_stream
@@ -153,7 +154,8 @@ def main():
             dist.all_reduce(word, op=dist.ReduceOp.MIN)      # the done/verdict flag, RCCL over xGMI
         return r
 
-    shape, classify_ms, classify_bytes = E.classify(system, device=local_rank)
+    _shape, classify_ms_cold, classify_bytes = E.classify(system, device=local_rank)     # first launch: code object load, cold caches
+    _shape, classify_ms, classify_bytes = E.classify(system, device=local_rank)          # the figure reported: a warm launch pair
     res = step()                       # first solve: layout upload + classification happen here (untimed)
     for _ in range(max(args.warmup - 1, 0)):
         res = step()
@@ -220,8 +222,11 @@ def main():
                        "verdict": bool(res.function_good), "status": int(res.status),
                        "outer_iterations": int(s.outer_iterations), "pops": int(s.pops),
                        "host_prep_s": {"generate": round(t_gen, 3), "parse": round(t_parse, 3), "abstract": round(t_abstract, 3)},
-                       "classify_kernel": {"ms": classify_ms, "bytes": classify_bytes,
-                                           "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6}},
+                       "classify_kernel": {"ms": classify_ms, "ms_first_call": classify_ms_cold, "bytes": classify_bytes,
+                                           "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6,
+                                           "frac_of_hbm_peak": classify_bytes / max(classify_ms, 1e-9) / 1e6 / 8000.0,
+                                           "note": "HIP events around the two passes; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
+                       "abstraction": abstract_stats},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,

@@ -123,6 +123,12 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     const W2Tab Tr = {tb + NMARK, tb + NS + NMARK, NROW - 1, 32 - LR};
     const W2Tab Tt = {tb + NMARK + NROW, tb + NS + NMARK + NROW, (1u << LT) - 1, 32 - LT};
 
+#ifdef ECNE_W2PROF
+    unsigned long long w2t_last = wall_clock64();
+#define W2T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (rank == 0) { const unsigned long long t_ = wall_clock64(); why[2 + (k)] += t_ - w2t_last; w2t_last = t_; } } while (0)
+#else
+#define W2T(k) do { } while (0)
+#endif
     // ---- 1, 2: my row
     const bool mine = rank < n;
     uint32_t row = 0;
@@ -136,6 +142,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         is_solved = solved[row];
         flip_in = flip_lds ? flipL[row] : flipG[row];
     }
+    W2T(0);        // queue + record + descriptor
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { w[4 * i] = w4[i].x; w[4 * i + 1] = w4[i].y; w[4 * i + 2] = w4[i].z; w[4 * i + 3] = w4[i].w; }
@@ -170,6 +177,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     uint8_t fa = 3, fb = 3, fx = 3;
     if (live && !slow && xy) { fa = ldF(k1); fb = ldF(k2); }
     if (live && !slow && f2 && (shape & SH_R2)) fx = ldF(rx);
+    W2T(1);        // flag bytes
     // ---- the decision, in registers
     uint32_t wva = 0, wvb = 0;            // variables whose flag byte (and maybe bounds) this pop changes
     uint8_t wfa = 0, wfb = 0;
@@ -329,6 +337,53 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
             } else if (f4 && cnt > 0 && !notknown) { slow = true; reason = 5; }       // R7 / R8 in reach
         }
     }
+    // ---- a long row at the head of the window (a decoder's 1 025-term sum, a long product) whose pop the lane could not
+    // settle from its first terms: the WHOLE wavefront walks it, lanes across its entries -- 16 strides for 1 025 terms
+    // instead of a round of its own on the workgroup. Only what R1 asks is gathered (plus whether R7 / R8 are in reach of a
+    // sum): exactly one non-unique variable in C with A and B unique -> it becomes unique; two or more, one of them not
+    // is_known -> nothing happens. Rank 0 is never blocked, so no read set is needed; what it writes is marked as usual.
+    uint32_t nnz_long = 0;
+    if constexpr (!WG) {
+        const bool cand0 = mine && !is_solved && (w[0] >> 24) == 0 && slow && (f4 || f1);
+        if (rdlane(cand0 ? 1u : 0u, 0)) {
+            const uint32_t row0 = rdlane(row, 0), shape0 = rdlane(shape, 0);
+            const bool lin0 = !(shape0 & SH_HAS_AB);
+            const ECNE_GLOBAL uint32_t* const rpA = as_global(J.rpA); const ECNE_GLOBAL uint32_t* const rpB = as_global(J.rpB);
+            const ECNE_GLOBAL uint32_t* const rpC = as_global(J.rpC);
+            const ECNE_GLOBAL uint32_t* const cA = as_global(J.colA); const ECNE_GLOBAL uint32_t* const cB = as_global(J.colB);
+            const ECNE_GLOBAL uint32_t* const cC = as_global(J.colC);
+            const uint32_t a0 = rpA[row0], a1 = rpA[row0 + 1], b0 = rpB[row0], b1 = rpB[row0 + 1], c0 = rpC[row0], c1 = rpC[row0 + 1];
+            bool nu = false;
+            for (uint32_t k = a0 + (uint32_t)lane; k < a1; k += 64) nu |= !(ldF(cA[k]) & 1);
+            for (uint32_t k = b0 + (uint32_t)lane; k < b1; k += 64) nu |= !(ldF(cB[k]) & 1);
+            const bool nuab = __ballot(nu) != 0;
+            uint32_t cnt = 0, u = 0, uf = 0;
+            bool nk = false;
+            for (uint32_t base = c0; base < c1; base += 64) {
+                const uint32_t k = base + (uint32_t)lane;
+                const bool act = k < c1;
+                const uint32_t v = act ? cC[k] : 1u;
+                const uint8_t f = act ? ldF(v) : (uint8_t)3;
+                const uint64_t m = __ballot(act && !(f & 1));
+                if (m && cnt == 0) { const int src = __ffsll((long long)m) - 1; u = rdlane(v, (uint32_t)src); uf = rdlane(f, (uint32_t)src); }
+                cnt += (uint32_t)__popcll(m);
+                nk |= act && !(f & 1) && !(f & 2);
+            }
+            const bool notknown = __ballot(nk) != 0;
+            const bool reach78 = lin0 && cnt > 0 && !(cnt == 1 && !nuab) && !notknown;      // R7 / R8 could fire: the general executor decides
+            if (!reach78) {
+                if (lane == 0) {
+                    slow = false;
+                    nnz_long = (a1 - a0) + (b1 - b0) + (c1 - c0);
+                    if (!nuab && cnt == 1) {
+                        wva = u; wfa = (uint8_t)(uf | 3u); wa = true;
+                        emit(u);
+                        d_nuniq = 1; d_steps = 1; d_h0 = 1;
+                    }
+                }
+            }
+        }
+    }
     // ---- the window ends in front of the first row this round does not take
     uint32_t cmax = n;
     {
@@ -341,6 +396,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         }
         if (fs_ < cmax) cmax = fs_;
     }
+    W2T(2);        // decisions (+ long row scan)
     const bool cand = mine && rank < cmax;
     // ---- write marks, then every lane looks its read set up: blocked iff an earlier rank writes what it reads
     if (cand && live) {
@@ -360,6 +416,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     }
     uint32_t c = cmax;
     { const uint32_t fb_ = first_rank(blocked, 1); if (fb_ < c) c = fb_; }      // >= 1: rank 0 is never blocked
+    W2T(3);        // marks + check
     // ---- 4: fan-out of the events of the prefix; an event with more than three target rows ends the prefix in front of it
     u32x4 fo[5] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     uint32_t ncand = 0;
@@ -389,11 +446,12 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         if (rank >= c) ncand = 0;
         cbase = excl_scan(ncand, &M);
     }
+    W2T(4);        // fan-out lists + candidate scan
     const bool in = mine && rank < c;
     // ---- commit the prefix (ranks below c), every lane its own pop
     if (in) {
         my_pops++;
-        my_nnz += bigsum ? lenC : nE;
+        my_nnz += nnz_long ? nnz_long : (bigsum ? lenC : nE);
         w2_min(Tr, row + 1u, rank);
     }
     if (in && live) {
@@ -415,6 +473,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[3] += d_h3; C.hits[4] += d_h4;
     }
     sync();
+    W2T(5);        // commit
     // ---- REQUEUE resolution in sequential order (rank, emission index, position in the variable's row list)
     uint32_t new_tail = tail;
     if (M) {
@@ -456,10 +515,12 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     // rows of the prefix that nobody re-queued are out of the queue now
     if (in && (M == 0 || w2_get(Tt, row + 1u) == 0xFFFFFFFFu)) stQ(row, (uint16_t)0);
     sync();
+    W2T(6);        // push resolution
     // ---- leave the tables clean
     for (uint32_t i = rank; i < NS; i += NT) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
     wg_fence();
     if (WG) __syncthreads();
+    W2T(7);        // wipe + final fence
     *out_tail = new_tail;
     *out_examined = cmax;      // rows the round looked at: a prefix shorter than THIS is a dependency (the caller's window adapts to it)
     return c;

@@ -1,12 +1,21 @@
-# Developer aid (GPU box): rocprofv3 kernel trace + the two PMC passes of bench.py, summarised into gpurun_out/prof_r01b/*.txt
+# Developer aid (GPU box): rocprofv3 kernel trace + the PMC passes of bench.py (separate runs: FETCH_SIZE costs 3 TCC slots,
+# WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots"), summarised into gpurun_out/prof_$TAG/*.txt
+# usage: bash tools/profile_bench.sh [TAG]     (default TAG = r02)
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-mkdir -p gpurun_out/prof_r01b
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r01b/trace -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_r01b/bench_trace.json 2> gpurun_out/prof_r01b/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_r01b/fetch -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_r01b/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_r01b/write -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_r01b/write.err
-for d in trace fetch write; do python tools/rocpd_summary.py $(find gpurun_out/prof_r01b/$d -name "*.db") > gpurun_out/prof_r01b/$d.txt 2>&1; done
-tail -1 gpurun_out/prof_r01b/bench_trace.json | head -c 400; echo
-head -20 gpurun_out/prof_r01b/trace.txt; head -12 gpurun_out/prof_r01b/fetch.txt; head -12 gpurun_out/prof_r01b/write.txt
-find gpurun_out/prof_r01b -name "*.db" -size +20M -delete
+O=gpurun_out/prof_$TAG
+mkdir -p $O
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/trace -- $CMD > $O/bench_under_rocprof.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -- $CMD > /dev/null 2> $O/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -- $CMD > /dev/null 2> $O/write.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $O/sq -- $CMD > /dev/null 2> $O/sq.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace -d $O/insts -- $CMD > /dev/null 2> $O/insts.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $O/tcc -- $CMD > /dev/null 2> $O/tcc.err
+rocprofv3 --kernel-trace --stats -d $O/suite -- python bench.py --workload suite --steps 5 --warmup 2 > $O/bench_suite_under_rocprof.json 2> $O/suite.err
+for d in trace fetch write sq insts tcc suite; do python tools/rocpd_summary.py $(find $O/$d -name "*.db") > $O/$d.txt 2>&1; done
+tail -1 $O/bench_under_rocprof.json | head -c 300; echo
+for d in trace fetch write sq insts tcc suite; do echo "== $d"; head -14 $O/$d.txt; done
+find $O -name "*.db" -delete
