@@ -67,126 +67,41 @@ __device__ __forceinline__ void w2_tables_init(uint32_t w2_off, bool big) {
     for (uint32_t i = threadIdx.x; i < nslots; i += ECNE_WG) { base[i] = 0u; base[nslots + i] = 0xFFFFFFFFu; }
 }
 
-// WG = false: wavefront 0 alone, up to 64 rows. WG = true: ALL threads of the workgroup, up to ECNE_WG rows (rank = thread),
-// the wave-level votes and scans become workgroup-level ones through LDS; the return values are uniform across the workgroup.
-template <bool LDS, bool WG>
-__device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
-                                                  uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail, uint32_t* out_examined,
-                                                  unsigned long long* why) {
-    const int lane = lane_id();
-    const uint32_t rank = WG ? (uint32_t)threadIdx.x : (uint32_t)lane;
-    const uint32_t NT = WG ? (uint32_t)ECNE_WG : 64u;          // threads taking part
-    __shared__ uint32_t s_red[8];                              // workgroup votes: lowest rank with a property (slots 0..3), rank 0's shape (4)
-    if (WG) { if (threadIdx.x < 8) s_red[threadIdx.x] = 0xFFFFFFFFu; __syncthreads(); }
-    auto sync = [&]() { if constexpr (WG) __syncthreads(); else lds_fence(); };
-    // lowest rank for which p holds (0xFFFFFFFF: none); slot: a vote of its own per call site
-    auto first_rank = [&](bool p, int slot) -> uint32_t {
-        const uint64_t m = __ballot(p);
-        if constexpr (!WG) { (void)slot; return m ? (uint32_t)(__ffsll((long long)m) - 1) : 0xFFFFFFFFu; }
-        else {
-            if (m && lane == 0) atomicMin(&s_red[slot], (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
-            __syncthreads();
-            return s_red[slot];
-        }
-    };
-    auto excl_scan = [&](uint32_t x, uint32_t* tot) -> uint32_t {
-        if constexpr (WG) return wg_exclusive_scan(x, S.scan, tot); else return wave_excl_scan(x, tot);
-    };
-    const bool big = WG;
-    const uint32_t MAXC = ECNE_W2_MAXCAND << (big ? 3 : 0);
-    auto uni = [](const void* p) -> uint64_t {
-        const uint64_t x = (uint64_t)p;
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
-    };
-    const ECNE_GLOBAL u32x4* const rec = (const ECNE_GLOBAL u32x4*)uni(J.rec);
-    const ECNE_GLOBAL u32x4* const foi = (const ECNE_GLOBAL u32x4*)uni(J.foi);
-    const ECNE_GLOBAL u32x4* const rinfo = (const ECNE_GLOBAL u32x4*)uni(J.rinfo);
-    ECNE_GLOBAL uint32_t* const queue = (ECNE_GLOBAL uint32_t*)uni(J.queue);
-    const uint32_t qmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.qmask);
-    ECNE_GLOBAL uint8_t* const solved = (ECNE_GLOBAL uint8_t*)uni(J.solved);
-    // flags / in_queue tags / orientation bytes: LDS (single-workgroup job, resident) or device memory
-    uint8_t* const Fl = (uint8_t*)(ecne_dyn_lds + (LDS ? J.lds_flags_off : 0u));
-    uint16_t* const Ql = (uint16_t*)(ecne_dyn_lds + (LDS ? J.lds_inq_off : 0u));
-    ECNE_GLOBAL uint8_t* const Fg = LDS ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flags);
-    ECNE_GLOBAL uint16_t* const Qg = LDS ? (ECNE_GLOBAL uint16_t*)nullptr : (ECNE_GLOBAL uint16_t*)uni(J.inq);
-    const bool flip_lds = LDS && J.lds_flip_off != 0xFFFFFFFFu;
-    uint8_t* const flipL = (uint8_t*)(ecne_dyn_lds + (flip_lds ? J.lds_flip_off : 0u));
-    ECNE_GLOBAL uint8_t* const flipG = flip_lds ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flip3);
-    auto ldF = [&](uint32_t v) -> uint8_t { if constexpr (LDS) return Fl[v]; else return Fg[v]; };
-    auto stF = [&](uint32_t v, uint8_t f) { if constexpr (LDS) Fl[v] = f; else Fg[v] = f; };
-    auto ldQ = [&](uint32_t r) -> uint16_t { if constexpr (LDS) return Ql[r]; else return Qg[r]; };
-    auto stQ = [&](uint32_t r, uint16_t x) { if constexpr (LDS) Ql[r] = x; else Qg[r] = x; };
-    uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + (WG ? J.lds_w2b_off : J.lds_w2_off));      // the two rounds have tables of their own
-    const uint32_t LM = ECNE_W2_LOG_MARKS + (big ? 3 : 0), LR = ECNE_W2_LOG_ROWS + (big ? 3 : 0), LT = ECNE_W2_LOG_TGT + (big ? 3 : 0);
-    const uint32_t NS = ECNE_W2_SLOTS(big), NMARK = 1u << LM, NROW = 1u << LR;
-    const W2Tab Tm = {tb, tb + NS, NMARK - 1, 32 - LM};
-    const W2Tab Tr = {tb + NMARK, tb + NS + NMARK, NROW - 1, 32 - LR};
-    const W2Tab Tt = {tb + NMARK + NROW, tb + NS + NMARK + NROW, (1u << LT) - 1, 32 - LT};
-
-#ifdef ECNE_W2PROF
-    unsigned long long w2t_last = wall_clock64();
-#define W2T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (rank == 0) { const unsigned long long t_ = wall_clock64(); why[2 + (k)] += t_ - w2t_last; w2t_last = t_; } } while (0)
-#else
-#define W2T(k) do { } while (0)
-#endif
-    // ---- 1, 2: my row
-    const bool mine = rank < n;
-    uint32_t row = 0;
-    if (mine) row = queue[(head + rank) & qmask];
-    u32x4 w4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ri4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    uint8_t is_solved = 0, flip_in = 0;
-    if (mine) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w4[i] = rec[4u * row + (uint32_t)i];
-        ri4[0] = rinfo[2u * row]; ri4[1] = rinfo[2u * row + 1u];
-        is_solved = solved[row];
-        flip_in = flip_lds ? flipL[row] : flipG[row];
-    }
-    W2T(0);        // queue + record + descriptor
-    uint32_t w[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { w[4 * i] = w4[i].x; w[4 * i + 1] = w4[i].y; w[4 * i + 2] = w4[i].z; w[4 * i + 3] = w4[i].w; }
-    const uint32_t shape = ri4[0].x, rx = ri4[0].y, kpos = ri4[0].z, kneg = ri4[0].w, k1 = ri4[1].x, k2 = ri4[1].y, validx = ri4[1].z;
-    uint32_t nA = w[0] & 0xFFu, nB = (w[0] >> 8) & 0xFFu, nCc = (w[0] >> 16) & 0xFFu, nE = nA + nB + nCc;
-    const uint32_t lenC = ri4[1].w;
-    const bool xy = (shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2);
-    const bool f1 = (shape & SH_HAS_AB) && !(shape & SH_C_EMPTY);
-    const bool f2 = (shape & SH_C_EMPTY) != 0;
-    const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
-    const bool live = mine && !is_solved;
-    // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
-    // A long plain sum (no record: more than 15 terms, up to the 1 025 of a decoder) is re-queued by each of its terms and
-    // nearly all of those pops do nothing: two of its variables non-unique, one of them not is_known -- R1 wants exactly
-    // one, R7 wants all of them known, R8 all of them tagged. The lane looks at the first 8 terms; if they show that, the
-    // pop is settled here (reading exactly those variables), anything else goes to the general executor.
-    const bool bigsum = live && (w[0] >> 24) == 0 && f4 && lenC > 15;
-    if (bigsum) {
-        const ECNE_GLOBAL uint32_t* const colC = as_global(J.colC);
-        const uint32_t c0 = as_global(J.rpC)[row];
-#pragma unroll
-        for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
-        nA = 0; nB = 0; nCc = 8; nE = 8;
-    }
-    bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4))));
-    uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
-    // ---- 3: flag bytes
-    const bool walk = live && !slow && !xy && !f2;        // products and plain sums look at every entry
-    uint8_t fl[15];
-#pragma unroll
-    for (uint32_t e = 0; e < 15; ++e) fl[e] = (walk && e < nE) ? ldF(w[1 + e]) : (uint8_t)3;
-    uint8_t fa = 3, fb = 3, fx = 3;
-    if (live && !slow && xy) { fa = ldF(k1); fb = ldF(k2); }
-    if (live && !slow && f2 && (shape & SH_R2)) fx = ldF(rx);
-    W2T(1);        // flag bytes
-    // ---- the decision, in registers
-    uint32_t wva = 0, wvb = 0;            // variables whose flag byte (and maybe bounds) this pop changes
+// ---- what one pop of a row of the four common shapes does, decided in registers from the row record and the flag bytes
+// (x == y rows with a bound of the third kind: from the limbs). Nothing is written: the caller commits FastOut for the rows
+// that make it into the prefix. Shared by the fast wavefront / workgroup round and the multi-workgroup round.
+struct FastIn {
+    uint32_t shape, rx, kpos, kneg, k1, k2, nA, nB, nE;
+    uint32_t w[16];                 // row record: w[1 + e] = variable of entry e (A, B, C)
+    uint8_t fl[15], fa, fb, fx;     // flag bytes: of the entries (products, sums), of k1 / k2 (x == y), of x (bit check)
+    uint8_t flip_in;
+    bool live, xy, f2, f4, bigsum;
+};
+struct FastOut {
+    uint32_t wva = 0, wvb = 0;      // variables whose flag byte (and maybe bounds) this pop changes
     uint8_t wfa = 0, wfb = 0;
     bool wa = false, wb = false, a01 = false, b01 = false, r2 = false, flip_w = false;
-    bool xa_w = false, xb_w = false;                 // x == y rows decided on the limbs: new bounds of k1 / k2
+    bool xa_w = false, xb_w = false;            // x == y rows decided on the limbs: new bounds of k1 / k2
     fp::u256 xlb0 = fp::make(0), xub0 = fp::make(0), xlb1 = fp::make(0), xub1 = fp::make(0);
     uint8_t flip_new = 0;
-    uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;
+    uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;  // REQUEUE events, in the reference's order
     uint32_t d_steps = 0, d_nuniq = 0, d_h0 = 0, d_h1 = 0, d_h3 = 0, d_h4 = 0;
+    bool slow = false;              // not settled here: the general executor takes the row
+    uint32_t reason = 7;
+};
+__device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastOut& O) {
+    const bool live = I.live, xy = I.xy, f2 = I.f2, f4 = I.f4, bigsum = I.bigsum;
+    const uint32_t shape = I.shape, rx = I.rx, kpos = I.kpos, kneg = I.kneg, k1 = I.k1, k2 = I.k2, nA = I.nA, nB = I.nB, nE = I.nE;
+    const uint32_t* const w = I.w;
+    const uint8_t* const fl = I.fl;
+    uint8_t fa = I.fa, fb = I.fb;
+    const uint8_t fx = I.fx, flip_in = I.flip_in;
+    uint32_t &wva = O.wva, &wvb = O.wvb, &nev = O.nev, &reason = O.reason;
+    uint8_t &wfa = O.wfa, &wfb = O.wfb, &flip_new = O.flip_new;
+    bool &wa = O.wa, &wb = O.wb, &a01 = O.a01, &b01 = O.b01, &r2 = O.r2, &flip_w = O.flip_w, &xa_w = O.xa_w, &xb_w = O.xb_w, &slow = O.slow;
+    fp::u256 &xlb0 = O.xlb0, &xub0 = O.xub0, &xlb1 = O.xlb1, &xub1 = O.xub1;
+    uint32_t* const ev = O.ev;
+    uint32_t &d_steps = O.d_steps, &d_nuniq = O.d_nuniq, &d_h0 = O.d_h0, &d_h1 = O.d_h1, &d_h3 = O.d_h3, &d_h4 = O.d_h4;
     auto emit = [&](uint32_t v) {
         if (nev == 0) ev[0] = v; else if (nev == 1) ev[1] = v; else if (nev == 2) ev[2] = v; else if (nev == 3) ev[3] = v; else ev[4] = v;
         ++nev;
@@ -337,6 +252,146 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
             } else if (f4 && cnt > 0 && !notknown) { slow = true; reason = 5; }       // R7 / R8 in reach
         }
     }
+}
+
+// WG = false: wavefront 0 alone, up to 64 rows. WG = true: ALL threads of the workgroup, up to ECNE_WG rows (rank = thread),
+// the wave-level votes and scans become workgroup-level ones through LDS; the return values are uniform across the workgroup.
+template <bool LDS, bool WG>
+__device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
+                                                  uint32_t& my_pops, uint32_t& my_nnz, uint32_t* out_tail, uint32_t* out_examined,
+                                                  unsigned long long* why) {
+    const int lane = lane_id();
+    const uint32_t rank = WG ? (uint32_t)threadIdx.x : (uint32_t)lane;
+    const uint32_t NT = WG ? (uint32_t)ECNE_WG : 64u;          // threads taking part
+    __shared__ uint32_t s_red[8];                              // workgroup votes: lowest rank with a property (slots 0..3), rank 0's shape (4)
+    if (WG) { if (threadIdx.x < 8) s_red[threadIdx.x] = 0xFFFFFFFFu; __syncthreads(); }
+    auto sync = [&]() { if constexpr (WG) __syncthreads(); else lds_fence(); };
+    // lowest rank for which p holds (0xFFFFFFFF: none); slot: a vote of its own per call site
+    auto first_rank = [&](bool p, int slot) -> uint32_t {
+        const uint64_t m = __ballot(p);
+        if constexpr (!WG) { (void)slot; return m ? (uint32_t)(__ffsll((long long)m) - 1) : 0xFFFFFFFFu; }
+        else {
+            if (m && lane == 0) atomicMin(&s_red[slot], (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
+            __syncthreads();
+            return s_red[slot];
+        }
+    };
+    auto excl_scan = [&](uint32_t x, uint32_t* tot) -> uint32_t {
+        if constexpr (WG) return wg_exclusive_scan(x, S.scan, tot); else return wave_excl_scan(x, tot);
+    };
+    const bool big = WG;
+    const uint32_t MAXC = ECNE_W2_MAXCAND << (big ? 3 : 0);
+    auto uni = [](const void* p) -> uint64_t {
+        const uint64_t x = (uint64_t)p;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    };
+    const ECNE_GLOBAL u32x4* const rec = (const ECNE_GLOBAL u32x4*)uni(J.rec);
+    const ECNE_GLOBAL u32x4* const foi = (const ECNE_GLOBAL u32x4*)uni(J.foi);
+    const ECNE_GLOBAL u32x4* const rinfo = (const ECNE_GLOBAL u32x4*)uni(J.rinfo);
+    ECNE_GLOBAL uint32_t* const queue = (ECNE_GLOBAL uint32_t*)uni(J.queue);
+    const uint32_t qmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.qmask);
+    ECNE_GLOBAL uint8_t* const solved = (ECNE_GLOBAL uint8_t*)uni(J.solved);
+    // flags / in_queue tags / orientation bytes: LDS (single-workgroup job, resident) or device memory
+    uint8_t* const Fl = (uint8_t*)(ecne_dyn_lds + (LDS ? J.lds_flags_off : 0u));
+    uint16_t* const Ql = (uint16_t*)(ecne_dyn_lds + (LDS ? J.lds_inq_off : 0u));
+    ECNE_GLOBAL uint8_t* const Fg = LDS ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flags);
+    ECNE_GLOBAL uint16_t* const Qg = LDS ? (ECNE_GLOBAL uint16_t*)nullptr : (ECNE_GLOBAL uint16_t*)uni(J.inq);
+    const bool flip_lds = LDS && J.lds_flip_off != 0xFFFFFFFFu;
+    uint8_t* const flipL = (uint8_t*)(ecne_dyn_lds + (flip_lds ? J.lds_flip_off : 0u));
+    ECNE_GLOBAL uint8_t* const flipG = flip_lds ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flip3);
+    auto ldF = [&](uint32_t v) -> uint8_t { if constexpr (LDS) return Fl[v]; else return Fg[v]; };
+    auto stF = [&](uint32_t v, uint8_t f) { if constexpr (LDS) Fl[v] = f; else Fg[v] = f; };
+    auto ldQ = [&](uint32_t r) -> uint16_t { if constexpr (LDS) return Ql[r]; else return Qg[r]; };
+    auto stQ = [&](uint32_t r, uint16_t x) { if constexpr (LDS) Ql[r] = x; else Qg[r] = x; };
+    uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + (WG ? J.lds_w2b_off : J.lds_w2_off));      // the two rounds have tables of their own
+    const uint32_t LM = ECNE_W2_LOG_MARKS + (big ? 3 : 0), LR = ECNE_W2_LOG_ROWS + (big ? 3 : 0), LT = ECNE_W2_LOG_TGT + (big ? 3 : 0);
+    const uint32_t NS = ECNE_W2_SLOTS(big), NMARK = 1u << LM, NROW = 1u << LR;
+    const W2Tab Tm = {tb, tb + NS, NMARK - 1, 32 - LM};
+    const W2Tab Tr = {tb + NMARK, tb + NS + NMARK, NROW - 1, 32 - LR};
+    const W2Tab Tt = {tb + NMARK + NROW, tb + NS + NMARK + NROW, (1u << LT) - 1, 32 - LT};
+
+#ifdef ECNE_W2PROF
+    unsigned long long w2t_last = wall_clock64();
+#define W2T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (rank == 0) { const unsigned long long t_ = wall_clock64(); why[2 + (k)] += t_ - w2t_last; w2t_last = t_; } } while (0)
+#else
+#define W2T(k) do { } while (0)
+#endif
+    // ---- 1, 2: my row
+    const bool mine = rank < n;
+    uint32_t row = 0;
+    if (mine) row = queue[(head + rank) & qmask];
+    u32x4 w4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ri4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint8_t is_solved = 0, flip_in = 0;
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[i] = rec[4u * row + (uint32_t)i];
+        ri4[0] = rinfo[2u * row]; ri4[1] = rinfo[2u * row + 1u];
+        is_solved = solved[row];
+        flip_in = flip_lds ? flipL[row] : flipG[row];
+    }
+    W2T(0);        // queue + record + descriptor
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[4 * i] = w4[i].x; w[4 * i + 1] = w4[i].y; w[4 * i + 2] = w4[i].z; w[4 * i + 3] = w4[i].w; }
+    const uint32_t shape = ri4[0].x, rx = ri4[0].y, kpos = ri4[0].z, kneg = ri4[0].w, k1 = ri4[1].x, k2 = ri4[1].y, validx = ri4[1].z;
+    uint32_t nA = w[0] & 0xFFu, nB = (w[0] >> 8) & 0xFFu, nCc = (w[0] >> 16) & 0xFFu, nE = nA + nB + nCc;
+    const uint32_t lenC = ri4[1].w;
+    const bool xy = (shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2);
+    const bool f1 = (shape & SH_HAS_AB) && !(shape & SH_C_EMPTY);
+    const bool f2 = (shape & SH_C_EMPTY) != 0;
+    const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+    const bool live = mine && !is_solved;
+    // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
+    // A long plain sum (no record: more than 15 terms, up to the 1 025 of a decoder) is re-queued by each of its terms and
+    // nearly all of those pops do nothing: two of its variables non-unique, one of them not is_known -- R1 wants exactly
+    // one, R7 wants all of them known, R8 all of them tagged. The lane looks at the first 8 terms; if they show that, the
+    // pop is settled here (reading exactly those variables), anything else goes to the general executor.
+    const bool bigsum = live && (w[0] >> 24) == 0 && f4 && lenC > 15;
+    if (bigsum) {
+        const ECNE_GLOBAL uint32_t* const colC = as_global(J.colC);
+        const uint32_t c0 = as_global(J.rpC)[row];
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
+        nA = 0; nB = 0; nCc = 8; nE = 8;
+    }
+    bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4))));
+    uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
+#ifdef ECNE_W2SHAPES
+    if (reason == 1) reason = (shape & SH_R3) ? 1u : (shape & SH_R6) ? 2u : (shape & (SH_R4_T | SH_R4_T2)) ? 5u : 3u;
+    if (reason == 0) reason = (shape & (SH_R4_T | SH_R4_T2)) ? 4u : 0u;
+#endif
+    // ---- 3: flag bytes
+    const bool walk = live && !slow && !xy && !f2;        // products and plain sums look at every entry
+    uint8_t fl[15];
+#pragma unroll
+    for (uint32_t e = 0; e < 15; ++e) fl[e] = (walk && e < nE) ? ldF(w[1 + e]) : (uint8_t)3;
+    uint8_t fa = 3, fb = 3, fx = 3;
+    if (live && !slow && xy) { fa = ldF(k1); fb = ldF(k2); }
+    if (live && !slow && f2 && (shape & SH_R2)) fx = ldF(rx);
+    W2T(1);        // flag bytes
+    // ---- the decision, in registers (fast_decide)
+    FastIn fin;
+    fin.shape = shape; fin.rx = rx; fin.kpos = kpos; fin.kneg = kneg; fin.k1 = k1; fin.k2 = k2; fin.nA = nA; fin.nB = nB; fin.nE = nE;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fin.w[i] = w[i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) fin.fl[i] = fl[i];
+    fin.fa = fa; fin.fb = fb; fin.fx = fx; fin.flip_in = flip_in;
+    fin.live = live; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum;
+    FastOut fo_;
+    fo_.slow = slow; fo_.reason = reason;
+    fast_decide(J, fin, fo_);
+    slow = fo_.slow; reason = fo_.reason;
+    uint32_t &wva = fo_.wva, &wvb = fo_.wvb, &nev = fo_.nev;
+    uint8_t &wfa = fo_.wfa, &wfb = fo_.wfb, &flip_new = fo_.flip_new;
+    bool &wa = fo_.wa, &wb = fo_.wb, &a01 = fo_.a01, &b01 = fo_.b01, &r2 = fo_.r2, &flip_w = fo_.flip_w, &xa_w = fo_.xa_w, &xb_w = fo_.xb_w;
+    fp::u256 &xlb0 = fo_.xlb0, &xub0 = fo_.xub0, &xlb1 = fo_.xlb1, &xub1 = fo_.xub1;
+    uint32_t* const ev = fo_.ev;
+    uint32_t &d_steps = fo_.d_steps, &d_nuniq = fo_.d_nuniq, &d_h0 = fo_.d_h0, &d_h1 = fo_.d_h1, &d_h3 = fo_.d_h3, &d_h4 = fo_.d_h4;
+    auto emit = [&](uint32_t v) {
+        if (nev == 0) ev[0] = v; else if (nev == 1) ev[1] = v; else if (nev == 2) ev[2] = v; else if (nev == 3) ev[3] = v; else ev[4] = v;
+        ++nev;
+    };
     // ---- a long row at the head of the window (a decoder's 1 025-term sum, a long product) whose pop the lane could not
     // settle from its first terms: the WHOLE wavefront walks it, lanes across its entries -- 16 strides for 1 025 terms
     // instead of a round of its own on the workgroup. Only what R1 asks is gathered (plus whether R7 / R8 are in reach of a
