@@ -84,6 +84,50 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         }
     }
     if (tid == 0) S.cut = 0xFFFFFFFFu;
+    // ---- rows of the four common shapes take the RECORD path (one row per lane rounds only): the pop is decided in registers
+    // from rec[row] and the flag bytes (fast_decide, wave2.hip.hpp) -- one round trip for the row, one for its flags -- instead
+    // of three CSR walks (no-op test, access sets twice) plus the executor's own. Same hazard rules as for every other row of
+    // the round: what the decision would write is marked, what it read is checked, the decision is taken again at commit time
+    // (its inputs cannot have changed for a row of the prefix) and committed.
+    bool fz = false;
+    FastIn fin;
+    uint32_t fz_wva = 0, fz_wvb = 0, fz_cls = 0;        // written variables; bit0/1: U / B class of wva, bit2/3: of wvb
+    uint8_t fz_flip = 0;
+    if (J.rec != nullptr && rpl == 1 && r0 < n && (live & 1u) && !(shape[0] & SH_BIG)) {
+        const ECNE_GLOBAL u32x4* const rec = as_global(reinterpret_cast<const u32x4*>(J.rec));
+        const ECNE_GLOBAL uint8_t* const Fg = as_global(J.flags);
+        const RowInfo ri = J.rinfo[row[0]];
+        u32x4 w4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[i] = rec[4u * row[0] + (uint32_t)i];
+        fz_flip = J.flip3[row[0]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fin.w[4 * i] = w4[i].x; fin.w[4 * i + 1] = w4[i].y; fin.w[4 * i + 2] = w4[i].z; fin.w[4 * i + 3] = w4[i].w; }
+        fin.shape = ri.shape; fin.rx = ri.x; fin.kpos = ri.kpos; fin.kneg = ri.kneg; fin.k1 = ri.k1; fin.k2 = ri.k2;
+        fin.nA = fin.w[0] & 0xFFu; fin.nB = (fin.w[0] >> 8) & 0xFFu; fin.nE = fin.nA + fin.nB + ((fin.w[0] >> 16) & 0xFFu);
+        fin.xy = (ri.shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2);
+        const bool f1 = (ri.shape & SH_HAS_AB) && !(ri.shape & SH_C_EMPTY);
+        fin.f2 = (ri.shape & SH_C_EMPTY) != 0;
+        fin.f4 = !(ri.shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+        fin.live = true; fin.bigsum = false; fin.flip_in = fz_flip;
+        if ((fin.w[0] >> 24) != 0 && (fin.xy || f1 || fin.f2 || fin.f4)) {
+            const bool walk = !fin.xy && !fin.f2;
+#pragma unroll
+            for (uint32_t e = 0; e < 15; ++e) fin.fl[e] = (walk && e < fin.nE) ? Fg[fin.w[1 + e]] : (uint8_t)3;
+            fin.fa = fin.fb = fin.fx = 3;
+            if (fin.xy) { fin.fa = Fg[fin.k1]; fin.fb = Fg[fin.k2]; }
+            if (fin.f2 && (ri.shape & SH_R2)) fin.fx = Fg[fin.rx];
+            FastOut D;
+            fast_decide(J, fin, D);
+            if (!D.slow) {
+                fz = true;
+                fz_wva = D.wva; fz_wvb = D.wvb;
+                const uint8_t ia = fin.xy ? fin.fa : fin.f2 ? fin.fx : (uint8_t)(D.wfa & ~3u), ib = fin.fb;     // flag bytes before (products / sums only set bits 0, 1)
+                if (D.wa) fz_cls |= (((D.wfa ^ ia) & 3u) ? 1u : 0u) | ((((D.wfa ^ ia) & ~3u) || D.a01 || D.xa_w || D.r2) ? 2u : 0u);
+                if (D.wb) fz_cls |= (((D.wfb ^ ib) & 3u) ? 4u : 0u) | ((((D.wfb ^ ib) & ~3u) || D.b01 || D.xb_w) ? 8u : 0u);
+            }
+        }
+    }
     __syncthreads();
     // ---- mark (write sets)
 #pragma unroll
@@ -91,6 +135,13 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         if (sl >= rpl || r0 + sl >= n) continue;
         const uint32_t rank = r0 + sl;
         if (!(live & (1u << sl))) continue;
+        if (sl == 0 && fz) {
+            if (fz_cls & 1u) atomicMin(&J.wmarkU[fz_wva], rank);
+            if (fz_cls & 2u) atomicMin(&J.wmarkB[fz_wva], rank);
+            if (fz_cls & 4u) atomicMin(&J.wmarkU[fz_wvb], rank);
+            if (fz_cls & 8u) atomicMin(&J.wmarkB[fz_wvb], rank);
+            continue;
+        }
         if (shape[sl] & SH_BIG) {   // plain long rows ride along, handled by this workgroup as a whole (see big_rows_*)
             if (!big_plain(shape[sl]) || !big_register(S, row[sl], rank)) atomicMin(&S.cut, rank);
             continue;
@@ -111,6 +162,21 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         if (sl >= rpl || r0 + sl >= n || !(live & (1u << sl)) || (shape[sl] & SH_BIG)) continue;
         const uint32_t rank = r0 + sl;
         bool blocked = false;
+        if (sl == 0 && fz) {
+            // read set of the record path: the flag bytes of the entries that can still change (products, sums; a sum also reads
+            // the group tag), flags and bounds of both variables (x == y), of x (bit check). An earlier writer blocks the row, a
+            // later one cuts the prefix in front of itself (the rows of a prefix execute in place, concurrently).
+            auto see = [&](uint32_t m) { if (m < rank) blocked = true; else if (m > rank && m < mycut) mycut = m; };
+            if (fin.xy) { see(ld_agent(&J.wmarkU[fin.k1])); see(ld_agent(&J.wmarkB[fin.k1])); see(ld_agent(&J.wmarkU[fin.k2])); see(ld_agent(&J.wmarkB[fin.k2])); }
+            else if (fin.f2) { if (fin.shape & SH_R2) { see(ld_agent(&J.wmarkU[fin.rx])); see(ld_agent(&J.wmarkB[fin.rx])); } }
+            else {
+#pragma unroll
+                for (uint32_t e = 0; e < 15; ++e)
+                    if (e < fin.nE && (fin.fl[e] & 3) != 3) { see(ld_agent(&J.wmarkU[fin.w[1 + e]])); if (fin.f4) see(ld_agent(&J.wmarkB[fin.w[1 + e]])); }
+            }
+            if (blocked && rank < mycut) mycut = rank;
+            continue;
+        }
         if (noop & (1u << sl)) {
             if (noop_b & (1u << sl)) blocked = row_noop_blocked_global(J, row[sl], rank);
         } else {
@@ -135,6 +201,43 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     for (uint32_t sl = 0; sl < 2; ++sl) {
         nev[sl] = 0;
         if (sl >= rpl || r0 + sl >= n) continue;
+        if (sl == 0 && fz) {
+            if (fz_cls & 1u) J.wmarkU[fz_wva] = 0xFFFFFFFFu;
+            if (fz_cls & 2u) J.wmarkB[fz_wva] = 0xFFFFFFFFu;
+            if (fz_cls & 4u) J.wmarkU[fz_wvb] = 0xFFFFFFFFu;
+            if (fz_cls & 8u) J.wmarkB[fz_wvb] = 0xFFFFFFFFu;
+            if (r0 >= c) continue;
+            // commit: the decision again (its inputs are what they were: nobody in the prefix writes what this row reads)
+            FastOut D;
+            fast_decide(J, fin, D);
+            J.inq[row[0]] = (uint16_t)2;
+            J.prank[row[0]] = r0;
+            my_pops++;
+            my_nnz += fin.nE;
+            if (D.wa) J.flags[D.wva] = D.wfa;
+            if (D.wb) J.flags[D.wvb] = D.wfb;
+            if (D.a01) { st256(J.lb + 4ull * D.wva, fp::make(0)); st256(J.ub + 4ull * D.wva, fp::make(1)); }
+            if (D.b01) { st256(J.lb + 4ull * D.wvb, fp::make(0)); st256(J.ub + 4ull * D.wvb, fp::make(1)); }
+            if (D.xa_w) { st256(J.lb + 4ull * D.wva, D.xlb0); st256(J.ub + 4ull * D.wva, D.xub0); }
+            if (D.xb_w) { st256(J.lb + 4ull * D.wvb, D.xlb1); st256(J.ub + 4ull * D.wvb, D.xub1); }
+            if (D.r2) {        // make_values (:921-927)
+                const uint32_t validx = J.rinfo[row[0]].validx;
+                st256(J.values + 8ull * fin.rx, ld256(J.vals + 4ull * validx));
+                st256(J.values + 8ull * fin.rx + 4, ld256(J.vals + 4ull * (validx + 1)));
+                J.nvalues[fin.rx] = 2;
+                J.abz[fin.rx] = -1;
+                J.solved[row[0]] = 1;
+            }
+            if (D.flip_w) J.flip3[row[0]] = D.flip_new;
+            C.steps += D.d_steps; C.nuniq += D.d_nuniq;
+            C.hits[0] += D.d_h0; C.hits[1] += D.d_h1; C.hits[3] += D.d_h3; C.hits[4] += D.d_h4;
+            uint32_t* ev = J.evbuf + (size_t)r0 * ECNE_EVCAP;
+            nev[0] = D.nev;
+#pragma unroll
+            for (uint32_t e = 0; e < 5; ++e) if (e < D.nev) { ev[e] = D.ev[e]; mycand += J.fo_ptr[D.ev[e] + 1] - J.fo_ptr[D.ev[e]]; }
+            ev[ECNE_EVCAP - 1] = D.nev;
+            continue;
+        }
         if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl))) row_unmark_global(J, row[sl], shape[sl], xv[sl]);
         if (r0 + sl >= c) continue;
         // rank tags must fit inq's 16 bits: multi rounds tag with the rank's low part plus a flag that
