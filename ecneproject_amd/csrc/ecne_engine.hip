@@ -1251,6 +1251,34 @@ int ecne_system_io(const ecne_system* sys, const int64_t** known, size_t* nk, co
     return ECNE_OK;
 }
 
+int ecne_fp_solve_quadratic(const uint64_t* a_, const uint64_t* b_, const uint64_t* c_, int literal, uint64_t* roots, int* n_roots) {
+    if (!a_ || !b_ || !c_ || !roots || !n_roots) return ECNE_EINVAL;
+    auto ld = [](const uint64_t* p) { return fp::reduce(fp::make(p[0], p[1], p[2], p[3])); };
+    auto st = [&](int i, const fp::u256& v) { for (int k = 0; k < 4; ++k) roots[4 * i + k] = v.w[k]; };
+    const fp::u256 a = ld(a_), b = ld(b_), c = ld(c_);
+    *n_roots = 0;
+    if (fp::is_zero(a)) {
+        if (fp::is_zero(b)) return fp::is_zero(c) ? 0 : 1;                       // "YES" / "NO" (:66-71)
+        st(0, fp::mul(fp::neg(c), fp::inv(b)));                                  // divexact(-c, b) (:73)
+        *n_roots = 1;
+        return 2;
+    }
+    const fp::u256 two_a_inv = fp::inv(fp::add(a, a));
+    const fp::u256 disc = fp::sub(fp::mul(b, b), fp::mul(fp::make(4), fp::mul(a, c)));   // b*b - 4*a*c (:77)
+    fp::u256 rt;
+    if (!fp::sqrt(disc, rt)) return 5;
+    if (fp::is_zero(rt)) {                                                        // (:85)
+        st(0, fp::mul(fp::neg(b), two_a_inv));
+        *n_roots = 1;
+        return 4;
+    }
+    const fp::u256 t = literal ? disc : rt;                                       // (:83-84) uses `disc` where `rt` was meant
+    st(0, fp::mul(fp::add(fp::neg(b), t), two_a_inv));
+    st(1, fp::mul(fp::sub(fp::neg(b), t), two_a_inv));
+    *n_roots = 2;
+    return 3;
+}
+
 const char* ecne_strerror(int st) {
     switch (st) {
         case ECNE_OK: return "ok";

@@ -181,6 +181,13 @@ int ecne_fp_selftest(int device, int op, size_t n, const uint64_t* a, const uint
 /* host-side utilities named by the north star (src/Math.jl:14-90 is dead code in the reference;
  * provided with self-consistency tests only): sqrt returns 1 and a root when one exists, else 0. */
 int ecne_fp_sqrt(const uint64_t* a, uint64_t* root);
+/* solveQuadratic (src/Math.jl:62-90; never called by the solver): a x^2 + b x + c = 0 over the field. Returns the kind of
+ * answer: 0 = every x ("YES", :68), 1 = none ("NO", :70), 2 = the one root -c/b of a linear equation (:73), 3 = two values,
+ * 4 = the double root -b/(2a) (:85), 5 = the discriminant has no square root (the reference's squareRoot never terminates on a
+ * non-residue: no counterpart). n_roots values of 4 limbs each go to roots (room for 2). literal != 0 reproduces the
+ * reference's two-value formula as written -- (-b +- disc)/(2a) with the DISCRIMINANT where the root was meant (:83-84) --
+ * literal == 0 gives the true roots (-b +- sqrt(disc))/(2a). */
+int ecne_fp_solve_quadratic(const uint64_t* a, const uint64_t* b, const uint64_t* c, int literal, uint64_t* roots, int* n_roots);
 
 int ecne_device_count(void);
 const char* ecne_strerror(int status);

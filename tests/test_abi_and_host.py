@@ -150,6 +150,50 @@ def test_field_sqrt_utility(E):
             assert orc.limbs_to_int(r) ** 2 % P == a
 
 
+def test_field_solve_quadratic_utility(E):
+    """solveQuadratic (src/Math.jl:62-90, dead code upstream): the kinds of answer, the true roots by substitution, and the
+    reference's two-value formula as written (the discriminant where its square root was meant, :83-84) against Python."""
+    import random
+    from ecneproject_amd import _lib
+    lib = _lib.lib()
+    P = orc.P
+    rng = random.Random(11)
+
+    def solve(a, b, c, literal):
+        roots, n = np.zeros(8, np.uint64), C.c_int(0)
+        la, lb, lc = orc.int_to_limbs(a), orc.int_to_limbs(b), orc.int_to_limbs(c)       # (kept alive across the call)
+        kind = lib.ecne_fp_solve_quadratic(la.ctypes.data, lb.ctypes.data, lc.ctypes.data, literal, roots.ctypes.data, C.byref(n))
+        return kind, [orc.limbs_to_int(roots[4 * i:4 * i + 4]) for i in range(n.value)]
+    import ctypes as C
+    assert solve(0, 0, 0, 0) == (0, []) and solve(0, 0, 5, 0) == (1, [])                 # "YES" / "NO"
+    assert solve(0, 3, 6, 0) == (2, [(-6 * pow(3, -1, P)) % P])
+    seen = set()
+    for _ in range(60):
+        a, r1, r2 = rng.randrange(1, P), rng.randrange(P), rng.randrange(P)
+        if rng.random() < 0.2:
+            r2 = r1                                                                        # double root
+        b, c = (-a * (r1 + r2)) % P, (a * r1 * r2) % P
+        kind, roots = solve(a, b, c, 0)
+        seen.add(kind)
+        if r1 == r2:
+            assert kind == 4 and roots == [r1]
+        else:
+            assert kind == 3 and sorted(roots) == sorted([r1, r2])
+            assert all((a * x * x + b * x + c) % P == 0 for x in roots)
+            disc = (b * b - 4 * a * c) % P
+            inv2a = pow(2 * a, -1, P)
+            assert solve(a, b, c, 1) == (3, [((-b + disc) * inv2a) % P, ((-b - disc) * inv2a) % P])
+    # a discriminant without a square root: the reference's squareRoot would not terminate
+    n_none = 0
+    for _ in range(20):
+        a, b, c = rng.randrange(1, P), rng.randrange(P), rng.randrange(P)
+        disc = (b * b - 4 * a * c) % P
+        if disc and pow(disc, (P - 1) // 2, P) != 1:
+            assert solve(a, b, c, 0)[0] == 5
+            n_none += 1
+    assert seen == {3, 4} and n_none > 3
+
+
 _DIGEST_SCRIPT = r"""
 import hashlib, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
