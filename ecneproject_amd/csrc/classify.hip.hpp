@@ -109,16 +109,26 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
                 // l > 255: powers 2^k wrap modulo p for k >= 254. Quick reject (exactly one 1 / one -1),
                 // then the literal multiset comparison, lanes striding over targets.
                 int n_one = 0, n_mone = 0;
-                for (uint32_t base = c0; base < c1; base += 64) {
-                    uint32_t k = base + lane;
-                    bool act = k < c1;
-                    fp::u256 c = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
-                    uint32_t v = act ? J.colC[k] : 0;
-                    uint64_t m1 = __ballot(act && fp::is_one(c)), m2 = __ballot(act && fp::is_one(fp::neg(c)));
-                    n_one += __popcll(m1);
-                    n_mone += __popcll(m2);
-                    if (m1) kpos = __shfl(v, __ffsll((long long)m1) - 1, 64);
-                    if (m2) kneg = __shfl(v, __ffsll((long long)m2) - 1, 64);
+                // (four entries per lane and step, all loads first: a 1 025-term row is 5 steps of loads in flight instead of 17
+                //  dependent round trips)
+                for (uint32_t base = c0; base < c1; base += 256) {
+                    fp::u256 c4[4];
+                    uint32_t v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t k = base + 64u * (uint32_t)j + (uint32_t)lane;
+                        const bool act = k < c1;
+                        c4[j] = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
+                        v4[j] = act ? J.colC[k] : 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint64_t m1 = __ballot(fp::is_one(c4[j])), m2 = __ballot(fp::is_one(fp::neg(c4[j])));
+                        n_one += __popcll(m1);
+                        n_mone += __popcll(m2);
+                        if (m1) kpos = __shfl(v4[j], __ffsll((long long)m1) - 1, 64);
+                        if (m2) kneg = __shfl(v4[j], __ffsll((long long)m2) - 1, 64);
+                    }
                 }
                 if (n_one == 1 && n_mone == 1) {
                     // T  <=> one "1"  and every 2^k mod p (k = 0..l-2) occurs exactly once among the -c
@@ -159,24 +169,59 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
         // A T2-only row has been negated by R4 before R7 first looks at it.
         {
             const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
+            // A binary decomposition (the row matched {1, -2^0 .. -2^(l-2)} or its negation) needs no sorting: in the orientation
+            // R7 sees, the |coefficients| are 1 (the pivot), 1 (the 2^0 term), 2, 4, ..., each once -- the two 1s keep their stored
+            // order, the term with exponent e > 0 has rank e + 1. (Up to l = 250: beyond, -2^e for e >= 249 lies below R7's
+            // "negative" threshold and counts as the large positive number it is, :1245-1259.) The rank sort below is O(l^2)
+            // 256-bit compares on one wavefront -- 60 us for an 87-term Num2Bits row.
+            const bool pattern = (shape & (SH_R4_T | SH_R4_T2)) && l >= 2 && l <= 250;
             // long sum rows usually carry one |coefficient| (all +-1): the stable order is then the stored one
-            bool all_same = true;
+            bool all_same = !pattern;
+            if (pattern) {
+                // positions of the two entries with |coefficient| 1 (the +1 and the -1 of the row)
+                uint32_t p_one = 0xFFFFFFFFu, p_mone = 0xFFFFFFFFu;
+                for (uint32_t base = c0; base < c1; base += 64) {
+                    const uint32_t k = base + lane;
+                    const bool act = k < c1;
+                    const fp::u256 c = act ? ld256(J.coefC + 4ull * k) : fp::make(2);
+                    const uint64_t m1 = __ballot(act && fp::is_one(c)), m2 = __ballot(act && fp::is_one(fp::neg(c)));
+                    if (m1 && p_one == 0xFFFFFFFFu) p_one = base + (uint32_t)(__ffsll((long long)m1) - 1);
+                    if (m2 && p_mone == 0xFFFFFFFFu) p_mone = base + (uint32_t)(__ffsll((long long)m2) - 1);
+                }
+                for (uint32_t base = c0; base < c1; base += 64) {
+                    const uint32_t k = base + lane;
+                    if (k >= c1) continue;
+                    fp::u256 c = ld256(J.coefC + 4ull * k);
+                    if (negated) c = fp::neg(c);
+                    uint32_t rank;
+                    if (k == p_one || k == p_mone) rank = (k == (p_one < p_mone ? p_one : p_mone)) ? 0u : 1u;
+                    else { const fp::u256 a = r7_abs(c); rank = (uint32_t)ctz256(a) + 1u; }
+                    J.csort[c0 + rank] = k - c0;
+                }
+            } else
             {
                 fp::u256 first = ld256(J.coefC + 4ull * c0);
                 if (negated) first = fp::neg(first);
                 first = r7_abs(first);
-                for (uint32_t base = c0; base < c1 && all_same; base += 64) {
-                    uint32_t k = base + lane;
+                for (uint32_t base = c0; base < c1 && all_same; base += 256) {
+                    fp::u256 c4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t k = base + 64u * (uint32_t)j + (uint32_t)lane;
+                        c4[j] = k < c1 ? ld256(J.coefC + 4ull * k) : ld256(J.coefC + 4ull * c0);
+                    }
                     bool diff = false;
-                    if (k < c1) {
-                        fp::u256 c = ld256(J.coefC + 4ull * k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        fp::u256 c = c4[j];
                         if (negated) c = fp::neg(c);
-                        diff = !fp::eq(r7_abs(c), first);
+                        diff |= !fp::eq(r7_abs(c), first);
                     }
                     if (__ballot(diff)) all_same = false;
                 }
             }
-            if (all_same)
+            if (pattern) { }
+            else if (all_same)
                 for (uint32_t k = c0 + lane; k < c1; k += 64) J.csort[k] = k - c0;
             else
             for (uint32_t base = c0; base < c1; base += 64) {
@@ -222,8 +267,10 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
 // 64 rows per wavefront, so the field inversions of bit-check / single-variable rows run on full
 // SIMDs instead of one lane of a wave. Same results as classify_row, written serially.
 #define ECNE_CLS_LANE 8
-__device__ void classify_row_lane(const Job& J, uint32_t row) {
-    RowInfo ri = J.rinfo[row];
+__device__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri) {
+    const uint32_t shape_in = ri.shape, kpos_in = ri.kpos, kneg_in = ri.kneg;
+    // a product a * b = c (or any row with C empty that is no bit check) needs nothing from this pass
+    if ((shape_in & SH_HAS_AB) && !(shape_in & SH_R2) && !((shape_in & SH_C_HAS1) && (shape_in & SH_R5))) return;
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
     const uint32_t l = c1 - c0;
     uint32_t shape = ri.shape;
@@ -304,24 +351,31 @@ __device__ void classify_row_lane(const Job& J, uint32_t row) {
         }
     }
     if ((shape & SH_C_HAS1) && (shape & (SH_R4_T | SH_R4_T2 | SH_R5))) shape |= SH_TOUCH1;
-    ri.shape = shape;
-    J.rinfo[row] = ri;
+    if (shape != shape_in || ri.kpos != kpos_in || ri.kneg != kneg_in) {     // (most descriptors come out as the host laid them down)
+        ri.shape = shape;
+        J.rinfo[row] = ri;
+    }
 }
 
-// pass 0: one lane per row for rows with lenC <= ECNE_CLS_LANE; pass 1: one wavefront per remaining row
-__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index, uint32_t pass) {
+// One launch, two kinds of workgroups: the first n_long_blocks take the long rows the host listed (cls_list: lenC >
+// ECNE_CLS_LANE), one wavefront per row; the others the short rows, one lane per row. The long rows are latency-bound (a few
+// hundred rows, each a chain of loads): dispatched first and in the same launch, they overlap with the streaming part.
+__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index, uint32_t n_long_blocks) {
     __shared__ uint32_t scratch[4][16];
     __shared__ Job sJ;
     if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
     __syncthreads();
-    if (pass == 0) {
-        for (uint32_t row = blockIdx.x * 256 + threadIdx.x; row < sJ.nC; row += gridDim.x * 256)
-            if (sJ.rinfo[row].lenC <= ECNE_CLS_LANE) classify_row_lane(sJ, row);
+    if (blockIdx.x >= n_long_blocks) {
+        const uint32_t nb0 = gridDim.x - n_long_blocks;
+        for (uint32_t row = (blockIdx.x - n_long_blocks) * 256 + threadIdx.x; row < sJ.nC; row += nb0 * 256)
+        {
+            const RowInfo ri = sJ.rinfo[row];
+            if (ri.lenC <= ECNE_CLS_LANE) classify_row_lane(sJ, row, ri);
+        }
         return;
     }
     const uint32_t wave = threadIdx.x >> 6;
-    // the long rows are listed by the host (big_list): one wavefront each
-    for (uint32_t i = blockIdx.x * 4 + wave; i < sJ.nBigCls; i += gridDim.x * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
+    for (uint32_t i = blockIdx.x * 4 + wave; i < sJ.nBigCls; i += n_long_blocks * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
 }
 
 }  // namespace ecne

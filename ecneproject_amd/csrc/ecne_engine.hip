@@ -664,8 +664,8 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     uint32_t nblk1 = ((uint32_t)S.L.cls_list.size() + 3) / 4;
     if (nblk1 > 256 * 16) nblk1 = 256 * 16;
     HIP_TRY(hipEventRecord(e0, stream));
-    hipLaunchKernelGGL(k_classify_rows, dim3(nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, 0u);
-    if (nblk1) hipLaunchKernelGGL(k_classify_rows, dim3(nblk1), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, 1u);
+    // one launch: the long-row workgroups first (latency-bound), the streaming ones behind them (see k_classify_rows)
+    hipLaunchKernelGGL(k_classify_rows, dim3(nblk1 + nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, nblk1);
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());
