@@ -755,6 +755,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             __syncthreads();
             q.head = S.head; q.tail = S.tail;
             pops_total += S.nbig;
+#ifdef ECNE_W2PROF
+            if (tid == 0) { S.sd[3] += 1; S.sd[4] += S.nbig; S.sd[5] += wall_clock64() - qt_last; }     // (profiling builds: sequential bursts instead of general wavefront rounds)
+#endif
             burst = 0;
             __syncthreads();
             QTICK(6);
@@ -786,7 +789,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 if (lane == 0) { S.nbig = cw; S.tail = nt; S.flag7 = fast ? 1u : 0u; S.bl_tmp[0] = nx; }
             }
             __syncthreads();
-            const uint32_t cw = S.nbig, ntw = S.tail, nx = S.bl_tmp[0];   // nx: rows the round examined (the fast round may stop short of n)
+            const uint32_t cw = S.nbig, ntw = S.tail, nx = S.bl_tmp[0] & 0x7FFFFFFFu;   // nx: rows the round examined (the fast round may stop short of n)
+            // (bit 31: the round stopped in front of something it does not take, not at a dependency -- then nx == cw, and the
+            //  streak below keeps counting; tried and dropped: treating short rounds of that kind like declines, 23.9 -> 25.5 ms)
             __syncthreads();
             if (cw == 0xFFFFFFFEu) {     // the fast round declined the row at the head
                 // one sequential pop of that row, then look again -- unless the head of a wide frontier keeps being declined
@@ -825,6 +830,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             uint32_t nt = q.tail, nx = n;
             const uint32_t cw = chain ? queue_round_fast<true, true>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
                                       : queue_round_fast<false, true>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
+            nx &= 0x7FFFFFFFu;
             if (cw == 0xFFFFFFFEu) {
                 if (J.nwg > 1) {
                     if (avail >= multi_min(J) && ++declined_run >= ECNE_V2_DECLINES) { declined_wide = true; declined_run = 0; }

@@ -76,12 +76,17 @@ struct FastIn {
     uint8_t fl[15], fa, fb, fx;     // flag bytes: of the entries (products, sums), of k1 / k2 (x == y), of x (bit check)
     uint8_t flip_in;
     bool live, xy, f2, f4, bigsum;
+    bool r4s = false;               // a short binary-decomposition row (R4 shape, l > 2): taken while R4's precondition fails
+    bool r3f = false;               // a constant row x = c (R3 shape and none of R4..R6's)
+    uint32_t validx = 0;            // the row's constants in J.vals (R3: c)
 };
 struct FastOut {
     uint32_t wva = 0, wvb = 0;      // variables whose flag byte (and maybe bounds) this pop changes
     uint8_t wfa = 0, wfb = 0;
     bool wa = false, wb = false, a01 = false, b01 = false, r2 = false, flip_w = false;
-    bool xa_w = false, xb_w = false;            // x == y rows decided on the limbs: new bounds of k1 / k2
+    bool xa_w = false, xb_w = false;            // x == y rows decided on the limbs: new bounds of k1 / k2 (a constant row: of x)
+    bool r3v = false;                           // a constant row: values[x] = {xlb0} (:955-961)
+    uint32_t d_h2 = 0;
     fp::u256 xlb0 = fp::make(0), xub0 = fp::make(0), xlb1 = fp::make(0), xub1 = fp::make(0);
     uint8_t flip_new = 0;
     uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;  // REQUEUE events, in the reference's order
@@ -90,7 +95,7 @@ struct FastOut {
     uint32_t reason = 7;
 };
 __device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastOut& O) {
-    const bool live = I.live, xy = I.xy, f2 = I.f2, f4 = I.f4, bigsum = I.bigsum;
+    const bool live = I.live, xy = I.xy, f2 = I.f2, f4 = I.f4, bigsum = I.bigsum, r4s = I.r4s;
     const uint32_t shape = I.shape, rx = I.rx, kpos = I.kpos, kneg = I.kneg, k1 = I.k1, k2 = I.k2, nA = I.nA, nB = I.nB, nE = I.nE;
     const uint32_t* const w = I.w;
     const uint8_t* const fl = I.fl;
@@ -180,6 +185,32 @@ __device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastO
                 const bool r7 = nua && nub && (first_is_a ? fp::cmp(ub0, lb0) <= 0 : fp::cmp(ub1, lb1) <= 0);
                 if (tagged || r7) { slow = true; reason = 4; }
             }
+        } else if (I.r3f) {
+            // a constant row c_x * x + c_1 = 0 (R3 check_linear :949-988; R1 first, nothing else has anything to do afterwards:
+            // x ends up unique, so R7 / R8 find no non-unique variable). fx = x's flag byte.
+            uint8_t f = fx;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 15; ++e) if (e < nE && !(fl[e] & 1)) ++cnt;
+            if (cnt == 1 && !(f & 1)) {                                   // R1 (:827-873): x is the one non-unique variable
+                f |= 3; emit(rx);
+                O.d_nuniq++; O.d_steps++; O.d_h0++;
+            } else if (cnt != 0) { slow = true; reason = 1; }             // (a non-unique constant wire: never seen; general executor)
+            if (!slow) {
+                // (all loads first; the pop of a constant row whose x already holds c -- every pop after the first -- writes nothing)
+                const fp::u256 tv = ld256(J.vals + 4ull * I.validx);
+                const uint8_t nv = J.nvalues[rx];
+                const fp::u256 va = ld256(J.values + 8ull * rx), lbx = ld256(J.lb + 4ull * rx), ubx = ld256(J.ub + 4ull * rx);
+                const bool same = nv == 1 && fp::eq(va, tv);
+                const bool bsame = fp::eq(lbx, tv) && fp::eq(ubx, tv);
+                bool new_info = false;
+                if (!same) { O.d_steps++; O.d_h2++; new_info = true; O.r3v = true; }
+                if (!(f & 1)) { O.d_nuniq++; new_info = true; }
+                f = (uint8_t)(((f | 3) & ~12u) | bounds_class_bits(tv, tv));
+                xlb0 = tv; xub0 = tv; xa_w = !bsame;
+                wva = rx; wfa = f; wa = f != fx || !same || !bsame;
+                if (new_info) emit(rx);
+            }
         } else if (xy) {
             if (((fa | fb) & 8u) || k1 == k2 || nE != 2) { slow = true; reason = 3; }
             else {
@@ -249,7 +280,18 @@ __device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastO
                 wva = u; wfa = (uint8_t)(uf | 3); wa = true;
                 emit(u);
                 d_nuniq = 1; d_steps = 1; d_h0 = 1;
-            } else if (f4 && cnt > 0 && !notknown) { slow = true; reason = 5; }       // R7 / R8 in reach
+            } else if ((f4 || r4s) && cnt > 0 && !notknown) { slow = true; reason = 5; }       // R7 / R8 in reach
+            if (r4s && !slow) {
+                // R4 checkBinary (:991-1076) on a decomposition of 3..15 terms: nothing happens while some variable other than
+                // the pivot lacks bounds exactly [0,1] (:1020-1029) -- the usual state of such a row's pops; otherwise the
+                // general executor does the arithmetic
+                const uint32_t pivot = (shape & SH_R4_T) ? kpos : kneg;
+                bool bad = false;
+#pragma unroll
+                for (uint32_t e = 0; e < 15; ++e)
+                    if (e < nE && w[1 + e] != pivot && !(fl[e] & 4)) bad = true;
+                if (!bad) { slow = true; reason = 1; }
+            }
         }
     }
 }
@@ -340,6 +382,8 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     const bool f1 = (shape & SH_HAS_AB) && !(shape & SH_C_EMPTY);
     const bool f2 = (shape & SH_C_EMPTY) != 0;
     const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+    const bool r4s = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R5 | SH_R6)) && (((shape & SH_R4_T) != 0) != ((shape & SH_R4_T2) != 0));
+    const bool r3f = (shape & SH_R3) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
     const bool live = mine && !is_solved;
     // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
     // A long plain sum (no record: more than 15 terms, up to the 1 025 of a decoder) is re-queued by each of its terms and
@@ -354,8 +398,17 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
         nA = 0; nB = 0; nCc = 8; nE = 8;
     }
-    bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4))));
+    bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4 || r4s || r3f))));
     uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
+    // A row of another shape (a constant x = c, 1 = x + y, ...) all of whose variables are unique and known, with values and
+    // bounds as its rules would leave them, is popped without effect (row_is_noop, schedule.hip.hpp: the test the
+    // multi-workgroup round uses) -- e.g. the second pop of every constant row, which its own REQUEUE causes.
+    bool nop_row = false;
+    if (slow && reason == 1u) {
+        const RowInfo ri_ = J.rinfo[row];
+        bool nb_ = false;
+        if (row_is_noop(J, row, ri_, nb_)) { slow = false; reason = 7u; nop_row = true; }
+    }
 #ifdef ECNE_W2SHAPES
     if (reason == 1) reason = (shape & SH_R3) ? 1u : (shape & SH_R6) ? 2u : (shape & (SH_R4_T | SH_R4_T2)) ? 5u : 3u;
     if (reason == 0) reason = (shape & (SH_R4_T | SH_R4_T2)) ? 4u : 0u;
@@ -367,7 +420,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     for (uint32_t e = 0; e < 15; ++e) fl[e] = (walk && e < nE) ? ldF(w[1 + e]) : (uint8_t)3;
     uint8_t fa = 3, fb = 3, fx = 3;
     if (live && !slow && xy) { fa = ldF(k1); fb = ldF(k2); }
-    if (live && !slow && f2 && (shape & SH_R2)) fx = ldF(rx);
+    if (live && !slow && ((f2 && (shape & SH_R2)) || r3f)) fx = ldF(rx);
     W2T(1);        // flag bytes
     // ---- the decision, in registers (fast_decide)
     FastIn fin;
@@ -377,7 +430,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
 #pragma unroll
     for (int i = 0; i < 15; ++i) fin.fl[i] = fl[i];
     fin.fa = fa; fin.fb = fb; fin.fx = fx; fin.flip_in = flip_in;
-    fin.live = live; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum;
+    fin.live = live; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !nop_row; fin.r3f = r3f && !nop_row; fin.validx = validx;
     FastOut fo_;
     fo_.slow = slow; fo_.reason = reason;
     fast_decide(J, fin, fo_);
@@ -392,6 +445,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         if (nev == 0) ev[0] = v; else if (nev == 1) ev[1] = v; else if (nev == 2) ev[2] = v; else if (nev == 3) ev[3] = v; else ev[4] = v;
         ++nev;
     };
+    if (nop_row && (shape & SH_R4_T) && (shape & SH_R4_T2)) { flip_w = true; flip_new = (uint8_t)(flip_in ^ 1); }     // the empty pop's only effect (:1001-1011)
     // ---- a long row at the head of the window (a decoder's 1 025-term sum, a long product) whose pop the lane could not
     // settle from its first terms: the WHOLE wavefront walks it, lanes across its entries -- 16 strides for 1 025 terms
     // instead of a round of its own on the workgroup. Only what R1 asks is gathered (plus whether R7 / R8 are in reach of a
@@ -414,15 +468,23 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
             const bool nuab = __ballot(nu) != 0;
             uint32_t cnt = 0, u = 0, uf = 0;
             bool nk = false;
-            for (uint32_t base = c0; base < c1; base += 64) {
-                const uint32_t k = base + (uint32_t)lane;
-                const bool act = k < c1;
-                const uint32_t v = act ? cC[k] : 1u;
-                const uint8_t f = act ? ldF(v) : (uint8_t)3;
-                const uint64_t m = __ballot(act && !(f & 1));
-                if (m && cnt == 0) { const int src = __ffsll((long long)m) - 1; u = rdlane(v, (uint32_t)src); uf = rdlane(f, (uint32_t)src); }
-                cnt += (uint32_t)__popcll(m);
-                nk |= act && !(f & 1) && !(f & 2);
+            // (four strides per trip: the loads of a trip are in flight together -- a 1 025-term sum is 5 dependent
+            //  round trips instead of 17)
+            for (uint32_t base = c0; base < c1; base += 256) {
+                uint32_t v4[4];
+                uint8_t f4_[4];
+                bool act4[4];
+#pragma unroll
+                for (uint32_t t = 0; t < 4; ++t) { const uint32_t k = base + 64u * t + (uint32_t)lane; act4[t] = k < c1; v4[t] = act4[t] ? cC[k] : 1u; }
+#pragma unroll
+                for (uint32_t t = 0; t < 4; ++t) f4_[t] = act4[t] ? ldF(v4[t]) : (uint8_t)3;
+#pragma unroll
+                for (uint32_t t = 0; t < 4; ++t) {
+                    const uint64_t m = __ballot(act4[t] && !(f4_[t] & 1));
+                    if (m && cnt == 0) { const int src = __ffsll((long long)m) - 1; u = rdlane(v4[t], (uint32_t)src); uf = rdlane(f4_[t], (uint32_t)src); }
+                    cnt += (uint32_t)__popcll(m);
+                    nk |= act4[t] && !(f4_[t] & 1) && !(f4_[t] & 2);
+                }
             }
             const bool notknown = __ballot(nk) != 0;
             const bool reach78 = lin0 && cnt > 0 && !(cnt == 1 && !nuab) && !notknown;      // R7 / R8 could fire: the general executor decides
@@ -465,12 +527,13 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         else if (xy) blocked = w2_get(Tm, k1 + 1u) < rank || w2_get(Tm, k2 + 1u) < rank;
         else {
 #pragma unroll
-            for (uint32_t e = 0; e < 15; ++e)
-                if (e < nE && (fl[e] & 3) != 3 && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
+            for (uint32_t e = 0; e < 15; ++e)       // (an empty pop and a decomposition row also depend on the bounds of their unique variables)
+                if (e < nE && ((fl[e] & 3) != 3 || nop_row || r4s || r3f) && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
         }
     }
     uint32_t c = cmax;
-    { const uint32_t fb_ = first_rank(blocked, 1); if (fb_ < c) c = fb_; }      // >= 1: rank 0 is never blocked
+    const uint32_t fb_ = first_rank(blocked, 1);
+    if (fb_ < c) c = fb_;                                                        // >= 1: rank 0 is never blocked
     W2T(3);        // marks + check
     // ---- 4: fan-out of the events of the prefix; an event with more than three target rows ends the prefix in front of it
     u32x4 fo[5] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -484,11 +547,53 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     }
     {
         const uint32_t f0 = first_rank(bigev, 2);
-        if (f0 == 0) {                                          // rank 0: the general executor takes it (only marks were written)
-            for (uint32_t i = rank; i < NMARK; i += NT) { Tm.key[i] = 0u; Tm.val[i] = 0xFFFFFFFFu; }
-            sync();
-            if (rank == 0) why[6] += 1;
-            return 0xFFFFFFFEu;
+        if (f0 == 0) {
+            if constexpr (WG) {                                 // rank 0: the general executor takes it (only marks were written)
+                for (uint32_t i = rank; i < NMARK; i += NT) { Tm.key[i] = 0u; Tm.val[i] = 0xFFFFFFFFu; }
+                sync();
+                if (rank == 0) why[6] += 1;
+                return 0xFFFFFFFEu;
+            } else {
+                // rank 0 makes a variable with a long row list unique (a bit feeding dozens of rows): the round is that one
+                // pop. Lane 0 commits it, then the wavefront walks the lists of its events in order (REQUEUE as the sequential
+                // executor does it, rules_wave.hip.hpp) -- a tenth of what declining the row and popping it through the
+                // general executor costs.
+                if (lane == 0) {
+                    my_pops++;
+                    my_nnz += nnz_long ? nnz_long : (bigsum ? lenC : nE);
+                    if (wa) stF(wva, wfa);
+                    if (wb) stF(wvb, wfb);
+                    if (a01) { st256(J.lb + 4ull * wva, fp::make(0)); st256(J.ub + 4ull * wva, fp::make(1)); }
+                    if (b01) { st256(J.lb + 4ull * wvb, fp::make(0)); st256(J.ub + 4ull * wvb, fp::make(1)); }
+                    if (xa_w) { st256(J.lb + 4ull * wva, xlb0); st256(J.ub + 4ull * wva, xub0); }
+                    if (xb_w) { st256(J.lb + 4ull * wvb, xlb1); st256(J.ub + 4ull * wvb, xub1); }
+                    if (r2) {
+                        st256(J.values + 8ull * rx, ld256(J.vals + 4ull * validx));
+                        st256(J.values + 8ull * rx + 4, ld256(J.vals + 4ull * (validx + 1)));
+                        J.nvalues[rx] = 2;
+                        J.abz[rx] = -1;
+                        solved[row] = 1;
+                    }
+                    if (fo_.r3v) { st256(J.values + 8ull * wva, xlb0); J.nvalues[wva] = 1; }
+                    if (flip_w) { if (flip_lds) flipL[row] = flip_new; else flipG[row] = flip_new; }
+                    C.steps += d_steps; C.nuniq += d_nuniq;
+                    C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[2] += fo_.d_h2; C.hits[3] += d_h3; C.hits[4] += d_h4;
+                    stQ(row, (uint16_t)0);                      // (:817) popped: its own events may queue it again
+                }
+                wg_fence();
+                QState qq;
+                qq.head = head + 1; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                const uint32_t nev0 = rdlane(nev, 0);
+#pragma unroll
+                for (uint32_t k = 0; k < 5; ++k)
+                    if (k < nev0) requeue(J, qq, rdlane(ev[k], 0));
+                for (uint32_t i = rank; i < NMARK; i += NT) { Tm.key[i] = 0u; Tm.val[i] = 0xFFFFFFFFu; }
+                wg_fence();
+                if (rank == 0) why[6] += 1;
+                *out_tail = qq.tail;
+                *out_examined = 1u | 0x80000000u;      // (not a dependency: see the end of this function)
+                return 1;
+            }
         }
         if (f0 < c) c = f0;
     }
@@ -523,9 +628,10 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
             J.abz[rx] = -1;
             solved[row] = 1;
         }
+        if (fo_.r3v) { st256(J.values + 8ull * wva, xlb0); J.nvalues[wva] = 1; }
         if (flip_w) { if (flip_lds) flipL[row] = flip_new; else flipG[row] = flip_new; }
         C.steps += d_steps; C.nuniq += d_nuniq;
-        C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[3] += d_h3; C.hits[4] += d_h4;
+        C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[2] += fo_.d_h2; C.hits[3] += d_h3; C.hits[4] += d_h4;
     }
     sync();
     W2T(5);        // commit
@@ -577,7 +683,11 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     if (WG) __syncthreads();
     W2T(7);        // wipe + final fence
     *out_tail = new_tail;
-    *out_examined = cmax;      // rows the round looked at: a prefix shorter than THIS is a dependency (the caller's window adapts to it)
+    // rows the round looked at: a prefix shorter than THIS is a dependency (the caller's window adapts to it). A prefix that ends
+    // in front of a row or an event the round does not take (general shape, long row list, candidate table full) says nothing
+    // about dependencies: reported as examined == committed, with bit 31 set (a wide frontier of such rows is the
+    // multi-workgroup round's business, see queue_phase)
+    *out_examined = (c < n && c != fb_) ? (c | 0x80000000u) : cmax;
     return c;
 }
 
