@@ -618,6 +618,9 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #ifndef ECNE_MULTI_MIN
 #define ECNE_MULTI_MIN 128    // queued rows from which a round runs on all workgroups of the job (measured optimum)
 #endif
+#ifndef ECNE_V2_BACKLOG
+#define ECNE_V2_BACKLOG 8192
+#endif
 #ifndef ECNE_V2_DECLINES
 #define ECNE_V2_DECLINES 4
 #endif
@@ -665,9 +668,10 @@ __device__ __forceinline__ void multi_window_update(uint32_t cm, uint32_t nm, ui
 // rows of the next chained round, 0 = back to the master's own loop (same tests as at its top)
 __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head, uint32_t tail, uint32_t window, uint32_t mwindow,
                                                      uint32_t c_last, uint32_t n_last) {
-    // with the fast rounds at hand, a round that a dependency cut short of ECNE_V2WG_WINDOW rows hands the frontier back to them
-    // (the next prefix is likely short as well, and they find that out for a fifth of the price)
-    if (fast_wave_ok(J) && c_last != n_last && c_last < ECNE_V2WG_WINDOW) return 0;
+    // with the fast rounds at hand, a round that a dependency cut short hands the frontier back to them: the next prefix is
+    // likely short as well -- on ecdsa_like(26) a 4 096-row window cut at row 3 968 (a multiplexer's 1 025-term sum) was
+    // followed by a round of ONE row 78 times, 65 us each -- and they find that out for a fifth of the price
+    if (fast_wave_ok(J) && c_last != n_last) return 0;
     const uint32_t avail = tail - head;
     const uint32_t n = avail < window ? avail : window;
     if (n <= 64 || avail < multi_min(J) || window < multi_window_min(J)) return 0;
@@ -758,6 +762,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #ifdef ECNE_W2PROF
             if (tid == 0) { S.sd[3] += 1; S.sd[4] += S.nbig; S.sd[5] += wall_clock64() - qt_last; }     // (profiling builds: sequential bursts instead of general wavefront rounds)
 #endif
+#ifdef ECNE_ROUNDLOG
+            if (tid == 0) printf("RL burst avail %u n %u c %u dt %llu\n", avail, S.nbig, S.nbig, wall_clock64() - qt_last);
+#endif
             burst = 0;
             __syncthreads();
             QTICK(6);
@@ -767,7 +774,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
         uint32_t n = avail < window ? avail : window;
         // with the fast wavefront round a frontier below the multi-workgroup threshold is taken 64 rows at a time
-        if (v2 && J.nwg > 1 && !declined_wide && (avail < multi_min(J) || streak < multi_window_min(J))) {
+        // (with a deep backlog one uncut fast round is evidence enough: the blocks of a multiplexer -- 4 096 independent rows, then
+        //  a 1 025-term sum that waits for them -- come back every 70 us on ecdsa_like(26))
+        const uint32_t streak_min = (v2 && avail >= ECNE_V2_BACKLOG) ? 64u : multi_window_min(J);
+        if (v2 && J.nwg > 1 && !declined_wide && (avail < multi_min(J) || streak < streak_min)) {
             const uint32_t cap_ = v2wg ? (uint32_t)ECNE_WG : 64u;        // below the multi-workgroup threshold the fast rounds take the frontier
             n = avail < cap_ ? avail : cap_;
         }
@@ -807,6 +817,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                     const int b_ = S.flag7 ? 0 : 3;
                     S.sd[b_] += 1; S.sd[b_ + 1] += cw; S.sd[b_ + 2] += dt_;
                 }
+#endif
+#ifdef ECNE_ROUNDLOG
+                if (tid == 0) printf("RL wave avail %u n %u c %u dt %llu\n", avail, nx, cw, wall_clock64() - qt_last);
 #endif
                 q.head += cw;
                 q.tail = ntw;
@@ -880,7 +893,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
-        if (!S.fallback && J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= multi_window_min(J) : window >= multi_window_min(J)) || declined_wide)) {
+        if (!S.fallback && J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide)) {
             declined_wide = false;
             // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
             const uint32_t cap_n = J.nwg * ECNE_WG * 2;
@@ -903,6 +916,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
                 hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
                 if (tid == 0) S.sd[cm < 64 ? 13 : cm < 4096 ? 14 : 15] += 1;   // schedule diagnostics: multi rounds by rows committed
+#ifdef ECNE_ROUNDLOG
+                if (tid == 0) { printf("RL multi avail %u n %u c %u dt %llu\n", avail, nm, cm, wall_clock64() - qt_last); qt_last = wall_clock64();
+                    if (cm < nm) for (uint32_t k_ = 0; k_ < 3; ++k_) { const uint32_t r_ = J.queue[(q.head + k_) & J.qmask]; printf("CUT+%u row %u shape %x nA %u nB %u nC %u solved %d\n", k_, r_, J.rinfo[r_].shape, J.rpA[r_ + 1] - J.rpA[r_], J.rpB[r_ + 1] - J.rpB[r_], J.rpC[r_ + 1] - J.rpC[r_], (int)J.solved[r_]); } }
+#endif
                 streak = cm == nm ? streak + cm : 0;
                 multi_window_update(cm, nm, cap_n, mwindow, window);
                 nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow, cm, nm) : 0;
@@ -948,6 +965,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             }
             pops_total++;
             hits[14]++;
+#ifdef ECNE_ROUNDLOG
+            if (tid == 0) printf("RL alone avail %u n %u c %u dt %llu\n", avail, S.nbig, 1u, wall_clock64() - qt_last);
+#endif
             if (tid == 0) S.hasbig = 0;
             __syncthreads();
             QTICK(6);

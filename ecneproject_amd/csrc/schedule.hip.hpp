@@ -392,6 +392,8 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
             nev = tot;
         }
     }
+    // a linear row all of whose terms are unique now stays that way: its later pops are recognised without a walk (J.hint)
+    if (tid == 0 && !(shape & SH_HAS_AB) && (tot == 0 || nev != 0)) J.hint[2u * row] = 0xFFFFFFFEu;
     if (tid == 0) *nev_out = nev;
     __syncthreads();
     return true;

@@ -391,12 +391,19 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     // one, R7 wants all of them known, R8 all of them tagged. The lane looks at the first 8 terms; if they show that, the
     // pop is settled here (reading exactly those variables), anything else goes to the general executor.
     const bool bigsum = live && (w[0] >> 24) == 0 && f4 && lenC > 15;
+    bool alldone = false;
     if (bigsum) {
         const ECNE_GLOBAL uint32_t* const colC = as_global(J.colC);
         const uint32_t c0 = as_global(J.rpC)[row];
+        // ... or, once a full walk of the row has found two such terms anywhere in it, at those two (J.hint: "watched" terms)
+        const uint32_t h0 = as_global(J.hint)[2u * row], h1 = as_global(J.hint)[2u * row + 1u];
+        if (h0 == 0xFFFFFFFEu) { alldone = true; nA = 0; nB = 0; nCc = 0; nE = 0; }        // every term unique (for good): nothing can happen
+        else if (h0 != 0xFFFFFFFFu) { w[1] = colC[h0]; w[2] = colC[h1]; nA = 0; nB = 0; nCc = 2; nE = 2; }
+        else {
 #pragma unroll
-        for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
-        nA = 0; nB = 0; nCc = 8; nE = 8;
+            for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
+            nA = 0; nB = 0; nCc = 8; nE = 8;
+        }
     }
     bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4 || r4s || r3f))));
     uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
@@ -430,7 +437,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
 #pragma unroll
     for (int i = 0; i < 15; ++i) fin.fl[i] = fl[i];
     fin.fa = fa; fin.fb = fb; fin.fx = fx; fin.flip_in = flip_in;
-    fin.live = live; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !nop_row; fin.r3f = r3f && !nop_row; fin.validx = validx;
+    fin.live = live; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum && !alldone; fin.r4s = r4s && !nop_row; fin.r3f = r3f && !nop_row; fin.validx = validx;
     FastOut fo_;
     fo_.slow = slow; fo_.reason = reason;
     fast_decide(J, fin, fo_);
@@ -467,6 +474,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
             for (uint32_t k = b0 + (uint32_t)lane; k < b1; k += 64) nu |= !(ldF(cB[k]) & 1);
             const bool nuab = __ballot(nu) != 0;
             uint32_t cnt = 0, u = 0, uf = 0;
+            uint32_t k_nu1 = 0xFFFFFFFFu, k_nu2 = 0xFFFFFFFFu, k_nk = 0xFFFFFFFFu;      // positions: first two non-unique terms, first one not is_known
             bool nk = false;
             // (four strides per trip: the loads of a trip are in flight together -- a 1 025-term sum is 5 dependent
             //  round trips instead of 17)
@@ -481,12 +489,28 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
 #pragma unroll
                 for (uint32_t t = 0; t < 4; ++t) {
                     const uint64_t m = __ballot(act4[t] && !(f4_[t] & 1));
+                    const uint64_t mk = __ballot(act4[t] && !(f4_[t] & 1) && !(f4_[t] & 2));
                     if (m && cnt == 0) { const int src = __ffsll((long long)m) - 1; u = rdlane(v4[t], (uint32_t)src); uf = rdlane(f4_[t], (uint32_t)src); }
+                    if (m && k_nu2 == 0xFFFFFFFFu) {
+                        const uint32_t kb = base + 64u * t;
+                        uint64_t mm = m;
+                        if (k_nu1 == 0xFFFFFFFFu) { k_nu1 = kb + (uint32_t)(__ffsll((long long)mm) - 1); mm &= mm - 1; }
+                        if (mm) k_nu2 = kb + (uint32_t)(__ffsll((long long)mm) - 1);
+                    }
+                    if (mk && k_nk == 0xFFFFFFFFu) k_nk = base + 64u * t + (uint32_t)(__ffsll((long long)mk) - 1);
                     cnt += (uint32_t)__popcll(m);
-                    nk |= act4[t] && !(f4_[t] & 1) && !(f4_[t] & 2);
+                    nk |= mk != 0;
                 }
             }
             const bool notknown = __ballot(nk) != 0;
+            // two terms that keep this row's pops empty for as long as they stay as they are: remembered (see bigsum above)
+            const bool bigsum0 = rdlane(bigsum ? 1u : 0u, 0) != 0;
+            if (bigsum0 && cnt >= 2 && notknown && lane == 0) {
+                ECNE_GLOBAL uint32_t* const hint = as_global(J.hint);
+                hint[2u * row0] = k_nk;
+                hint[2u * row0 + 1u] = k_nk == k_nu1 ? k_nu2 : k_nu1;
+            }
+            if (bigsum0 && (cnt == 0 || (cnt == 1 && !nuab)) && lane == 0) as_global(J.hint)[2u * row0] = 0xFFFFFFFEu;      // (after R1, below:) every term unique, for good (reset by the next solve's setup)
             const bool reach78 = lin0 && cnt > 0 && !(cnt == 1 && !nuab) && !notknown;      // R7 / R8 could fire: the general executor decides
             if (!reach78) {
                 if (lane == 0) {
