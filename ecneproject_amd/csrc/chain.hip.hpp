@@ -17,18 +17,9 @@
 // statement as exec_row() does; anything else (and any of these when R7 / R8 could fire, or when a bound is neither
 // [0,1] nor the initial [0,p-1]) goes through exec_row() / exec_r78_wave() on the same state.
 #pragma once
-#include "rules_wave.hip.hpp"
+#include "fastrow.hip.hpp"
 
 namespace ecne {
-
-// Loads / stores that are known to hit device memory go through global-address-space pointers: a generic (flat) access
-// also counts on the LDS counter, so waiting for a ds_read would wait for every flat load in flight as well.
-#define ECNE_GLOBAL __attribute__((address_space(1)))
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <class T> __device__ __forceinline__ ECNE_GLOBAL T* as_global(T* p) { return (ECNE_GLOBAL T*)p; }
-template <class T> __device__ __forceinline__ const ECNE_GLOBAL T* as_global(const T* p) { return (const ECNE_GLOBAL T*)p; }
-
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // the chain executor's preconditions: one workgroup, flags and in_queue tags resident in LDS, row records uploaded
 __device__ __forceinline__ bool chain_ok(const Job& J) {

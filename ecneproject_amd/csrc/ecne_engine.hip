@@ -512,7 +512,7 @@ static int upload_system(ecne_system& S, int device) {
                 const uint32_t la = L.rp[0][r + 1] - L.rp[0][r], lb = L.rp[1][r + 1] - L.rp[1][r], lc = L.rp[2][r + 1] - L.rp[2][r];
                 uint32_t* w = &rec[16ull * r];
                 std::memset(w, 0, 64);
-                if (la + lb + lc > 15) continue;
+                if (la + lb + lc > 15) { w[1] = 0xFFFFFFFFu; continue; }      // no record; words 1, 2: the row's watched pair (fastrow.hip.hpp), none yet
                 w[0] = la | lb << 8 | lc << 16 | 1u << 24;
                 uint32_t k = 1;
                 for (int p = 0; p < 3; ++p)
@@ -547,7 +547,6 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_htlist = c.take(4ull * ((size_t)nC + (size_t)ECNE_MAX_NWG * 2049 + 64));
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
     size_t o_wmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1)), o_prank = c.take(4ull * std::max<size_t>(nC, 1));
-    size_t o_hint = c.take(8ull * std::max<size_t>(nC, 1));
     // one event slot list per rank of a round: single-workgroup rounds examine <= 4 * 512 queue entries,
     // multi-workgroup rounds <= min(rows, ECNE_MAX_NWG workgroups * 512 lanes * 2)
     const size_t max_ranks = std::max<size_t>((size_t)4 * ECNE_WG, std::min<size_t>((size_t)nC + 1, (size_t)ECNE_MAX_NWG * ECNE_WG * 2));
@@ -638,8 +637,6 @@ static int upload_system(ecne_system& S, int device) {
     J.ht_list = (uint32_t*)(base + o_htlist);
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
     J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best); J.prank = (uint32_t*)(base + o_prank);
-    J.hint = (uint32_t*)(base + o_hint);
-    HIP_TRY(hipMemset(base + o_hint, 0xFF, 8ull * std::max<size_t>(nC, 1)));
     J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
     J.candcap = (uint32_t)std::max<size_t>(ECNE_CANDCAP, 8ull * nC);
     J.fvar = (uint32_t*)(base + o_fvar); J.frank = (uint32_t*)(base + o_frank); J.fbase = (uint32_t*)(base + o_fbase);

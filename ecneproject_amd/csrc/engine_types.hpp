@@ -172,9 +172,6 @@ struct Job {
     uint32_t *wmarkU, *wmarkB;
     uint32_t* best;            // per row: lowest candidate index that wants to push it
     uint32_t* prank;           // per row: its rank while it is being popped in a multi-workgroup round
-    uint32_t* hint;            // per row, two words: positions (in colC) of two non-unique terms of a long plain sum, one of them not
-                               // is_known, as the last full walk found them (0xFFFFFFFF: none yet). A cache: while both still
-                               // hold, a pop of the row does nothing (R1 wants one non-unique term, R7 / R8 all of them known).
     uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there
     uint32_t *fvar, *frank, *fbase;   // flat event list of one resolution round: variable, rank, candidate base
     uint32_t* bigev;           // events of a big row popped alone

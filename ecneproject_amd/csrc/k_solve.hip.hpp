@@ -81,7 +81,11 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         J.wmarkU[v] = 0xFFFFFFFFu;
         J.wmarkB[v] = 0xFFFFFFFFu;
     }
-    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; J.hint[2u * r] = 0xFFFFFFFFu; }
+    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
+    // the watched pairs of the long rows (a cache in words 1, 2 of their otherwise unused record lines, fastrow.hip.hpp) start empty
+    if (J.rec != nullptr)
+        for (uint32_t r = gtid; r < nC; r += gstride)
+            if ((J.rec[16ull * r] >> 24) == 0) const_cast<uint32_t*>(J.rec)[16ull * r + 1] = 0xFFFFFFFFu;
     for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
     for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
     if (master && tid == 0) { ctr->err_key = ~0ull; ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; }

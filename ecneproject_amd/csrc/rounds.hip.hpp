@@ -1166,6 +1166,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (sl < rpl && r0 + sl < c && J.inq[row[sl]] >= 2) J.inq[row[sl]] = 0;
         if (tid == 0) big_reset(S);
         __syncthreads();
+#ifdef ECNE_ROUNDLOG
+        if (tid == 0) printf("RL wg avail %u n %u c %u dt %llu\n", avail, n, c, wall_clock64() - qt_last);
+#endif
         q.head += c;
         q.tail = new_tail;
         pops_total += c;

@@ -392,8 +392,9 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
             nev = tot;
         }
     }
-    // a linear row all of whose terms are unique now stays that way: its later pops are recognised without a walk (J.hint)
-    if (tid == 0 && !(shape & SH_HAS_AB) && (tot == 0 || nev != 0)) J.hint[2u * row] = 0xFFFFFFFEu;
+    // a linear row all of whose terms are unique now stays that way: its later pops are recognised without a walk (word 1 of its
+    // record line, see long_row_walk in fastrow.hip.hpp)
+    if (tid == 0 && J.rec != nullptr && !(shape & SH_HAS_AB) && (tot == 0 || nev != 0)) const_cast<uint32_t*>(J.rec)[16ull * row + 1] = 0xFFFFFFFEu;
     if (tid == 0) *nev_out = nev;
     __syncthreads();
     return true;

@@ -67,235 +67,6 @@ __device__ __forceinline__ void w2_tables_init(uint32_t w2_off, bool big) {
     for (uint32_t i = threadIdx.x; i < nslots; i += ECNE_WG) { base[i] = 0u; base[nslots + i] = 0xFFFFFFFFu; }
 }
 
-// ---- what one pop of a row of the four common shapes does, decided in registers from the row record and the flag bytes
-// (x == y rows with a bound of the third kind: from the limbs). Nothing is written: the caller commits FastOut for the rows
-// that make it into the prefix. Shared by the fast wavefront / workgroup round and the multi-workgroup round.
-struct FastIn {
-    uint32_t shape, rx, kpos, kneg, k1, k2, nA, nB, nE;
-    uint32_t w[16];                 // row record: w[1 + e] = variable of entry e (A, B, C)
-    uint8_t fl[15], fa, fb, fx;     // flag bytes: of the entries (products, sums), of k1 / k2 (x == y), of x (bit check)
-    uint8_t flip_in;
-    bool live, xy, f2, f4, bigsum;
-    bool r4s = false;               // a short binary-decomposition row (R4 shape, l > 2): taken while R4's precondition fails
-    bool r3f = false;               // a constant row x = c (R3 shape and none of R4..R6's)
-    uint32_t validx = 0;            // the row's constants in J.vals (R3: c)
-};
-struct FastOut {
-    uint32_t wva = 0, wvb = 0;      // variables whose flag byte (and maybe bounds) this pop changes
-    uint8_t wfa = 0, wfb = 0;
-    bool wa = false, wb = false, a01 = false, b01 = false, r2 = false, flip_w = false;
-    bool xa_w = false, xb_w = false;            // x == y rows decided on the limbs: new bounds of k1 / k2 (a constant row: of x)
-    bool r3v = false;                           // a constant row: values[x] = {xlb0} (:955-961)
-    uint32_t d_h2 = 0;
-    fp::u256 xlb0 = fp::make(0), xub0 = fp::make(0), xlb1 = fp::make(0), xub1 = fp::make(0);
-    uint8_t flip_new = 0;
-    uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;  // REQUEUE events, in the reference's order
-    uint32_t d_steps = 0, d_nuniq = 0, d_h0 = 0, d_h1 = 0, d_h3 = 0, d_h4 = 0;
-    bool slow = false;              // not settled here: the general executor takes the row
-    uint32_t reason = 7;
-};
-__device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastOut& O) {
-    const bool live = I.live, xy = I.xy, f2 = I.f2, f4 = I.f4, bigsum = I.bigsum, r4s = I.r4s;
-    const uint32_t shape = I.shape, rx = I.rx, kpos = I.kpos, kneg = I.kneg, k1 = I.k1, k2 = I.k2, nA = I.nA, nB = I.nB, nE = I.nE;
-    const uint32_t* const w = I.w;
-    const uint8_t* const fl = I.fl;
-    uint8_t fa = I.fa, fb = I.fb;
-    const uint8_t fx = I.fx, flip_in = I.flip_in;
-    uint32_t &wva = O.wva, &wvb = O.wvb, &nev = O.nev, &reason = O.reason;
-    uint8_t &wfa = O.wfa, &wfb = O.wfb, &flip_new = O.flip_new;
-    bool &wa = O.wa, &wb = O.wb, &a01 = O.a01, &b01 = O.b01, &r2 = O.r2, &flip_w = O.flip_w, &xa_w = O.xa_w, &xb_w = O.xb_w, &slow = O.slow;
-    fp::u256 &xlb0 = O.xlb0, &xub0 = O.xub0, &xlb1 = O.xlb1, &xub1 = O.xub1;
-    uint32_t* const ev = O.ev;
-    uint32_t &d_steps = O.d_steps, &d_nuniq = O.d_nuniq, &d_h0 = O.d_h0, &d_h1 = O.d_h1, &d_h3 = O.d_h3, &d_h4 = O.d_h4;
-    auto emit = [&](uint32_t v) {
-        if (nev == 0) ev[0] = v; else if (nev == 1) ev[1] = v; else if (nev == 2) ev[2] = v; else if (nev == 3) ev[3] = v; else ev[4] = v;
-        ++nev;
-    };
-    if (live && !slow) {
-        if (f2) {
-            // R2 check_quadratic (:875-942); errors are the general executor's business
-            if (shape & SH_R2_BOUNDSERR) { slow = true; reason = 2; }
-            else if ((shape & SH_R2) && !(fx & 2)) {
-                if (shape & SH_R2_DIV0) { slow = true; reason = 2; }
-                else {
-                    wva = rx; wa = true; r2 = true;
-                    wfa = (uint8_t)((fx | 2) & ~16u);
-                    if (shape & SH_R2_IS01) { wfa = (uint8_t)((wfa & ~12u) | 4u); a01 = true; }
-                    emit(rx);
-                    d_steps = 1; d_h1 = 1;
-                }
-            }
-        } else if (xy && ((fa | fb) & 8u) && k1 != k2 && nE == 2) {
-            // x == y with a bound that is neither [0,1] nor [0,p-1] (a constant wired on, say): the same three rules on the
-            // limbs themselves, statement for statement exec_xy_lane() (rules_lane.hip.hpp)
-            const bool sw = (shape & SH_R56_SWAP) != 0;
-            const uint8_t fa_in = fa, fb_in = fb;
-            fp::u256 lb0 = (fa & 8u) ? ld256(J.lb + 4ull * k1) : fp::make(0), ub0 = (fa & 8u) ? ld256(J.ub + 4ull * k1) : ((fa & 4u) ? fp::make(1) : fp::pminus1());
-            fp::u256 lb1 = (fb & 8u) ? ld256(J.lb + 4ull * k2) : fp::make(0), ub1 = (fb & 8u) ? ld256(J.ub + 4ull * k2) : ((fb & 4u) ? fp::make(1) : fp::pminus1());
-            if (((fa ^ fb) & 1u)) {                               // R1
-                if (!(fa & 1)) { fa |= 3; emit(k1); } else { fb |= 3; emit(k2); }
-                d_nuniq++; d_steps++; d_h0++;
-            }
-            {                                                     // R4, l == 2
-                flip_new = (uint8_t)(flip_in ^ 1);
-                flip_w = true;
-                const uint32_t new_key = flip_new ? kneg : kpos;
-                const bool n_is_a = new_key == k1;
-                uint8_t fn = n_is_a ? fa : fb, fo_ = n_is_a ? fb : fa;
-                const fp::u256 lbn = n_is_a ? lb0 : lb1, ubn = n_is_a ? ub0 : ub1;
-                if (fo_ & 4) {
-                    if (!(fp::is_zero(lbn) && fp::is_one(ubn)) && fp::cmp(ubn, fp::make(1)) > 0) {
-                        if (n_is_a) { lb0 = fp::make(0); ub0 = fp::make(1); xa_w = true; } else { lb1 = fp::make(0); ub1 = fp::make(1); xb_w = true; }
-                        fn = (uint8_t)((fn & ~12u) | 4u | 2u);
-                        d_steps++; d_h3++;
-                        emit(new_key);
-                    }
-                    if ((fn & 1) && !(fo_ & 1)) {
-                        fo_ |= 3;
-                        d_nuniq++; d_steps++; d_h3++;
-                        emit(n_is_a ? k2 : k1);
-                    }
-                }
-                if (n_is_a) { fa = fn; fb = fo_; } else { fb = fn; fa = fo_; }
-            }
-            if (!fp::eq(ub1, ub0) || !fp::eq(lb1, lb0) || ((fa ^ fb) & 1u)) {      // R5
-                bool cha = false, chb = false;
-                if ((fa ^ fb) & 1u) { fa |= 3; d_nuniq += 2; cha = chb = true; }
-                const fp::u256 mn = fp::cmp(ub0, ub1) <= 0 ? ub0 : ub1;
-                const fp::u256 mx = fp::cmp(lb0, lb1) >= 0 ? lb0 : lb1;
-                const bool na = fp::cmp(ub0, mn) > 0 || fp::cmp(lb0, mx) < 0, nb = fp::cmp(ub1, mn) > 0 || fp::cmp(lb1, mx) < 0;
-                if (na) { lb0 = mx; ub0 = mn; xa_w = true; fa = (uint8_t)((fa & ~12u) | bounds_class_bits(mx, mn) | 2u); }
-                if (nb) { lb1 = mx; ub1 = mn; xb_w = true; fb = (uint8_t)((fb & ~12u) | bounds_class_bits(mx, mn) | 2u); }
-                cha |= na; chb |= nb;
-                const uint32_t nset = (cha ? 1u : 0u) + (chb ? 1u : 0u);
-                d_steps += nset;
-                if (nset) d_h4++;
-                if (sw) { if (chb) emit(k2); if (cha) emit(k1); }
-                else { if (cha) emit(k1); if (chb) emit(k2); }
-            }
-            xlb0 = lb0; xub0 = ub0; xlb1 = lb1; xub1 = ub1;
-            wva = k1; wfa = fa; wa = fa != fa_in || xa_w;
-            wvb = k2; wfb = fb; wb = fb != fb_in || xb_w;
-            // R7 / R8 in reach? R7 with two non-unique, known variables and coefficients +-1 fires iff the first one (C order)
-            // has ub <= lb (:1267-1269); R8 needs a group tag on every non-unique variable
-            const bool nua = !(fa & 1), nub = !(fb & 1);
-            if ((nua || nub) && !((nua && !(fa & 2)) || (nub && !(fb & 2)))) {
-                const bool tagged = !((nua && !(fa & 16)) || (nub && !(fb & 16)));
-                const bool first_is_a = !sw;
-                const bool r7 = nua && nub && (first_is_a ? fp::cmp(ub0, lb0) <= 0 : fp::cmp(ub1, lb1) <= 0);
-                if (tagged || r7) { slow = true; reason = 4; }
-            }
-        } else if (I.r3f) {
-            // a constant row c_x * x + c_1 = 0 (R3 check_linear :949-988; R1 first, nothing else has anything to do afterwards:
-            // x ends up unique, so R7 / R8 find no non-unique variable). fx = x's flag byte.
-            uint8_t f = fx;
-            uint32_t cnt = 0;
-#pragma unroll
-            for (uint32_t e = 0; e < 15; ++e) if (e < nE && !(fl[e] & 1)) ++cnt;
-            if (cnt == 1 && !(f & 1)) {                                   // R1 (:827-873): x is the one non-unique variable
-                f |= 3; emit(rx);
-                O.d_nuniq++; O.d_steps++; O.d_h0++;
-            } else if (cnt != 0) { slow = true; reason = 1; }             // (a non-unique constant wire: never seen; general executor)
-            if (!slow) {
-                // (all loads first; the pop of a constant row whose x already holds c -- every pop after the first -- writes nothing)
-                const fp::u256 tv = ld256(J.vals + 4ull * I.validx);
-                const uint8_t nv = J.nvalues[rx];
-                const fp::u256 va = ld256(J.values + 8ull * rx), lbx = ld256(J.lb + 4ull * rx), ubx = ld256(J.ub + 4ull * rx);
-                const bool same = nv == 1 && fp::eq(va, tv);
-                const bool bsame = fp::eq(lbx, tv) && fp::eq(ubx, tv);
-                bool new_info = false;
-                if (!same) { O.d_steps++; O.d_h2++; new_info = true; O.r3v = true; }
-                if (!(f & 1)) { O.d_nuniq++; new_info = true; }
-                f = (uint8_t)(((f | 3) & ~12u) | bounds_class_bits(tv, tv));
-                xlb0 = tv; xub0 = tv; xa_w = !bsame;
-                wva = rx; wfa = f; wa = f != fx || !same || !bsame;
-                if (new_info) emit(rx);
-            }
-        } else if (xy) {
-            if (((fa | fb) & 8u) || k1 == k2 || nE != 2) { slow = true; reason = 3; }
-            else {
-                const bool sw = (shape & SH_R56_SWAP) != 0;          // C order starts with k2
-                const uint8_t fa_in = fa, fb_in = fb;
-                // R1 (:827-873)
-                if (((fa ^ fb) & 1u)) {
-                    if (!(fa & 1)) { fa |= 3; emit(k1); } else { fb |= 3; emit(k2); }
-                    d_nuniq++; d_steps++; d_h0++;
-                }
-                // R4 (:991-1076), l == 2: the row is negated on every visit, the pivot alternates
-                {
-                    flip_new = (uint8_t)(flip_in ^ 1);
-                    flip_w = true;
-                    const uint32_t new_key = flip_new ? kneg : kpos;
-                    const bool n_is_a = new_key == k1;
-                    uint8_t fn = n_is_a ? fa : fb, fo_ = n_is_a ? fb : fa;
-                    if (fo_ & 4) {
-                        if (!(fn & 4)) {
-                            fn = (uint8_t)((fn & ~12u) | 4u | 2u);
-                            if (n_is_a) a01 = true; else b01 = true;
-                            d_steps++; d_h3++;
-                            emit(new_key);
-                        }
-                        if ((fn & 1) && !(fo_ & 1)) {
-                            fo_ |= 3;
-                            d_nuniq++; d_steps++; d_h3++;
-                            emit(n_is_a ? k2 : k1);
-                        }
-                    }
-                    if (n_is_a) { fa = fn; fb = fo_; } else { fb = fn; fa = fo_; }
-                }
-                // R5 (:1078-1146): bounds are [0,1] or [0,p-1] here, equal iff the class bits agree
-                if (((fa ^ fb) & 4u) || ((fa ^ fb) & 1u)) {
-                    bool cha = false, chb = false;
-                    if ((fa ^ fb) & 1u) { fa |= 3; d_nuniq += 2; cha = chb = true; }        // key_1 written twice (sic, :1107-1108)
-                    const bool na = ((fa ^ fb) & 4u) && !(fa & 4u), nb = ((fa ^ fb) & 4u) && !(fb & 4u);
-                    if (na) { fa = (uint8_t)((fa & ~12u) | 4u | 2u); a01 = true; }
-                    if (nb) { fb = (uint8_t)((fb & ~12u) | 4u | 2u); b01 = true; }
-                    cha |= na; chb |= nb;
-                    const uint32_t nset = (cha ? 1u : 0u) + (chb ? 1u : 0u);
-                    d_steps += nset;
-                    if (nset) d_h4++;
-                    if (sw) { if (chb) emit(k2); if (cha) emit(k1); }
-                    else { if (cha) emit(k1); if (chb) emit(k2); }
-                }
-                wva = k1; wfa = fa; wa = fa != fa_in || a01;
-                wvb = k2; wfb = fb; wb = fb != fb_in || b01;
-                // R7 / R8 (:1235-1348) in reach (see chain.hip.hpp): the general executor decides
-                const bool nua = !(fa & 1), nub = !(fb & 1);
-                if ((nua || nub) && !((nua && (fa & 18u) != 18u) || (nub && (fb & 18u) != 18u))) { slow = true; reason = 4; }
-            }
-        } else {
-            // products and plain sums: R1 (:827-873)
-            bool nuab = false, notknown = false;
-            uint32_t cnt = 0, u = 0;
-            uint8_t uf = 0;
-#pragma unroll
-            for (uint32_t e = 0; e < 15; ++e) {
-                if (e >= nE) continue;
-                const uint8_t f = fl[e];
-                if (e < nA + nB) nuab |= !(f & 1);
-                else if (!(f & 1)) { if (!cnt) { u = w[1 + e]; uf = f; } ++cnt; if (!(f & 2)) notknown = true; }
-            }
-            if (bigsum) { if (!(cnt >= 2 && notknown)) { slow = true; reason = 0; } }
-            else if (!nuab && cnt == 1) {
-                wva = u; wfa = (uint8_t)(uf | 3); wa = true;
-                emit(u);
-                d_nuniq = 1; d_steps = 1; d_h0 = 1;
-            } else if ((f4 || r4s) && cnt > 0 && !notknown) { slow = true; reason = 5; }       // R7 / R8 in reach
-            if (r4s && !slow) {
-                // R4 checkBinary (:991-1076) on a decomposition of 3..15 terms: nothing happens while some variable other than
-                // the pivot lacks bounds exactly [0,1] (:1020-1029) -- the usual state of such a row's pops; otherwise the
-                // general executor does the arithmetic
-                const uint32_t pivot = (shape & SH_R4_T) ? kpos : kneg;
-                bool bad = false;
-#pragma unroll
-                for (uint32_t e = 0; e < 15; ++e)
-                    if (e < nE && w[1 + e] != pivot && !(fl[e] & 4)) bad = true;
-                if (!bad) { slow = true; reason = 1; }
-            }
-        }
-    }
-}
-
 // WG = false: wavefront 0 alone, up to 64 rows. WG = true: ALL threads of the workgroup, up to ECNE_WG rows (rank = thread),
 // the wave-level votes and scans become workgroup-level ones through LDS; the return values are uniform across the workgroup.
 template <bool LDS, bool WG>
@@ -386,26 +157,30 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     const bool r3f = (shape & SH_R3) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
     const bool live = mine && !is_solved;
     // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
-    // A long plain sum (no record: more than 15 terms, up to the 1 025 of a decoder) is re-queued by each of its terms and
-    // nearly all of those pops do nothing: two of its variables non-unique, one of them not is_known -- R1 wants exactly
-    // one, R7 wants all of them known, R8 all of them tagged. The lane looks at the first 8 terms; if they show that, the
-    // pop is settled here (reading exactly those variables), anything else goes to the general executor.
-    const bool bigsum = live && (w[0] >> 24) == 0 && f4 && lenC > 15;
-    bool alldone = false;
-    if (bigsum) {
-        const ECNE_GLOBAL uint32_t* const colC = as_global(J.colC);
-        const uint32_t c0 = as_global(J.rpC)[row];
-        // ... or, once a full walk of the row has found two such terms anywhere in it, at those two (J.hint: "watched" terms)
-        const uint32_t h0 = as_global(J.hint)[2u * row], h1 = as_global(J.hint)[2u * row + 1u];
-        if (h0 == 0xFFFFFFFEu) { alldone = true; nA = 0; nB = 0; nCc = 0; nE = 0; }        // every term unique (for good): nothing can happen
-        else if (h0 != 0xFFFFFFFFu) { w[1] = colC[h0]; w[2] = colC[h1]; nA = 0; nB = 0; nCc = 2; nE = 2; }
-        else {
+    // A long linear row (no record: more than 15 terms -- the 1 025-term sum of a decoder, the 254 bits of a Num2Bits) is
+    // re-queued by each of its terms and nearly all of those pops do nothing. Words 1 and 2 of its record line hold two
+    // watched variables that say why (long_row_walk, fastrow.hip.hpp): while they still do, the pop is settled here from their
+    // two flag bytes, at any rank. Without a pair yet, a plain sum's lane tries the first 8 terms (two of them non-unique, one
+    // of those not is_known); anything else waits for rank 0, where the whole wavefront walks the row.
+    const bool norec = (w[0] >> 24) == 0;
+    const bool lr4 = r4s;                                      // (a binary decomposition; r4s proper needs the record)
+    const bool biglin = live && norec && (f4 || lr4) && lenC > 15;
+    bool alldone = false, watched = false;
+    if (biglin) {
+        const uint32_t h0 = w[1], h1 = w[2];
+        if (h0 == 0xFFFFFFFEu && f4) { alldone = true; nA = 0; nB = 0; nCc = 0; nE = 0; }        // every term unique (for good): nothing can happen
+        else if (h0 < 0xFFFFFFFEu) { watched = true; w[1] = h0; w[2] = h1; nA = 0; nB = 0; nCc = 2; nE = 2; }
+        else if (f4) {
+            const ECNE_GLOBAL uint32_t* const colC = as_global(J.colC);
+            const uint32_t c0 = as_global(J.rpC)[row];
 #pragma unroll
             for (uint32_t e = 0; e < 8; ++e) w[1 + e] = colC[c0 + e];
             nA = 0; nB = 0; nCc = 8; nE = 8;
         }
     }
-    bool slow = mine && !bigsum && ((w[0] >> 24) == 0 || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4 || r4s || r3f))));
+    const bool bigsum = biglin && f4 && !alldone && !watched;      // the first-8-terms test (fast_decide)
+    const bool bl_local = biglin && (alldone || watched || f4);    // settled (or declined) by this lane
+    bool slow = mine && !bl_local && (norec || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4 || (r4s && !norec) || r3f))));
     uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
     // A row of another shape (a constant x = c, 1 = x + y, ...) all of whose variables are unique and known, with values and
     // bounds as its rules would leave them, is popped without effect (row_is_noop, schedule.hip.hpp: the test the
@@ -437,7 +212,9 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
 #pragma unroll
     for (int i = 0; i < 15; ++i) fin.fl[i] = fl[i];
     fin.fa = fa; fin.fb = fb; fin.fx = fx; fin.flip_in = flip_in;
-    fin.live = live; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum && !alldone; fin.r4s = r4s && !nop_row; fin.r3f = r3f && !nop_row; fin.validx = validx;
+    bool wnop = false;                                            // the watched pair still holds: an empty pop
+    if (watched) { if (long_watch_holds(fl[0], fl[1], lr4)) wnop = true; else { slow = true; reason = 0; } }
+    fin.live = live && !wnop; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !norec && !nop_row; fin.r3f = r3f && !nop_row; fin.validx = validx;
     FastOut fo_;
     fo_.slow = slow; fo_.reason = reason;
     fast_decide(J, fin, fo_);
@@ -460,65 +237,22 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     // is_known -> nothing happens. Rank 0 is never blocked, so no read set is needed; what it writes is marked as usual.
     uint32_t nnz_long = 0;
     if constexpr (!WG) {
-        const bool cand0 = mine && !is_solved && (w[0] >> 24) == 0 && slow && (f4 || f1);
+        const bool cand0 = mine && !is_solved && (w[0] >> 24) == 0 && slow && (f4 || f1 || long_r4(shape));
         if (rdlane(cand0 ? 1u : 0u, 0)) {
             const uint32_t row0 = rdlane(row, 0), shape0 = rdlane(shape, 0);
-            const bool lin0 = !(shape0 & SH_HAS_AB);
-            const ECNE_GLOBAL uint32_t* const rpA = as_global(J.rpA); const ECNE_GLOBAL uint32_t* const rpB = as_global(J.rpB);
-            const ECNE_GLOBAL uint32_t* const rpC = as_global(J.rpC);
-            const ECNE_GLOBAL uint32_t* const cA = as_global(J.colA); const ECNE_GLOBAL uint32_t* const cB = as_global(J.colB);
-            const ECNE_GLOBAL uint32_t* const cC = as_global(J.colC);
-            const uint32_t a0 = rpA[row0], a1 = rpA[row0 + 1], b0 = rpB[row0], b1 = rpB[row0 + 1], c0 = rpC[row0], c1 = rpC[row0 + 1];
-            bool nu = false;
-            for (uint32_t k = a0 + (uint32_t)lane; k < a1; k += 64) nu |= !(ldF(cA[k]) & 1);
-            for (uint32_t k = b0 + (uint32_t)lane; k < b1; k += 64) nu |= !(ldF(cB[k]) & 1);
-            const bool nuab = __ballot(nu) != 0;
-            uint32_t cnt = 0, u = 0, uf = 0;
-            uint32_t k_nu1 = 0xFFFFFFFFu, k_nu2 = 0xFFFFFFFFu, k_nk = 0xFFFFFFFFu;      // positions: first two non-unique terms, first one not is_known
-            bool nk = false;
-            // (four strides per trip: the loads of a trip are in flight together -- a 1 025-term sum is 5 dependent
-            //  round trips instead of 17)
-            for (uint32_t base = c0; base < c1; base += 256) {
-                uint32_t v4[4];
-                uint8_t f4_[4];
-                bool act4[4];
-#pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) { const uint32_t k = base + 64u * t + (uint32_t)lane; act4[t] = k < c1; v4[t] = act4[t] ? cC[k] : 1u; }
-#pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) f4_[t] = act4[t] ? ldF(v4[t]) : (uint8_t)3;
-#pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) {
-                    const uint64_t m = __ballot(act4[t] && !(f4_[t] & 1));
-                    const uint64_t mk = __ballot(act4[t] && !(f4_[t] & 1) && !(f4_[t] & 2));
-                    if (m && cnt == 0) { const int src = __ffsll((long long)m) - 1; u = rdlane(v4[t], (uint32_t)src); uf = rdlane(f4_[t], (uint32_t)src); }
-                    if (m && k_nu2 == 0xFFFFFFFFu) {
-                        const uint32_t kb = base + 64u * t;
-                        uint64_t mm = m;
-                        if (k_nu1 == 0xFFFFFFFFu) { k_nu1 = kb + (uint32_t)(__ffsll((long long)mm) - 1); mm &= mm - 1; }
-                        if (mm) k_nu2 = kb + (uint32_t)(__ffsll((long long)mm) - 1);
-                    }
-                    if (mk && k_nk == 0xFFFFFFFFu) k_nk = base + 64u * t + (uint32_t)(__ffsll((long long)mk) - 1);
-                    cnt += (uint32_t)__popcll(m);
-                    nk |= mk != 0;
-                }
-            }
-            const bool notknown = __ballot(nk) != 0;
-            // two terms that keep this row's pops empty for as long as they stay as they are: remembered (see bigsum above)
-            const bool bigsum0 = rdlane(bigsum ? 1u : 0u, 0) != 0;
-            if (bigsum0 && cnt >= 2 && notknown && lane == 0) {
-                ECNE_GLOBAL uint32_t* const hint = as_global(J.hint);
-                hint[2u * row0] = k_nk;
-                hint[2u * row0 + 1u] = k_nk == k_nu1 ? k_nu2 : k_nu1;
-            }
-            if (bigsum0 && (cnt == 0 || (cnt == 1 && !nuab)) && lane == 0) as_global(J.hint)[2u * row0] = 0xFFFFFFFEu;      // (after R1, below:) every term unique, for good (reset by the next solve's setup)
-            const bool reach78 = lin0 && cnt > 0 && !(cnt == 1 && !nuab) && !notknown;      // R7 / R8 could fire: the general executor decides
-            if (!reach78) {
+            const bool lin0 = !(shape0 & SH_HAS_AB), r40 = long_r4(shape0);
+            const uint32_t pivot0 = r40 ? ((shape0 & SH_R4_T) ? rdlane(kpos, 0) : rdlane(kneg, 0)) : 0xFFFFFFFFu;
+            LongWalk R;
+            long_row_walk<LDS>(J, row0, pivot0, rdlane(biglin ? (f4 ? 1u : 2u) : 0u, 0), R);
+            const bool reach78 = lin0 && R.cnt > 0 && !(R.cnt == 1 && !R.nuab) && !R.notknown;      // R7 / R8 could fire: the general executor decides
+            const bool r4go = r40 && !R.bad;                                                          // R4's precondition holds: likewise
+            if (!reach78 && !r4go) {
                 if (lane == 0) {
                     slow = false;
-                    nnz_long = (a1 - a0) + (b1 - b0) + (c1 - c0);
-                    if (!nuab && cnt == 1) {
-                        wva = u; wfa = (uint8_t)(uf | 3u); wa = true;
-                        emit(u);
+                    nnz_long = R.nnz;
+                    if (!R.nuab && R.cnt == 1) {
+                        wva = R.u; wfa = (uint8_t)(R.uf | 3u); wa = true;
+                        emit(R.u);
                         d_nuniq = 1; d_steps = 1; d_h0 = 1;
                     }
                 }
@@ -552,7 +286,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         else {
 #pragma unroll
             for (uint32_t e = 0; e < 15; ++e)       // (an empty pop and a decomposition row also depend on the bounds of their unique variables)
-                if (e < nE && ((fl[e] & 3) != 3 || nop_row || r4s || r3f) && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
+                if (e < nE && ((fl[e] & 3) != 3 || nop_row || (r4s && !norec) || r3f) && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
         }
     }
     uint32_t c = cmax;
@@ -584,7 +318,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
                 // general executor costs.
                 if (lane == 0) {
                     my_pops++;
-                    my_nnz += nnz_long ? nnz_long : (bigsum ? lenC : nE);
+                    my_nnz += nnz_long ? nnz_long : (biglin ? lenC : nE);
                     if (wa) stF(wva, wfa);
                     if (wb) stF(wvb, wfb);
                     if (a01) { st256(J.lb + 4ull * wva, fp::make(0)); st256(J.ub + 4ull * wva, fp::make(1)); }
@@ -635,7 +369,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     // ---- commit the prefix (ranks below c), every lane its own pop
     if (in) {
         my_pops++;
-        my_nnz += nnz_long ? nnz_long : (bigsum ? lenC : nE);
+        my_nnz += nnz_long ? nnz_long : (biglin ? lenC : nE);
         w2_min(Tr, row + 1u, rank);
     }
     if (in && live) {
