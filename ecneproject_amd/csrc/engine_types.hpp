@@ -27,7 +27,7 @@ namespace ecne {
 #define ECNE_MAX_NWG 96      // workgroups one system can get (q_part[][128] and the scratch sizes follow it)
 #endif
 #ifndef ECNE_ROWS_PER_WG
-#define ECNE_ROWS_PER_WG 16384   // measured on ecdsa_like(26): 32-64 workgroups beat 85 (cheaper job barriers), 16 are too few
+#define ECNE_ROWS_PER_WG 8192    // measured on ecdsa_like(26), round 2 (rows mostly on the record path): 85 workgroups 22.2 ms, 57: 22.5, 43: 23.0, 22: 26.7, 11: 31.1
 #endif
 #ifndef ECNE_BIGK
 #define ECNE_BIGK 8         // long rows one workgroup takes along in one round

@@ -874,10 +874,13 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         const uint32_t r0 = (uint32_t)tid * rpl;                    // my first rank
         uint32_t row[ECNE_RPL], shape[ECNE_RPL], xv[ECNE_RPL];
         uint32_t live = 0, noop = 0, noop_b = 0;                    // bit s = slot s
+        // (a frontier that goes to all workgroups anyway: only the row at the head matters here -- is it a long row that has to be
+        //  popped alone? -- the round loads its rows itself)
+        const bool want_multi = J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide);
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
             row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
-            if (sl < rpl && r0 + sl < n) {
+            if (sl < rpl && r0 + sl < n && (!want_multi || (tid == 0 && sl == 0))) {
                 row[sl] = J.queue[(q.head + r0 + sl) & J.qmask];
                 const RowInfo ri = J.rinfo[row[sl]];
                 shape[sl] = ri.shape;
@@ -893,7 +896,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
-        if (!S.fallback && J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide)) {
+        if (!S.fallback && want_multi) {
             declined_wide = false;
             // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
             const uint32_t cap_n = J.nwg * ECNE_WG * 2;
