@@ -155,7 +155,8 @@ def main():
         return r
 
     _shape, classify_ms_cold, classify_bytes = E.classify(system, device=local_rank)     # first launch: code object load, cold caches
-    _shape, classify_ms, classify_bytes = E.classify(system, device=local_rank)          # the figure reported: a warm launch pair
+    warm = sorted(E.classify(system, device=local_rank)[1] for _ in range(7))                 # warm launches (idempotent kernel)
+    classify_ms, classify_ms_best = warm[len(warm) // 2], warm[0]                             # the figure reported: their median
     res = step()                       # first solve: layout upload + classification happen here (untimed)
     for _ in range(max(args.warmup - 1, 0)):
         res = step()
@@ -222,10 +223,10 @@ def main():
                        "verdict": bool(res.function_good), "status": int(res.status),
                        "outer_iterations": int(s.outer_iterations), "pops": int(s.pops),
                        "host_prep_s": {"generate": round(t_gen, 3), "parse": round(t_parse, 3), "abstract": round(t_abstract, 3)},
-                       "classify_kernel": {"ms": classify_ms, "ms_first_call": classify_ms_cold, "bytes": classify_bytes,
+                       "classify_kernel": {"ms": classify_ms, "ms_best": classify_ms_best, "ms_first_call": classify_ms_cold, "bytes": classify_bytes,
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6,
                                            "frac_of_hbm_peak": classify_bytes / max(classify_ms, 1e-9) / 1e6 / 8000.0,
-                                           "note": "HIP events around the two passes; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
+                                           "note": "HIP events around the launch; ms = median of 7 warm launches, ms_best their minimum; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
                        "abstraction": abstract_stats},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
