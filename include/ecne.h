@@ -144,8 +144,9 @@ typedef struct ecne_summary {
     int64_t sched[16];       /* schedule diagnostics (master workgroup): 0 fast wavefront rounds, 1 rows they committed, 2 their
                                 100 MHz ticks; 3..5 the same for general wavefront rounds; 6..12 why the fast round declined at
                                 rank 0: no record / long row, other shape, error row, bound of the third kind, R7/R8 in reach
-                                (x == y), R7/R8 in reach (sum), event with > 3 target rows (12); 13..15 multi-workgroup rounds that committed
-                                < 64, < 4096, more rows */
+                                (x == y), R7/R8 in reach (sum); 12 = rounds of ONE pop whose events had more than three target
+                                rows (committed by the fast round itself since round 2, not a decline); 13..15 multi-workgroup
+                                rounds that committed < 64, < 4096, more rows */
 } ecne_summary;
 
 /* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is

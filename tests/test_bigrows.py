@@ -37,7 +37,7 @@ def test_gpu_bigrow_parity(big_dir, force_nwg):
         assert_bit_exact("bigrow " + n, g, orc.run(str(big_dir / (n + ".r1cs"))))
         if n == "hub_fanout":
             # the over-long candidate list was replayed sequentially (general rounds), or the fast wavefront round handed
-            # the high-fan-out events to the sequential executor (sched[12]: declined, event with > 3 target rows)
+            # the high-fan-out events in a round of that one pop (sched[12]: events with > 3 target rows, walked by the wavefront)
             assert (g.summary.rule_hits[15] & 0xFF) or g.summary.sched[12] > 0, "high-fan-out path not exercised"
 
 
