@@ -27,6 +27,7 @@ struct FastIn {
     bool live, xy, f2, f4, bigsum;
     bool r4s = false;               // a short binary-decomposition row (R4 shape, l > 2): taken while R4's precondition fails
     bool r3f = false;               // a constant row x = c (R3 shape and none of R4..R6's)
+    bool r6f = false;               // 1 = x + y (R6 shape and none of R3..R5's), record = {constant wire, x, y}
     uint32_t validx = 0;            // the row's constants in J.vals (R3: c)
 };
 struct FastOut {
@@ -35,7 +36,8 @@ struct FastOut {
     bool wa = false, wb = false, a01 = false, b01 = false, r2 = false, flip_w = false;
     bool xa_w = false, xb_w = false;            // x == y rows decided on the limbs: new bounds of k1 / k2 (a constant row: of x)
     bool r3v = false;                           // a constant row: values[x] = {xlb0} (:955-961)
-    uint32_t d_h2 = 0;
+    bool v6a = false, v6b = false;              // 1 = x + y: values[k1] / values[k2] = {ub, lb} as written (:1205-1213)
+    uint32_t d_h2 = 0, d_h5 = 0;
     fp::u256 xlb0 = fp::make(0), xub0 = fp::make(0), xlb1 = fp::make(0), xub1 = fp::make(0);
     uint8_t flip_new = 0;
     uint32_t ev[5] = {0, 0, 0, 0, 0}, nev = 0;  // REQUEUE events, in the reference's order
@@ -160,6 +162,55 @@ __device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastO
                 wva = rx; wfa = f; wa = f != fx || !same || !bsame;
                 if (new_info) emit(rx);
             }
+        } else if (I.r6f) {
+            // 1 = x + y (R6 checkOnePropagateBounds :1148-1232, after R1), on the limbs, statement for statement exec_row()
+            // (rules_wave.hip.hpp). The record has to be {constant wire, x, y}, the constant wire unique -- anything else is the
+            // general executor's.
+            bool ok = nE == 3 && nA + nB == 0 && k1 != k2;
+            uint32_t seen = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 3; ++e) {
+                const uint32_t v = w[1 + e];
+                if (v == 1u) { seen |= 1u; if ((fl[e] & 3) != 3) ok = false; }
+                else if (v == k1) seen |= 2u;
+                else if (v == k2) seen |= 4u;
+                else ok = false;
+            }
+            if (!ok || seen != 7u) { slow = true; reason = 1; }
+            else {
+                const bool sw = (shape & SH_R56_SWAP) != 0;
+                const uint8_t fa_in = fa, fb_in = fb;
+                if (((fa ^ fb) & 1u)) {                               // R1 (:827-873): one of the two is the only non-unique variable
+                    if (!(fa & 1)) { fa |= 3; emit(k1); } else { fb |= 3; emit(k2); }
+                    d_nuniq++; d_steps++; d_h0++;
+                }
+                fp::u256 lb0 = ld256(J.lb + 4ull * k1), ub0 = ld256(J.ub + 4ull * k1);
+                fp::u256 lb1 = ld256(J.lb + 4ull * k2), ub1 = ld256(J.ub + 4ull * k2);
+                if (!fp::eq(ub1, ub0) || !fp::eq(lb1, lb0) || ((fa ^ fb) & 1u)) {
+                    bool cha = false, chb = false, proceed = true;
+                    if ((fa ^ fb) & 1u) { fa |= 3; fb |= 3; d_nuniq += 2; cha = chb = true; }      // (:1186-1189)
+                    const fp::u256 mn = fp::cmp(ub0, ub1) <= 0 ? ub0 : ub1;
+                    const fp::u256 mx = fp::cmp(lb0, lb1) >= 0 ? lb0 : lb1;
+                    if (!fp::is_one(mn) || !fp::is_zero(mx)) proceed = false;                 // (:1196-1199) returns before counting
+                    const bool na = proceed && (fp::cmp(ub0, mn) > 0 || fp::cmp(lb0, mx) < 0);
+                    const bool nb = proceed && (fp::cmp(ub1, mn) > 0 || fp::cmp(lb1, mx) < 0);
+                    if (na) { xlb0 = mx; xub0 = mn; xa_w = true; O.v6a = true; fa = (uint8_t)(((fa | 2u) & ~12u) | bounds_class_bits(mx, mn)); }
+                    if (nb) { xlb1 = mx; xub1 = mn; xb_w = true; O.v6b = true; fb = (uint8_t)(((fb | 2u) & ~12u) | bounds_class_bits(mx, mn)); }
+                    if (proceed) {
+                        cha |= na; chb |= nb;
+                        const uint32_t nset = (cha ? 1u : 0u) + (chb ? 1u : 0u);
+                        d_steps += nset;
+                        if (nset) O.d_h5++;
+                        if (sw) { if (chb) emit(k2); if (cha) emit(k1); }
+                        else { if (cha) emit(k1); if (chb) emit(k2); }
+                    }
+                }
+                wva = k1; wfa = fa; wa = fa != fa_in || xa_w;
+                wvb = k2; wfb = fb; wb = fb != fb_in || xb_w;
+                // R7 / R8 (:1235-1348) in reach: every non-unique variable is_known -> the general executor decides
+                const bool nua = !(fa & 1), nub = !(fb & 1);
+                if ((nua || nub) && !((nua && !(fa & 2)) || (nub && !(fb & 2)))) { slow = true; reason = 4; }
+            }
         } else if (xy) {
             if (((fa | fb) & 8u) || k1 == k2 || nE != 2) { slow = true; reason = 3; }
             else {
@@ -262,9 +313,11 @@ __device__ __forceinline__ void fast_commit(const Job& J, const FastOut& D, uint
         J.solved[row] = 1;
     }
     if (D.r3v) { st256(J.values + 8ull * D.wva, D.xlb0); J.nvalues[D.wva] = 1; }
+    if (D.v6a) { st256(J.values + 8ull * D.wva, D.xub0); st256(J.values + 8ull * D.wva + 4, D.xlb0); J.nvalues[D.wva] = 2; }
+    if (D.v6b) { st256(J.values + 8ull * D.wvb, D.xub1); st256(J.values + 8ull * D.wvb + 4, D.xlb1); J.nvalues[D.wvb] = 2; }
     if (D.flip_w) J.flip3[row] = D.flip_new;
     C.steps += D.d_steps; C.nuniq += D.d_nuniq;
-    C.hits[0] += D.d_h0; C.hits[1] += D.d_h1; C.hits[2] += D.d_h2; C.hits[3] += D.d_h3; C.hits[4] += D.d_h4;
+    C.hits[0] += D.d_h0; C.hits[1] += D.d_h1; C.hits[2] += D.d_h2; C.hits[3] += D.d_h3; C.hits[4] += D.d_h4; C.hits[5] += D.d_h5;
 }
 
 // ---- one long row (no record: more than 15 terms), walked by a whole wavefront, lanes across its entries, four strides per

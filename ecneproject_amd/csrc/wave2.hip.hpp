@@ -155,6 +155,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
     const bool r4s = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R5 | SH_R6)) && (((shape & SH_R4_T) != 0) != ((shape & SH_R4_T2) != 0));
     const bool r3f = (shape & SH_R3) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+    const bool r6f = (shape & SH_R6) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5));
     const bool live = mine && !is_solved;
     // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
     // A long linear row (no record: more than 15 terms -- the 1 025-term sum of a decoder, the 254 bits of a Num2Bits) is
@@ -180,7 +181,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     }
     const bool bigsum = biglin && f4 && !alldone && !watched;      // the first-8-terms test (fast_decide)
     const bool bl_local = biglin && (alldone || watched || f4);    // settled (or declined) by this lane
-    bool slow = mine && !bl_local && (norec || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4 || (r4s && !norec) || r3f))));
+    bool slow = mine && !bl_local && (norec || (!is_solved && ((shape & SH_BIG) || !(xy || f1 || f2 || f4 || (r4s && !norec) || r3f || r6f))));
     uint32_t reason = slow ? (((w[0] >> 24) == 0 || (shape & SH_BIG)) ? 0u : 1u) : 7u;
     // A row of another shape (a constant x = c, 1 = x + y, ...) all of whose variables are unique and known, with values and
     // bounds as its rules would leave them, is popped without effect (row_is_noop, schedule.hip.hpp: the test the
@@ -201,7 +202,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
 #pragma unroll
     for (uint32_t e = 0; e < 15; ++e) fl[e] = (walk && e < nE) ? ldF(w[1 + e]) : (uint8_t)3;
     uint8_t fa = 3, fb = 3, fx = 3;
-    if (live && !slow && xy) { fa = ldF(k1); fb = ldF(k2); }
+    if (live && !slow && (xy || r6f)) { fa = ldF(k1); fb = ldF(k2); }
     if (live && !slow && ((f2 && (shape & SH_R2)) || r3f)) fx = ldF(rx);
     W2T(1);        // flag bytes
     // ---- the decision, in registers (fast_decide)
@@ -214,7 +215,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     fin.fa = fa; fin.fb = fb; fin.fx = fx; fin.flip_in = flip_in;
     bool wnop = false;                                            // the watched pair still holds: an empty pop
     if (watched) { if (long_watch_holds(fl[0], fl[1], lr4)) wnop = true; else { slow = true; reason = 0; } }
-    fin.live = live && !wnop; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !norec && !nop_row; fin.r3f = r3f && !nop_row; fin.validx = validx;
+    fin.live = live && !wnop; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !norec && !nop_row; fin.r3f = r3f && !nop_row; fin.r6f = r6f && !nop_row; fin.validx = validx;
     FastOut fo_;
     fo_.slow = slow; fo_.reason = reason;
     fast_decide(J, fin, fo_);
@@ -266,6 +267,9 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         const uint32_t fs_ = first_rank(slow, 0);
         if (fs_ == 0) {                                         // nothing has been touched
             if (rank == 0) why[reason] += 1;
+#ifdef ECNE_DECLINELOG
+            if (rank == 0) printf("DECL reason %u shape %x nE %u norec %d row %u fa %x fb %x fx %x\n", reason, shape, nE, (int)norec, row, fa, fb, fx);
+#endif
             const uint32_t shape0 = WG ? s_red[4] : rdlane(shape, 0);
             return (shape0 & SH_BIG) ? 0xFFFFFFFFu : 0xFFFFFFFEu;
         }
@@ -286,7 +290,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
         else {
 #pragma unroll
             for (uint32_t e = 0; e < 15; ++e)       // (an empty pop and a decomposition row also depend on the bounds of their unique variables)
-                if (e < nE && ((fl[e] & 3) != 3 || nop_row || (r4s && !norec) || r3f) && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
+                if (e < nE && ((fl[e] & 3) != 3 || nop_row || (r4s && !norec) || r3f || r6f) && w2_get(Tm, w[1 + e] + 1u) < rank) blocked = true;
         }
     }
     uint32_t c = cmax;
@@ -333,9 +337,11 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
                         solved[row] = 1;
                     }
                     if (fo_.r3v) { st256(J.values + 8ull * wva, xlb0); J.nvalues[wva] = 1; }
+                    if (fo_.v6a) { st256(J.values + 8ull * wva, xub0); st256(J.values + 8ull * wva + 4, xlb0); J.nvalues[wva] = 2; }
+                    if (fo_.v6b) { st256(J.values + 8ull * wvb, xub1); st256(J.values + 8ull * wvb + 4, xlb1); J.nvalues[wvb] = 2; }
                     if (flip_w) { if (flip_lds) flipL[row] = flip_new; else flipG[row] = flip_new; }
                     C.steps += d_steps; C.nuniq += d_nuniq;
-                    C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[2] += fo_.d_h2; C.hits[3] += d_h3; C.hits[4] += d_h4;
+                    C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[2] += fo_.d_h2; C.hits[3] += d_h3; C.hits[4] += d_h4; C.hits[5] += fo_.d_h5;
                     stQ(row, (uint16_t)0);                      // (:817) popped: its own events may queue it again
                 }
                 wg_fence();
@@ -387,9 +393,11 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
             solved[row] = 1;
         }
         if (fo_.r3v) { st256(J.values + 8ull * wva, xlb0); J.nvalues[wva] = 1; }
+        if (fo_.v6a) { st256(J.values + 8ull * wva, xub0); st256(J.values + 8ull * wva + 4, xlb0); J.nvalues[wva] = 2; }
+        if (fo_.v6b) { st256(J.values + 8ull * wvb, xub1); st256(J.values + 8ull * wvb + 4, xlb1); J.nvalues[wvb] = 2; }
         if (flip_w) { if (flip_lds) flipL[row] = flip_new; else flipG[row] = flip_new; }
         C.steps += d_steps; C.nuniq += d_nuniq;
-        C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[2] += fo_.d_h2; C.hits[3] += d_h3; C.hits[4] += d_h4;
+        C.hits[0] += d_h0; C.hits[1] += d_h1; C.hits[2] += fo_.d_h2; C.hits[3] += d_h3; C.hits[4] += d_h4; C.hits[5] += fo_.d_h5;
     }
     sync();
     W2T(5);        // commit
