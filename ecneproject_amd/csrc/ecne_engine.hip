@@ -659,7 +659,9 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     uint32_t nblk0 = (S.L.nC + 255) / 256;
-    if (nblk0 > 256 * 16) nblk0 = 256 * 16;   // >> 256 workgroups: fills all 8 XCDs, grid-strides the rest
+    uint32_t blk_cap = 256 * 16;               // >> 256 workgroups: fills all 8 XCDs, grid-strides the rest
+    if (const char* e = getenv("ECNE_CLS_BLOCKS")) blk_cap = (uint32_t)atoi(e);   // experiment hook
+    if (nblk0 > blk_cap) nblk0 = blk_cap;
     if (nblk0 == 0) nblk0 = 1;
     uint32_t nblk1 = ((uint32_t)S.L.cls_list.size() + 3) / 4;
     if (nblk1 > 256 * 16) nblk1 = 256 * 16;
