@@ -293,6 +293,20 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     const uint32_t cbase = team_block_scan(J, wgrank, mycand, 0, &M, s_err, &err);   // candidates in rank order
     MTICK(2);
     if (err) return err;
+    if (M == 0) {
+        // nobody re-queues anything (a block of empty pops -- the rows a multiplexer's sum re-queued, say): the rows of the prefix
+        // leave the queue and that is all; the expansion, the winners' scan and two of the barriers drop out
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl)
+            if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
+        if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
+        if (tid == 0) big_reset(S);
+        if ((err = job_barrier(J, s_err))) return err;
+        MTICK(5);
+        *out_c = c;
+        *out_tail = tail;
+        return 0;
+    }
     if (M > J.candcap) {
         // a variable with a huge fan-out: the master replays all events sequentially (rare)
         if (wgrank == 0) {
