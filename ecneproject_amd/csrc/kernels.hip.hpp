@@ -1,7 +1,7 @@
 // kernels.hip.hpp — gfx950 device code of the Ecne propagation engine (included by ecne_engine.hip).
 //
 // Kernels
-//   k_classify_rows   two passes (one lane per short row, one wavefront per longer row): streams the
+//   k_classify_rows   one launch, two kinds of workgroups (one lane per short row, one wavefront per longer row): streams the
 //                     row's (col, coeff) pairs once, decides the static shape of the row (which of the
 //                     reference's rules R2..R8 it can ever feed), computes the rule constants that need
 //                     field arithmetic (the two roots of a bit-check row, the value of a
@@ -14,7 +14,11 @@
 //                     1..96 cooperating workgroups of 512 threads (SPMD, hand-rolled job barrier), FIFO
 //                     worklist in HBM/L2, rules R1-R8, batch phases P1-P5, verdict counts.  All
 //                     ordering-sensitive steps follow the reference's sequential order exactly (see
-//                     DESIGN.md "Schedule").
+//                     DESIGN.md "Schedule"). Files, bottom up: rules_wave / rules_lane (one pop by a wavefront / a lane),
+//                     schedule (access sets, long rows, ordered REQUEUE), job_barrier, fastrow (the pop of the common row
+//                     shapes decided in registers, the walk of a long row), chain (sequential pops of a single-workgroup
+//                     job out of LDS), wave2 (the fast wavefront round), rounds (multi-workgroup round, the queue
+//                     phase's policy), k_solve (setup, outer loop, P1-P5, verdict).
 //   k_abs_*           abstraction's O(rows) part (reference :237-395): row fingerprints, a weighted prefix scan and the
 //                     window-candidate test (abstract.hip.hpp); verification and the greedy replacement stay on the host.
 //   k_fp_selftest     field-arithmetic known-answer vectors on the device.
