@@ -27,6 +27,7 @@ struct FastIn {
     bool live, xy, f2, f4, bigsum;
     bool r4s = false;               // a short binary-decomposition row (R4 shape, l > 2): taken while R4's precondition fails
     bool r3f = false;               // a constant row x = c (R3 shape and none of R4..R6's)
+    bool r3x = false;               // ... x = c written as x - 1 = 0 / 1 - x = 0: the R4 (l = 2) and R5 shapes against the constant wire as well
     bool r6f = false;               // 1 = x + y (R6 shape and none of R3..R5's), record = {constant wire, x, y}
     uint32_t validx = 0;            // the row's constants in J.vals (R3: c)
 };
@@ -161,6 +162,26 @@ __device__ __forceinline__ void fast_decide(const Job& J, const FastIn& I, FastO
                 xlb0 = tv; xub0 = tv; xa_w = !bsame;
                 wva = rx; wfa = f; wa = f != fx || !same || !bsame;
                 if (new_info) emit(rx);
+                if (I.r3x) {
+                    // the row also has the x == y shapes, the other variable being the constant wire: R4 (:991-1076, l = 2) negates
+                    // the row and then needs the variable that is not the pivot to have bounds exactly [0,1] -- x has [c,c] now, the
+                    // constant wire must not have them either; R5 (:1078-1146) does nothing while both bounds and both unique bits
+                    // agree. Anything else: the general executor.
+                    uint8_t f1w = 0;
+                    bool okw = nE == 2 && nA + nB == 0;
+#pragma unroll
+                    for (uint32_t e = 0; e < 2; ++e) {
+                        if (w[1 + e] == 1u) f1w = fl[e];
+                        else if (w[1 + e] != rx) okw = false;
+                    }
+                    okw = okw && rx != 1u && (w[1] == 1u || w[2] == 1u) && (f1w & 3) == 3 && !(f1w & 4);
+                    if (okw) {
+                        const fp::u256 lb1 = ld256(J.lb + 4ull), ub1 = ld256(J.ub + 4ull);       // bounds of the constant wire (variable 1)
+                        okw = fp::eq(lb1, tv) && fp::eq(ub1, tv);
+                    }
+                    if (!okw) { slow = true; reason = 1; }
+                    else { flip_w = true; flip_new = (uint8_t)(flip_in ^ 1); }
+                }
             }
         } else if (I.r6f) {
             // 1 = x + y (R6 checkOnePropagateBounds :1148-1232, after R1), on the limbs, statement for statement exec_row()

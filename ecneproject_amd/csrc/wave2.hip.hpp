@@ -154,7 +154,8 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     const bool f2 = (shape & SH_C_EMPTY) != 0;
     const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
     const bool r4s = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R5 | SH_R6)) && (((shape & SH_R4_T) != 0) != ((shape & SH_R4_T2) != 0));
-    const bool r3f = (shape & SH_R3) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+    const bool r3x = (shape & (SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6 | SH_HAS_AB | SH_C_EMPTY)) == (SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5);
+    const bool r3f = ((shape & SH_R3) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6))) || r3x;
     const bool r6f = (shape & SH_R6) && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5));
     const bool live = mine && !is_solved;
     // (a row without a record is declined even when it is solved: its pop still counts the row's non-zeros)
@@ -215,7 +216,7 @@ __device__ __noinline__ uint32_t queue_round_fast(const Job& J, ChunkShared& S, 
     fin.fa = fa; fin.fb = fb; fin.fx = fx; fin.flip_in = flip_in;
     bool wnop = false;                                            // the watched pair still holds: an empty pop
     if (watched) { if (long_watch_holds(fl[0], fl[1], lr4)) wnop = true; else { slow = true; reason = 0; } }
-    fin.live = live && !wnop; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !norec && !nop_row; fin.r3f = r3f && !nop_row; fin.r6f = r6f && !nop_row; fin.validx = validx;
+    fin.live = live && !wnop; fin.xy = xy; fin.f2 = f2; fin.f4 = f4; fin.bigsum = bigsum; fin.r4s = r4s && !norec && !nop_row; fin.r3f = r3f && !nop_row; fin.r3x = r3x && !nop_row; fin.r6f = r6f && !nop_row; fin.validx = validx;
     FastOut fo_;
     fo_.slow = slow; fo_.reason = reason;
     fast_decide(J, fin, fo_);
