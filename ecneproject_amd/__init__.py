@@ -25,7 +25,7 @@ from ._lib import Info, Opts, Summary, SystemInfo
 
 __all__ = ["readR1CS", "SolveConstraintsSymbolic", "solveWithTrustedFunctions", "solve_batch",
            "R1CS", "System", "SolveResult", "EcneError", "BoundsError", "DivideError", "UndefVarError",
-           "device_count", "classify", "set_host_threads"]
+           "device_count", "classify", "set_host_threads", "set_frontend", "frontend_stats"]
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -86,6 +86,24 @@ def set_host_threads(n=0):
     """Opt in to host worker threads for parsing, abstraction and the flat-array layout (n <= 0: the cores present,
     at most 32). The library works on the calling thread unless asked. Returns the count now in effect."""
     return int(_lib.lib().ecne_set_host_threads(int(n)))
+
+
+FRONTEND_HOST, FRONTEND_DEVICE, FRONTEND_AUTO = 0, 1, 2
+
+
+def set_frontend(mode=-1):
+    """Which front-end turns files into the solver's arrays: FRONTEND_HOST, FRONTEND_DEVICE (parse, abstraction and layout as
+    kernels on the current HIP device), FRONTEND_AUTO (device from 100 000 constraints on; the default). mode < 0 only reads."""
+    return int(_lib.lib().ecne_set_frontend(int(mode)))
+
+
+def frontend_stats():
+    """timing of the calling thread's last trip through the front-end (include/ecne.h: ecne_frontend_stats)"""
+    a = (C.c_double * 16)()
+    _check(_lib.lib().ecne_frontend_stats(a))
+    k = ["parse_device", "upload_ms", "offsets_ms", "fill_ms", "parse_ms", "file_bytes", "abstract_device", "prep_ms", "fingerprint_ms",
+         "scan_ms", "verify_ms", "compact_ms", "candidates", "matched", "layout_device", "layout_ms"]
+    return dict(zip(k, list(a)))
 
 
 class R1CS:
@@ -196,6 +214,22 @@ class System:
 
     def __len__(self):
         return int(self.info.n_rows)
+
+    def dict_rows(self, part):
+        """(rowptr, var, coeff[n,4]) of part 0/1/2 in the reference's DICTIONARY order (zeros and placeholders included); copies."""
+        rp, var, cf, n = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), C.c_uint64()
+        _check(_lib.lib().ecne_system_dict_rows(self._h, part, C.byref(rp), C.byref(var), C.byref(cf), C.byref(n)))
+        rowptr = np.ctypeslib.as_array(rp, (n.value + 1,)).copy()
+        m = int(rowptr[-1])
+        if m == 0:
+            return rowptr, np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64)
+        return rowptr, np.ctypeslib.as_array(var, (m,)).copy(), np.ctypeslib.as_array(cf, (m * 4,)).reshape(m, 4).copy()
+
+    def static_array(self, which, device=0):
+        """test hook: bytes of static array `which` of the device image (ecne_debug_static_array)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(_lib.lib().ecne_debug_static_array(self._h, device, which, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
 
     def rows(self, part):
         """(rowptr, col, coeff[nnz,4]) of part 0/1/2 in the reference's nonzeroKeys order; copies."""

@@ -24,14 +24,30 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+TUS = ["ecne_engine.hip", "ecne_frontend.hip"]      # translation units (everything else under csrc/ is a header of one or both)
+
+
 def build(force=False, verbose=True):
+    """hipcc --offload-arch=gfx950: the two translation units are compiled side by side, then linked into libecne_hip.so."""
     if not force and not needs_build():
         return SO
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-shared", "-fPIC",
-           "-o", SO, os.path.join(CSRC, "ecne_engine.hip")] + os.environ.get("ECNE_BUILD_FLAGS", "").split()   # e.g. -DECNE_POPPROF (developer builds)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-fPIC"] + os.environ.get("ECNE_BUILD_FLAGS", "").split()   # e.g. -DECNE_POPPROF (developer builds)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for tu in TUS:
+        obj = os.path.join(objdir, tu.replace(".hip", ".o"))
+        cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, tu), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, obj, subprocess.Popen(cmd)))
+    for cmd, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", SO] + [obj for _c, obj, _p in procs]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return SO
 
 

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <set>
@@ -24,6 +25,7 @@
 #include "../../include/ecne.h"
 #include "engine_types.hpp"
 #include "fp256.hpp"
+#include "frontend.hpp"
 #include "host_model.hpp"
 #include "jlorder.hpp"
 #include "kernels.hip.hpp"
@@ -33,7 +35,51 @@ using namespace ecne;
 struct ecne_r1cs {
     std::shared_ptr<R1CSFile> file = std::make_shared<R1CSFile>();   // shared with the systems made from it
     R1CSFile& f = *file;
+    // the same rows resident on a device (device front-end, frontend.hpp): what ecne_r1cs_load produced when the file went through
+    // fe::parse_on_device; the host rows of `file` are then fetched only when somebody asks for them (ensure_host_rows)
+    std::shared_ptr<fe::DevRows> drows;
 };
+
+// Which front-end a file / system goes through: 0 = host (host_model.hpp), 1 = device whenever a HIP device is there,
+// 2 = auto (device for files of ECNE_FRONTEND_DEVICE_ROWS rows and more). ECNE_FRONTEND=host|device|auto, ecne_set_frontend().
+#ifndef ECNE_FRONTEND_DEVICE_ROWS
+#define ECNE_FRONTEND_DEVICE_ROWS 100000
+#endif
+static std::atomic<int>& frontend_setting() {
+    static std::atomic<int> m{[] {
+        const char* e = std::getenv("ECNE_FRONTEND");
+        if (!e) return 2;
+        return !std::strcmp(e, "host") ? 0 : !std::strcmp(e, "device") ? 1 : 2;
+    }()};
+    return m;
+}
+static bool frontend_wants_device(uint64_t n_rows) {
+    const int m = frontend_setting().load(std::memory_order_relaxed);
+    if (m == 0) return false;
+    if (m == 2 && n_rows < ECNE_FRONTEND_DEVICE_ROWS) return false;
+    return ecne_device_count() > 0;
+}
+static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+// timing of the calling thread's last trip through the device front-end (ecne_frontend_stats)
+struct FrontendStats { fe::ParseStats parse; fe::AbstractDevStats abs; double layout_ms = 0; int parse_dev = 0, abs_dev = 0, layout_dev = 0; };
+static thread_local FrontendStats g_fe_stats;
+
+// host rows of a file that was parsed on the device only
+static int ensure_host_rows(const ecne_r1cs* h) {
+    R1CSFile& f = const_cast<ecne_r1cs*>(h)->f;
+    if (f.host_rows) return K_OK;
+    if (h->drows) {
+        const int rc = fe::download_rows(*h->drows, f.rows);
+        if (rc != K_OK) return rc;
+        f.host_rows = true;
+        return K_OK;
+    }
+    return K_EINVAL;
+}
 
 // Host image of the flat arrays (built once per system, uploaded once per device)
 struct Layout {
@@ -52,10 +98,15 @@ struct Layout {
     std::vector<uint32_t> p4_list, p5_rows, p5_y, cls_list;
     uint64_t nnz[3] = {0, 0, 0};
     uint64_t stream_bytes = 0;   // bytes k_classify_rows reads + writes (roofline numerator)
+    // a system laid out by the device front-end keeps its big arrays (rp / col / coef / rinfo / fan-out / lists) on the device
+    // only; the counts the arena is carved from and the small lists above are filled either way
+    bool host_arrays = false;    // rp, col, coef, rinfo hold data on the host
+    uint32_t n_p4 = 0, n_p5 = 0, n_cls = 0, n_long = 0, n_bigrows = 0, fo_total = 0, maxrowC = 0;
 };
 
 struct DeviceImage {
     int device = -1;
+    std::unique_ptr<fe::LayoutDev> lay;   // static arrays built by the device front-end (else they sit in `arena`, uploaded from the host Layout)
     void* arena = nullptr;
     size_t arena_bytes = 0;
     Job job;          // host copy with device pointers
@@ -65,11 +116,14 @@ struct DeviceImage {
 
 struct ecne_system {
     // dictionary order, current rows: the parsed file's own arrays until the first abstraction (no copy;
-    // `base` keeps them alive after ecne_r1cs_free), `reduced` afterwards
-    std::shared_ptr<const R1CSFile> base;
+    // `base` keeps them alive after ecne_r1cs_free), `reduced` afterwards. A system that came through the device front-end
+    // holds the rows on the device (`drows`) and fetches the host copy only when somebody needs it (sys_host_rows).
+    std::shared_ptr<R1CSFile> base;
+    std::shared_ptr<fe::DevRows> drows;
     Rows reduced;
     const Rows* cur = nullptr;
-    const Rows& rows() const { return *cur; }
+    const Rows& rows() const { return *cur; }      // after sys_host_rows()
+    uint64_t n_rows() const { return cur ? cur->n() : drows ? drows->n : 0; }
     std::vector<Special> specials;
     std::vector<int64_t> knowns, targets;
     int64_t n_vars = 0, n_rows_main = 0;
@@ -80,11 +134,35 @@ struct ecne_system {
     std::vector<int64_t> order_buf;   // ecne_system_report_order
     ~ecne_system() {
         if (dev.arena) {
+            int prev = -1;
+            (void)hipGetDevice(&prev);
             (void)hipSetDevice(dev.device);
             (void)hipFree(dev.arena);
+            if (prev >= 0) (void)hipSetDevice(prev);
         }
     }
 };
+// host copy of the system's current rows (lazily: a device-front-end system downloads them on first use)
+static std::mutex g_lazy_rows_mu;
+static int sys_host_rows(ecne_system& S) {
+    if (S.cur) return K_OK;
+    std::lock_guard<std::mutex> g(g_lazy_rows_mu);
+    if (S.base) {
+        if (!S.base->host_rows) {
+            if (!S.drows) return K_EINVAL;
+            const int rc = fe::download_rows(*S.drows, S.base->rows);
+            if (rc != K_OK) return rc;
+            S.base->host_rows = true;
+        }
+        S.cur = &S.base->rows;
+        return K_OK;
+    }
+    if (!S.drows) return K_EINVAL;
+    const int rc = fe::download_rows(*S.drows, S.reduced);
+    if (rc != K_OK) return rc;
+    S.cur = &S.reduced;
+    return K_OK;
+}
 
 static void system_changed_rows(ecne_system* sys);
 struct ecne_result {
@@ -157,6 +235,7 @@ struct LaunchScratch {
 static LaunchScratch& launch_scratch() { static thread_local LaunchScratch s; return s; }
 
 // ------------------------------------------------------------------------------------ layout
+static void build_small_lists(ecne_system& S, uint32_t nVall, std::vector<uint32_t>* marks);
 static void build_layout(ecne_system& S) {
     Layout& L = S.L;
     const Rows& R = S.rows();
@@ -413,19 +492,12 @@ static void build_layout(ecne_system& S) {
         for_chunks(nrange, [&](size_t rg, unsigned) { walk(rg, true, cursor); });
     }
     // specials, I/O lists, nontrivial set (:600-618)
-    L.sp_in_ptr.assign(1, 0);
-    L.sp_out_ptr.assign(1, 0);
-    for (auto& sp : S.specials) {
-        for (int64_t v : sp.inputs) { L.sp_in.push_back((uint32_t)v); L.nontrivial[(size_t)v] = 1; }
-        for (int64_t v : sp.outputs) { L.sp_out.push_back((uint32_t)v); L.nontrivial[(size_t)v] = 1; }
-        L.sp_in_ptr.push_back((uint32_t)L.sp_in.size());
-        L.sp_out_ptr.push_back((uint32_t)L.sp_out.size());
-        L.sp_kind.push_back(sp.name == "BigMultModP" ? 1 : sp.name == "BigLessThan" ? 2 : 0);
-    }
-    for (int64_t v : S.knowns) if (v >= 1 && (uint64_t)v <= nVall) L.knowns.push_back((uint32_t)v);
-    for (int64_t v : S.targets) if (v >= 1 && (uint64_t)v <= nVall) { L.targets.push_back((uint32_t)v); L.nontrivial[(size_t)v] = 1; }
+    build_small_lists(S, nVall, nullptr);
     uint64_t nnz = L.nnz[0] + L.nnz[1] + L.nnz[2];
     L.stream_bytes = (uint64_t)nC * (12 + 32 + 32) + nnz * 36 + L.nnz[2] * 4 + (uint64_t)L.n_vals * 32;
+    L.host_arrays = true;
+    L.n_p4 = (uint32_t)L.p4_list.size(); L.n_p5 = (uint32_t)L.p5_rows.size(); L.n_cls = (uint32_t)L.cls_list.size();
+    L.fo_total = (uint32_t)L.fo_rows.size();
     S.laid_out = true;
 }
 
@@ -451,29 +523,83 @@ static uint32_t pow2_at_least(uint64_t x) {
     return (uint32_t)p;
 }
 
+// specials, I/O lists and their nontrivial marks (:600-618): small, host side for both front-ends
+static void build_small_lists(ecne_system& S, uint32_t nVall, std::vector<uint32_t>* marks) {
+    Layout& L = S.L;
+    L.sp_in_ptr.assign(1, 0);
+    L.sp_out_ptr.assign(1, 0);
+    L.sp_in.clear(); L.sp_out.clear(); L.sp_kind.clear(); L.knowns.clear(); L.targets.clear();
+    for (auto& sp : S.specials) {
+        for (int64_t v : sp.inputs) { L.sp_in.push_back((uint32_t)v); if (marks) marks->push_back((uint32_t)v); else L.nontrivial[(size_t)v] = 1; }
+        for (int64_t v : sp.outputs) { L.sp_out.push_back((uint32_t)v); if (marks) marks->push_back((uint32_t)v); else L.nontrivial[(size_t)v] = 1; }
+        L.sp_in_ptr.push_back((uint32_t)L.sp_in.size());
+        L.sp_out_ptr.push_back((uint32_t)L.sp_out.size());
+        L.sp_kind.push_back(sp.name == "BigMultModP" ? 1 : sp.name == "BigLessThan" ? 2 : 0);
+    }
+    for (int64_t v : S.knowns) if (v >= 1 && (uint64_t)v <= nVall) L.knowns.push_back((uint32_t)v);
+    for (int64_t v : S.targets)
+        if (v >= 1 && (uint64_t)v <= nVall) { L.targets.push_back((uint32_t)v); if (marks) marks->push_back((uint32_t)v); else L.nontrivial[(size_t)v] = 1; }
+}
+
 static int upload_system(ecne_system& S, int device) {
     if (S.dev.arena && S.dev.device == device) return K_OK;
     if (S.dev.arena) { (void)hipSetDevice(S.dev.device); (void)hipFree(S.dev.arena); S.dev = DeviceImage(); }
-    if (!S.laid_out) build_layout(S);
-    const Layout& L = S.L;
     HIP_TRY(hipSetDevice(device));
+    // Static arrays: built on the device when the rows are there (device front-end), else laid out on the host and uploaded
+    bool dev_layout = false;
+    std::vector<uint32_t> marks;
+    if (S.drows && S.drows->device == device && !(S.laid_out && S.L.host_arrays)) {
+        uint32_t min_nv = 0;
+        for (auto& sp : S.specials) {
+            for (int64_t v : sp.inputs) min_nv = std::max<uint32_t>(min_nv, (uint32_t)v);
+            for (int64_t v : sp.outputs) min_nv = std::max<uint32_t>(min_nv, (uint32_t)v);
+        }
+        const int rc = fe::layout_on_device(*S.drows, (uint32_t)S.n_vars, min_nv, S.dev.lay);
+        if (rc == K_OK) {
+            dev_layout = true;
+            const fe::LayoutCounts& C = S.dev.lay->cnt;
+            Layout& L = S.L;
+            L = Layout();
+            L.nC = C.nC; L.nV = C.nVall;
+            for (int p = 0; p < 3; ++p) L.nnz[p] = C.nnz[p];
+            L.n_vals = C.n_vals; L.n_p4 = C.nP4; L.n_p5 = C.nP5; L.n_cls = C.nCls; L.n_long = C.nLong; L.n_bigrows = C.nBigRows;
+            L.fo_total = C.fo_total; L.maxrowC = C.maxrowC;
+            L.host_arrays = false;
+            build_small_lists(S, C.nVall, &marks);
+            const uint64_t nnz = L.nnz[0] + L.nnz[1] + L.nnz[2];
+            L.stream_bytes = (uint64_t)L.nC * (12 + 32 + 32) + nnz * 36 + L.nnz[2] * 4 + (uint64_t)L.n_vals * 32;
+            S.laid_out = true;
+            g_fe_stats.layout_ms = S.dev.lay->ms;
+            g_fe_stats.layout_dev = 1;
+        } else if (rc != fe::FE_FALLBACK) return rc;
+        else S.dev.lay.reset();
+    }
+    if (!dev_layout) {
+        { const int rc = sys_host_rows(S); if (rc != K_OK) return rc; }
+        if (!S.laid_out || !S.L.host_arrays) build_layout(S);
+        g_fe_stats.layout_dev = 0;
+    }
+    const Layout& L = S.L;
     const uint32_t nC = L.nC, nV = L.nV, nSp = (uint32_t)L.sp_kind.size();
     const uint32_t qcap = pow2_at_least((uint64_t)nC + 2);
     const uint32_t htcap = pow2_at_least((uint64_t)nC * 2 + 16);
     const uint32_t hotcap = 4096;
-    const uint32_t nev = std::max<uint32_t>((uint32_t)L.p4_list.size(), 64);
+    const uint32_t nev = std::max<uint32_t>(L.n_p4, 64);
+    const size_t fo_ptr_n = (size_t)nV + 2;
     Carver c;
+    // host layout: the static arrays live in the arena; device layout: they live in S.dev.lay and the arena holds the rest
+    auto take_h = [&](size_t bytes) { return dev_layout ? (size_t)0 : c.take(bytes); };
     size_t o_rp[3], o_col[3], o_coef[3];
     for (int p = 0; p < 3; ++p) {
-        o_rp[p] = c.take(4ull * (nC + 1));
-        o_col[p] = c.take(4ull * std::max<size_t>(L.col[p].size(), 1));
-        o_coef[p] = c.take(8ull * std::max<size_t>(L.coef[p].size(), 4));
+        o_rp[p] = take_h(4ull * (nC + 1));
+        o_col[p] = take_h(4ull * std::max<uint64_t>(L.nnz[p], 1));
+        o_coef[p] = take_h(32ull * std::max<uint64_t>(L.nnz[p], 1));
     }
-    size_t o_csort = c.take(4ull * std::max<size_t>(L.col[2].size(), 1));
-    size_t o_rinfo = c.take(sizeof(RowInfo) * std::max<size_t>(nC, 1));
+    size_t o_csort = c.take(4ull * std::max<uint64_t>(L.nnz[2], 1));
+    size_t o_rinfo = take_h(sizeof(RowInfo) * std::max<size_t>(nC, 1));
     size_t o_vals = c.take(32ull * std::max<uint32_t>(L.n_vals, 1));
-    size_t o_foptr = c.take(4ull * L.fo_ptr.size());
-    size_t o_forows = c.take(4ull * std::max<size_t>(L.fo_rows.size(), 1));
+    size_t o_foptr = take_h(4ull * fo_ptr_n);
+    size_t o_forows = take_h(4ull * std::max<size_t>(L.fo_total, 1));
     size_t o_spinptr = c.take(4ull * L.sp_in_ptr.size()), o_spin = c.take(4ull * std::max<size_t>(L.sp_in.size(), 1));
     size_t o_spoutptr = c.take(4ull * L.sp_out_ptr.size()), o_spout = c.take(4ull * std::max<size_t>(L.sp_out.size(), 1));
     size_t o_spkind = c.take(std::max<size_t>(nSp, 1));
@@ -481,29 +607,34 @@ static int upload_system(ecne_system& S, int device) {
     for (uint32_t i = 0; i < nSp; ++i) { if (L.sp_kind[i] == 1) k1_list.push_back(i); else if (L.sp_kind[i] == 2) k2_list.push_back(i); }
     size_t o_k1 = c.take(4ull * std::max<size_t>(k1_list.size(), 1)), o_k2 = c.take(4ull * std::max<size_t>(k2_list.size(), 1));
     size_t o_knowns = c.take(4ull * std::max<size_t>(L.knowns.size(), 1)), o_targets = c.take(4ull * std::max<size_t>(L.targets.size(), 1));
-    size_t o_nontriv = c.take((size_t)nV + 1);
-    size_t o_p4 = c.take(4ull * std::max<size_t>(L.p4_list.size(), 1));
-    std::vector<uint32_t> p4_b(L.p4_list.size()), p4_s(L.p4_list.size());
-    for (size_t i = 0; i < L.p4_list.size(); ++i) {
-        const RowInfo& ri = L.rinfo[L.p4_list[i]];
-        p4_b[i] = ri.kpos;
-        p4_s[i] = ri.kneg | ((ri.shape & SH_P4_DIV0) ? 0x80000000u : 0u);
+    size_t o_nontriv = take_h((size_t)nV + 1);
+    size_t o_p4 = take_h(4ull * std::max<size_t>(L.n_p4, 1));
+    std::vector<uint32_t> p4_b, p4_s;
+    std::vector<uint16_t> tbig;
+    std::vector<uint32_t> bigrows, long_list;
+    std::vector<uint32_t, RawAlloc<uint32_t>> rec, foi;
+    uint32_t maxrowC = L.maxrowC;
+    if (!dev_layout) {
+        p4_b.resize(L.p4_list.size()); p4_s.resize(L.p4_list.size());
+        for (size_t i = 0; i < L.p4_list.size(); ++i) {
+            const RowInfo& ri = L.rinfo[L.p4_list[i]];
+            p4_b[i] = ri.kpos;
+            p4_s[i] = ri.kneg | ((ri.shape & SH_P4_DIV0) ? 0x80000000u : 0u);
+        }
+        tbig.assign(std::max<size_t>(nC, 1), 0);
+        for (uint32_t r = 0; r < nC && bigrows.size() < ECNE_BIGTAB; ++r)
+            if (L.rinfo[r].shape & SH_BIG) { bigrows.push_back(r); tbig[r] = (uint16_t)bigrows.size(); }
+        for (uint32_t r = 0; r < nC; ++r) if (L.rinfo[r].shape & SH_BIG) long_list.push_back(r);
     }
-    size_t o_p4b = c.take(4ull * std::max<size_t>(p4_b.size(), 1)), o_p4s = c.take(4ull * std::max<size_t>(p4_s.size(), 1));
-    size_t o_cls = c.take(4ull * std::max<size_t>(L.cls_list.size(), 1));
-    std::vector<uint16_t> tbig(std::max<size_t>(nC, 1), 0);
-    std::vector<uint32_t> bigrows;
-    for (uint32_t r = 0; r < nC && bigrows.size() < ECNE_BIGTAB; ++r)
-        if (L.rinfo[r].shape & SH_BIG) { bigrows.push_back(r); tbig[r] = (uint16_t)bigrows.size(); }
-    size_t o_tbig = c.take(2ull * tbig.size()), o_bigrows = c.take(4ull * std::max<size_t>(bigrows.size(), 1));
-    std::vector<uint32_t> long_list;
-    for (uint32_t r = 0; r < nC; ++r) if (L.rinfo[r].shape & SH_BIG) long_list.push_back(r);
-    size_t o_long = c.take(4ull * std::max<size_t>(long_list.size(), 1));
-    size_t o_p5r = c.take(4ull * std::max<size_t>(L.p5_rows.size(), 1)), o_p5y = c.take(4ull * std::max<size_t>(L.p5_y.size(), 1));
+    const size_t n_bigrows = dev_layout ? L.n_bigrows : bigrows.size(), n_long = dev_layout ? L.n_long : long_list.size();
+    size_t o_p4b = take_h(4ull * std::max<size_t>(L.n_p4, 1)), o_p4s = take_h(4ull * std::max<size_t>(L.n_p4, 1));
+    size_t o_cls = take_h(4ull * std::max<size_t>(L.n_cls, 1));
+    size_t o_tbig = take_h(2ull * std::max<size_t>(nC, 1)), o_bigrows = take_h(4ull * std::max<size_t>(n_bigrows, 1));
+    size_t o_long = take_h(4ull * std::max<size_t>(n_long, 1));
+    size_t o_p5r = take_h(4ull * std::max<size_t>(L.n_p5, 1)), o_p5y = take_h(4ull * std::max<size_t>(L.n_p5, 1));
     // row records and inline fan-out lists (chain executor, fast wavefront rounds): the row in one line, the fan-out inline
     const bool chain = true;
-    std::vector<uint32_t, RawAlloc<uint32_t>> rec, foi;
-    {
+    if (!dev_layout) {
         rec.resize(16ull * std::max<size_t>(nC, 1));
         const size_t RB = 8192, nrb = ((size_t)nC + RB - 1) / RB;
         if (nC == 0) std::fill(rec.begin(), rec.end(), 0u);
@@ -532,8 +663,10 @@ static int upload_system(ecne_system& S, int device) {
                 else w[1] = f0;
             }
         });
+        maxrowC = 0;
+        for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
     }
-    size_t o_rec = c.take(4ull * std::max<size_t>(rec.size(), 4)), o_foi = c.take(4ull * std::max<size_t>(foi.size(), 4));
+    size_t o_rec = take_h(64ull * std::max<size_t>(nC, 1)), o_foi = take_h(16ull * fo_ptr_n);
     const size_t static_end = c.off;   // [o_rp[0], static_end): everything the solve only reads
     size_t o_flags = c.take((size_t)nV + 1), o_abz = c.take(4ull * (nV + 1));
     size_t o_lb = c.take(32ull * (nV + 1)), o_ub = c.take(32ull * (nV + 1));
@@ -551,8 +684,6 @@ static int upload_system(ecne_system& S, int device) {
     // multi-workgroup rounds <= min(rows, ECNE_MAX_NWG workgroups * 512 lanes * 2)
     const size_t max_ranks = std::max<size_t>((size_t)4 * ECNE_WG, std::min<size_t>((size_t)nC + 1, (size_t)ECNE_MAX_NWG * ECNE_WG * 2));
     size_t o_evbuf = c.take(4ull * max_ranks * ECNE_EVCAP), o_cand = c.take(4ull * std::max<size_t>(ECNE_CANDCAP, 8ull * nC));
-    uint32_t maxrowC = 0;
-    for (uint32_t r = 0; r < nC; ++r) maxrowC = std::max(maxrowC, L.rp[2][r + 1] - L.rp[2][r]);
     const size_t flatcap = std::max<size_t>((size_t)4 * ECNE_WG * ECNE_EVCAP, 16384) + (size_t)ECNE_BIGK * (maxrowC + 8);
     size_t o_fvar = c.take(4ull * flatcap), o_frank = c.take(4ull * flatcap), o_fbase = c.take(4ull * (flatcap + 1));
     size_t o_bigev = c.take(4ull * ((size_t)maxrowC * 3 + 64));
@@ -568,14 +699,31 @@ static int upload_system(ecne_system& S, int device) {
         if (!bytes) return hipSuccess;
         return hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
     };
-    for (int p = 0; p < 3; ++p) {
-        HIP_TRY(up(o_rp[p], L.rp[p].data(), 4ull * L.rp[p].size()));
-        HIP_TRY(up(o_col[p], L.col[p].data(), 4ull * L.col[p].size()));
-        HIP_TRY(up(o_coef[p], L.coef[p].data(), 8ull * L.coef[p].size()));
+    if (!dev_layout) {
+        for (int p = 0; p < 3; ++p) {
+            HIP_TRY(up(o_rp[p], L.rp[p].data(), 4ull * L.rp[p].size()));
+            HIP_TRY(up(o_col[p], L.col[p].data(), 4ull * L.col[p].size()));
+            HIP_TRY(up(o_coef[p], L.coef[p].data(), 8ull * L.coef[p].size()));
+        }
+        HIP_TRY(up(o_rinfo, L.rinfo.data(), sizeof(RowInfo) * L.rinfo.size()));
+        HIP_TRY(up(o_foptr, L.fo_ptr.data(), 4ull * L.fo_ptr.size()));
+        HIP_TRY(up(o_forows, L.fo_rows.data(), 4ull * L.fo_rows.size()));
+        HIP_TRY(up(o_nontriv, L.nontrivial.data(), L.nontrivial.size()));
+        HIP_TRY(up(o_p4, L.p4_list.data(), 4ull * L.p4_list.size()));
+        HIP_TRY(up(o_p4b, p4_b.data(), 4ull * p4_b.size()));
+        HIP_TRY(up(o_p4s, p4_s.data(), 4ull * p4_s.size()));
+        HIP_TRY(up(o_cls, L.cls_list.data(), 4ull * L.cls_list.size()));
+        HIP_TRY(up(o_tbig, tbig.data(), 2ull * tbig.size()));
+        HIP_TRY(up(o_bigrows, bigrows.data(), 4ull * bigrows.size()));
+        HIP_TRY(up(o_long, long_list.data(), 4ull * long_list.size()));
+        HIP_TRY(up(o_p5r, L.p5_rows.data(), 4ull * L.p5_rows.size()));
+        HIP_TRY(up(o_p5y, L.p5_y.data(), 4ull * L.p5_y.size()));
+        HIP_TRY(up(o_rec, rec.data(), 4ull * rec.size()));
+        HIP_TRY(up(o_foi, foi.data(), 4ull * foi.size()));
+    } else {
+        const int rc = fe::mark_bytes(device, S.dev.lay->dst.nontrivial, marks);
+        if (rc != K_OK) return rc;
     }
-    HIP_TRY(up(o_rinfo, L.rinfo.data(), sizeof(RowInfo) * L.rinfo.size()));
-    HIP_TRY(up(o_foptr, L.fo_ptr.data(), 4ull * L.fo_ptr.size()));
-    HIP_TRY(up(o_forows, L.fo_rows.data(), 4ull * L.fo_rows.size()));
     HIP_TRY(up(o_spinptr, L.sp_in_ptr.data(), 4ull * L.sp_in_ptr.size()));
     HIP_TRY(up(o_spin, L.sp_in.data(), 4ull * L.sp_in.size()));
     HIP_TRY(up(o_spoutptr, L.sp_out_ptr.data(), 4ull * L.sp_out_ptr.size()));
@@ -585,43 +733,52 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_k2, k2_list.data(), 4ull * k2_list.size()));
     HIP_TRY(up(o_knowns, L.knowns.data(), 4ull * L.knowns.size()));
     HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
-    HIP_TRY(up(o_nontriv, L.nontrivial.data(), L.nontrivial.size()));
-    HIP_TRY(up(o_p4, L.p4_list.data(), 4ull * L.p4_list.size()));
-    HIP_TRY(up(o_p4b, p4_b.data(), 4ull * p4_b.size()));
-    HIP_TRY(up(o_p4s, p4_s.data(), 4ull * p4_s.size()));
-    HIP_TRY(up(o_cls, L.cls_list.data(), 4ull * L.cls_list.size()));
-    HIP_TRY(up(o_tbig, tbig.data(), 2ull * tbig.size()));
-    HIP_TRY(up(o_bigrows, bigrows.data(), 4ull * bigrows.size()));
-    HIP_TRY(up(o_long, long_list.data(), 4ull * long_list.size()));
-    HIP_TRY(up(o_p5r, L.p5_rows.data(), 4ull * L.p5_rows.size()));
-    HIP_TRY(up(o_p5y, L.p5_y.data(), 4ull * L.p5_y.size()));
-    HIP_TRY(up(o_rec, rec.data(), 4ull * rec.size()));
-    HIP_TRY(up(o_foi, foi.data(), 4ull * foi.size()));
     Job& J = S.dev.job;
     std::memset(&J, 0, sizeof J);
     J.nC = nC; J.nV = nV; J.nSp = nSp;
     J.nKnown = (uint32_t)L.knowns.size(); J.nTarget = (uint32_t)L.targets.size();
-    J.nP4 = (uint32_t)L.p4_list.size(); J.nP5 = (uint32_t)L.p5_rows.size();
+    J.nP4 = L.n_p4; J.nP5 = L.n_p5;
     J.qmask = qcap - 1; J.htmask = htcap - 1; J.hotcap = hotcap;
-    J.rpA = (const uint32_t*)(base + o_rp[0]); J.rpB = (const uint32_t*)(base + o_rp[1]); J.rpC = (const uint32_t*)(base + o_rp[2]);
-    J.colA = (const uint32_t*)(base + o_col[0]); J.colB = (const uint32_t*)(base + o_col[1]); J.colC = (const uint32_t*)(base + o_col[2]);
-    J.coefA = (const uint64_t*)(base + o_coef[0]); J.coefB = (const uint64_t*)(base + o_coef[1]); J.coefC = (const uint64_t*)(base + o_coef[2]);
+    if (!dev_layout) {
+        J.rpA = (const uint32_t*)(base + o_rp[0]); J.rpB = (const uint32_t*)(base + o_rp[1]); J.rpC = (const uint32_t*)(base + o_rp[2]);
+        J.colA = (const uint32_t*)(base + o_col[0]); J.colB = (const uint32_t*)(base + o_col[1]); J.colC = (const uint32_t*)(base + o_col[2]);
+        J.coefA = (const uint64_t*)(base + o_coef[0]); J.coefB = (const uint64_t*)(base + o_coef[1]); J.coefC = (const uint64_t*)(base + o_coef[2]);
+        J.rinfo = (RowInfo*)(base + o_rinfo);
+        J.fo_ptr = (const uint32_t*)(base + o_foptr); J.fo_rows = (const uint32_t*)(base + o_forows);
+        J.nontrivial = (const uint8_t*)(base + o_nontriv);
+        J.p4_list = (const uint32_t*)(base + o_p4);
+        J.p4_b = (const uint32_t*)(base + o_p4b); J.p4_s = (const uint32_t*)(base + o_p4s);
+        J.cls_list = (const uint32_t*)(base + o_cls);
+        J.p5_rows = (const uint32_t*)(base + o_p5r); J.p5_y = (const uint32_t*)(base + o_p5y);
+        J.long_list = (const uint32_t*)(base + o_long);
+        J.tbig = (const uint16_t*)(base + o_tbig); J.bigrows = (const uint32_t*)(base + o_bigrows);
+        J.rec = chain ? (const uint32_t*)(base + o_rec) : nullptr;
+        J.foi = chain ? (const uint32_t*)(base + o_foi) : nullptr;
+    } else {
+        const fe::LayoutDst& D = S.dev.lay->dst;
+        J.rpA = D.rp[0]; J.rpB = D.rp[1]; J.rpC = D.rp[2];
+        J.colA = D.col[0]; J.colB = D.col[1]; J.colC = D.col[2];
+        J.coefA = D.coef[0]; J.coefB = D.coef[1]; J.coefC = D.coef[2];
+        J.rinfo = D.rinfo;
+        J.fo_ptr = D.fo_ptr; J.fo_rows = D.fo_rows;
+        J.nontrivial = D.nontrivial;
+        J.p4_list = D.p4_list; J.p4_b = D.p4_b; J.p4_s = D.p4_s;
+        J.cls_list = D.cls_list;
+        J.p5_rows = D.p5_rows; J.p5_y = D.p5_y;
+        J.long_list = D.long_list;
+        J.tbig = D.tbig; J.bigrows = D.bigrows;
+        J.rec = chain ? D.rec : nullptr;
+        J.foi = chain ? D.foi : nullptr;
+    }
     J.csort = (uint32_t*)(base + o_csort);
-    J.rinfo = (RowInfo*)(base + o_rinfo);
     J.vals = (uint64_t*)(base + o_vals);
-    J.fo_ptr = (const uint32_t*)(base + o_foptr); J.fo_rows = (const uint32_t*)(base + o_forows);
     J.sp_in_ptr = (const uint32_t*)(base + o_spinptr); J.sp_in = (const uint32_t*)(base + o_spin);
     J.sp_out_ptr = (const uint32_t*)(base + o_spoutptr); J.sp_out = (const uint32_t*)(base + o_spout);
     J.sp_kind = (const uint8_t*)(base + o_spkind);
     J.k1_list = (const uint32_t*)(base + o_k1); J.k2_list = (const uint32_t*)(base + o_k2);
     J.nK1 = (uint32_t)k1_list.size(); J.nK2 = (uint32_t)k2_list.size();
     J.knowns = (const uint32_t*)(base + o_knowns); J.targets = (const uint32_t*)(base + o_targets);
-    J.nontrivial = (const uint8_t*)(base + o_nontriv);
-    J.p4_list = (const uint32_t*)(base + o_p4);
-    J.p4_b = (const uint32_t*)(base + o_p4b); J.p4_s = (const uint32_t*)(base + o_p4s);
-    J.cls_list = (const uint32_t*)(base + o_cls);
-    J.nBigCls = (uint32_t)L.cls_list.size();
-    J.p5_rows = (const uint32_t*)(base + o_p5r); J.p5_y = (const uint32_t*)(base + o_p5y);
+    J.nBigCls = L.n_cls;
     J.flags = (uint8_t*)(base + o_flags); J.abz = (int32_t*)(base + o_abz);
     J.lb = (uint64_t*)(base + o_lb); J.ub = (uint64_t*)(base + o_ub);
     J.nvalues = (uint8_t*)(base + o_nvalues); J.values = (uint64_t*)(base + o_values);
@@ -629,8 +786,8 @@ static int upload_system(ecne_system& S, int device) {
     J.queue = (uint32_t*)(base + o_queue);
     J.varmin = (uint32_t*)(base + o_varmin);
     J.rdead = (uint8_t*)(base + o_rdead);
-    J.long_list = (const uint32_t*)(base + o_long); J.nLong = (uint32_t)long_list.size();
-    J.tbig = (const uint16_t*)(base + o_tbig); J.bigrows = (const uint32_t*)(base + o_bigrows); J.nBigRows = (uint32_t)bigrows.size();
+    J.nLong = (uint32_t)n_long;
+    J.nBigRows = (uint32_t)n_bigrows;
     J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
@@ -643,10 +800,9 @@ static int upload_system(ecne_system& S, int device) {
     J.bigev = (uint32_t*)(base + o_bigev);
     J.bigpool = (uint32_t*)(base + o_bigpool); J.bigstride = bigstride;
     J.ctr = (Counters*)(base + o_ctr);
-    J.rec = chain ? (const uint32_t*)(base + o_rec) : nullptr;
-    J.foi = chain ? (const uint32_t*)(base + o_foi) : nullptr;
     J.lds_flags_off = J.lds_inq_off = J.lds_flip_off = J.lds_w2_off = J.lds_w2b_off = 0xFFFFFFFFu;
-    J.warm_bytes = (static_end - o_rp[0]) <= (7u << 19) ? (uint32_t)(static_end - o_rp[0]) : 0u;   // fits one XCD's 4 MB L2 beside the state
+    // (the L2 warm-up streams one contiguous range: the arena's static part; a device-laid system's static arrays are elsewhere)
+    J.warm_bytes = (!dev_layout && (static_end - o_rp[0]) <= (7u << 19)) ? (uint32_t)(static_end - o_rp[0]) : 0u;   // fits one XCD's 4 MB L2 beside the state
     S.dev.classified = false;
     return K_OK;
 }
@@ -663,7 +819,7 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     if (const char* e = getenv("ECNE_CLS_BLOCKS")) blk_cap = (uint32_t)atoi(e);   // experiment hook
     if (nblk0 > blk_cap) nblk0 = blk_cap;
     if (nblk0 == 0) nblk0 = 1;
-    uint32_t nblk1 = ((uint32_t)S.L.cls_list.size() + 3) / 4;
+    uint32_t nblk1 = (S.L.n_cls + 3) / 4;
     if (nblk1 > 256 * 16) nblk1 = 256 * 16;
     HIP_TRY(hipEventRecord(e0, stream));
     // one launch: the long-row workgroups first (latency-bound), the streaming ones behind them (see k_classify_rows)
@@ -710,13 +866,10 @@ static int fetch_states(ecne_result* r) {
         if (nvals[v] >= 1) std::memcpy(&r->values[8 * (v - 1)], &vals[8 * v], 32);
         if (nvals[v] >= 2) std::memcpy(&r->values[8 * (v - 1) + 4], &vals[8 * v + 4], 32);
     }
-    // "Bad Constraints": rows with a variable that is not uniquely determined (:1609-1618)
-    for (uint32_t row = 0; row < L.nC; ++row) {
-        bool bad = false;
-        for (int p = 0; p < 3 && !bad; ++p)
-            for (uint32_t k = L.rp[p][row]; k < L.rp[p][row + 1]; ++k)
-                if (!(flags[L.col[p][k]] & 1)) { bad = true; break; }
-        if (bad) r->bad_rows.push_back((int64_t)row + 1);
+    // "Bad Constraints": rows with a variable that is not uniquely determined (:1609-1618) -- flagged and compacted on the device
+    {
+        const int rc = fe::bad_rows(S.dev.device, J, r->bad_rows);
+        if (rc != K_OK) return rc;
     }
     r->have_states = true;
     return K_OK;
@@ -727,10 +880,30 @@ extern "C" {
 
 static int ecne_r1cs_load_impl(const char* path, ecne_r1cs** out) {
     if (!path || !out) return ECNE_EINVAL;
-    ecne_r1cs* r = new ecne_r1cs();
-    int st = load_r1cs(path, r->f);
-    if (st != K_OK) { delete r; *out = nullptr; return st; }
-    *out = r;
+    *out = nullptr;
+    std::unique_ptr<ecne_r1cs> r(new ecne_r1cs());
+    FileView fv(path);
+    size_t cons_off = 0;
+    int st = read_r1cs_header(fv, r->f, cons_off);
+    if (st != K_OK) return st;
+    r->f.path = path;
+    g_fe_stats.parse = fe::ParseStats();
+    g_fe_stats.parse_dev = 0;
+    bool done = false;
+    if (frontend_wants_device(r->f.n_cons)) {
+        // the constraint section goes to the device as it is; rows come out in the reference's dictionary order there
+        st = fe::parse_on_device(fv.data + cons_off, fv.size - cons_off, r->f.n_cons, current_device(), r->drows, g_fe_stats.parse);
+        if (st == K_OK) {
+            for (int p = 0; p < 3; ++p) r->f.nnz[p] = r->drows->nnz[p];
+            g_fe_stats.parse_dev = 1;
+            done = true;
+        } else if (st != fe::FE_FALLBACK) return st;
+    }
+    if (!done) {
+        st = read_r1cs_rows(fv, cons_off, path, r->f);
+        if (st != K_OK) return st;
+    }
+    *out = r.release();
     return ECNE_OK;
 }
 int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* o) {
@@ -767,97 +940,49 @@ static int ecne_system_from_r1cs_impl(const ecne_r1cs* m, ecne_system** out) {
     if (!m || !out) return ECNE_EINVAL;
     ecne_system* s = new ecne_system();
     s->base = m->file;
-    s->cur = &s->base->rows;
+    s->drows = m->drows;
+    s->cur = m->f.host_rows ? &s->base->rows : nullptr;
     s->knowns = m->f.knowns;
     s->targets = m->f.outputs;
     s->n_vars = m->f.n_vars;
-    s->n_rows_main = (int64_t)m->f.rows.n();
+    s->n_rows_main = (int64_t)m->f.n_cons;
     { std::lock_guard<std::mutex> g(g_live_mu); live_systems().insert(s); }
     *out = s;
     return ECNE_OK;
 }
-// abstraction's candidate scan on the GPU (abstract.hip.hpp). Returns K_OK and the ascending candidate list, or an error
-// (the caller then scans on the host). stats: [0] fingerprint kernel ms (main file), [1] scan + candidate kernels ms,
-// [2] bytes the fingerprint kernel streamed, [3] upload ms
+// statistics of the calling thread's last ecne_abstract (ecne_abstract_stats)
 struct AbstractStats { double fp_ms = 0, scan_ms = 0, bytes = 0, upload_ms = 0; int used_device = 0; size_t n_cand = 0; };
 static thread_local AbstractStats g_last_abstract;
-static int device_candidates(const Rows& rows, const Rows& sub, int device, std::vector<size_t>& cand) {
-    AbstractStats& st = g_last_abstract;
-    st = AbstractStats();
-    const uint64_t nC = rows.n(), nS = sub.n();
-    cand.clear();
-    if (nS == 0 || nC < nS) { st.used_device = 1; return K_OK; }
-    if (nC >= 0xFFFFFFF0ull) return K_EINVAL;
-    HIP_TRY(hipSetDevice(device));
-    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } };
-    auto upload = [&](const Rows& R, Buf* ptrb, Buf* coefb, AbsRows& A) -> int {
-        A.n = R.n();
-        for (int p = 0; p < 3; ++p) {
-            const size_t pb = 8ull * (A.n + 1), cb = 32ull * std::max<size_t>(R.coef[p].size(), 1);
-            HIP_TRY(hipMalloc(&ptrb[p].p, pb));
-            HIP_TRY(hipMalloc(&coefb[p].p, cb));
-            HIP_TRY(hipMemcpy(ptrb[p].p, R.ptr[p].data(), pb, hipMemcpyHostToDevice));
-            if (!R.coef[p].empty()) HIP_TRY(hipMemcpy(coefb[p].p, R.coef[p].data(), 32ull * R.coef[p].size(), hipMemcpyHostToDevice));
-            A.ptr[p] = (const uint64_t*)ptrb[p].p;
-            A.coef[p] = (const uint64_t*)coefb[p].p;
-            st.bytes += (&R == &rows) ? (double)(pb + 32ull * R.coef[p].size()) : 0.0;
-        }
-        return K_OK;
-    };
-    Buf mp[3], mc[3], sp[3], sc[3], bf, bfs, bP, btops, bcand, bn;
-    AbsRows M, S;
-    hipEvent_t e[4];
-    for (auto& x : e) HIP_TRY(hipEventCreate(&x));
-    struct Ev { hipEvent_t* e; ~Ev() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); } } ev{e};
-    const auto t_up = std::chrono::steady_clock::now();
-    { const int rc = upload(rows, mp, mc, M); if (rc != K_OK) return rc; }
-    { const int rc = upload(sub, sp, sc, S); if (rc != K_OK) return rc; }
-    st.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count();
-    const uint64_t nb = (nC + 1 + 1023) / 1024;
-    HIP_TRY(hipMalloc(&bf.p, 8ull * (nC + 1)));
-    HIP_TRY(hipMalloc(&bfs.p, 8ull * nS));
-    HIP_TRY(hipMalloc(&bP.p, 8ull * (nC + 1)));
-    HIP_TRY(hipMalloc(&btops.p, 8ull * nb));
-    HIP_TRY(hipMalloc(&bcand.p, 4ull * nC));
-    HIP_TRY(hipMalloc(&bn.p, 8));
-    HIP_TRY(hipMemset(bn.p, 0, 8));
-    HIP_TRY(hipMemset((char*)bf.p + 8ull * nC, 0, 8));
-    const unsigned g_rows = (unsigned)std::min<uint64_t>((nC + 255) / 256, 256 * 16), g_sub = (unsigned)std::min<uint64_t>((nS + 255) / 256, 256 * 16);
-    HIP_TRY(hipEventRecord(e[0], 0));
-    hipLaunchKernelGGL(k_abs_fingerprint, dim3(g_rows), dim3(256), 0, 0, M, (uint64_t*)bf.p);
-    HIP_TRY(hipEventRecord(e[1], 0));
-    hipLaunchKernelGGL(k_abs_fingerprint, dim3(g_sub), dim3(256), 0, 0, S, (uint64_t*)bfs.p);
-    // the pattern's value T = sum_j g_j r^j over its first nS - 1 rows (host: a few thousand terms)
-    std::vector<uint64_t> fs(nS);
-    HIP_TRY(hipMemcpy(fs.data(), bfs.p, 8ull * nS, hipMemcpyDeviceToHost));
-    uint64_t T = 0, w = 1;
-    for (uint64_t j = 0; j + 1 < nS; ++j) { T += fs[j] * w; w *= ECNE_ABS_R; }
-    HIP_TRY(hipEventRecord(e[2], 0));
-    hipLaunchKernelGGL(k_abs_weighted_scan, dim3((unsigned)nb), dim3(256), 0, 0, (const uint64_t*)bf.p, nC + 1, (uint64_t*)bP.p, (uint64_t*)btops.p);
-    hipLaunchKernelGGL(k_abs_scan_tops, dim3(1), dim3(256), 0, 0, (uint64_t*)btops.p, nb);
-    hipLaunchKernelGGL(k_abs_candidates, dim3(g_rows), dim3(256), 0, 0, (const uint64_t*)bP.p, (const uint64_t*)btops.p, nC, nS - 1, nS, T,
-                       (uint32_t*)bcand.p, (unsigned long long*)bn.p, nC);
-    HIP_TRY(hipEventRecord(e[3], 0));
-    HIP_TRY(hipEventSynchronize(e[3]));
-    HIP_TRY(hipGetLastError());
-    float a = 0, b = 0;
-    (void)hipEventElapsedTime(&a, e[0], e[1]);
-    (void)hipEventElapsedTime(&b, e[2], e[3]);
-    st.fp_ms = a; st.scan_ms = b;
-    unsigned long long n = 0;
-    HIP_TRY(hipMemcpy(&n, bn.p, 8, hipMemcpyDeviceToHost));
-    if (n > nC) return K_ECAPACITY;
-    std::vector<uint32_t> c32((size_t)n);
-    if (n) HIP_TRY(hipMemcpy(c32.data(), bcand.p, 4ull * n, hipMemcpyDeviceToHost));
-    std::sort(c32.begin(), c32.end());
-    cand.assign(c32.begin(), c32.end());
-    st.used_device = 1;
-    st.n_cand = cand.size();
-    return K_OK;
-}
 
 static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
     if (!sys || !trusted || !name) return ECNE_EINVAL;
+    { const int rc = ensure_host_rows(trusted); if (rc != K_OK) return rc; }      // the pattern side is prepared on the host (small)
+    g_last_abstract = AbstractStats();
+    g_fe_stats.abs = fe::AbstractDevStats();
+    g_fe_stats.abs_dev = 0;
+    // rows on a device (device front-end): fingerprints, window scan, exact verification and compaction all happen there
+    if (sys->drows && frontend_setting().load(std::memory_order_relaxed) != 0) {
+        std::shared_ptr<fe::DevRows> red;
+        std::vector<Special> fresh = sys->specials;
+        const int rc = fe::abstract_on_device(name, sys->drows, trusted->f, fresh, red, g_fe_stats.abs);
+        if (rc == K_OK) {
+            system_changed_rows(sys);   // layout and device image are stale, earlier results unreadable
+            sys->specials = std::move(fresh);
+            if (red != sys->drows) {
+                sys->drows = red;
+                sys->reduced = Rows();
+                sys->cur = nullptr;
+                sys->base.reset();
+            }
+            g_fe_stats.abs_dev = 1;
+            g_last_abstract.used_device = 1;
+            g_last_abstract.fp_ms = g_fe_stats.abs.fp_ms; g_last_abstract.scan_ms = g_fe_stats.abs.scan_ms;
+            g_last_abstract.bytes = (double)g_fe_stats.abs.bytes; g_last_abstract.n_cand = g_fe_stats.abs.n_cand;
+            return K_OK;
+        }
+        if (rc != fe::FE_FALLBACK) return rc;
+    }
+    { const int rc = sys_host_rows(*sys); if (rc != K_OK) return rc; }
     Rows red;
     // The candidate scan runs on the GPU for files worth the upload (ECNE_ABSTRACT_DEVICE=0 / 1 forces host / device);
     // verification and replacement are the same host code either way, so the result does not depend on the choice.
@@ -866,8 +991,15 @@ static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const 
     {
         const char* e = getenv("ECNE_ABSTRACT_DEVICE");
         const bool want = e ? atoi(e) != 0 : sys->rows().n() >= ECNE_ABSTRACT_DEVICE_ROWS;
-        g_last_abstract = AbstractStats();
-        if (want && ecne_device_count() > 0) have_dcand = device_candidates(sys->rows(), trusted->f.rows, 0, dcand) == K_OK;
+        if (want && ecne_device_count() > 0) {
+            fe::AbstractDevStats ds;
+            double up_ms = 0;
+            have_dcand = fe::candidates_for_host_rows(sys->rows(), trusted->f.rows, current_device(), dcand, ds, up_ms) == K_OK;
+            if (have_dcand) {
+                g_last_abstract.used_device = 1; g_last_abstract.fp_ms = ds.fp_ms; g_last_abstract.scan_ms = ds.scan_ms;
+                g_last_abstract.bytes = (double)ds.bytes; g_last_abstract.upload_ms = up_ms; g_last_abstract.n_cand = dcand.size();
+            }
+        }
     }
     const int rc = abstract_one(name, sys->rows(), trusted->f, sys->specials, red, have_dcand ? &dcand : nullptr);
     if (rc != K_OK) return rc;
@@ -875,13 +1007,15 @@ static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const 
     sys->reduced = std::move(red);
     sys->cur = &sys->reduced;
     sys->base.reset();
+    sys->drows.reset();         // (the device copy, if any, holds the rows before this abstraction)
     return K_OK;
 }
+static int ensure_layout(ecne_system& S);
 static int ecne_system_info_get_impl(const ecne_system* sys, ecne_system_info* o) {
     if (!sys || !o) return ECNE_EINVAL;
     ecne_system* s = const_cast<ecne_system*>(sys);
-    if (!s->laid_out) build_layout(*s);
-    o->n_rows = (int64_t)sys->rows().n();
+    { const int rc = ensure_layout(*s); if (rc != K_OK) return rc; }
+    o->n_rows = (int64_t)s->L.nC;
     o->n_rows_main = sys->n_rows_main;
     o->n_vars = sys->n_vars;
     o->n_specials = (int64_t)sys->specials.size();
@@ -901,12 +1035,45 @@ int ecne_system_special(const ecne_system* sys, int64_t idx, const char** name, 
     if (nout) *nout = sp.outputs.size();
     return ECNE_OK;
 }
+// the system laid out (flat arrays + counts) by whichever front-end it belongs to, without solving it
+static int ensure_layout(ecne_system& S) {
+    if (S.laid_out) return K_OK;
+    if (S.drows && frontend_setting().load(std::memory_order_relaxed) != 0 && ecne_device_count() > S.drows->device) {
+        const int prev = current_device();
+        const int rc = upload_system(S, S.drows->device);
+        (void)hipSetDevice(prev);
+        return rc;
+    }
+    const int rc = sys_host_rows(S);
+    if (rc != K_OK) return rc;
+    build_layout(S);
+    return K_OK;
+}
 static int ecne_system_rows_impl(ecne_system* sys, int part, const uint32_t** rowptr, const uint32_t** col, const uint64_t** coeff) {
     if (!sys || part < 0 || part > 2) return ECNE_EINVAL;
-    if (!sys->laid_out) build_layout(*sys);
-    if (rowptr) *rowptr = sys->L.rp[part].data();
-    if (col) *col = sys->L.col[part].data();
-    if (coeff) *coeff = sys->L.coef[part].data();
+    { const int rc = ensure_layout(*sys); if (rc != K_OK) return rc; }
+    Layout& L = sys->L;
+    if (!L.host_arrays && L.rp[0].size() != (size_t)L.nC + 1) {
+        // laid out on the device: fetch the three CSR parts (once)
+        if (!sys->dev.lay) return ECNE_EINVAL;
+        const fe::LayoutDst& D = sys->dev.lay->dst;
+        const int prev = current_device();
+        HIP_TRY(hipSetDevice(sys->dev.lay->device));
+        for (int p = 0; p < 3; ++p) {
+            L.rp[p].resize((size_t)L.nC + 1);
+            L.col[p].resize(L.nnz[p]);
+            L.coef[p].resize(4 * L.nnz[p]);
+            HIP_TRY(hipMemcpy(L.rp[p].data(), D.rp[p], 4ull * ((size_t)L.nC + 1), hipMemcpyDeviceToHost));
+            if (L.nnz[p]) {
+                HIP_TRY(hipMemcpy(L.col[p].data(), D.col[p], 4ull * L.nnz[p], hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(L.coef[p].data(), D.coef[p], 32ull * L.nnz[p], hipMemcpyDeviceToHost));
+            }
+        }
+        (void)hipSetDevice(prev);
+    }
+    if (rowptr) *rowptr = L.rp[part].data();
+    if (col) *col = L.col[part].data();
+    if (coeff) *coeff = L.coef[part].data();
     return ECNE_OK;
 }
 void ecne_system_free(ecne_system* sys) {
@@ -1102,8 +1269,9 @@ static int ecne_classify_impl(ecne_system* sys, const ecne_opts* opts, uint32_t*
     Job* d_job = nullptr;
     HIP_TRY(hipMalloc((void**)&d_job, sizeof(Job)));
     sys->dev.classified = false;
-    // restore the host-computed structural words so that repeated calls time the same work
-    (void)hipMemcpy(sys->dev.job.rinfo, sys->L.rinfo.data(), sizeof(RowInfo) * sys->L.rinfo.size(), hipMemcpyHostToDevice);
+    // restore the structural words as the front-end laid them down so that repeated calls time the same work
+    if (sys->dev.lay) (void)hipMemcpy(sys->dev.job.rinfo, sys->dev.lay->dst.rinfo0, sizeof(RowInfo) * (size_t)sys->L.nC, hipMemcpyDeviceToDevice);
+    else (void)hipMemcpy(sys->dev.job.rinfo, sys->L.rinfo.data(), sizeof(RowInfo) * sys->L.rinfo.size(), hipMemcpyHostToDevice);
     st = classify_system(*sys, (hipStream_t)o.stream, d_job);
     (void)hipFree(d_job);
     if (st != K_OK) return st;
@@ -1167,6 +1335,96 @@ int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64
 }
 
 int ecne_set_host_threads(int n) { return (int)set_host_threads(n); }
+
+// rows in DICTIONARY order (what readR1CS / abstraction hand to the solver: explicit zeros and the {1 => 0} placeholder of an empty
+// part included), host copy; borrowed until the system changes
+int ecne_system_dict_rows(ecne_system* sys, int part, const uint64_t** rowptr, const uint32_t** var, const uint64_t** coeff, uint64_t* n_rows) {
+    if (!sys || part < 0 || part > 2) return ECNE_EINVAL;
+    return guarded([&] {
+        { const int rc = sys_host_rows(*sys); if (rc != K_OK) return rc; }
+        const Rows& R = sys->rows();
+        if (rowptr) *rowptr = R.ptr[part].data();
+        if (var) *var = R.var[part].data();
+        if (coeff) *coeff = reinterpret_cast<const uint64_t*>(R.coef[part].data());
+        if (n_rows) *n_rows = R.n();
+        return (int)ECNE_OK;
+    });
+}
+// test hook: a host copy of one static array of the system's device image (uploaded / laid out on `device` first, not classified):
+// 0-2 rp A/B/C, 3-5 col, 6-8 coef, 9 rinfo, 10 fo_ptr, 11 fo_rows, 12 nontrivial, 13 p4_list, 14 p4_b, 15 p4_s, 16 cls_list, 17 tbig,
+// 18 bigrows, 19 long_list, 20 p5_rows, 21 p5_y, 22 rec, 23 foi, 24 {nC, nV, nP4, nP5, nBigCls, nLong, nBigRows, n_vals, device-laid}
+int ecne_debug_static_array(ecne_system* sys, int device, int which, const void** data, size_t* bytes) {
+    if (!sys || !data || !bytes) return ECNE_EINVAL;
+    return guarded([&] {
+        if (ecne_device_count() <= device) return (int)ECNE_ENODEVICE;
+        const int prev = current_device();
+        int rc = upload_system(*sys, device);
+        if (rc != K_OK) { (void)hipSetDevice(prev); return rc; }
+        const Job& J = sys->dev.job;
+        const Layout& L = sys->L;
+        const void* src = nullptr;
+        size_t n = 0;
+        const size_t nC = L.nC, nvar2 = (size_t)L.nV + 2;
+        switch (which) {
+            case 0: src = J.rpA; n = 4 * (nC + 1); break;
+            case 1: src = J.rpB; n = 4 * (nC + 1); break;
+            case 2: src = J.rpC; n = 4 * (nC + 1); break;
+            case 3: src = J.colA; n = 4 * L.nnz[0]; break;
+            case 4: src = J.colB; n = 4 * L.nnz[1]; break;
+            case 5: src = J.colC; n = 4 * L.nnz[2]; break;
+            case 6: src = J.coefA; n = 32 * L.nnz[0]; break;
+            case 7: src = J.coefB; n = 32 * L.nnz[1]; break;
+            case 8: src = J.coefC; n = 32 * L.nnz[2]; break;
+            case 9: src = sys->dev.lay ? sys->dev.lay->dst.rinfo0 : nullptr; n = sizeof(RowInfo) * nC; break;
+            case 10: src = J.fo_ptr; n = 4 * nvar2; break;
+            case 11: src = J.fo_rows; n = 4 * (size_t)L.fo_total; break;
+            case 12: src = J.nontrivial; n = (size_t)L.nV + 1; break;
+            case 13: src = J.p4_list; n = 4 * (size_t)L.n_p4; break;
+            case 14: src = J.p4_b; n = 4 * (size_t)L.n_p4; break;
+            case 15: src = J.p4_s; n = 4 * (size_t)L.n_p4; break;
+            case 16: src = J.cls_list; n = 4 * (size_t)L.n_cls; break;
+            case 17: src = J.tbig; n = 2 * nC; break;
+            case 18: src = J.bigrows; n = 4 * (size_t)J.nBigRows; break;
+            case 19: src = J.long_list; n = 4 * (size_t)J.nLong; break;
+            case 20: src = J.p5_rows; n = 4 * (size_t)L.n_p5; break;
+            case 21: src = J.p5_y; n = 4 * (size_t)L.n_p5; break;
+            case 22: src = J.rec; n = 64 * nC; break;
+            case 23: src = J.foi; n = 16 * nvar2; break;
+            case 24: break;
+            default: (void)hipSetDevice(prev); return (int)ECNE_EINVAL;
+        }
+        std::vector<int64_t>& buf = sys->order_buf;
+        if (which == 24) {
+            const int64_t v[9] = {(int64_t)J.nC, (int64_t)J.nV, (int64_t)J.nP4, (int64_t)J.nP5, (int64_t)J.nBigCls, (int64_t)J.nLong, (int64_t)J.nBigRows,
+                                  (int64_t)L.n_vals, sys->dev.lay ? 1 : 0};
+            buf.assign(v, v + 9);
+            n = sizeof v;
+        } else if (which == 9 && !sys->dev.lay) {      // host layout: the structural words are the host's copy
+            buf.assign((n + 7) / 8, 0);
+            std::memcpy(buf.data(), L.rinfo.data(), n);
+        } else {
+            buf.assign((n + 7) / 8, 0);
+            if (n && hipMemcpy(buf.data(), src, n, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(prev); return (int)ECNE_ENODEVICE; }
+        }
+        (void)hipSetDevice(prev);
+        *data = buf.data();
+        *bytes = n;
+        return (int)ECNE_OK;
+    });
+}
+int ecne_set_frontend(int mode) {
+    if (mode >= 0 && mode <= 2) frontend_setting().store(mode, std::memory_order_relaxed);
+    return frontend_setting().load(std::memory_order_relaxed);
+}
+int ecne_frontend_stats(double* out16) {
+    if (!out16) return ECNE_EINVAL;
+    const FrontendStats& f = g_fe_stats;
+    const double v[16] = {(double)f.parse_dev, f.parse.upload_ms, f.parse.offsets_ms, f.parse.fill_ms, f.parse.total_ms, (double)f.parse.file_bytes,
+                          (double)f.abs_dev, f.abs.prep_ms, f.abs.fp_ms, f.abs.scan_ms, f.abs.verify_ms, f.abs.compact_ms, (double)f.abs.n_cand,
+                          (double)f.abs.n_matched + 1e6 * (double)f.abs.n_host_verified, (double)f.layout_dev, f.layout_ms};
+    for (int i = 0; i < 16; ++i) out16[i] = v[i];
+    return ECNE_OK;
+}
 int ecne_abstract_stats(double* out6) {
     if (!out6) return ECNE_EINVAL;
     const AbstractStats& st = g_last_abstract;
@@ -1184,8 +1442,10 @@ static void row_variables_in_set_order(const Rows& R, size_t i, jl::SlotTable& s
     set.for_each([&](int64_t key, int64_t) { out.push_back(key); });
 }
 int ecne_system_report_order(ecne_system* sys, int64_t row, const int64_t** vars, size_t* n) {
-    if (!sys || row < 0 || (uint64_t)row > sys->rows().n()) return ECNE_EINVAL;
+    if (!sys || row < 0) return ECNE_EINVAL;
     return guarded([&] {
+        { const int rc = sys_host_rows(*sys); if (rc != K_OK) return rc; }
+        if ((uint64_t)row > sys->rows().n()) return (int)ECNE_EINVAL;
         const Rows& R = sys->rows();
         std::vector<int64_t>& out = sys->order_buf;
         out.clear();

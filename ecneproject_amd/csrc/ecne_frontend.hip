@@ -1,0 +1,832 @@
+// ecne_frontend.hip — host orchestration of the device front-end (second translation unit of libecne_hip; kernels in
+// frontend.hip.hpp and abstract.hip.hpp, interface in frontend.hpp). Nothing here evaluates a propagation rule.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <unordered_map>
+
+#include "abstract.hip.hpp"
+#include "frontend.hip.hpp"
+
+namespace ecne {
+namespace fe {
+
+#define FE_TRY(x)                                      \
+    do {                                               \
+        hipError_t e_ = (x);                           \
+        if (e_ != hipSuccess) return K_ENODEVICE;      \
+    } while (0)
+
+namespace {
+struct DeviceGuard {      // the front-end works on the device it is told to and leaves the caller's current device alone
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+struct DevMem {      // one allocation, carved
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    ~DevMem() { if (base) (void)hipFree(base); }
+    int alloc(size_t bytes) {
+        cap = bytes + 256;
+        return hipMalloc((void**)&base, cap) == hipSuccess ? K_OK : K_ENODEVICE;
+    }
+    template <class T> T* take(size_t n) {
+        const size_t o = off;
+        off += (n * sizeof(T) + 255) & ~(size_t)255;
+        return off <= cap ? reinterpret_cast<T*>(base + o) : nullptr;
+    }
+    static size_t sz(size_t n, size_t elem) { return (n * elem + 255) & ~(size_t)255; }
+};
+double ms_since(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+}
+inline unsigned blocks(uint64_t n, unsigned per = 256) { return (unsigned)std::max<uint64_t>(1, (n + per - 1) / per); }
+
+// exclusive scan of n u32 (in place allowed); tops: scratch of ceil(n / 1024) + 1 words; total (device word) optional
+void scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tops, uint32_t* total, hipStream_t s) {
+    if (n == 0) { if (total) (void)hipMemsetAsync(total, 0, 4, s); return; }
+    const uint32_t nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, in, n, out, tops);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(256), 0, s, tops, nb, total);
+    if (nb > 1) hipLaunchKernelGGL(k_scan_add, dim3(blocks(n)), dim3(256), 0, s, out, n, (const uint32_t*)tops);
+}
+uint32_t pow2_ge(uint64_t x, uint32_t lo) {
+    uint64_t p = lo;
+    while (p < x) p <<= 1;
+    return (uint32_t)std::min<uint64_t>(p, 0x80000000ull);
+}
+AbsRowsDev view(const DevRows& D) {
+    AbsRowsDev R;
+    for (int p = 0; p < 3; ++p) { R.ptr[p] = D.ptr[p]; R.var[p] = D.var[p]; R.coef[p] = D.coef[p]; }
+    return R;
+}
+// arrays of a DevRows with `n` rows and `terms[p]` entries, carved from one allocation
+int alloc_rows(DevRows& D, int device, uint64_t n, const uint64_t terms[3]) {
+    D.device = device;
+    D.n = n;
+    size_t bytes = 0;
+    for (int p = 0; p < 3; ++p) bytes += DevMem::sz(n + 1, 8) + DevMem::sz(std::max<uint64_t>(terms[p], 1), 4) + DevMem::sz(std::max<uint64_t>(terms[p], 1), 32);
+    FE_TRY(hipMalloc(&D.arena, bytes + 256));
+    D.arena_bytes = bytes + 256;
+    char* b = (char*)D.arena;
+    size_t off = 0;
+    for (int p = 0; p < 3; ++p) {
+        D.ptr[p] = (uint64_t*)(b + off); off += DevMem::sz(n + 1, 8);
+        D.var[p] = (uint32_t*)(b + off); off += DevMem::sz(std::max<uint64_t>(terms[p], 1), 4);
+        D.coef[p] = (uint64_t*)(b + off); off += DevMem::sz(std::max<uint64_t>(terms[p], 1), 32);
+        D.terms[p] = terms[p];
+    }
+    return K_OK;
+}
+FeRowsOut out_view(DevRows& D) {
+    FeRowsOut O;
+    for (int p = 0; p < 3; ++p) { O.ptr[p] = D.ptr[p]; O.var[p] = D.var[p]; O.coef[p] = D.coef[p]; }
+    return O;
+}
+}  // namespace
+
+DevRows::~DevRows() {
+    if (arena) {
+        DeviceGuard g(device);
+        (void)hipFree(arena);
+    }
+}
+
+// ====================================================================================== parse
+int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device, std::shared_ptr<DevRows>& out, ParseStats& st) {
+    st = ParseStats();
+    const auto t_all = std::chrono::steady_clock::now();
+    if (len >= ((size_t)1 << 32) - 4096) return FE_FALLBACK;
+    const uint64_t total64 = 3ull * n_cons;
+    if (total64 * 4 > len) return K_EFORMAT;                 // every part needs its 4-byte count
+    DeviceGuard guard(device);
+    if (!guard.ok) return K_ENODEVICE;
+    auto D = std::make_shared<DevRows>();
+    const uint32_t nC = n_cons, total = (uint32_t)total64;
+    if (nC == 0) {
+        const uint64_t z[3] = {0, 0, 0};
+        { const int rc = alloc_rows(*D, device, 0, z); if (rc != K_OK) return rc; }
+        for (int p = 0; p < 3; ++p) FE_TRY(hipMemset(D->ptr[p], 0, 8));
+        out = D;
+        return K_OK;
+    }
+    const uint32_t NW = (uint32_t)((len + 3) / 4);
+    const uint32_t nchunks = (NW + FE_CH - 1) / FE_CH, ntiles = (NW + FE_TILE_W - 1) / FE_TILE_W;
+    // file words + scratch of the offset passes
+    DevMem m;
+    {
+        size_t b = DevMem::sz((size_t)NW + 16, 4) + 2 * DevMem::sz(NW, 8) + DevMem::sz(ntiles, 8) + DevMem::sz(nchunks, 8) + DevMem::sz(total, 4)
+                 + 2 * DevMem::sz(3 * ((size_t)nC + 1), 4) + 2 * DevMem::sz(total, 4) + DevMem::sz((size_t)nC / 1024 + 8, 4) + 4 * 256 + DevMem::sz(3 * ((size_t)nC + 1), 4);
+        const int rc = m.alloc(b);
+        if (rc != K_OK) return rc;
+    }
+    uint32_t* W = m.take<uint32_t>((size_t)NW + 16);
+    uint64_t* E1 = m.take<uint64_t>(NW);
+    uint64_t* E2 = m.take<uint64_t>(NW);
+    uint64_t* tile_entry = m.take<uint64_t>(ntiles);
+    uint64_t* chunk_entry = m.take<uint64_t>(nchunks);
+    uint32_t* poff = m.take<uint32_t>(total);
+    uint32_t* cnt = m.take<uint32_t>(3 * ((size_t)nC + 1));      // term counts -> positions (exclusive scan, in place)
+    uint32_t* lenA = m.take<uint32_t>(3 * ((size_t)nC + 1));     // entries every part really came out with
+    uint32_t* midlist = m.take<uint32_t>(total);
+    uint32_t* largelist = m.take<uint32_t>(total);
+    uint32_t* tops = m.take<uint32_t>((size_t)nC / 1024 + 8);
+    FeMeta* M = m.take<FeMeta>(1);
+    uint64_t* final_state = m.take<uint64_t>(2);
+    uint32_t* totals = m.take<uint32_t>(4);
+    uint32_t* npos = m.take<uint32_t>(3 * ((size_t)nC + 1));
+    if (!npos) return K_ECAPACITY;
+    hipStream_t s = 0;
+    const auto t_up = std::chrono::steady_clock::now();
+    FE_TRY(hipMemsetAsync(W + (NW - 1), 0, 4 * 17, s));           // the last (partial) word and the pad
+    FE_TRY(hipMemcpy(W, cons, len, hipMemcpyHostToDevice));
+    st.upload_ms = ms_since(t_up);
+    st.file_bytes = len;
+    const auto t_off = std::chrono::steady_clock::now();
+    FE_TRY(hipMemsetAsync(tile_entry, 0xFF, 8ull * ntiles, s));
+    FE_TRY(hipMemsetAsync(chunk_entry, 0xFF, 8ull * nchunks, s));
+    FE_TRY(hipMemsetAsync(M, 0, sizeof(FeMeta), s));
+    FE_TRY(hipMemsetAsync(cnt, 0, 12ull * ((size_t)nC + 1), s));
+    FE_TRY(hipMemsetAsync(lenA, 0, 12ull * ((size_t)nC + 1), s));
+    {
+        FeMeta h;
+        std::memset(&h, 0, sizeof h);
+        h.err_idx = 0xFFFFFFFFu;
+        FE_TRY(hipMemcpyAsync(M, &h, sizeof h, hipMemcpyHostToDevice, s));
+        FE_TRY(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_fe_exit1, dim3(std::min<uint32_t>(nchunks, 256 * 32)), dim3(256), 0, s, (const uint32_t*)W, NW, E1);
+    hipLaunchKernelGGL(k_fe_exit2, dim3(std::min<uint32_t>(ntiles, 256 * 8)), dim3(256), 0, s, (const uint64_t*)E1, E2, NW);
+    hipLaunchKernelGGL(k_fe_chain, dim3(1), dim3(64), 0, s, (const uint64_t*)E2, NW, total, tile_entry, final_state);
+    hipLaunchKernelGGL(k_fe_chunk_entries, dim3(blocks(ntiles)), dim3(256), 0, s, (const uint64_t*)E1, (const uint64_t*)tile_entry, chunk_entry, NW, total);
+    hipLaunchKernelGGL(k_fe_part_offsets, dim3(blocks(nchunks)), dim3(256), 0, s, (const uint32_t*)W, (const uint64_t*)chunk_entry, poff, NW, (uint64_t)len, total, &M->err_idx);
+    uint64_t fin[2];
+    FeMeta hm;
+    FE_TRY(hipMemcpy(fin, final_state, 16, hipMemcpyDeviceToHost));
+    FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
+    FE_TRY(hipGetLastError());
+    if (hm.err_idx != 0xFFFFFFFFu || fin[1] < total) return K_EFORMAT;      // the walk leaves the file
+    hipLaunchKernelGGL(k_fe_terms, dim3(blocks(total)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, cnt, midlist, largelist, M);
+    for (int p = 0; p < 3; ++p) scan_u32(cnt + (size_t)p * (nC + 1), cnt + (size_t)p * (nC + 1), nC + 1, tops, totals + p, s);
+    uint32_t ht[4];
+    FE_TRY(hipMemcpy(ht, totals, 12, hipMemcpyDeviceToHost));
+    FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
+    st.offsets_ms = ms_since(t_off);
+    if (hm.maxn >= (1u << 18)) return FE_FALLBACK;
+    const auto t_fill = std::chrono::steady_clock::now();
+    const uint64_t terms[3] = {ht[0], ht[1], ht[2]};
+    { const int rc = alloc_rows(*D, device, nC, terms); if (rc != K_OK) return rc; }
+    FeRowsOut O = out_view(*D);
+    hipLaunchKernelGGL(k_fe_fill_small, dim3(blocks(total)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, (const uint32_t*)cnt, O, lenA, M);
+    if (hm.n_mid)
+        hipLaunchKernelGGL(k_fe_fill_big<true>, dim3(std::min<uint32_t>((hm.n_mid + 3) / 4, 256 * 8)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff,
+                           (const uint32_t*)midlist, hm.n_mid, nC, (const uint32_t*)cnt, O, lenA, M, (uint32_t*)nullptr, 0u);
+    DevMem big;
+    if (hm.n_large) {
+        const uint32_t gcap = pow2_ge(8ull * hm.maxn, 1024);
+        const uint32_t g = std::min<uint32_t>((hm.n_large + 3) / 4, 64);
+        { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
+        hipLaunchKernelGGL(k_fe_fill_big<false>, dim3(g), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, (const uint32_t*)largelist, hm.n_large, nC,
+                           (const uint32_t*)cnt, O, lenA, M, (uint32_t*)big.base, gcap);
+    }
+    hipLaunchKernelGGL(k_fe_ptr, dim3(blocks((uint64_t)nC + 1)), dim3(256), 0, s, (const uint32_t*)cnt, nC, O);
+    FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
+    FE_TRY(hipGetLastError());
+    if (hm.unsupported) return FE_FALLBACK;
+    if (hm.dup) {      // some part repeated a wire id: close the gaps it left
+        for (int p = 0; p < 3; ++p) scan_u32(lenA + (size_t)p * (nC + 1), npos + (size_t)p * (nC + 1), nC + 1, tops, totals + p, s);
+        FE_TRY(hipMemcpy(ht, totals, 12, hipMemcpyDeviceToHost));
+        auto D2 = std::make_shared<DevRows>();
+        const uint64_t t2[3] = {ht[0], ht[1], ht[2]};
+        { const int rc = alloc_rows(*D2, device, nC, t2); if (rc != K_OK) return rc; }
+        FeRowsOut O2 = out_view(*D2);
+        hipLaunchKernelGGL(k_fe_close_gaps, dim3(blocks(total)), dim3(256), 0, s, nC, (const uint32_t*)cnt, (const uint32_t*)npos, (const uint32_t*)lenA, O, O2);
+        hipLaunchKernelGGL(k_fe_ptr, dim3(blocks((uint64_t)nC + 1)), dim3(256), 0, s, (const uint32_t*)npos, nC, O2);
+        FE_TRY(hipStreamSynchronize(s));
+        D = D2;
+    }
+    for (int p = 0; p < 3; ++p) D->nnz[p] = hm.nnz[p];
+    FE_TRY(hipStreamSynchronize(s));
+    FE_TRY(hipGetLastError());
+    st.fill_ms = ms_since(t_fill);
+    st.total_ms = ms_since(t_all);
+    out = D;
+    return K_OK;
+}
+
+int download_rows(const DevRows& D, Rows& out) {
+    DeviceGuard guard(D.device);
+    if (!guard.ok) return K_ENODEVICE;
+    for (int p = 0; p < 3; ++p) {
+        out.ptr[p].resize(D.n + 1);
+        out.var[p].resize(D.terms[p]);
+        out.coef[p].resize(D.terms[p]);
+        FE_TRY(hipMemcpy(out.ptr[p].data(), D.ptr[p], 8ull * (D.n + 1), hipMemcpyDeviceToHost));
+        if (D.terms[p]) {
+            FE_TRY(hipMemcpy(out.var[p].data(), D.var[p], 4ull * D.terms[p], hipMemcpyDeviceToHost));
+            FE_TRY(hipMemcpy(out.coef[p].data(), D.coef[p], 32ull * D.terms[p], hipMemcpyDeviceToHost));
+        }
+    }
+    return K_OK;
+}
+
+// ====================================================================================== abstraction
+namespace {
+struct PatternHostDev {      // host image of AbsPattern
+    uint32_t nS = 0, nvS = 0, nEnt = 0, nclass = 0, capP = 0, nio = 0;
+    std::vector<uint32_t> ent_cnt0, ent_var, part_nz, tab_class, class_start, class_members, io_idx;
+    std::vector<uint64_t> ent_coef, tab_h1, tab_h2;
+    bool io_tied = false;      // a mapped input / output shares its signature with another variable: the reference breaks the
+                               // tie by hash-table order of the WINDOW's variables -- host path
+};
+void build_pattern(const R1CSFile& sub, PatternHostDev& P) {
+    const Rows& R = sub.rows;
+    P.nS = (uint32_t)R.n();
+    std::unordered_map<uint32_t, uint32_t> dense;
+    std::vector<uint64_t> h1, h2;
+    P.part_nz.assign(3ull * P.nS, 0);
+    for (uint32_t j = 0; j < P.nS; ++j)
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t q = 3 * j + (uint32_t)p;
+            for (uint64_t k = R.ptr[p][j]; k < R.ptr[p][j + 1]; ++k) {
+                if (fp::is_zero(R.coef[p][k])) continue;
+                auto it = dense.find(R.var[p][k]);
+                uint32_t u;
+                if (it == dense.end()) { u = (uint32_t)dense.size(); dense.emplace(R.var[p][k], u); h1.push_back(0); h2.push_back(0); }
+                else u = it->second;
+                uint64_t a, b;
+                sig_hash((uint64_t)q + 1ull, R.coef[p][k].w, a, b);
+                h1[u] += a; h2[u] += b;
+                P.ent_cnt0.push_back(q);
+                P.ent_var.push_back(u);
+                for (int w = 0; w < 4; ++w) P.ent_coef.push_back(R.coef[p][k].w[w]);
+                P.part_nz[q]++;
+            }
+        }
+    P.nvS = (uint32_t)dense.size();
+    P.nEnt = (uint32_t)P.ent_var.size();
+    // classes of equal signature hash
+    struct Key { uint64_t a, b; bool operator==(const Key& o) const { return a == o.a && b == o.b; } };
+    struct KeyHash { size_t operator()(const Key& k) const { return (size_t)sig_mix(k.a ^ (k.b * 0x9e3779b97f4a7c15ULL)); } };
+    std::unordered_map<Key, uint32_t, KeyHash> cls;
+    std::vector<uint32_t> cls_of(P.nvS), cls_size;
+    for (uint32_t u = 0; u < P.nvS; ++u) {
+        auto it = cls.find(Key{h1[u], h2[u]});
+        if (it == cls.end()) { cls_of[u] = (uint32_t)cls_size.size(); cls.emplace(Key{h1[u], h2[u]}, cls_of[u]); cls_size.push_back(1); }
+        else { cls_of[u] = it->second; cls_size[it->second]++; }
+    }
+    P.nclass = (uint32_t)cls_size.size();
+    P.class_start.assign(P.nclass + 1, 0);
+    for (uint32_t c = 0; c < P.nclass; ++c) P.class_start[c + 1] = P.class_start[c] + cls_size[c];
+    P.class_members.resize(P.nvS);
+    {
+        std::vector<uint32_t> fill(P.class_start.begin(), P.class_start.end() - 1);
+        for (uint32_t u = 0; u < P.nvS; ++u) P.class_members[fill[cls_of[u]]++] = u;
+    }
+    P.capP = pow2_ge(2ull * P.nclass + 2, 16);
+    P.tab_h1.assign(P.capP, 0); P.tab_h2.assign(P.capP, 0); P.tab_class.assign(P.capP, 0);
+    for (auto& kv : cls) {
+        uint32_t t = (uint32_t)(sig_mix(kv.first.a ^ (kv.first.b * 0x9e3779b97f4a7c15ULL)) & (P.capP - 1));
+        while (P.tab_class[t]) t = (t + 1) & (P.capP - 1);
+        P.tab_class[t] = kv.second + 1;
+        P.tab_h1[t] = kv.first.a;
+        P.tab_h2[t] = kv.first.b;
+    }
+    auto io = [&](int64_t x) {
+        auto it = x >= 0 && x <= 0xFFFFFFFFll ? dense.find((uint32_t)x) : dense.end();
+        if (it == dense.end()) { P.io_idx.push_back(0xFFFFFFFFu); return; }
+        P.io_idx.push_back(it->second);
+        if (cls_size[cls_of[it->second]] != 1) P.io_tied = true;
+    };
+    for (int64_t x : sub.knowns) if (x != 1) io(x);
+    for (int64_t x : sub.outputs) io(x);
+    P.nio = (uint32_t)P.io_idx.size();
+}
+template <class T>
+int upload_vec(DevMem& m, const std::vector<T>& v, const T*& d) {
+    T* p = m.take<T>(std::max<size_t>(v.size(), 1));
+    if (!p) return K_ECAPACITY;
+    if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return K_ENODEVICE;
+    d = p;
+    return K_OK;
+}
+}  // namespace
+
+// candidate window starts by fingerprint + weighted prefix scan (abstract.hip.hpp); `sub` uploaded from the host
+static int candidates_dev(const AbsRowsDev& Rm, uint64_t nC, const Rows& sub, std::vector<size_t>& cand, AbstractDevStats& st) {
+    const uint64_t nS = sub.n();
+    cand.clear();
+    if (nC >= 0xFFFFFFF0ull) return FE_FALLBACK;
+    DevMem m;
+    const uint64_t nb = (nC + 1 + 1023) / 1024;
+    size_t bytes = DevMem::sz(nC + 1, 8) * 2 + DevMem::sz(nS, 8) + DevMem::sz(nb, 8) + DevMem::sz(nC, 4) + 256;
+    for (int p = 0; p < 3; ++p) bytes += DevMem::sz(nS + 1, 8) + DevMem::sz(std::max<size_t>(sub.coef[p].size(), 1), 32);
+    { const int rc = m.alloc(bytes); if (rc != K_OK) return rc; }
+    AbsRows M, S;
+    M.n = nC; S.n = nS;
+    for (int p = 0; p < 3; ++p) {
+        M.ptr[p] = Rm.ptr[p]; M.coef[p] = Rm.coef[p];
+        uint64_t* sp = m.take<uint64_t>(nS + 1);
+        uint64_t* sc = m.take<uint64_t>(4 * std::max<size_t>(sub.coef[p].size(), 1));
+        FE_TRY(hipMemcpy(sp, sub.ptr[p].data(), 8ull * (nS + 1), hipMemcpyHostToDevice));
+        if (!sub.coef[p].empty()) FE_TRY(hipMemcpy(sc, sub.coef[p].data(), 32ull * sub.coef[p].size(), hipMemcpyHostToDevice));
+        S.ptr[p] = sp; S.coef[p] = sc;
+    }
+    uint64_t* bf = m.take<uint64_t>(nC + 1);
+    uint64_t* bP = m.take<uint64_t>(nC + 1);
+    uint64_t* bfs = m.take<uint64_t>(nS);
+    uint64_t* btops = m.take<uint64_t>(nb);
+    uint32_t* bcand = m.take<uint32_t>(nC);
+    unsigned long long* bn = m.take<unsigned long long>(1);
+    if (!bn) return K_ECAPACITY;
+    FE_TRY(hipMemset(bn, 0, 8));
+    FE_TRY(hipMemset(bf + nC, 0, 8));
+    hipEvent_t e[4];
+    for (auto& x : e) FE_TRY(hipEventCreate(&x));
+    struct Ev { hipEvent_t* e; ~Ev() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); } } ev{e};
+    const unsigned g_rows = (unsigned)std::min<uint64_t>((nC + 255) / 256, 256 * 16), g_sub = (unsigned)std::min<uint64_t>((nS + 255) / 256, 256 * 16);
+    FE_TRY(hipEventRecord(e[0], 0));
+    hipLaunchKernelGGL(k_abs_fingerprint, dim3(g_rows), dim3(256), 0, 0, M, bf);
+    FE_TRY(hipEventRecord(e[1], 0));
+    hipLaunchKernelGGL(k_abs_fingerprint, dim3(g_sub), dim3(256), 0, 0, S, bfs);
+    std::vector<uint64_t> fs(nS);
+    FE_TRY(hipMemcpy(fs.data(), bfs, 8ull * nS, hipMemcpyDeviceToHost));
+    uint64_t T = 0, w = 1;
+    for (uint64_t j = 0; j + 1 < nS; ++j) { T += fs[j] * w; w *= ECNE_ABS_R; }
+    FE_TRY(hipEventRecord(e[2], 0));
+    hipLaunchKernelGGL(k_abs_weighted_scan, dim3((unsigned)nb), dim3(256), 0, 0, (const uint64_t*)bf, nC + 1, bP, btops);
+    hipLaunchKernelGGL(k_abs_scan_tops, dim3(1), dim3(256), 0, 0, btops, nb);
+    hipLaunchKernelGGL(k_abs_candidates, dim3(g_rows), dim3(256), 0, 0, (const uint64_t*)bP, (const uint64_t*)btops, nC, nS - 1, nS, T, bcand, bn, nC);
+    FE_TRY(hipEventRecord(e[3], 0));
+    FE_TRY(hipEventSynchronize(e[3]));
+    FE_TRY(hipGetLastError());
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, e[0], e[1]);
+    (void)hipEventElapsedTime(&b, e[2], e[3]);
+    st.fp_ms = a; st.scan_ms = b;
+    for (int p = 0; p < 3; ++p) st.bytes += 8ull * (nC + 1);
+    unsigned long long n = 0;
+    FE_TRY(hipMemcpy(&n, bn, 8, hipMemcpyDeviceToHost));
+    if (n > nC) return K_ECAPACITY;
+    std::vector<uint32_t> c32((size_t)n);
+    if (n) FE_TRY(hipMemcpy(c32.data(), bcand, 4ull * n, hipMemcpyDeviceToHost));
+    std::sort(c32.begin(), c32.end());
+    cand.assign(c32.begin(), c32.end());
+    st.n_cand = cand.size();
+    return K_OK;
+}
+
+// the same scan for a system whose rows live on the host (what ecne_abstract did before the device front-end existed):
+// uploads the coefficients first
+int candidates_for_host_rows(const Rows& rows, const Rows& sub, int device, std::vector<size_t>& cand, AbstractDevStats& st, double& upload_ms) {
+    st = AbstractDevStats();
+    cand.clear();
+    const uint64_t nC = rows.n(), nS = sub.n();
+    if (nS == 0) return FE_FALLBACK;            // (the host scan treats an empty pattern its own way)
+    if (nC < nS) return K_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return K_ENODEVICE;
+    DevMem m;
+    size_t bytes = 256;
+    for (int p = 0; p < 3; ++p) bytes += DevMem::sz(nC + 1, 8) + DevMem::sz(std::max<size_t>(rows.coef[p].size(), 1), 32);
+    { const int rc = m.alloc(bytes); if (rc != K_OK) return rc; }
+    AbsRowsDev R;
+    const auto t_up = std::chrono::steady_clock::now();
+    for (int p = 0; p < 3; ++p) {
+        uint64_t* dp = m.take<uint64_t>(nC + 1);
+        uint64_t* dc = m.take<uint64_t>(4 * std::max<size_t>(rows.coef[p].size(), 1));
+        FE_TRY(hipMemcpy(dp, rows.ptr[p].data(), 8ull * (nC + 1), hipMemcpyHostToDevice));
+        if (!rows.coef[p].empty()) FE_TRY(hipMemcpy(dc, rows.coef[p].data(), 32ull * rows.coef[p].size(), hipMemcpyHostToDevice));
+        R.ptr[p] = dp; R.coef[p] = dc; R.var[p] = nullptr;
+        st.bytes += 32ull * rows.coef[p].size();
+    }
+    upload_ms = ms_since(t_up);
+    return candidates_dev(R, nC, sub, cand, st);
+}
+
+int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& rows, const R1CSFile& sub, std::vector<Special>& specials,
+                       std::shared_ptr<DevRows>& red, AbstractDevStats& st) {
+    st = AbstractDevStats();
+    const uint64_t nC = rows->n, nS = sub.rows.n();
+    if (nS == 0 || nS >= 0x40000000ull) return FE_FALLBACK;
+    if (nC < nS) { red = rows; return K_OK; }
+    DeviceGuard guard(rows->device);
+    if (!guard.ok) return K_ENODEVICE;
+    const auto t_prep = std::chrono::steady_clock::now();
+    PatternHostDev PH;
+    build_pattern(sub, PH);
+    st.prep_ms = ms_since(t_prep);
+    if (PH.io_tied) return FE_FALLBACK;
+    const AbsRowsDev R = view(*rows);
+    std::vector<size_t> cand;
+    { const int rc = candidates_dev(R, nC, sub.rows, cand, st); if (rc != K_OK) return rc; }
+    for (int p = 0; p < 3; ++p) st.bytes += 32ull * rows->terms[p];
+    std::vector<uint8_t> matched(cand.size(), 0);
+    std::vector<uint32_t> io_img((size_t)cand.size() * std::max<uint32_t>(PH.nio, 1), 0xFFFFFFFFu);
+    const auto t_ver = std::chrono::steady_clock::now();
+    if (!cand.empty()) {
+        // pattern to the device
+        DevMem pm;
+        size_t pb = 4096;
+        pb += DevMem::sz(PH.nEnt + 1, 4) * 2 + DevMem::sz(4ull * PH.nEnt + 4, 8) + DevMem::sz(3ull * PH.nS + 1, 4) + DevMem::sz(PH.capP, 8) * 2 + DevMem::sz(PH.capP, 4)
+            + DevMem::sz(PH.nclass + 2, 4) + DevMem::sz(PH.nvS + 1, 4) + DevMem::sz(PH.nio + 1, 4);
+        { const int rc = pm.alloc(pb); if (rc != K_OK) return rc; }
+        AbsPattern P;
+        P.nS = PH.nS; P.nvS = PH.nvS; P.nEnt = PH.nEnt; P.nclass = PH.nclass; P.capP = PH.capP; P.nio = PH.nio;
+        int rc = K_OK;
+        if ((rc = upload_vec(pm, PH.ent_cnt0, P.ent_cnt0)) || (rc = upload_vec(pm, PH.ent_var, P.ent_var)) || (rc = upload_vec(pm, PH.ent_coef, P.ent_coef)) ||
+            (rc = upload_vec(pm, PH.part_nz, P.part_nz)) || (rc = upload_vec(pm, PH.tab_h1, P.tab_h1)) || (rc = upload_vec(pm, PH.tab_h2, P.tab_h2)) ||
+            (rc = upload_vec(pm, PH.tab_class, P.tab_class)) || (rc = upload_vec(pm, PH.class_start, P.class_start)) ||
+            (rc = upload_vec(pm, PH.class_members, P.class_members)) || (rc = upload_vec(pm, PH.io_idx, P.io_idx)))
+            return rc;
+        // windows in batches bounded by scratch memory
+        const uint32_t capW = pow2_ge(4ull * PH.nvS + 64, 64);
+        const size_t per_win = (size_t)capW * 24 + 4ull * PH.nclass + 4ull * PH.nvS + 4ull * PH.nio + 64;
+        const size_t batch = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(cand.size(), 32768), ((size_t)1 << 30) / per_win));
+        DevMem wm;
+        {
+            const size_t wb = DevMem::sz(batch, 4) * 4 + DevMem::sz(batch * capW, 8) * 3 + DevMem::sz(batch * std::max<uint32_t>(PH.nclass, 1), 4) + DevMem::sz(batch * std::max<uint32_t>(PH.nvS, 1), 4) +
+                              DevMem::sz(batch * std::max<uint32_t>(PH.nio, 1), 4) + 4096;
+            const int rc2 = wm.alloc(wb);
+            if (rc2 != K_OK) return rc2;
+        }
+        AbsWindows Wn;
+        Wn.capW = capW;
+        uint32_t* d_start = wm.take<uint32_t>(batch);
+        Wn.start = d_start;
+        Wn.wkey = wm.take<unsigned long long>(batch * capW);
+        Wn.wh1 = wm.take<unsigned long long>(batch * capW);
+        Wn.wh2 = wm.take<unsigned long long>(batch * capW);
+        Wn.ccount = wm.take<uint32_t>(batch * std::max<uint32_t>(PH.nclass, 1));
+        Wn.phi = wm.take<uint32_t>(batch * std::max<uint32_t>(PH.nvS, 1));
+        Wn.nvars = wm.take<uint32_t>(batch);
+        Wn.nmatched = wm.take<uint32_t>(batch);
+        Wn.status = wm.take<uint32_t>(batch);
+        Wn.io_out = wm.take<uint32_t>(batch * std::max<uint32_t>(PH.nio, 1));
+        if (!Wn.io_out) return K_ECAPACITY;
+        std::vector<uint32_t> h_start(batch), h_status(batch), h_nv(batch), h_nm(batch), h_io(batch * std::max<uint32_t>(PH.nio, 1));
+        std::vector<size_t> ambiguous;
+        for (size_t b0 = 0; b0 < cand.size(); b0 += batch) {
+            const uint32_t nb = (uint32_t)std::min(batch, cand.size() - b0);
+            for (uint32_t i = 0; i < nb; ++i) h_start[i] = (uint32_t)cand[b0 + i];
+            Wn.nwin = nb;
+            FE_TRY(hipMemcpyAsync(d_start, h_start.data(), 4ull * nb, hipMemcpyHostToDevice, 0));
+            FE_TRY(hipMemsetAsync(Wn.wkey, 0, 8ull * nb * capW, 0));
+            FE_TRY(hipMemsetAsync(Wn.wh1, 0, 8ull * nb * capW, 0));
+            FE_TRY(hipMemsetAsync(Wn.wh2, 0, 8ull * nb * capW, 0));
+            FE_TRY(hipMemsetAsync(Wn.ccount, 0, 4ull * nb * std::max<uint32_t>(PH.nclass, 1), 0));
+            FE_TRY(hipMemsetAsync(Wn.phi, 0xFF, 4ull * nb * std::max<uint32_t>(PH.nvS, 1), 0));
+            FE_TRY(hipMemsetAsync(Wn.nvars, 0, 4ull * nb, 0));
+            FE_TRY(hipMemsetAsync(Wn.nmatched, 0, 4ull * nb, 0));
+            FE_TRY(hipMemsetAsync(Wn.status, 0, 4ull * nb, 0));
+            hipLaunchKernelGGL(k_abs_sig, dim3(blocks(3ull * PH.nS), nb), dim3(256), 0, 0, R, P, Wn);
+            hipLaunchKernelGGL(k_abs_match, dim3(blocks(capW), nb), dim3(256), 0, 0, P, Wn);
+            if (PH.nEnt) hipLaunchKernelGGL(k_abs_exact, dim3(blocks(PH.nEnt), nb), dim3(256), 0, 0, R, P, Wn);
+            if (PH.nio) hipLaunchKernelGGL(k_abs_io, dim3(blocks((uint64_t)nb * PH.nio)), dim3(256), 0, 0, P, Wn);
+            FE_TRY(hipMemcpy(h_status.data(), Wn.status, 4ull * nb, hipMemcpyDeviceToHost));
+            FE_TRY(hipMemcpy(h_nv.data(), Wn.nvars, 4ull * nb, hipMemcpyDeviceToHost));
+            FE_TRY(hipMemcpy(h_nm.data(), Wn.nmatched, 4ull * nb, hipMemcpyDeviceToHost));
+            if (PH.nio) FE_TRY(hipMemcpy(h_io.data(), Wn.io_out, 4ull * nb * PH.nio, hipMemcpyDeviceToHost));
+            FE_TRY(hipGetLastError());
+            for (uint32_t i = 0; i < nb; ++i) {
+                const size_t ci = b0 + i;
+                if ((h_status[i] & 1u) || h_nv[i] != PH.nvS || h_nm[i] != PH.nvS) continue;       // no isomorphism: no match
+                if (h_status[i] & 2u) { ambiguous.push_back(ci); continue; }                        // hashes agreed, the proof failed
+                matched[ci] = 1;
+                for (uint32_t t = 0; t < PH.nio; ++t) io_img[ci * PH.nio + t] = h_io[(size_t)i * PH.nio + t];
+            }
+        }
+        // windows whose signature hashes agreed but whose bijection did not check out (a 128-bit collision): decided by the host
+        // code on a copy of the window
+        if (!ambiguous.empty()) {
+            PatternHost HP;
+            HP.build(sub);
+            detail::AppearMap cur;
+            std::vector<fp::u256> va;
+            for (size_t ci : ambiguous) {
+                Rows win;
+                const uint64_t at = cand[ci];
+                for (int p = 0; p < 3; ++p) {
+                    win.ptr[p].resize(nS + 1);
+                    FE_TRY(hipMemcpy(win.ptr[p].data(), rows->ptr[p] + at, 8ull * (nS + 1), hipMemcpyDeviceToHost));
+                    const uint64_t k0 = win.ptr[p][0], k1 = win.ptr[p][nS];
+                    win.var[p].resize(k1 - k0);
+                    win.coef[p].resize(k1 - k0);
+                    if (k1 > k0) {
+                        FE_TRY(hipMemcpy(win.var[p].data(), rows->var[p] + k0, 4ull * (k1 - k0), hipMemcpyDeviceToHost));
+                        FE_TRY(hipMemcpy(win.coef[p].data(), rows->coef[p] + 4 * k0, 32ull * (k1 - k0), hipMemcpyDeviceToHost));
+                    }
+                    for (auto& x : win.ptr[p]) x -= k0;
+                }
+                std::vector<int64_t> image;
+                if (!verify_window(HP, win, 0, cur, va, image)) continue;
+                matched[ci] = 1;
+                uint32_t t = 0;
+                auto put = [&](int64_t x) {
+                    auto it = HP.where.find(x);
+                    io_img[ci * PH.nio + t++] = it == HP.where.end() ? 0xFFFFFFFFu : (uint32_t)image[it->second];
+                };
+                for (int64_t x : sub.knowns) if (x != 1) put(x);
+                for (int64_t x : sub.outputs) put(x);
+                st.n_host_verified++;
+            }
+        }
+    }
+    st.verify_ms = ms_since(t_ver);
+    for (uint8_t mm : matched) st.n_matched += mm;
+    // greedy replacement (host: a handful of windows), in the order sub.knowns \ {1}, sub.outputs were mapped
+    std::vector<std::pair<size_t, size_t>> keep;
+    std::vector<Special> fresh;
+    size_t cursor_ci = (size_t)-1;
+    uint32_t cursor_t = 0;
+    const int grc = greedy_replace(name, sub, (size_t)nC, cand, matched, [&](size_t ci, int64_t, int64_t& v) {
+        if (ci != cursor_ci) { cursor_ci = ci; cursor_t = 0; }
+        const uint32_t img = io_img[ci * PH.nio + cursor_t++];
+        if (img == 0xFFFFFFFFu) return false;
+        v = (int64_t)img;
+        return true;
+    }, keep, fresh);
+    if (grc != K_OK) return grc;
+    const auto t_cmp = std::chrono::steady_clock::now();
+    if (fresh.empty()) red = rows;      // nothing replaced: the rows are the same rows
+    else {
+        // surviving ranges -> new rows
+        std::vector<uint64_t> ka, kb, row0(1, 0);
+        for (auto& r : keep) { ka.push_back(r.first); kb.push_back(r.second); row0.push_back(row0.back() + (r.second - r.first)); }
+        const uint32_t nk = (uint32_t)ka.size();
+        const uint64_t nrow = row0.back();
+        DevMem km;
+        { const int rc = km.alloc(DevMem::sz(nk + 1, 8) * 16 + 4096); if (rc != K_OK) return rc; }
+        KeepRanges K;
+        K.n = nk;
+        const uint64_t *d_a, *d_b, *d_row0;
+        int rc = K_OK;
+        if ((rc = upload_vec(km, ka, d_a)) || (rc = upload_vec(km, kb, d_b)) || (rc = upload_vec(km, row0, d_row0))) return rc;
+        K.a = d_a; K.b = d_b; K.row0 = d_row0;
+        // ptr[p][a_i], ptr[p][b_i] of every range
+        std::vector<uint64_t> idx;
+        for (uint32_t i = 0; i < nk; ++i) { idx.push_back(ka[i]); idx.push_back(kb[i]); }
+        const uint64_t* d_idx;
+        if ((rc = upload_vec(km, idx, d_idx))) return rc;
+        uint64_t* d_g = km.take<uint64_t>(2ull * nk + 1);
+        if (!d_g) return K_ECAPACITY;
+        std::vector<uint64_t> at[3], src0[3], g(2ull * nk);
+        uint64_t terms[3];
+        for (int p = 0; p < 3; ++p) {
+            if (nk) {
+                hipLaunchKernelGGL(k_fe_gather_u64, dim3(blocks(2ull * nk)), dim3(256), 0, 0, (const uint64_t*)rows->ptr[p], d_idx, 2 * nk, d_g);
+                FE_TRY(hipMemcpy(g.data(), d_g, 16ull * nk, hipMemcpyDeviceToHost));
+            }
+            at[p].assign(1, 0);
+            for (uint32_t i = 0; i < nk; ++i) { src0[p].push_back(g[2 * i]); at[p].push_back(at[p].back() + (g[2 * i + 1] - g[2 * i])); }
+            terms[p] = at[p].back();
+        }
+        auto D = std::make_shared<DevRows>();
+        { const int rc2 = alloc_rows(*D, rows->device, nrow, terms); if (rc2 != K_OK) return rc2; }
+        for (int p = 0; p < 3; ++p) {
+            const uint64_t *d_at, *d_s0;
+            if ((rc = upload_vec(km, at[p], d_at)) || (rc = upload_vec(km, src0[p], d_s0))) return rc;
+            K.at[p] = d_at; K.src0[p] = d_s0;
+        }
+        FeRowsOut O = out_view(*D);
+        hipLaunchKernelGGL(k_fe_compact_ptr, dim3(blocks(nrow + 1)), dim3(256), 0, 0, R, K, nrow, O);
+        for (int p = 0; p < 3; ++p)
+            if (terms[p]) hipLaunchKernelGGL(k_fe_compact_entries, dim3((unsigned)std::min<uint64_t>(blocks(terms[p]), 256 * 16)), dim3(256), 0, 0, R, K, p, terms[p], O);
+        FE_TRY(hipDeviceSynchronize());
+        FE_TRY(hipGetLastError());
+        red = D;
+    }
+    st.compact_ms = ms_since(t_cmp);
+    for (auto& sp : fresh) specials.push_back(std::move(sp));
+    return K_OK;
+}
+
+// ====================================================================================== layout
+LayoutDev::~LayoutDev() {
+    if (mem[0] || mem[1] || mem[2]) {
+        DeviceGuard g(device);
+        for (void* m : mem) if (m) (void)hipFree(m);
+    }
+}
+
+int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::unique_ptr<LayoutDev>& out) {
+    DeviceGuard guard(D.device);
+    if (!guard.ok) return K_ENODEVICE;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (D.n >= 0x7FFFFFF0ull) return FE_FALLBACK;
+    const uint32_t nC = (uint32_t)D.n;
+    const uint64_t tall = D.terms[0] + D.terms[1] + D.terms[2];
+    if (tall >= 0xFFFFFFF0ull) return FE_FALLBACK;
+    std::unique_ptr<LayoutDev> LD(new LayoutDev());
+    LD->device = D.device;
+    LayoutCounts& C = LD->cnt;
+    LayoutDst& Dst = LD->dst;
+    std::memset(&Dst, 0, sizeof Dst);
+    hipStream_t s = 0;
+    const AbsRowsDev R = view(D);
+    // ---- temporaries (freed on return)
+    DevMem tm;
+    {
+        const size_t b = DevMem::sz(3 * ((size_t)nC + 1), 4) + DevMem::sz(3 * (size_t)std::max<uint32_t>(nC, 1), sizeof(PartSum)) + 2 * DevMem::sz(3ull * nC + 1, 4) +
+                         5 * DevMem::sz((size_t)nC + 2, 4) + DevMem::sz((size_t)nC + 1, 1) + 2 * DevMem::sz(tall + 1, 8) + DevMem::sz(tall + 2, 4) + 8192 +
+                         DevMem::sz((size_t)std::max<uint64_t>(tall, (uint64_t)nC) / 1024 + 16, 4);
+        const int rc = tm.alloc(b);
+        if (rc != K_OK) return rc;
+    }
+    uint32_t* nzc = tm.take<uint32_t>(3 * ((size_t)nC + 1));
+    PartSum* sum = tm.take<PartSum>(3 * (size_t)std::max<uint32_t>(nC, 1));
+    uint32_t* midlist = tm.take<uint32_t>(3ull * nC + 1);
+    uint32_t* largelist = tm.take<uint32_t>(3ull * nC + 1);
+    uint32_t* f_p4 = tm.take<uint32_t>((size_t)nC + 2);
+    uint32_t* f_cls = tm.take<uint32_t>((size_t)nC + 2);
+    uint32_t* f_big = tm.take<uint32_t>((size_t)nC + 2);
+    uint32_t* f_val = tm.take<uint32_t>((size_t)nC + 2);
+    uint32_t* f_p5 = tm.take<uint32_t>((size_t)nC + 2);
+    uint8_t* aeq = tm.take<uint8_t>((size_t)nC + 1);
+    uint64_t* pairs = tm.take<uint64_t>(tall + 1);
+    uint64_t* pairs2 = tm.take<uint64_t>(tall + 1);
+    uint32_t* f_uniq = tm.take<uint32_t>(tall + 2);
+    FeMeta* M = tm.take<FeMeta>(1);
+    uint32_t* totals = tm.take<uint32_t>(16);
+    uint32_t* tops = tm.take<uint32_t>((size_t)std::max<uint64_t>(tall, (uint64_t)nC) / 1024 + 16);
+    if (!tops) return K_ECAPACITY;
+    // ---- A. non-zero counts -> CSR row pointers; largest variable id
+    FE_TRY(hipMemsetAsync(M, 0, sizeof(FeMeta), s));
+    FE_TRY(hipMemsetAsync(nzc, 0, 12ull * ((size_t)nC + 1), s));
+    if (nC) hipLaunchKernelGGL(k_lay_count, dim3(blocks(3ull * nC)), dim3(256), 0, s, R, nC, nzc, midlist, largelist, M);
+    for (int p = 0; p < 3; ++p) scan_u32(nzc + (size_t)p * (nC + 1), nzc + (size_t)p * (nC + 1), nC + 1, tops, totals + p, s);
+    FeMeta hm;
+    FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
+    FE_TRY(hipGetLastError());
+    if (hm.maxn >= (1u << 18)) return FE_FALLBACK;
+    C.nC = nC;
+    C.nVall = std::max(std::max(n_vars, min_nv), hm.maxvar);
+    if (C.nVall >= 0xFFFFFFF0u) return FE_FALLBACK;
+    for (int p = 0; p < 3; ++p) C.nnz[p] = hm.nnz[p];
+    C.maxrowC = hm.maxlenC;
+    const uint64_t npairs = C.nnz[0] + C.nnz[1] + C.nnz[2];
+    const size_t nvar = (size_t)C.nVall + 1;      // ids 0..nVall
+    // ---- first allocation: everything whose size is known now
+    DevMem a1;
+    {
+        size_t b = 4096 + 2 * DevMem::sz(std::max<uint32_t>(nC, 1), sizeof(RowInfo)) + DevMem::sz(nvar, 1) + DevMem::sz(std::max<uint32_t>(nC, 1), 2) + DevMem::sz(16ull * std::max<uint32_t>(nC, 1), 4) +
+                   DevMem::sz(nvar + 2, 4) + DevMem::sz(4 * (nvar + 1), 4);
+        for (int p = 0; p < 3; ++p) b += DevMem::sz((size_t)nC + 1, 4) + DevMem::sz(std::max<uint64_t>(C.nnz[p], 1), 4) + DevMem::sz(std::max<uint64_t>(C.nnz[p], 1), 32);
+        const int rc = a1.alloc(b);
+        if (rc != K_OK) return rc;
+    }
+    LayCsr L;
+    for (int p = 0; p < 3; ++p) {
+        Dst.rp[p] = L.rp[p] = a1.take<uint32_t>((size_t)nC + 1);
+        Dst.col[p] = L.col[p] = a1.take<uint32_t>(std::max<uint64_t>(C.nnz[p], 1));
+        Dst.coef[p] = L.coef[p] = a1.take<uint64_t>(4 * std::max<uint64_t>(C.nnz[p], 1));
+    }
+    Dst.rinfo = a1.take<RowInfo>(std::max<uint32_t>(nC, 1));
+    Dst.rinfo0 = a1.take<RowInfo>(std::max<uint32_t>(nC, 1));
+    Dst.nontrivial = a1.take<uint8_t>(nvar);
+    Dst.tbig = a1.take<uint16_t>(std::max<uint32_t>(nC, 1));
+    Dst.rec = a1.take<uint32_t>(16ull * std::max<uint32_t>(nC, 1));
+    Dst.fo_ptr = a1.take<uint32_t>(nvar + 2);
+    Dst.foi = a1.take<uint32_t>(4 * (nvar + 1));
+    if (!Dst.foi) return K_ECAPACITY;
+    LD->mem[0] = a1.base; a1.base = nullptr;
+    FE_TRY(hipMemsetAsync(Dst.nontrivial, 0, nvar, s));
+    FE_TRY(hipMemsetAsync(Dst.fo_ptr, 0, 4 * (nvar + 2), s));
+    FE_TRY(hipMemsetAsync(Dst.tbig, 0, 2ull * std::max<uint32_t>(nC, 1), s));
+    if (nC == 0) FE_TRY(hipMemsetAsync(Dst.rec, 0, 64, s));
+    for (int p = 0; p < 3; ++p) FE_TRY(hipMemcpyAsync(Dst.rp[p], nzc + (size_t)p * (nC + 1), 4ull * ((size_t)nC + 1), hipMemcpyDeviceToDevice, s));
+    // ---- B. nonzeroKeys order, per-part summaries
+    DevMem big;
+    if (nC) {
+        hipLaunchKernelGGL(k_lay_order_small, dim3(blocks(3ull * nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial);
+        if (hm.n_mid)
+            hipLaunchKernelGGL(k_lay_order_big<true>, dim3(std::min<uint32_t>((hm.n_mid + 3) / 4, 256 * 8)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial,
+                               (const uint32_t*)midlist, hm.n_mid, M, (uint32_t*)nullptr, 0u);
+        if (hm.n_large) {
+            const uint32_t gcap = pow2_ge(8ull * hm.maxn, 1024);
+            const uint32_t g = std::min<uint32_t>((hm.n_large + 3) / 4, 64);
+            { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
+            hipLaunchKernelGGL(k_lay_order_big<false>, dim3(g), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial, (const uint32_t*)largelist, hm.n_large, M,
+                               (uint32_t*)big.base, gcap);
+        }
+        // ---- C. row descriptors, flags, P5 candidates, (variable, row) pairs
+        FE_TRY(hipMemsetAsync(f_p4, 0, 4ull * ((size_t)nC + 2), s));
+        FE_TRY(hipMemsetAsync(f_cls, 0, 4ull * ((size_t)nC + 2), s));
+        FE_TRY(hipMemsetAsync(f_big, 0, 4ull * ((size_t)nC + 2), s));
+        FE_TRY(hipMemsetAsync(f_val, 0, 4ull * ((size_t)nC + 2), s));
+        FE_TRY(hipMemsetAsync(f_p5, 0, 4ull * ((size_t)nC + 2), s));
+        hipLaunchKernelGGL(k_lay_rows, dim3(blocks(nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, (const PartSum*)sum, Dst.rinfo, f_p4, f_cls, f_big, f_val, aeq);
+        hipLaunchKernelGGL(k_lay_p5_flag, dim3(blocks(nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, (const uint8_t*)aeq, f_p5);
+        scan_u32(f_p4, f_p4, nC + 1, tops, totals + 4, s);
+        scan_u32(f_cls, f_cls, nC + 1, tops, totals + 5, s);
+        scan_u32(f_big, f_big, nC + 1, tops, totals + 6, s);
+        scan_u32(f_val, f_val, nC + 1, tops, totals + 7, s);
+        scan_u32(f_p5, f_p5, nC + 1, tops, totals + 8, s);
+    } else FE_TRY(hipMemsetAsync(totals, 0, 64, s));
+    // variable_to_indices: sort the (variable, row) pairs, drop repeats (a variable in two parts of one row), count per variable
+    uint32_t* deg = Dst.fo_ptr;      // counted in place, then scanned in place
+    DevMem sortm;
+    if (npairs) {
+        hipLaunchKernelGGL(k_lay_pairs, dim3(blocks(3ull * nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, (uint64_t)C.nnz[0], (uint64_t)(C.nnz[0] + C.nnz[1]), pairs);
+        unsigned vbits = 1;
+        while (vbits < 32 && (C.nVall >> vbits)) ++vbits;
+        size_t sb = 0;
+        FE_TRY(rocprim::radix_sort_keys(nullptr, sb, pairs, pairs2, (size_t)npairs, 0u, 32u + vbits, s));
+        { const int rc = sortm.alloc(sb + 256); if (rc != K_OK) return rc; }
+        FE_TRY(rocprim::radix_sort_keys((void*)sortm.base, sb, pairs, pairs2, (size_t)npairs, 0u, 32u + vbits, s));
+        FE_TRY(hipMemsetAsync(f_uniq + npairs, 0, 8, s));
+        hipLaunchKernelGGL(k_lay_uniq_flag, dim3(blocks(npairs)), dim3(256), 0, s, (const uint64_t*)pairs2, (uint32_t)npairs, f_uniq, deg);
+        scan_u32(f_uniq, f_uniq, (uint32_t)npairs + 1, tops, totals + 9, s);
+    } else FE_TRY(hipMemsetAsync(totals + 9, 0, 4, s));
+    scan_u32(deg, deg, (uint32_t)nvar + 1, tops, nullptr, s);
+    uint32_t ht[16];
+    FE_TRY(hipMemcpy(ht, totals, 64, hipMemcpyDeviceToHost));
+    FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
+    FE_TRY(hipGetLastError());
+    if (hm.unsupported) return FE_FALLBACK;
+    C.nP4 = ht[4]; C.nCls = ht[5]; C.nLong = ht[6]; C.n_vals = 2 * ht[7]; C.nP5 = ht[8]; C.fo_total = ht[9];
+    C.nBigRows = std::min<uint32_t>(C.nLong, ECNE_BIGTAB);
+    // ---- second allocation: the lists
+    DevMem a2;
+    {
+        const size_t b = 4096 + 3 * DevMem::sz(std::max<uint32_t>(C.nP4, 1), 4) + DevMem::sz(std::max<uint32_t>(C.nCls, 1), 4) + 2 * DevMem::sz(std::max<uint32_t>(C.nLong, 1), 4) +
+                         2 * DevMem::sz(std::max<uint32_t>(C.nP5, 1), 4) + DevMem::sz(std::max<uint32_t>(C.fo_total, 1), 4);
+        const int rc = a2.alloc(b);
+        if (rc != K_OK) return rc;
+    }
+    Dst.p4_list = a2.take<uint32_t>(std::max<uint32_t>(C.nP4, 1));
+    Dst.p4_b = a2.take<uint32_t>(std::max<uint32_t>(C.nP4, 1));
+    Dst.p4_s = a2.take<uint32_t>(std::max<uint32_t>(C.nP4, 1));
+    Dst.cls_list = a2.take<uint32_t>(std::max<uint32_t>(C.nCls, 1));
+    Dst.bigrows = a2.take<uint32_t>(std::max<uint32_t>(C.nLong, 1));
+    Dst.long_list = a2.take<uint32_t>(std::max<uint32_t>(C.nLong, 1));
+    Dst.p5_rows = a2.take<uint32_t>(std::max<uint32_t>(C.nP5, 1));
+    Dst.p5_y = a2.take<uint32_t>(std::max<uint32_t>(C.nP5, 1));
+    Dst.fo_rows = a2.take<uint32_t>(std::max<uint32_t>(C.fo_total, 1));
+    if (!Dst.fo_rows) return K_ECAPACITY;
+    LD->mem[1] = a2.base; a2.base = nullptr;
+    if (nC) {
+        hipLaunchKernelGGL(k_lay_lists, dim3(blocks(nC)), dim3(256), 0, s, nC, Dst.rinfo, (const uint32_t*)f_p4, (const uint32_t*)f_cls, (const uint32_t*)f_big, (const uint32_t*)f_val, Dst);
+        hipLaunchKernelGGL(k_lay_p5_write, dim3(blocks(nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, (const uint32_t*)f_p5, Dst);
+        hipLaunchKernelGGL(k_lay_rec, dim3(blocks(nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, Dst.rec);
+        FE_TRY(hipMemcpyAsync(Dst.rinfo0, Dst.rinfo, sizeof(RowInfo) * (size_t)nC, hipMemcpyDeviceToDevice, s));
+    }
+    if (npairs) hipLaunchKernelGGL(k_lay_fo_rows, dim3(blocks(npairs)), dim3(256), 0, s, (const uint64_t*)pairs2, (uint32_t)npairs, (const uint32_t*)f_uniq, Dst.fo_rows);
+    hipLaunchKernelGGL(k_lay_foi, dim3(blocks(nvar + 1)), dim3(256), 0, s, (uint32_t)nvar, (const uint32_t*)Dst.fo_ptr, (const uint32_t*)Dst.fo_rows, Dst.foi);
+    FE_TRY(hipStreamSynchronize(s));
+    FE_TRY(hipGetLastError());
+    LD->ms = ms_since(t0);
+    out = std::move(LD);
+    return K_OK;
+}
+
+int mark_bytes(int device, uint8_t* dst, const std::vector<uint32_t>& ids) {
+    if (ids.empty()) return K_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return K_ENODEVICE;
+    uint32_t* d = nullptr;
+    FE_TRY(hipMalloc((void**)&d, 4 * ids.size()));
+    hipError_t e = hipMemcpy(d, ids.data(), 4 * ids.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_mark_bytes, dim3(blocks(ids.size())), dim3(256), 0, 0, dst, (const uint32_t*)d, (uint32_t)ids.size());
+        e = hipDeviceSynchronize();
+    }
+    (void)hipFree(d);
+    return e == hipSuccess ? K_OK : K_ENODEVICE;
+}
+
+int bad_rows(int device, const Job& J, std::vector<int64_t>& out) {
+    out.clear();
+    if (J.nC == 0) return K_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return K_ENODEVICE;
+    DevMem m;
+    { const int rc = m.alloc(DevMem::sz((size_t)J.nC + 2, 4) * 2 + DevMem::sz((size_t)J.nC / 1024 + 16, 4) + 1024); if (rc != K_OK) return rc; }
+    uint32_t* f = m.take<uint32_t>((size_t)J.nC + 2);
+    uint32_t* list = m.take<uint32_t>((size_t)J.nC + 2);
+    uint32_t* tops = m.take<uint32_t>((size_t)J.nC / 1024 + 16);
+    uint32_t* total = m.take<uint32_t>(4);
+    FE_TRY(hipMemsetAsync(f + J.nC, 0, 8, 0));
+    hipLaunchKernelGGL(k_bad_flag, dim3(blocks(J.nC)), dim3(256), 0, 0, J, f);
+    scan_u32(f, f, J.nC + 1, tops, total, 0);
+    hipLaunchKernelGGL(k_bad_write, dim3(blocks(J.nC)), dim3(256), 0, 0, J.nC, (const uint32_t*)f, list);
+    uint32_t n = 0;
+    FE_TRY(hipMemcpy(&n, total, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> h(n);
+    if (n) FE_TRY(hipMemcpy(h.data(), list, 4ull * n, hipMemcpyDeviceToHost));
+    FE_TRY(hipGetLastError());
+    out.resize(n);
+    for (uint32_t i = 0; i < n; ++i) out[i] = (int64_t)h[i] + 1;
+    return K_OK;
+}
+
+}  // namespace fe
+}  // namespace ecne

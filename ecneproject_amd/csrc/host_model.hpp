@@ -138,6 +138,7 @@ struct R1CSFile {
     // file-order CSR views handed out by ecne_r1cs_csr (non-zero entries only): built on first use from
     // the file (the solve path never needs them)
     std::string path;
+    bool host_rows = false;      // `rows` is filled (false: the file was parsed on the device only; rows are fetched on demand)
     bool csr_built = false;
     std::vector<uint64_t> csr_ptr[3];
     std::vector<uint32_t> csr_col[3];
@@ -181,8 +182,8 @@ inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)r
 // readR1CS semantics: magic unchecked, version == 1, exactly 3 sections of
 // type 1..3 in any order, prime never compared, coefficient width fixed at 32 bytes, duplicate
 // wire ids "last wins" at the first occurrence's position, wire id == nWires accepted.
-inline int load_r1cs(const char* path, R1CSFile& out) {
-    FileView fv(path);
+// header + section table of a mapped file; cons_off = offset of the first constraint
+inline int read_r1cs_header(const FileView& fv, R1CSFile& out, size_t& cons_off) {
     if (!fv.ok) return K_EIO;
     const size_t N = fv.size;
     const uint8_t* b = fv.data;
@@ -214,6 +215,30 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
     out.n_prv_in = rd32(b + h + 12);
     out.n_labels = rd64(b + h + 16);
     out.n_cons = rd32(b + h + 24);
+    cons_off = start[2];
+    out.knowns.assign(1, 1);
+    for (int64_t i = 2 + (int64_t)out.n_pub_out; i <= 1 + (int64_t)out.n_pub_out + out.n_pub_in + out.n_prv_in; ++i)
+        out.knowns.push_back(i);
+    out.outputs.clear();
+    for (int64_t i = 2; i <= 1 + (int64_t)out.n_pub_out; ++i) out.outputs.push_back(i);
+    out.n_vars = (int64_t)out.n_wires + 1;
+    return K_OK;
+}
+
+inline int read_r1cs_rows(const FileView& fv, size_t cons_off, const char* path, R1CSFile& out);
+inline int load_r1cs(const char* path, R1CSFile& out) {
+    FileView fv(path);
+    size_t cons_off = 0;
+    const int st = read_r1cs_header(fv, out, cons_off);
+    if (st != K_OK) return st;
+    return read_r1cs_rows(fv, cons_off, path, out);
+}
+// the constraint section -> rows in dictionary order (host path)
+inline int read_r1cs_rows(const FileView& fv, size_t cons_off, const char* path, R1CSFile& out) {
+    const size_t N = fv.size;
+    const uint8_t* b = fv.data;
+    auto need = [&](size_t off, size_t len) { return len <= N && off <= N - len; };   // (no wrap-around)
+    size_t start[4] = {0, 0, cons_off, 0};
 
     // pass 1 over the constraint section (sequential: record lengths are only known by walking them): term
     // counts per part, bounds check, and where every block of PARSE_BLOCK rows starts in the file and in the arrays
@@ -322,12 +347,7 @@ inline int load_r1cs(const char* path, R1CSFile& out) {
             R.coef[p].resize(terms[p] - shift);
         }
     }
-    out.knowns.assign(1, 1);
-    for (int64_t i = 2 + (int64_t)out.n_pub_out; i <= 1 + (int64_t)out.n_pub_out + out.n_pub_in + out.n_prv_in; ++i)
-        out.knowns.push_back(i);
-    out.outputs.clear();
-    for (int64_t i = 2; i <= 1 + (int64_t)out.n_pub_out; ++i) out.outputs.push_back(i);
-    out.n_vars = (int64_t)out.n_wires + 1;
+    out.host_rows = true;
     return K_OK;
 }
 
@@ -474,6 +494,101 @@ struct AppearMap {
 };
 }  // namespace detail
 
+// ---- abstraction in three steps (so that the device front-end, frontend.hpp, can replace the first two and keep the third)
+// The trusted function's side of the comparison, prepared once per abstraction: its appearance signatures sorted (l2), its
+// per-part sorted coefficient lists, and where each of its variables sits in l2.
+struct PatternHost {
+    detail::AppearMap orig;
+    std::vector<std::pair<int64_t, int64_t>> l2;
+    std::vector<fp::u256> subvals;
+    std::vector<size_t> subptr;
+    std::unordered_map<int64_t, size_t> where;   // pattern variable -> position in l2 (later duplicates win, as in the map it replaces)
+    size_t nS = 0;
+    void build(const R1CSFile& sub) {
+        using namespace detail;
+        nS = sub.rows.n();
+        int64_t counter = 1;
+        for (size_t j = 0; j < nS; ++j)
+            for (int p = 0; p < 3; ++p) {
+                for (uint64_t k = sub.rows.ptr[p][j]; k < sub.rows.ptr[p][j + 1]; ++k)
+                    if (!fp::is_zero(sub.rows.coef[p][k])) orig.add(sub.rows.var[p][k], counter, &sub.rows.coef[p][k]);
+                ++counter;
+            }
+        orig.finish();
+        l2 = orig.sorted();
+        subptr.assign(1, 0);
+        std::vector<fp::u256> vb;
+        for (size_t j = 0; j < nS; ++j)
+            for (int p = 0; p < 3; ++p) {
+                part_values(sub.rows, p, j, vb);
+                subvals.insert(subvals.end(), vb.begin(), vb.end());
+                subptr.push_back(subvals.size());
+            }
+        for (size_t x = 0; x < l2.size(); ++x) where[l2[x].first] = x;
+    }
+};
+// Is the window rows[at, at + nS) an occurrence of the pattern (:272-351)? On success image[x] = the window's variable for the
+// pattern variable l2[x]. cur / va: scratch of the calling worker.
+inline bool verify_window(const PatternHost& P, const Rows& rows, size_t at, detail::AppearMap& cur, std::vector<fp::u256>& va,
+                          std::vector<int64_t>& image) {
+    using namespace detail;
+    cur.clear();
+    int64_t counter = 0;
+    for (size_t j = 0; j < P.nS; ++j)
+        for (int p = 0; p < 3; ++p) {
+            ++counter;
+            part_values(rows, p, at + j, va);
+            const size_t s0 = P.subptr[j * 3 + (size_t)p], s1 = P.subptr[j * 3 + (size_t)p + 1];
+            if (va.size() != s1 - s0) return false;
+            for (size_t t = 0; t < va.size(); ++t)
+                if (!fp::eq(va[t], P.subvals[s0 + t])) return false;
+            for (uint64_t k = rows.ptr[p][at + j]; k < rows.ptr[p][at + j + 1]; ++k)
+                if (!fp::is_zero(rows.coef[p][k])) cur.add(rows.var[p][k], counter, &rows.coef[p][k]);
+        }
+    cur.finish();
+    const auto l1 = cur.sorted();
+    if (l1.size() != P.l2.size()) return false;
+    for (size_t x = 0; x < l1.size(); ++x)
+        if (AppearMap::compare(cur, (size_t)l1[x].second, P.orig, (size_t)P.l2[x].second) != 0) return false;
+    image.resize(l1.size());
+    for (size_t x = 0; x < l1.size(); ++x) image[x] = l1[x].first;
+    return true;
+}
+// Greedy left to right with the reference's stuck cursor (:368-388): a match that starts inside the previous window is never
+// reached again, and neither is any later one. Rows outside the replaced windows survive as ranges [a, b) in `keep`; the new
+// special constraints go to `fresh`. image_of(ci, pattern variable, &window variable) -> false = KeyError (:381-382).
+template <class ImageOf>
+inline int greedy_replace(const std::string& name, const R1CSFile& sub, size_t nC, const std::vector<size_t>& cand,
+                          const std::vector<uint8_t>& matched, ImageOf&& image_of, std::vector<std::pair<size_t, size_t>>& keep,
+                          std::vector<Special>& fresh) {
+    const size_t nS = sub.rows.n();
+    size_t i = 0;
+    for (size_t ci = 0; ci <= cand.size(); ++ci) {
+        if (ci < cand.size() && !matched[ci]) continue;
+        const size_t stop = ci < cand.size() ? cand[ci] : nC;
+        if (stop < i) { keep.push_back({i, nC}); i = nC; break; }
+        keep.push_back({i, stop});
+        i = stop;
+        if (ci == cand.size()) break;
+        Special sp;
+        sp.name = name;
+        for (int64_t x : sub.knowns)
+            if (x != 1) {
+                int64_t v;
+                if (!image_of(ci, x, v)) return K_EKEY;
+                sp.inputs.push_back(v);
+            }
+        for (int64_t x : sub.outputs) {
+            int64_t v;
+            if (!image_of(ci, x, v)) return K_EKEY;
+            sp.outputs.push_back(v);
+        }
+        fresh.push_back(std::move(sp));
+        i += nS;
+    }
+    return K_OK;
+}
+
 // Replaces every (greedy, left to right, stuck-cursor) occurrence of `sub` in `rows` by a special
 // constraint: the reduced rows go to `red`, the new specials are appended. Returns K_OK or K_EKEY (then
 // `red` and `specials` are left as they were).  Fingerprints, the per-window variable matching and the
@@ -504,30 +619,8 @@ inline int abstract_one(const std::string& name, const Rows& rows, const R1CSFil
             if (m) cand.push_back(i);
         }
     }
-    AppearMap orig;
-    {
-        int64_t counter = 1;
-        for (size_t j = 0; j < nS; ++j)
-            for (int p = 0; p < 3; ++p) {
-                for (uint64_t k = sub.rows.ptr[p][j]; k < sub.rows.ptr[p][j + 1]; ++k)
-                    if (!fp::is_zero(sub.rows.coef[p][k])) orig.add(sub.rows.var[p][k], counter, &sub.rows.coef[p][k]);
-                ++counter;
-            }
-    }
-    orig.finish();
-    const auto l2 = orig.sorted();
-    // the pattern's sorted coefficient lists, once (every candidate window is compared against them)
-    std::vector<fp::u256> subvals;
-    std::vector<size_t> subptr(1, 0);
-    if (!cand.empty()) {
-        std::vector<fp::u256> vb;
-        for (size_t j = 0; j < nS; ++j)
-            for (int p = 0; p < 3; ++p) {
-                part_values(sub.rows, p, j, vb);
-                subvals.insert(subvals.end(), vb.begin(), vb.end());
-                subptr.push_back(subvals.size());
-            }
-    }
+    PatternHost P;
+    P.build(sub);
     // one candidate window per task; image[c] = the window's variable for every pattern variable in l2 order
     std::vector<std::vector<int64_t>> image(cand.size());
     std::vector<uint8_t> matched(cand.size(), 0);
@@ -535,64 +628,17 @@ inline int abstract_one(const std::string& name, const Rows& rows, const R1CSFil
         const unsigned W = for_chunks_workers(cand.size());
         std::vector<AppearMap> curs(W);
         std::vector<std::vector<fp::u256>> vas(W);
-        for_chunks(cand.size(), [&](size_t ci, unsigned w) {
-            AppearMap& cur = curs[w];
-            std::vector<fp::u256>& va = vas[w];
-            const size_t at = cand[ci];
-            cur.clear();
-            int64_t counter = 0;
-            for (size_t j = 0; j < nS; ++j)
-                for (int p = 0; p < 3; ++p) {
-                    ++counter;
-                    part_values(rows, p, at + j, va);
-                    const size_t s0 = subptr[j * 3 + (size_t)p], s1 = subptr[j * 3 + (size_t)p + 1];
-                    if (va.size() != s1 - s0) return;
-                    for (size_t t = 0; t < va.size(); ++t)
-                        if (!fp::eq(va[t], subvals[s0 + t])) return;
-                    for (uint64_t k = rows.ptr[p][at + j]; k < rows.ptr[p][at + j + 1]; ++k)
-                        if (!fp::is_zero(rows.coef[p][k])) cur.add(rows.var[p][k], counter, &rows.coef[p][k]);
-                }
-            cur.finish();
-            const auto l1 = cur.sorted();
-            if (l1.size() != l2.size()) return;
-            for (size_t x = 0; x < l1.size(); ++x)
-                if (AppearMap::compare(cur, (size_t)l1[x].second, orig, (size_t)l2[x].second) != 0) return;
-            image[ci].resize(l1.size());
-            for (size_t x = 0; x < l1.size(); ++x) image[ci][x] = l1[x].first;
-            matched[ci] = 1;
-        });
+        for_chunks(cand.size(), [&](size_t ci, unsigned w) { matched[ci] = verify_window(P, rows, cand[ci], curs[w], vas[w], image[ci]) ? 1 : 0; });
     }
-    // greedy left to right with the reference's stuck cursor (:368-388): a match that starts inside the
-    // previous window is never reached again, and neither is any later one. Rows outside the replaced
-    // windows survive as ranges [a, b).
     std::vector<std::pair<size_t, size_t>> keep;
     std::vector<Special> fresh;
-    std::unordered_map<int64_t, size_t> where;   // pattern variable -> position in l2 (later duplicates win, as in the map it replaces)
-    for (size_t x = 0; x < l2.size(); ++x) where[l2[x].first] = x;
-    size_t i = 0;
-    for (size_t ci = 0; ci <= cand.size(); ++ci) {
-        if (ci < cand.size() && !matched[ci]) continue;
-        const size_t stop = ci < cand.size() ? cand[ci] : nC;
-        if (stop < i) { keep.push_back({i, nC}); i = nC; break; }
-        keep.push_back({i, stop});
-        i = stop;
-        if (ci == cand.size()) break;
-        Special sp;
-        sp.name = name;
-        for (int64_t x : sub.knowns)
-            if (x != 1) {
-                auto it = where.find(x);
-                if (it == where.end()) return K_EKEY;
-                sp.inputs.push_back(image[ci][it->second]);
-            }
-        for (int64_t x : sub.outputs) {
-            auto it = where.find(x);
-            if (it == where.end()) return K_EKEY;
-            sp.outputs.push_back(image[ci][it->second]);
-        }
-        fresh.push_back(std::move(sp));
-        i += nS;
-    }
+    const int rc = greedy_replace(name, sub, nC, cand, matched, [&](size_t ci, int64_t x, int64_t& v) {
+        auto it = P.where.find(x);
+        if (it == P.where.end()) return false;
+        v = image[ci][it->second];
+        return true;
+    }, keep, fresh);
+    if (rc != K_OK) return rc;
     // lay the surviving ranges out back to back, then copy them in pieces on the worker threads
     struct Piece { size_t a, b, row; uint64_t at[3]; };
     const size_t COPY_BLOCK = 16384;

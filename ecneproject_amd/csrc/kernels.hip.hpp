@@ -19,13 +19,12 @@
 //                     shapes decided in registers, the walk of a long row), chain (sequential pops of a single-workgroup
 //                     job out of LDS), wave2 (the fast wavefront round), rounds (multi-workgroup round, the queue
 //                     phase's policy), k_solve (setup, outer loop, P1-P5, verdict).
-//   k_abs_*           abstraction's O(rows) part (reference :237-395): row fingerprints, a weighted prefix scan and the
-//                     window-candidate test (abstract.hip.hpp); verification and the greedy replacement stay on the host.
+//   (k_abs_*, k_fe_*, k_lay_*: the device front-end -- parse, abstraction, layout -- lives in the second translation unit,
+//                     ecne_frontend.hip / frontend.hip.hpp / abstract.hip.hpp)
 //   k_fp_selftest     field-arithmetic known-answer vectors on the device.
 #pragma once
 #include "k_solve.hip.hpp"
 #include "classify.hip.hpp"
-#include "abstract.hip.hpp"
 
 namespace ecne {
 

@@ -64,6 +64,20 @@ typedef struct ecne_info {
  * own. Results do not depend on the count. Returns the count now in effect. */
 int ecne_set_host_threads(int n);
 
+/* Which front-end turns a file into the flat arrays the solve runs on: 0 = host (reader, abstraction and layout in host C++),
+ * 1 = device whenever a HIP device is present (the constraint section is uploaded as it is and parsed, abstracted and laid out by
+ * kernels on the calling thread's CURRENT HIP device; host copies of the rows are fetched only when an entry point needs them),
+ * 2 = auto (device for files of 100 000 constraints and more) -- the default; ECNE_FRONTEND=host|device|auto in the environment
+ * sets the initial value. Both produce the same arrays (tests/test_gpu_frontend.py); inputs the device path does not take (4 GiB
+ * files, parts of 2^18 terms, a trusted function whose mapped inputs / outputs tie with other variables) go through the host
+ * path on their own. mode < 0 only reads. Returns the mode in effect. */
+int ecne_set_frontend(int mode);
+/* Timing of the calling thread's last trip through the front-end: out16 = {parse on device (0/1), upload ms, part-offset kernels ms,
+ * row-fill kernels ms, parse total ms, file bytes, abstraction on device (0/1), pattern prep ms, fingerprint ms, window scan ms,
+ * verification ms, compaction ms, candidate windows, matched windows (+ 1e6 x windows re-verified on the host), layout on device
+ * (0/1), layout ms}. */
+int ecne_frontend_stats(double* out16);
+
 /* readR1CS — ParseR1CS.jl:50-124. */
 int ecne_r1cs_load(const char* path, ecne_r1cs** out);
 int ecne_r1cs_info(const ecne_r1cs* f, ecne_info* out);
@@ -106,6 +120,14 @@ int ecne_system_rows(ecne_system* sys, int part, const uint32_t** rowptr, const 
  * (:600-618: every variable of every row, of the specials and the targets, as Set(l) iterates). Borrowed until the next
  * call on this system. */
 int ecne_system_report_order(ecne_system* sys, int64_t row, const int64_t** vars, size_t* n);
+/* The same rows in DICTIONARY order -- what readR1CS / abstraction hand to the solver (ParseR1CS.jl:94-115): every key of the part's
+ * DefaultDict in iteration order, explicit zeros and the {1 => 0} placeholder of an empty part included. Host copy (a system that
+ * came through the device front-end downloads it on first use); borrowed until the system changes. */
+int ecne_system_dict_rows(ecne_system* sys, int part, const uint64_t** rowptr, const uint32_t** var, const uint64_t** coeff, uint64_t* n_rows);
+/* Test hook: host copy of static array `which` of the system's device image after upload / layout on `device` (list in
+ * ecne_engine.hip); borrowed until the next call on this system. tests/test_gpu_frontend.py compares host-laid and device-laid
+ * systems with it, array by array. */
+int ecne_debug_static_array(ecne_system* sys, int device, int which, const void** data, size_t* bytes);
 /* SolveConstraintsSymbolic takes its known / target lists and special constraints as ARGUMENTS (:583-592); a system
  * made from a file starts with the file's lists (ParseR1CS.jl:123) and the specials abstraction produced. A caller
  * that edits them says so here (ids 1-based; copied). Changing them invalidates the device image of the system. */

@@ -1,0 +1,60 @@
+// CPU check of csrc/jlslot.hpp (the slot-order model the device front-end runs) against csrc/jlorder.hpp's jl::SlotTable
+// (the host model, itself pinned to the reference's dumps by tests/test_julia_order.py). Built and run by tests/test_jlslot_host.py.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../../ecneproject_amd/csrc/jlorder.hpp"
+#include "../../ecneproject_amd/csrc/jlslot.hpp"
+
+template <int ADD>
+static int one(std::mt19937_64& rng, size_t n, uint64_t keyspace, uint32_t stride) {
+    std::vector<uint32_t> keys(n);
+    for (auto& k : keys) k = (uint32_t)(rng() % keyspace) + (keyspace > 1000000 ? 0xFFFFFF00u : 0u) * (rng() % 7 == 0);
+    uint32_t cap = 16;
+    while (cap < 8 * n + 64) cap <<= 1;
+    std::vector<uint32_t> a((size_t)cap * stride), b((size_t)cap * stride), c((size_t)cap * stride), d((size_t)cap * stride);
+    jlslot::Tab t{a.data(), b.data(), c.data(), d.data(), cap, stride, 0, 0, 0};
+    jlslot::tab_init(t);
+    jl::SlotTable ref;
+    for (size_t i = 0; i < n; ++i) {
+        bool ins;
+        int64_t& slot = ref.upsert((int64_t)keys[i] + ADD, (int64_t)i, ins);
+        if (!ins) slot = (int64_t)i;
+        if (jlslot::tab_upsert<ADD>(t, keys[i], (uint32_t)i)) { std::printf("capacity\n"); return 1; }
+    }
+    std::vector<std::pair<int64_t, int64_t>> want, got;
+    ref.for_each([&](int64_t k, int64_t p) { want.push_back({k, p}); });
+    for (uint32_t s = 0; s < t.sz; ++s)
+        if (t.pay[s * stride]) got.push_back({(int64_t)t.key[s * stride] + ADD, (int64_t)t.pay[s * stride] - 1});
+    if (want != got) { std::printf("MISMATCH n=%zu keyspace=%llu add=%d\n", n, (unsigned long long)keyspace, ADD); return 1; }
+    return 0;
+}
+
+int main() {
+    std::mt19937_64 rng(12345);
+    int bad = 0;
+    size_t cases = 0;
+    for (int rep = 0; rep < 4000; ++rep) {
+        const size_t n = 1 + rng() % (rep % 50 == 0 ? 3000 : rep % 7 == 0 ? 200 : 24);
+        const uint64_t ks = rep % 3 == 0 ? 16 + rng() % 64 : rep % 3 == 1 ? 1 + rng() % 100000 : 4000000000ull;
+        bad += one<0>(rng, n, ks, 1 + rep % 3);
+        bad += one<1>(rng, n, ks, 1 + rep % 3);
+        cases += 2;
+    }
+    for (size_t n : {64001u, 70000u, 130000u}) { bad += one<0>(rng, n, 1u << 30, 1); bad += one<1>(rng, n, 50000, 1); cases += 2; }
+    // the two-key shortcut
+    for (int rep = 0; rep < 200000; ++rep) {
+        const uint32_t k1 = (uint32_t)(rng() % (rep % 2 ? 64 : 2000000)) + 1, k2 = (uint32_t)(rng() % (rep % 2 ? 64 : 2000000)) + 1;
+        if (k1 == k2) continue;
+        jl::SlotTable s;
+        bool ins;
+        s.upsert(k1, 0, ins);
+        s.upsert(k2, 1, ins);
+        int64_t first = -1;
+        s.for_each([&](int64_t k, int64_t) { if (first < 0) first = k; });
+        if (((uint32_t)first == k2) != jlslot::pair_second_first(k1, k2)) { std::printf("PAIR MISMATCH %u %u\n", k1, k2); ++bad; }
+    }
+    std::printf("%zu sequences, %d mismatches\n", cases, bad);
+    return bad ? 1 : 0;
+}

@@ -1,0 +1,236 @@
+"""Device front-end (ecne_frontend.hip: parse, abstraction and layout as gfx950 kernels) against the host front-end
+(host_model.hpp + build_layout) and the oracle, through the C ABI.
+
+* rows in DICTIONARY order after the device parse == after the host parse (ParseR1CS.jl:50-124), on every fixture, on the fuzz
+  files (repeated wire ids, explicit zeros, un-reduced coefficients, all three section orders) and on damaged files (same accept /
+  reject as the oracle's reader);
+* after abstraction on the device: the same reduced rows and the same special constraints as the host path
+  (R1CSConstraintSolver.jl:237-395) on the reference configurations and on the abstraction fuzz family (overlapping windows,
+  near-copies, KeyError);
+* every static array of the device image (CSR in nonzeroKeys order, row descriptors, fan-out, P4 / P5 / long-row lists, row
+  records) byte for byte equal between a host-laid and a device-laid system;
+* solves through the device front-end bit-exact against the oracle.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import fixtures
+import fuzz_r1cs
+import orc
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = ["rpA", "rpB", "rpC", "colA", "colB", "colC", "coefA", "coefB", "coefC", "rinfo", "fo_ptr", "fo_rows", "nontrivial",
+          "p4_list", "p4_b", "p4_s", "cls_list", "tbig", "bigrows", "long_list", "p5_rows", "p5_y", "rec", "foi", "scalars"]
+
+
+@pytest.fixture(autouse=True)
+def _restore_frontend():
+    import ecneproject_amd as E
+    before = E.set_frontend()
+    yield
+    E.set_frontend(before)
+
+
+def _system(E, mode, rel=None, trusted=(), names=(), path=None):
+    E.set_frontend(mode)
+    main = E.R1CS(path or fixtures.path(rel))
+    fl = [(n, E.R1CS(fixtures.path(t) if not os.path.isabs(t) else t)) for t, n in zip(trusted, names)]
+    fl.sort(key=lambda x: -len(x[1]))
+    s = E.System(main)
+    for n, f in fl:
+        s.abstract(f, n)
+    return main, s
+
+
+def _same_dict_rows(tag, a, b):
+    for part in range(3):
+        ra, rb = a.dict_rows(part), b.dict_rows(part)
+        for x, y, what in zip(ra, rb, ("ptr", "var", "coef")):
+            assert np.array_equal(x, y), (tag, part, what)
+
+
+def _same_static_arrays(tag, a, b):
+    sa, sb = a.static_array(24), b.static_array(24)
+    va, vb = np.frombuffer(sa, np.int64), np.frombuffer(sb, np.int64)
+    assert va[8] == 0 and vb[8] == 1, (tag, "which front-end laid the system out", va[8], vb[8])
+    assert va[:8].tolist() == vb[:8].tolist(), (tag, "scalars", va.tolist(), vb.tolist())
+    for which, name in enumerate(ARRAYS[:-1]):
+        xa, xb = a.static_array(which), b.static_array(which)
+        if xa != xb:
+            w = 4
+            ia, ib = np.frombuffer(xa[:len(xa) // w * w], np.uint32), np.frombuffer(xb[:len(xb) // w * w], np.uint32)
+            first = int(np.argmax(ia != ib)) if len(ia) == len(ib) else -1
+            raise AssertionError((tag, name, len(xa), len(xb), first, ia[first:first + 8].tolist() if first >= 0 else None,
+                                  ib[first:first + 8].tolist() if first >= 0 else None))
+
+
+def test_parse_and_layout_all_fixtures():
+    import ecneproject_amd as E
+    for rel in fixtures.all_r1cs():
+        mh, sh = _system(E, E.FRONTEND_HOST, rel)
+        md, sd = _system(E, E.FRONTEND_DEVICE, rel)
+        assert E.frontend_stats()["parse_device"] == 1.0, rel
+        assert list(mh.info.nnz) == list(md.info.nnz) and mh.io() == md.io() and int(mh.info.n_vars) == int(md.info.n_vars), rel
+        _same_dict_rows(rel, sh, sd)
+        _same_static_arrays(rel, sh, sd)
+
+
+def test_abstraction_reference_configs():
+    import ecneproject_amd as E
+    for rel, trusted, names, _secp, _verdict in fixtures.REFERENCE_ASSERTED:
+        if not trusted:
+            continue
+        _mh, sh = _system(E, E.FRONTEND_HOST, rel, trusted, names)
+        _md, sd = _system(E, E.FRONTEND_DEVICE, rel, trusted, names)
+        assert E.frontend_stats()["abstract_device"] == 1.0, rel
+        assert sh.specials() == sd.specials(), rel
+        assert len(sh) == len(sd), rel
+        _same_dict_rows(rel, sh, sd)
+        _same_static_arrays(rel, sh, sd)
+
+
+def test_fuzz_files_section_orders_and_damage(tmp_path):
+    import ecneproject_amd as E
+    # the fuzz family of test_fuzz.py: degenerate rows, duplicates, zeros, values >= p
+    for seed in range(0, 120, 3):
+        p = str(tmp_path / ("f%d.r1cs" % seed))
+        fuzz_r1cs.write(p, fuzz_r1cs.make(seed))
+        _mh, sh = _system(E, E.FRONTEND_HOST, path=p)
+        md, sd = _system(E, E.FRONTEND_DEVICE, path=p)
+        st, d = orc.read_info(p)
+        assert st == 0 and list(md.info.nnz) == d["nnz"], seed
+        _same_dict_rows(seed, sh, sd)
+        _same_static_arrays(seed, sh, sd)
+    rows = [([], [], [(3, 5), (2, 1), (3, 7), (1, orc.P - 9)])]
+    for order in ((2, 1, 3), (1, 2, 3), (3, 1, 2)):
+        p = str(tmp_path / ("s%d%d%d.r1cs" % order))
+        fuzz_r1cs.write_raw(p, 3, 1, 0, 1, rows, section_order=order)
+        _mh, sh = _system(E, E.FRONTEND_HOST, path=p)
+        md, sd = _system(E, E.FRONTEND_DEVICE, path=p)
+        assert list(md.info.nnz) == [0, 0, 3]
+        _same_dict_rows(order, sh, sd)
+    # damaged files: accept / reject like the oracle's reader
+    rng = random.Random(5)
+    src = str(tmp_path / "good.r1cs")
+    fuzz_r1cs.write(src, fuzz_r1cs.make(3))
+    data = open(src, "rb").read()
+    E.set_frontend(E.FRONTEND_DEVICE)
+    n_rej = 0
+    for case in range(150):
+        d = bytearray(data)
+        if case % 3 == 0:
+            d = d[:rng.randrange(0, len(d))]
+        elif case % 3 == 1:
+            pos = rng.randrange(0, min(len(d), 200))
+            d[pos] ^= 1 << rng.randrange(8)
+        else:
+            pos = rng.randrange(0, len(d) - 4)
+            d[pos:pos + 4] = rng.choice([bytes([255, 255, 255, 127]), bytes(4), bytes([16, 0, 0, 0])])
+        p = str(tmp_path / ("bad%d.r1cs" % case))
+        open(p, "wb").write(bytes(d))
+        st_o, info = orc.read_info(p)
+        try:
+            f = E.R1CS(p)
+            st_n = 0
+        except E.EcneError as e:
+            st_n = e.status
+        assert (st_n == 0) == (st_o == 0), (case, st_n, st_o)
+        if st_n == 0:
+            assert list(f.info.nnz) == info["nnz"] and int(f.info.n_constraints) == info["nConstraints"], case
+        n_rej += st_n != 0
+    assert n_rej > 30
+
+
+def test_many_rows_with_repeated_wire_ids(tmp_path):
+    """7 000 rows, every ~8th part repeating a wire id (the device parse closes the gaps in a second pass), long parts woven in"""
+    import ecneproject_amd as E
+    from test_fuzz import _many_block_rows
+    rng = random.Random(99)
+    n_vars = 3000
+    rows = _many_block_rows(7000, 400, 4242)
+    for i in range(0, 7000, 500):      # parts of 11..170 terms (tables in LDS) and beyond (tables in HBM), some with repeats
+        for n in (12, 43, 90, 171, 700, 1100):
+            terms = [(rng.randint(1, n_vars), rng.choice([0, 1, 2, orc.P - 1, orc.P + 3, rng.getrandbits(250)])) for _ in range(n)]
+            if rng.random() < 0.5:
+                terms[rng.randrange(1, n)] = (terms[0][0], 7)
+            a = list(rows[i + (n % 17)])
+            a[rng.randrange(3)] = terms
+            rows[i + (n % 17)] = tuple(a)
+    p = str(tmp_path / "blocks.r1cs")
+    fuzz_r1cs.write_raw(p, n_vars - 1, 1, 1, n_vars - 3, rows)
+    _mh, sh = _system(E, E.FRONTEND_HOST, path=p)
+    md, sd = _system(E, E.FRONTEND_DEVICE, path=p)
+    st, d = orc.read_info(p)
+    assert st == 0 and list(md.info.nnz) == d["nnz"]
+    _same_dict_rows("blocks", sh, sd)
+    _same_static_arrays("blocks", sh, sd)
+
+
+def test_abstraction_fuzz_family(tmp_path):
+    import ecneproject_amd as E
+    import r1cs_py
+    import test_abstraction_fuzz as TA
+    n = n_inst = 0
+    for seed in range(0, TA.N_CASES):
+        rng = random.Random(77000 + seed)
+        sub, tag = TA._rand_sub(rng)
+        main = TA._rand_main(rng, sub, tag)
+        sp, mp = str(tmp_path / ("sub%d.r1cs" % seed)), str(tmp_path / ("main%d.r1cs" % seed))
+        r1cs_py.write(sp, sub["nwires"], sub["nout"], sub["npub"], sub["nprv"], sub["rows"])
+        r1cs_py.write(mp, main["nwires"], main["nout"], main["npub"], main["nprv"], main["rows"])
+        outs = []
+        for mode in (E.FRONTEND_HOST, E.FRONTEND_DEVICE):
+            E.set_frontend(mode)
+            try:
+                s = E.System(E.R1CS(mp))
+                s.abstract(E.R1CS(sp), "T")
+                outs.append((0, s.specials(), len(s), s))
+            except E.EcneError as e:
+                outs.append((e.status, None, None, None))
+        assert outs[0][:3] == outs[1][:3], (seed, outs[0][:3], outs[1][:3])
+        if outs[0][0] == 0:
+            o = orc.run(mp, [sp], ["T"], want_states=False)
+            assert outs[1][1] == o.specials and outs[1][2] == o.summary.n_rows_reduced, seed
+            _same_dict_rows(seed, outs[0][3], outs[1][3])
+            n += 1
+            n_inst += len(outs[1][1])
+    assert n > 100 and n_inst > 150
+
+
+@pytest.mark.parametrize("force_nwg", [0, 3])
+def test_solves_through_the_device_frontend(force_nwg):
+    import ecneproject_amd as E
+    from gpu_common import assert_bit_exact
+    E.set_frontend(E.FRONTEND_DEVICE)
+    for rel, trusted, names, secp, verdict in fixtures.REFERENCE_ASSERTED:
+        _m, s = _system(E, E.FRONTEND_DEVICE, rel, trusted, names)
+        g = E.solve_batch([s], secp_solve=secp, force_nwg=force_nwg)[0]
+        o = orc.run(fixtures.path(rel), [fixtures.path(t) for t in trusted], names, secp)
+        assert_bit_exact(rel, g, o)
+        assert g.function_good == verdict, rel
+    suite = fixtures.circomlib_suite()
+    systems = [_system(E, E.FRONTEND_DEVICE, rel)[1] for rel in suite]
+    for rel, g in zip(suite, E.solve_batch(systems, force_nwg=force_nwg)):
+        assert_bit_exact(rel, g, orc.run(fixtures.path(rel)))
+
+
+def test_ecdsa_like_small_through_both_frontends():
+    import ecneproject_amd as E
+    import ecdsa_like
+    from gpu_common import assert_bit_exact
+    p = ecdsa_like.cached(3, 10)
+    tr = fixtures.path("secp256k1.r1cs")
+    _mh, sh = _system(E, E.FRONTEND_HOST, path=p, trusted=[tr], names=["Secp256k1AddUnequal"])
+    _md, sd = _system(E, E.FRONTEND_DEVICE, path=p, trusted=[tr], names=["Secp256k1AddUnequal"])
+    st = E.frontend_stats()
+    assert st["abstract_device"] == 1.0 and st["matched"] == 2.0, st
+    assert sh.specials() == sd.specials()
+    _same_dict_rows("ecdsa_like(3)", sh, sd)
+    _same_static_arrays("ecdsa_like(3)", sh, sd)
+    g = E.solve_batch([sd])[0]
+    o = orc.run(p, [tr], ["Secp256k1AddUnequal"], False)
+    assert_bit_exact("ecdsa_like(3)", g, o)
