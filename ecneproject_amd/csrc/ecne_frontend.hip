@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <unordered_map>
 
 #include "abstract.hip.hpp"
@@ -62,6 +64,13 @@ uint32_t pow2_ge(uint64_t x, uint32_t lo) {
     uint64_t p = lo;
     while (p < x) p <<= 1;
     return (uint32_t)std::min<uint64_t>(p, 0x80000000ull);
+}
+// HBM tier of the hash-order kernels: slots per table buffer (room for two early growth steps beyond what the count asks for)
+// and workgroups (4 wavefronts each, 4 buffers per wavefront), bounded to 2 GiB of scratch
+void big_tier_shape(uint32_t maxn, uint32_t n_parts, uint32_t& gcap, uint32_t& g) {
+    gcap = pow2_ge(32ull * std::max<uint32_t>(maxn, 16), 4096);
+    const uint64_t per_wg = 4ull * 4 * gcap * 4;
+    g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((n_parts + 3) / 4, 64), ((uint64_t)2 << 30) / per_wg));
 }
 AbsRowsDev view(const DevRows& D) {
     AbsRowsDev R;
@@ -180,26 +189,30 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
     FE_TRY(hipMemcpy(ht, totals, 12, hipMemcpyDeviceToHost));
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     st.offsets_ms = ms_since(t_off);
+    if (std::getenv("ECNE_FE_DEBUG")) std::fprintf(stderr, "[fe] parse: NW %u total %u final (%llu, %llu) err %u n_mid %u n_large %u maxn %u terms %u %u %u\n", NW, total, (unsigned long long)fin[0], (unsigned long long)fin[1], hm.err_idx, hm.n_mid, hm.n_large, hm.maxn, ht[0], ht[1], ht[2]);
     if (hm.maxn >= (1u << 18)) return FE_FALLBACK;
     const auto t_fill = std::chrono::steady_clock::now();
     const uint64_t terms[3] = {ht[0], ht[1], ht[2]};
     { const int rc = alloc_rows(*D, device, nC, terms); if (rc != K_OK) return rc; }
     FeRowsOut O = out_view(*D);
     hipLaunchKernelGGL(k_fe_fill_small, dim3(blocks(total)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, (const uint32_t*)cnt, O, lenA, M);
-    if (hm.n_mid)
-        hipLaunchKernelGGL(k_fe_fill_big<true>, dim3(std::min<uint32_t>((hm.n_mid + 3) / 4, 256 * 8)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff,
-                           (const uint32_t*)midlist, hm.n_mid, nC, (const uint32_t*)cnt, O, lenA, M, (uint32_t*)nullptr, 0u);
+    if (hm.n_mid) {
+        hipLaunchKernelGGL(k_fe_fill_big<true>, dim3(std::min<uint32_t>((hm.n_mid + FE_MID_WAVES - 1) / FE_MID_WAVES, 256 * 8)), dim3(64 * FE_MID_WAVES), 0, s, (const uint32_t*)W,
+                           (const uint32_t*)poff, (const uint32_t*)midlist, hm.n_mid, nC, (const uint32_t*)cnt, O, lenA, M, (uint32_t*)nullptr, 0u, largelist);
+        FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));      // (parts whose table outgrew the LDS tier joined the large list)
+    }
     DevMem big;
     if (hm.n_large) {
-        const uint32_t gcap = pow2_ge(8ull * hm.maxn, 1024);
-        const uint32_t g = std::min<uint32_t>((hm.n_large + 3) / 4, 64);
+        uint32_t gcap, g;
+        big_tier_shape(hm.maxn, hm.n_large, gcap, g);
         { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
         hipLaunchKernelGGL(k_fe_fill_big<false>, dim3(g), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, (const uint32_t*)largelist, hm.n_large, nC,
-                           (const uint32_t*)cnt, O, lenA, M, (uint32_t*)big.base, gcap);
+                           (const uint32_t*)cnt, O, lenA, M, (uint32_t*)big.base, gcap, (uint32_t*)nullptr);
     }
     hipLaunchKernelGGL(k_fe_ptr, dim3(blocks((uint64_t)nC + 1)), dim3(256), 0, s, (const uint32_t*)cnt, nC, O);
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     FE_TRY(hipGetLastError());
+    if (std::getenv("ECNE_FE_DEBUG")) std::fprintf(stderr, "[fe] fill: dup %u unsupported %u maxvar %u nnz %llu %llu %llu\n", hm.dup, hm.unsupported, hm.maxvar, hm.nnz[0], hm.nnz[1], hm.nnz[2]);
     if (hm.unsupported) return FE_FALLBACK;
     if (hm.dup) {      // some part repeated a wire id: close the gaps it left
         for (int p = 0; p < 3; ++p) scan_u32(lenA + (size_t)p * (nC + 1), npos + (size_t)p * (nC + 1), nC + 1, tops, totals + p, s);
@@ -707,15 +720,17 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     DevMem big;
     if (nC) {
         hipLaunchKernelGGL(k_lay_order_small, dim3(blocks(3ull * nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial);
-        if (hm.n_mid)
-            hipLaunchKernelGGL(k_lay_order_big<true>, dim3(std::min<uint32_t>((hm.n_mid + 3) / 4, 256 * 8)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial,
-                               (const uint32_t*)midlist, hm.n_mid, M, (uint32_t*)nullptr, 0u);
+        if (hm.n_mid) {
+            hipLaunchKernelGGL(k_lay_order_big<true>, dim3(std::min<uint32_t>((hm.n_mid + FE_MID_WAVES - 1) / FE_MID_WAVES, 256 * 8)), dim3(64 * FE_MID_WAVES), 0, s, R, nC, (const uint32_t*)nzc, L, sum,
+                               Dst.nontrivial, (const uint32_t*)midlist, hm.n_mid, M, (uint32_t*)nullptr, 0u, largelist);
+            FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
+        }
         if (hm.n_large) {
-            const uint32_t gcap = pow2_ge(8ull * hm.maxn, 1024);
-            const uint32_t g = std::min<uint32_t>((hm.n_large + 3) / 4, 64);
+            uint32_t gcap, g;
+            big_tier_shape(hm.maxn, hm.n_large, gcap, g);
             { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
             hipLaunchKernelGGL(k_lay_order_big<false>, dim3(g), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial, (const uint32_t*)largelist, hm.n_large, M,
-                               (uint32_t*)big.base, gcap);
+                               (uint32_t*)big.base, gcap, (uint32_t*)nullptr);
         }
         // ---- C. row descriptors, flags, P5 candidates, (variable, row) pairs
         FE_TRY(hipMemsetAsync(f_p4, 0, 4ull * ((size_t)nC + 2), s));

@@ -36,8 +36,11 @@ namespace fe {
 #define FE_TILE_W (FE_CH * FE_TILE_CH)
 #define FE_NONE 0xFFFFFFFFFFFFFFFFull
 #define FE_LANE_MAX 10u                 // parts of up to this many terms: one lane each (a 16-slot table never grows with <= 10 keys)
-#define FE_MID_MAX 170u                 // up to this many: one wavefront, tables of <= 512 slots in LDS; beyond: tables in HBM scratch
-#define FE_MID_CAP 512u
+#define FE_MID_MAX 170u                 // up to this many: one wavefront, tables of <= 1024 slots in LDS (256 by count; a probe sequence of 16 -- which
+                                        // Julia's hash of consecutive ids does produce -- quadruples the table early); beyond, or when
+                                        // even that overflows: tables in HBM scratch
+#define FE_MID_CAP 1024u
+#define FE_MID_WAVES 2u                 // wavefronts per workgroup in the LDS tier (2 x 4 arrays x 1024 slots x 4 B = 32 KB)
 
 __device__ __forceinline__ uint64_t ld64_agent(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -280,12 +283,13 @@ __global__ __launch_bounds__(256) void k_fe_fill_small(const uint32_t* __restric
 // One wavefront per listed part. LDS_TABLES: tables of up to FE_MID_CAP slots in LDS (parts of 11..170 terms), else in the
 // wavefront's HBM scratch (gcap slots per buffer). Lane 0 replays the dictionary insertions; all lanes emit the slots.
 template <bool LDS_TABLES>
-__global__ __launch_bounds__(256) void k_fe_fill_big(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(LDS_TABLES ? 64 * FE_MID_WAVES : 256) void k_fe_fill_big(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, const uint32_t* __restrict__ list,
                                                      uint32_t nlist, uint32_t nC, const uint32_t* __restrict__ pos, FeRowsOut O,
-                                                     uint32_t* __restrict__ len, FeMeta* M, uint32_t* gscratch, uint32_t gcap) {
-    __shared__ uint32_t s_tab[LDS_TABLES ? 4 * 4 * FE_MID_CAP : 4];
+                                                     uint32_t* __restrict__ len, FeMeta* M, uint32_t* gscratch, uint32_t gcap, uint32_t* __restrict__ overflow_list) {
+    constexpr uint32_t WAVES = LDS_TABLES ? FE_MID_WAVES : 4u;
+    __shared__ uint32_t s_tab[LDS_TABLES ? FE_MID_WAVES * 4 * FE_MID_CAP : 4];
     const int lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * 4u + wave, nw = gridDim.x * 4u;
+    const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FE_MID_CAP : gscratch + (size_t)gw * 4 * gcap;
     const uint32_t cap = LDS_TABLES ? FE_MID_CAP : gcap;
     for (uint32_t b = gw; b < nlist; b += nw) {
@@ -306,7 +310,10 @@ __global__ __launch_bounds__(256) void k_fe_fill_big(const uint32_t* __restrict_
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
-        if (bad) { if (lane == 0) atomicOr(&M->unsupported, 1u); continue; }
+        if (bad) {      // the table outgrew this tier: hand the part to the HBM tier, or give the file back to the host path
+            if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(&M->n_large, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
+            continue;
+        }
         const uint32_t* key = flipped ? base + 2 * cap : base;
         const uint32_t* pay = flipped ? base + 3 * cap : base + cap;
         uint32_t m = 0, nz = 0, mv = 0;
@@ -621,12 +628,13 @@ __global__ __launch_bounds__(256) void k_lay_order_small(AbsRowsDev R, uint32_t 
 }
 // ... and for longer parts: one wavefront per part (lane 0 replays the Set insertions, all lanes emit the slots)
 template <bool LDS_TABLES>
-__global__ __launch_bounds__(256) void k_lay_order_big(AbsRowsDev R, uint32_t nC, const uint32_t* __restrict__ rp, LayCsr L, PartSum* __restrict__ sum,
+__global__ __launch_bounds__(LDS_TABLES ? 64 * FE_MID_WAVES : 256) void k_lay_order_big(AbsRowsDev R, uint32_t nC, const uint32_t* __restrict__ rp, LayCsr L, PartSum* __restrict__ sum,
                                                        uint8_t* __restrict__ nontrivial, const uint32_t* __restrict__ list, uint32_t nlist, FeMeta* M,
-                                                       uint32_t* gscratch, uint32_t gcap) {
-    __shared__ uint32_t s_tab[LDS_TABLES ? 4 * 4 * FE_MID_CAP : 4];
+                                                       uint32_t* gscratch, uint32_t gcap, uint32_t* __restrict__ overflow_list) {
+    constexpr uint32_t WAVES = LDS_TABLES ? FE_MID_WAVES : 4u;
+    __shared__ uint32_t s_tab[LDS_TABLES ? FE_MID_WAVES * 4 * FE_MID_CAP : 4];
     const int lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * 4u + wave, nw = gridDim.x * 4u;
+    const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FE_MID_CAP : gscratch + (size_t)gw * 4 * gcap;
     const uint32_t cap = LDS_TABLES ? FE_MID_CAP : gcap;
     for (uint32_t b = gw; b < nlist; b += nw) {
@@ -662,7 +670,10 @@ __global__ __launch_bounds__(256) void k_lay_order_big(AbsRowsDev R, uint32_t nC
         if (lane == 0) { sz = t.sz; flipped = t.key != base; }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
-        if (bad) { if (lane == 0) atomicOr(&M->unsupported, 1u); continue; }
+        if (bad) {
+            if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(&M->n_large, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
+            continue;
+        }
         const uint32_t* key = flipped ? base + 2 * cap : base;
         const uint32_t* pay = flipped ? base + 3 * cap : base + cap;
         uint32_t m = 0, first_var = 0, first_non1 = 0, last_non1 = 0, n_non1 = 0, has1 = 0;
