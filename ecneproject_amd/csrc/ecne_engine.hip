@@ -64,6 +64,18 @@ static int current_device() {
     if (hipGetDevice(&d) != hipSuccess) d = 0;
     return d;
 }
+// ECNE_FE_DEBUG=1: wall-clock of the steps of an entry point on stderr (developer aid)
+struct AbiTick {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    AbiTick() : on(std::getenv("ECNE_FE_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char* label) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[abi] %-40s %8.3f ms\n", label, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 // timing of the calling thread's last trip through the device front-end (ecne_frontend_stats)
 struct FrontendStats { fe::ParseStats parse; fe::AbstractDevStats abs; double layout_ms = 0; int parse_dev = 0, abs_dev = 0, layout_dev = 0; };
 static thread_local FrontendStats g_fe_stats;
@@ -72,6 +84,17 @@ static thread_local FrontendStats g_fe_stats;
 static int ensure_host_rows(const ecne_r1cs* h) {
     R1CSFile& f = const_cast<ecne_r1cs*>(h)->f;
     if (f.host_rows) return K_OK;
+    if (!f.path.empty()) {      // from the file again where it still is (a download into fresh pageable memory costs more than parsing a small file)
+        FileView fv(f.path.c_str());
+        R1CSFile again;
+        size_t cons_off = 0;
+        if (read_r1cs_header(fv, again, cons_off) == K_OK && again.n_cons == f.n_cons && again.n_wires == f.n_wires &&
+            read_r1cs_rows(fv, cons_off, f.path.c_str(), again) == K_OK && again.nnz[0] == f.nnz[0] && again.nnz[1] == f.nnz[1] && again.nnz[2] == f.nnz[2]) {
+            f.rows = std::move(again.rows);
+            f.host_rows = true;
+            return K_OK;
+        }
+    }
     if (h->drows) {
         const int rc = fe::download_rows(*h->drows, f.rows);
         if (rc != K_OK) return rc;
@@ -881,23 +904,26 @@ extern "C" {
 static int ecne_r1cs_load_impl(const char* path, ecne_r1cs** out) {
     if (!path || !out) return ECNE_EINVAL;
     *out = nullptr;
+    AbiTick tick;
     std::unique_ptr<ecne_r1cs> r(new ecne_r1cs());
     FileView fv(path);
     size_t cons_off = 0;
     int st = read_r1cs_header(fv, r->f, cons_off);
     if (st != K_OK) return st;
+    tick("load: open + map + header");
     r->f.path = path;
     g_fe_stats.parse = fe::ParseStats();
     g_fe_stats.parse_dev = 0;
     bool done = false;
     if (frontend_wants_device(r->f.n_cons)) {
         // the constraint section goes to the device as it is; rows come out in the reference's dictionary order there
-        st = fe::parse_on_device(fv.data + cons_off, fv.size - cons_off, r->f.n_cons, current_device(), r->drows, g_fe_stats.parse);
+        st = fe::parse_on_device(fv.data, fv.size, cons_off, r->f.n_cons, current_device(), r->drows, g_fe_stats.parse);
         if (st == K_OK) {
             for (int p = 0; p < 3; ++p) r->f.nnz[p] = r->drows->nnz[p];
             g_fe_stats.parse_dev = 1;
             done = true;
         } else if (st != fe::FE_FALLBACK) return st;
+        tick("load: parse_on_device");
     }
     if (!done) {
         st = read_r1cs_rows(fv, cons_off, path, r->f);
@@ -956,7 +982,9 @@ static thread_local AbstractStats g_last_abstract;
 
 static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const char* name) {
     if (!sys || !trusted || !name) return ECNE_EINVAL;
+    AbiTick tick;
     { const int rc = ensure_host_rows(trusted); if (rc != K_OK) return rc; }      // the pattern side is prepared on the host (small)
+    tick("abstract: host rows of the trusted file");
     g_last_abstract = AbstractStats();
     g_fe_stats.abs = fe::AbstractDevStats();
     g_fe_stats.abs_dev = 0;
@@ -965,6 +993,7 @@ static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const 
         std::shared_ptr<fe::DevRows> red;
         std::vector<Special> fresh = sys->specials;
         const int rc = fe::abstract_on_device(name, sys->drows, trusted->f, fresh, red, g_fe_stats.abs);
+        tick("abstract: abstract_on_device");
         if (rc == K_OK) {
             system_changed_rows(sys);   // layout and device image are stale, earlier results unreadable
             sys->specials = std::move(fresh);
@@ -978,6 +1007,7 @@ static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const 
             g_last_abstract.used_device = 1;
             g_last_abstract.fp_ms = g_fe_stats.abs.fp_ms; g_last_abstract.scan_ms = g_fe_stats.abs.scan_ms;
             g_last_abstract.bytes = (double)g_fe_stats.abs.bytes; g_last_abstract.n_cand = g_fe_stats.abs.n_cand;
+            tick("abstract: handle update");
             return K_OK;
         }
         if (rc != fe::FE_FALLBACK) return rc;

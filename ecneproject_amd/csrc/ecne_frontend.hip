@@ -35,7 +35,8 @@ struct DeviceGuard {      // the front-end works on the device it is told to and
 struct DevMem {      // one allocation, carved
     char* base = nullptr;
     size_t cap = 0, off = 0;
-    ~DevMem() { if (base) (void)hipFree(base); }
+    ~DevMem() { free_now(); }
+    void free_now() { if (base) (void)hipFree(base); base = nullptr; }
     int alloc(size_t bytes) {
         cap = bytes + 256;
         return hipMalloc((void**)&base, cap) == hipSuccess ? K_OK : K_ENODEVICE;
@@ -46,6 +47,20 @@ struct DevMem {      // one allocation, carved
         return off <= cap ? reinterpret_cast<T*>(base + o) : nullptr;
     }
     static size_t sz(size_t n, size_t elem) { return (n * elem + 255) & ~(size_t)255; }
+};
+// ECNE_FE_DEBUG=1: every phase synchronises the device and prints what it took (developer aid; off, it costs a getenv per call)
+struct Tick {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    const char* what;
+    explicit Tick(const char* w) : on(std::getenv("ECNE_FE_DEBUG") != nullptr), t(std::chrono::steady_clock::now()), what(w) {}
+    void operator()(const char* label) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[fe] %-10s %-28s %8.3f ms\n", what, label, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
 };
 double ms_since(std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
@@ -110,8 +125,15 @@ DevRows::~DevRows() {
 }
 
 // ====================================================================================== parse
-int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device, std::shared_ptr<DevRows>& out, ParseStats& st) {
+int parse_on_device(const uint8_t* file, size_t file_size, size_t cons_off, uint32_t n_cons, int device, std::shared_ptr<DevRows>& out, ParseStats& st) {
     st = ParseStats();
+    if (cons_off > file_size) return K_EFORMAT;
+    // The whole file is copied from the (page-aligned) start of the mapping when the constraints start on a word boundary --
+    // every file a circom compiler writes: a pageable hipMemcpy from a page-aligned source runs at 47 GB/s, from an odd
+    // address at 14 -- and the kernels see the words from the first constraint on.
+    const size_t head = (cons_off % 4 == 0) ? cons_off : 0;
+    const uint8_t* cons = file + cons_off;
+    const size_t len = file_size - cons_off;
     const auto t_all = std::chrono::steady_clock::now();
     if (len >= ((size_t)1 << 32) - 4096) return FE_FALLBACK;
     const uint64_t total64 = 3ull * n_cons;
@@ -132,12 +154,13 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
     // file words + scratch of the offset passes
     DevMem m;
     {
-        size_t b = DevMem::sz((size_t)NW + 16, 4) + 2 * DevMem::sz(NW, 8) + DevMem::sz(ntiles, 8) + DevMem::sz(nchunks, 8) + DevMem::sz(total, 4)
-                 + 2 * DevMem::sz(3 * ((size_t)nC + 1), 4) + 2 * DevMem::sz(total, 4) + DevMem::sz((size_t)nC / 1024 + 8, 4) + 4 * 256 + DevMem::sz(3 * ((size_t)nC + 1), 4);
+        size_t b = DevMem::sz((size_t)NW + 16 + head / 4, 4) + 2 * DevMem::sz(NW, 8) + DevMem::sz(ntiles, 8) + DevMem::sz(nchunks, 8) + DevMem::sz(total, 4)
+                 + 2 * DevMem::sz(3 * ((size_t)nC + 1), 4) + 3 * DevMem::sz(total, 4) + DevMem::sz((size_t)nC / 1024 + 8, 4) + 4 * 256 + DevMem::sz(3 * ((size_t)nC + 1), 4);
         const int rc = m.alloc(b);
         if (rc != K_OK) return rc;
     }
-    uint32_t* W = m.take<uint32_t>((size_t)NW + 16);
+    uint32_t* Wbuf = m.take<uint32_t>((size_t)NW + 16 + head / 4);
+    uint32_t* W = Wbuf + head / 4;
     uint64_t* E1 = m.take<uint64_t>(NW);
     uint64_t* E2 = m.take<uint64_t>(NW);
     uint64_t* tile_entry = m.take<uint64_t>(ntiles);
@@ -147,6 +170,7 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
     uint32_t* lenA = m.take<uint32_t>(3 * ((size_t)nC + 1));     // entries every part really came out with
     uint32_t* midlist = m.take<uint32_t>(total);
     uint32_t* largelist = m.take<uint32_t>(total);
+    uint32_t* hugelist = m.take<uint32_t>(total);
     uint32_t* tops = m.take<uint32_t>((size_t)nC / 1024 + 8);
     FeMeta* M = m.take<FeMeta>(1);
     uint64_t* final_state = m.take<uint64_t>(2);
@@ -154,11 +178,15 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
     uint32_t* npos = m.take<uint32_t>(3 * ((size_t)nC + 1));
     if (!npos) return K_ECAPACITY;
     hipStream_t s = 0;
+    Tick tick("parse");
+    tick("alloc scratch");
     const auto t_up = std::chrono::steady_clock::now();
     FE_TRY(hipMemsetAsync(W + (NW - 1), 0, 4 * 17, s));           // the last (partial) word and the pad
-    FE_TRY(hipMemcpy(W, cons, len, hipMemcpyHostToDevice));
+    if (head) FE_TRY(hipMemcpy(Wbuf, file, file_size, hipMemcpyHostToDevice));
+    else FE_TRY(hipMemcpy(W, cons, len, hipMemcpyHostToDevice));
     st.upload_ms = ms_since(t_up);
     st.file_bytes = len;
+    tick("upload");
     const auto t_off = std::chrono::steady_clock::now();
     FE_TRY(hipMemsetAsync(tile_entry, 0xFF, 8ull * ntiles, s));
     FE_TRY(hipMemsetAsync(chunk_entry, 0xFF, 8ull * nchunks, s));
@@ -172,9 +200,13 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
         FE_TRY(hipMemcpyAsync(M, &h, sizeof h, hipMemcpyHostToDevice, s));
         FE_TRY(hipStreamSynchronize(s));
     }
+    tick("memsets");
     hipLaunchKernelGGL(k_fe_exit1, dim3(std::min<uint32_t>(nchunks, 256 * 32)), dim3(256), 0, s, (const uint32_t*)W, NW, E1);
+    tick("k_fe_exit1");
     hipLaunchKernelGGL(k_fe_exit2, dim3(std::min<uint32_t>(ntiles, 256 * 8)), dim3(256), 0, s, (const uint64_t*)E1, E2, NW);
+    tick("k_fe_exit2");
     hipLaunchKernelGGL(k_fe_chain, dim3(1), dim3(64), 0, s, (const uint64_t*)E2, NW, total, tile_entry, final_state);
+    tick("k_fe_chain");
     hipLaunchKernelGGL(k_fe_chunk_entries, dim3(blocks(ntiles)), dim3(256), 0, s, (const uint64_t*)E1, (const uint64_t*)tile_entry, chunk_entry, NW, total);
     hipLaunchKernelGGL(k_fe_part_offsets, dim3(blocks(nchunks)), dim3(256), 0, s, (const uint32_t*)W, (const uint64_t*)chunk_entry, poff, NW, (uint64_t)len, total, &M->err_idx);
     uint64_t fin[2];
@@ -182,36 +214,50 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
     FE_TRY(hipMemcpy(fin, final_state, 16, hipMemcpyDeviceToHost));
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     FE_TRY(hipGetLastError());
+    tick("chunk entries + part offsets");
     if (hm.err_idx != 0xFFFFFFFFu || fin[1] < total) return K_EFORMAT;      // the walk leaves the file
-    hipLaunchKernelGGL(k_fe_terms, dim3(blocks(total)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, cnt, midlist, largelist, M);
+    hipLaunchKernelGGL(k_fe_terms, dim3(std::min<unsigned>(blocks(total), 2048)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, cnt, midlist, largelist, hugelist, M);
     for (int p = 0; p < 3; ++p) scan_u32(cnt + (size_t)p * (nC + 1), cnt + (size_t)p * (nC + 1), nC + 1, tops, totals + p, s);
     uint32_t ht[4];
     FE_TRY(hipMemcpy(ht, totals, 12, hipMemcpyDeviceToHost));
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     st.offsets_ms = ms_since(t_off);
-    if (std::getenv("ECNE_FE_DEBUG")) std::fprintf(stderr, "[fe] parse: NW %u total %u final (%llu, %llu) err %u n_mid %u n_large %u maxn %u terms %u %u %u\n", NW, total, (unsigned long long)fin[0], (unsigned long long)fin[1], hm.err_idx, hm.n_mid, hm.n_large, hm.maxn, ht[0], ht[1], ht[2]);
+    tick("terms + scans");
+    if (std::getenv("ECNE_FE_DEBUG")) std::fprintf(stderr, "[fe] parse: NW %u total %u final (%llu, %llu) err %u n_mid %u n_large %u maxn %u terms %u %u %u\n", NW, total, (unsigned long long)fin[0], (unsigned long long)fin[1], hm.err_idx, hm.n_mid, hm.n_large + hm.n_huge, hm.maxn, ht[0], ht[1], ht[2]);
     if (hm.maxn >= (1u << 18)) return FE_FALLBACK;
     const auto t_fill = std::chrono::steady_clock::now();
     const uint64_t terms[3] = {ht[0], ht[1], ht[2]};
     { const int rc = alloc_rows(*D, device, nC, terms); if (rc != K_OK) return rc; }
     FeRowsOut O = out_view(*D);
-    hipLaunchKernelGGL(k_fe_fill_small, dim3(blocks(total)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, (const uint32_t*)cnt, O, lenA, M);
+    tick("alloc rows");
+    hipLaunchKernelGGL(k_fe_fill_small, dim3(std::min<unsigned>(blocks(total), 4096)), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, total, nC, (const uint32_t*)cnt, O, lenA, M);
+    tick("k_fe_fill_small");
     if (hm.n_mid) {
-        hipLaunchKernelGGL(k_fe_fill_big<true>, dim3(std::min<uint32_t>((hm.n_mid + FE_MID_WAVES - 1) / FE_MID_WAVES, 256 * 8)), dim3(64 * FE_MID_WAVES), 0, s, (const uint32_t*)W,
-                           (const uint32_t*)poff, (const uint32_t*)midlist, hm.n_mid, nC, (const uint32_t*)cnt, O, lenA, M, (uint32_t*)nullptr, 0u, largelist);
-        FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));      // (parts whose table outgrew the LDS tier joined the large list)
+        hipLaunchKernelGGL(k_fe_fill_big<1>, dim3(std::min<uint32_t>((hm.n_mid + FE_MID_WAVES - 1) / FE_MID_WAVES, 256 * 8)), dim3(64 * FE_MID_WAVES), FeTier<1>::lds_bytes, s, (const uint32_t*)W,
+                           (const uint32_t*)poff, (const uint32_t*)midlist, hm.n_mid, nC, (const uint32_t*)cnt, O, lenA, M, (uint32_t*)nullptr, 0u, largelist, &M->n_large);
+        FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));      // (parts whose table outgrew the tier joined the next list)
     }
-    DevMem big;
+    tick("k_fe_fill_big<lds 1024>");
     if (hm.n_large) {
-        uint32_t gcap, g;
-        big_tier_shape(hm.maxn, hm.n_large, gcap, g);
-        { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
-        hipLaunchKernelGGL(k_fe_fill_big<false>, dim3(g), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, (const uint32_t*)largelist, hm.n_large, nC,
-                           (const uint32_t*)cnt, O, lenA, M, (uint32_t*)big.base, gcap, (uint32_t*)nullptr);
+        FE_TRY(hipFuncSetAttribute((const void*)k_fe_fill_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FeTier<2>::lds_bytes));
+        hipLaunchKernelGGL(k_fe_fill_big<2>, dim3(std::min<uint32_t>(hm.n_large, 256 * 4)), dim3(64), FeTier<2>::lds_bytes, s, (const uint32_t*)W,
+                           (const uint32_t*)poff, (const uint32_t*)largelist, hm.n_large, nC, (const uint32_t*)cnt, O, lenA, M, (uint32_t*)nullptr, 0u, hugelist, &M->n_huge);
+        FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     }
+    tick("k_fe_fill_big<lds 4096>");
+    DevMem big;
+    if (hm.n_huge) {
+        uint32_t gcap, g;
+        big_tier_shape(hm.maxn, hm.n_huge, gcap, g);
+        { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
+        hipLaunchKernelGGL(k_fe_fill_big<0>, dim3(g), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, (const uint32_t*)hugelist, hm.n_huge, nC,
+                           (const uint32_t*)cnt, O, lenA, M, (uint32_t*)big.base, gcap, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    }
+    tick("k_fe_fill_big<hbm>");
     hipLaunchKernelGGL(k_fe_ptr, dim3(blocks((uint64_t)nC + 1)), dim3(256), 0, s, (const uint32_t*)cnt, nC, O);
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     FE_TRY(hipGetLastError());
+    tick("k_fe_ptr");
     if (std::getenv("ECNE_FE_DEBUG")) std::fprintf(stderr, "[fe] fill: dup %u unsupported %u maxvar %u nnz %llu %llu %llu\n", hm.dup, hm.unsupported, hm.maxvar, hm.nnz[0], hm.nnz[1], hm.nnz[2]);
     if (hm.unsupported) return FE_FALLBACK;
     if (hm.dup) {      // some part repeated a wire id: close the gaps it left
@@ -230,6 +276,9 @@ int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device
     FE_TRY(hipStreamSynchronize(s));
     FE_TRY(hipGetLastError());
     st.fill_ms = ms_since(t_fill);
+    m.free_now();
+    big.free_now();
+    tick("free scratch");
     st.total_ms = ms_since(t_all);
     out = D;
     return K_OK;
@@ -263,7 +312,23 @@ struct PatternHostDev {      // host image of AbsPattern
 void build_pattern(const R1CSFile& sub, PatternHostDev& P) {
     const Rows& R = sub.rows;
     P.nS = (uint32_t)R.n();
-    std::unordered_map<uint32_t, uint32_t> dense;
+    // pattern variable -> dense index in first-seen order (ids are wire ids + 1 of a small file: a flat array)
+    struct DenseMap {
+        std::vector<uint32_t> a;
+        std::unordered_map<uint32_t, uint32_t> big;
+        uint32_t n = 0;
+        explicit DenseMap(size_t lim) : a(lim, 0xFFFFFFFFu) {}
+        uint32_t* find(uint32_t v) {
+            if (v < a.size()) return a[v] == 0xFFFFFFFFu ? nullptr : &a[v];
+            auto it = big.find(v);
+            return it == big.end() ? nullptr : &it->second;
+        }
+        uint32_t add(uint32_t v) {
+            if (v < a.size()) a[v] = n; else big.emplace(v, n);
+            return n++;
+        }
+        size_t size() const { return n; }
+    } dense((size_t)std::min<int64_t>(std::max<int64_t>(sub.n_vars + 2, 16), 1 << 24));
     std::vector<uint64_t> h1, h2;
     P.part_nz.assign(3ull * P.nS, 0);
     for (uint32_t j = 0; j < P.nS; ++j)
@@ -271,10 +336,10 @@ void build_pattern(const R1CSFile& sub, PatternHostDev& P) {
             const uint32_t q = 3 * j + (uint32_t)p;
             for (uint64_t k = R.ptr[p][j]; k < R.ptr[p][j + 1]; ++k) {
                 if (fp::is_zero(R.coef[p][k])) continue;
-                auto it = dense.find(R.var[p][k]);
+                uint32_t* it = dense.find(R.var[p][k]);
                 uint32_t u;
-                if (it == dense.end()) { u = (uint32_t)dense.size(); dense.emplace(R.var[p][k], u); h1.push_back(0); h2.push_back(0); }
-                else u = it->second;
+                if (!it) { u = dense.add(R.var[p][k]); h1.push_back(0); h2.push_back(0); }
+                else u = *it;
                 uint64_t a, b;
                 sig_hash((uint64_t)q + 1ull, R.coef[p][k].w, a, b);
                 h1[u] += a; h2[u] += b;
@@ -314,10 +379,10 @@ void build_pattern(const R1CSFile& sub, PatternHostDev& P) {
         P.tab_h2[t] = kv.first.b;
     }
     auto io = [&](int64_t x) {
-        auto it = x >= 0 && x <= 0xFFFFFFFFll ? dense.find((uint32_t)x) : dense.end();
-        if (it == dense.end()) { P.io_idx.push_back(0xFFFFFFFFu); return; }
-        P.io_idx.push_back(it->second);
-        if (cls_size[cls_of[it->second]] != 1) P.io_tied = true;
+        uint32_t* it = x >= 0 && x <= 0xFFFFFFFFll ? dense.find((uint32_t)x) : nullptr;
+        if (!it) { P.io_idx.push_back(0xFFFFFFFFu); return; }
+        P.io_idx.push_back(*it);
+        if (cls_size[cls_of[*it]] != 1) P.io_tied = true;
     };
     for (int64_t x : sub.knowns) if (x != 1) io(x);
     for (int64_t x : sub.outputs) io(x);
@@ -433,15 +498,18 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
     if (nC < nS) { red = rows; return K_OK; }
     DeviceGuard guard(rows->device);
     if (!guard.ok) return K_ENODEVICE;
+    Tick tick("abstract");
     const auto t_prep = std::chrono::steady_clock::now();
     PatternHostDev PH;
     build_pattern(sub, PH);
     st.prep_ms = ms_since(t_prep);
+    tick("pattern prep (host)");
     if (PH.io_tied) return FE_FALLBACK;
     const AbsRowsDev R = view(*rows);
     std::vector<size_t> cand;
     { const int rc = candidates_dev(R, nC, sub.rows, cand, st); if (rc != K_OK) return rc; }
     for (int p = 0; p < 3; ++p) st.bytes += 32ull * rows->terms[p];
+    tick("fingerprints + window scan");
     std::vector<uint8_t> matched(cand.size(), 0);
     std::vector<uint32_t> io_img((size_t)cand.size() * std::max<uint32_t>(PH.nio, 1), 0xFFFFFFFFu);
     const auto t_ver = std::chrono::steady_clock::now();
@@ -485,6 +553,7 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
         Wn.status = wm.take<uint32_t>(batch);
         Wn.io_out = wm.take<uint32_t>(batch * std::max<uint32_t>(PH.nio, 1));
         if (!Wn.io_out) return K_ECAPACITY;
+        tick("pattern upload + window alloc");
         std::vector<uint32_t> h_start(batch), h_status(batch), h_nv(batch), h_nm(batch), h_io(batch * std::max<uint32_t>(PH.nio, 1));
         std::vector<size_t> ambiguous;
         for (size_t b0 = 0; b0 < cand.size(); b0 += batch) {
@@ -500,9 +569,13 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
             FE_TRY(hipMemsetAsync(Wn.nvars, 0, 4ull * nb, 0));
             FE_TRY(hipMemsetAsync(Wn.nmatched, 0, 4ull * nb, 0));
             FE_TRY(hipMemsetAsync(Wn.status, 0, 4ull * nb, 0));
+            tick("window memsets");
             hipLaunchKernelGGL(k_abs_sig, dim3(blocks(3ull * PH.nS), nb), dim3(256), 0, 0, R, P, Wn);
+            tick("k_abs_sig");
             hipLaunchKernelGGL(k_abs_match, dim3(blocks(capW), nb), dim3(256), 0, 0, P, Wn);
+            tick("k_abs_match");
             if (PH.nEnt) hipLaunchKernelGGL(k_abs_exact, dim3(blocks(PH.nEnt), nb), dim3(256), 0, 0, R, P, Wn);
+            tick("k_abs_exact");
             if (PH.nio) hipLaunchKernelGGL(k_abs_io, dim3(blocks((uint64_t)nb * PH.nio)), dim3(256), 0, 0, P, Wn);
             FE_TRY(hipMemcpy(h_status.data(), Wn.status, 4ull * nb, hipMemcpyDeviceToHost));
             FE_TRY(hipMemcpy(h_nv.data(), Wn.nvars, 4ull * nb, hipMemcpyDeviceToHost));
@@ -554,6 +627,7 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
         }
     }
     st.verify_ms = ms_since(t_ver);
+    tick("verdicts to host + frees");
     for (uint8_t mm : matched) st.n_matched += mm;
     // greedy replacement (host: a handful of windows), in the order sub.knowns \ {1}, sub.outputs were mapped
     std::vector<std::pair<size_t, size_t>> keep;
@@ -618,6 +692,7 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
         red = D;
     }
     st.compact_ms = ms_since(t_cmp);
+    tick("compaction");
     for (auto& sp : fresh) specials.push_back(std::move(sp));
     return K_OK;
 }
@@ -648,7 +723,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     // ---- temporaries (freed on return)
     DevMem tm;
     {
-        const size_t b = DevMem::sz(3 * ((size_t)nC + 1), 4) + DevMem::sz(3 * (size_t)std::max<uint32_t>(nC, 1), sizeof(PartSum)) + 2 * DevMem::sz(3ull * nC + 1, 4) +
+        const size_t b = DevMem::sz(3 * ((size_t)nC + 1), 4) + DevMem::sz(3 * (size_t)std::max<uint32_t>(nC, 1), sizeof(PartSum)) + 3 * DevMem::sz(3ull * nC + 1, 4) +
                          5 * DevMem::sz((size_t)nC + 2, 4) + DevMem::sz((size_t)nC + 1, 1) + 2 * DevMem::sz(tall + 1, 8) + DevMem::sz(tall + 2, 4) + 8192 +
                          DevMem::sz((size_t)std::max<uint64_t>(tall, (uint64_t)nC) / 1024 + 16, 4);
         const int rc = tm.alloc(b);
@@ -658,6 +733,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     PartSum* sum = tm.take<PartSum>(3 * (size_t)std::max<uint32_t>(nC, 1));
     uint32_t* midlist = tm.take<uint32_t>(3ull * nC + 1);
     uint32_t* largelist = tm.take<uint32_t>(3ull * nC + 1);
+    uint32_t* hugelist = tm.take<uint32_t>(3ull * nC + 1);
     uint32_t* f_p4 = tm.take<uint32_t>((size_t)nC + 2);
     uint32_t* f_cls = tm.take<uint32_t>((size_t)nC + 2);
     uint32_t* f_big = tm.take<uint32_t>((size_t)nC + 2);
@@ -671,14 +747,17 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     uint32_t* totals = tm.take<uint32_t>(16);
     uint32_t* tops = tm.take<uint32_t>((size_t)std::max<uint64_t>(tall, (uint64_t)nC) / 1024 + 16);
     if (!tops) return K_ECAPACITY;
+    Tick tick("layout");
+    tick("alloc temporaries");
     // ---- A. non-zero counts -> CSR row pointers; largest variable id
     FE_TRY(hipMemsetAsync(M, 0, sizeof(FeMeta), s));
     FE_TRY(hipMemsetAsync(nzc, 0, 12ull * ((size_t)nC + 1), s));
-    if (nC) hipLaunchKernelGGL(k_lay_count, dim3(blocks(3ull * nC)), dim3(256), 0, s, R, nC, nzc, midlist, largelist, M);
+    if (nC) hipLaunchKernelGGL(k_lay_count, dim3(std::min<unsigned>(blocks(3ull * nC), 4096)), dim3(256), 0, s, R, nC, nzc, midlist, largelist, hugelist, M);
     for (int p = 0; p < 3; ++p) scan_u32(nzc + (size_t)p * (nC + 1), nzc + (size_t)p * (nC + 1), nC + 1, tops, totals + p, s);
     FeMeta hm;
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     FE_TRY(hipGetLastError());
+    tick("k_lay_count + scans");
     if (hm.maxn >= (1u << 18)) return FE_FALLBACK;
     C.nC = nC;
     C.nVall = std::max(std::max(n_vars, min_nv), hm.maxvar);
@@ -716,22 +795,31 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     FE_TRY(hipMemsetAsync(Dst.tbig, 0, 2ull * std::max<uint32_t>(nC, 1), s));
     if (nC == 0) FE_TRY(hipMemsetAsync(Dst.rec, 0, 64, s));
     for (int p = 0; p < 3; ++p) FE_TRY(hipMemcpyAsync(Dst.rp[p], nzc + (size_t)p * (nC + 1), 4ull * ((size_t)nC + 1), hipMemcpyDeviceToDevice, s));
+    tick("alloc 1 + memsets");
     // ---- B. nonzeroKeys order, per-part summaries
     DevMem big;
     if (nC) {
         hipLaunchKernelGGL(k_lay_order_small, dim3(blocks(3ull * nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial);
+        tick("k_lay_order_small");
         if (hm.n_mid) {
-            hipLaunchKernelGGL(k_lay_order_big<true>, dim3(std::min<uint32_t>((hm.n_mid + FE_MID_WAVES - 1) / FE_MID_WAVES, 256 * 8)), dim3(64 * FE_MID_WAVES), 0, s, R, nC, (const uint32_t*)nzc, L, sum,
-                               Dst.nontrivial, (const uint32_t*)midlist, hm.n_mid, M, (uint32_t*)nullptr, 0u, largelist);
+            hipLaunchKernelGGL(k_lay_order_big<1>, dim3(std::min<uint32_t>((hm.n_mid + FE_MID_WAVES - 1) / FE_MID_WAVES, 256 * 8)), dim3(64 * FE_MID_WAVES), FeTier<1>::lds_bytes, s, R, nC,
+                               (const uint32_t*)nzc, L, sum, Dst.nontrivial, (const uint32_t*)midlist, hm.n_mid, M, (uint32_t*)nullptr, 0u, largelist, &M->n_large);
             FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
         }
         if (hm.n_large) {
-            uint32_t gcap, g;
-            big_tier_shape(hm.maxn, hm.n_large, gcap, g);
-            { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
-            hipLaunchKernelGGL(k_lay_order_big<false>, dim3(g), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial, (const uint32_t*)largelist, hm.n_large, M,
-                               (uint32_t*)big.base, gcap, (uint32_t*)nullptr);
+            FE_TRY(hipFuncSetAttribute((const void*)k_lay_order_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FeTier<2>::lds_bytes));
+            hipLaunchKernelGGL(k_lay_order_big<2>, dim3(std::min<uint32_t>(hm.n_large, 256 * 4)), dim3(64), FeTier<2>::lds_bytes, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial,
+                               (const uint32_t*)largelist, hm.n_large, M, (uint32_t*)nullptr, 0u, hugelist, &M->n_huge);
+            FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
         }
+        if (hm.n_huge) {
+            uint32_t gcap, g;
+            big_tier_shape(hm.maxn, hm.n_huge, gcap, g);
+            { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
+            hipLaunchKernelGGL(k_lay_order_big<0>, dim3(g), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial, (const uint32_t*)hugelist, hm.n_huge, M,
+                               (uint32_t*)big.base, gcap, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        }
+        tick("k_lay_order_big");
         // ---- C. row descriptors, flags, P5 candidates, (variable, row) pairs
         FE_TRY(hipMemsetAsync(f_p4, 0, 4ull * ((size_t)nC + 2), s));
         FE_TRY(hipMemsetAsync(f_cls, 0, 4ull * ((size_t)nC + 2), s));
@@ -739,6 +827,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         FE_TRY(hipMemsetAsync(f_val, 0, 4ull * ((size_t)nC + 2), s));
         FE_TRY(hipMemsetAsync(f_p5, 0, 4ull * ((size_t)nC + 2), s));
         hipLaunchKernelGGL(k_lay_rows, dim3(blocks(nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, (const PartSum*)sum, Dst.rinfo, f_p4, f_cls, f_big, f_val, aeq);
+        tick("k_lay_rows");
         hipLaunchKernelGGL(k_lay_p5_flag, dim3(blocks(nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, (const uint8_t*)aeq, f_p5);
         scan_u32(f_p4, f_p4, nC + 1, tops, totals + 4, s);
         scan_u32(f_cls, f_cls, nC + 1, tops, totals + 5, s);
@@ -746,8 +835,8 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         scan_u32(f_val, f_val, nC + 1, tops, totals + 7, s);
         scan_u32(f_p5, f_p5, nC + 1, tops, totals + 8, s);
     } else FE_TRY(hipMemsetAsync(totals, 0, 64, s));
-    // variable_to_indices: sort the (variable, row) pairs, drop repeats (a variable in two parts of one row), count per variable
-    uint32_t* deg = Dst.fo_ptr;      // counted in place, then scanned in place
+    tick("p5 flags + 5 scans");
+    // variable_to_indices: sort the (variable, row) pairs, drop repeats (a variable in two parts of one row)
     DevMem sortm;
     if (npairs) {
         hipLaunchKernelGGL(k_lay_pairs, dim3(blocks(3ull * nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, (uint64_t)C.nnz[0], (uint64_t)(C.nnz[0] + C.nnz[1]), pairs);
@@ -757,15 +846,16 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         FE_TRY(rocprim::radix_sort_keys(nullptr, sb, pairs, pairs2, (size_t)npairs, 0u, 32u + vbits, s));
         { const int rc = sortm.alloc(sb + 256); if (rc != K_OK) return rc; }
         FE_TRY(rocprim::radix_sort_keys((void*)sortm.base, sb, pairs, pairs2, (size_t)npairs, 0u, 32u + vbits, s));
+        tick("pairs + radix sort");
         FE_TRY(hipMemsetAsync(f_uniq + npairs, 0, 8, s));
-        hipLaunchKernelGGL(k_lay_uniq_flag, dim3(blocks(npairs)), dim3(256), 0, s, (const uint64_t*)pairs2, (uint32_t)npairs, f_uniq, deg);
+        hipLaunchKernelGGL(k_lay_uniq_flag, dim3(blocks(npairs)), dim3(256), 0, s, (const uint64_t*)pairs2, (uint32_t)npairs, f_uniq);
         scan_u32(f_uniq, f_uniq, (uint32_t)npairs + 1, tops, totals + 9, s);
     } else FE_TRY(hipMemsetAsync(totals + 9, 0, 4, s));
-    scan_u32(deg, deg, (uint32_t)nvar + 1, tops, nullptr, s);
     uint32_t ht[16];
     FE_TRY(hipMemcpy(ht, totals, 64, hipMemcpyDeviceToHost));
     FE_TRY(hipMemcpy(&hm, M, sizeof hm, hipMemcpyDeviceToHost));
     FE_TRY(hipGetLastError());
+    tick("uniq + scans");
     if (hm.unsupported) return FE_FALLBACK;
     C.nP4 = ht[4]; C.nCls = ht[5]; C.nLong = ht[6]; C.n_vals = 2 * ht[7]; C.nP5 = ht[8]; C.fo_total = ht[9];
     C.nBigRows = std::min<uint32_t>(C.nLong, ECNE_BIGTAB);
@@ -794,10 +884,13 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         hipLaunchKernelGGL(k_lay_rec, dim3(blocks(nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, Dst.rec);
         FE_TRY(hipMemcpyAsync(Dst.rinfo0, Dst.rinfo, sizeof(RowInfo) * (size_t)nC, hipMemcpyDeviceToDevice, s));
     }
-    if (npairs) hipLaunchKernelGGL(k_lay_fo_rows, dim3(blocks(npairs)), dim3(256), 0, s, (const uint64_t*)pairs2, (uint32_t)npairs, (const uint32_t*)f_uniq, Dst.fo_rows);
+    if (npairs) hipLaunchKernelGGL(k_lay_fo_rows, dim3(blocks(npairs)), dim3(256), 0, s, (const uint64_t*)pairs2, (uint32_t)npairs, (const uint32_t*)f_uniq, Dst.fo_rows, Dst.fo_ptr, (uint32_t)nvar + 1);
     hipLaunchKernelGGL(k_lay_foi, dim3(blocks(nvar + 1)), dim3(256), 0, s, (uint32_t)nvar, (const uint32_t*)Dst.fo_ptr, (const uint32_t*)Dst.fo_rows, Dst.foi);
     FE_TRY(hipStreamSynchronize(s));
     FE_TRY(hipGetLastError());
+    tick("lists, rec, foi");
+    tm.free_now(); big.free_now(); sortm.free_now();
+    tick("free temporaries");
     LD->ms = ms_since(t0);
     out = std::move(LD);
     return K_OK;

@@ -41,6 +41,14 @@ namespace fe {
                                         // even that overflows: tables in HBM scratch
 #define FE_MID_CAP 1024u
 #define FE_MID_WAVES 2u                 // wavefronts per workgroup in the LDS tier (2 x 4 arrays x 1024 slots x 4 B = 32 KB)
+#define FE_LARGE_MAX 2730u              // up to this many: one wavefront per workgroup, tables of <= 4096 slots in 64 KB of (dynamic) LDS
+#define FE_LARGE_CAP 4096u
+// tiers of the hash-order kernels: 1 = LDS 1024 slots x 2 wavefronts, 2 = LDS 4096 slots x 1 wavefront, 0 = HBM scratch x 4 wavefronts
+template <int TIER> struct FeTier {
+    static constexpr uint32_t cap = TIER == 1 ? FE_MID_CAP : TIER == 2 ? FE_LARGE_CAP : 0u;
+    static constexpr uint32_t waves = TIER == 1 ? FE_MID_WAVES : TIER == 2 ? 1u : 4u;
+    static constexpr uint32_t lds_bytes = waves * 4u * cap * 4u;
+};
 
 __device__ __forceinline__ uint64_t ld64_agent(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void k_fe_part_offsets(const uint32_t* __restr
 
 // ====================================================================================== 1. parse: the rows in dictionary order
 struct FeMeta {      // device-side results of the parse / layout passes (zeroed before use)
-    uint32_t n_mid, n_large, maxn, dup, unsupported, maxvar, err_idx, maxlenC;
+    uint32_t n_mid, n_large, n_huge, maxn, dup, unsupported, maxvar, err_idx, maxlenC, pad_;
     unsigned long long nnz[3];
 };
 struct FeRowsOut { uint64_t* ptr[3]; uint32_t* var[3]; uint64_t* coef[3]; };
@@ -210,20 +218,26 @@ __device__ __forceinline__ fp::u256 fe_ld_coef(const uint32_t* __restrict__ W, u
 
 // cnt[p * (nC + 1) + r] = entries part p of row r will hold at most (an empty part becomes {1 => 0}, :113-115)
 __global__ __launch_bounds__(256) void k_fe_terms(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, uint32_t total, uint32_t nC,
-                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ midlist, uint32_t* __restrict__ largelist, FeMeta* M) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t n = 0;
-    if (i < total) {
-        n = W[poff[i]];
+                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ midlist, uint32_t* __restrict__ largelist,
+                                                  uint32_t* __restrict__ hugelist, FeMeta* M) {
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t n = W[poff[i]];
         const uint32_t r = i / 3u, p = i - 3u * r;
         cnt[(size_t)p * (nC + 1) + r] = n ? n : 1u;
-        if (n > FE_MID_MAX) largelist[atomicAdd(&M->n_large, 1u)] = i;
+        if (n > FE_LARGE_MAX) hugelist[atomicAdd(&M->n_huge, 1u)] = i;
+        else if (n > FE_MID_MAX) largelist[atomicAdd(&M->n_large, 1u)] = i;
         else if (n > FE_LANE_MAX) midlist[atomicAdd(&M->n_mid, 1u)] = i;
+        mx = n > mx ? n : mx;
     }
-    uint32_t mx = n;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(mx, d, 64); mx = y > mx ? y : mx; }
-    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&M->maxn, mx);
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(&M->maxn, s_max);      // (one device atomic per workgroup: thousands on one word cost milliseconds)
 }
 
 __global__ __launch_bounds__(256) void k_fe_fill_small(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, uint32_t total, uint32_t nC,
@@ -233,65 +247,76 @@ __global__ __launch_bounds__(256) void k_fe_fill_small(const uint32_t* __restric
     if (threadIdx.x < 3) s_nz[threadIdx.x] = 0;
     if (threadIdx.x == 3) { s_maxvar = 0; s_dup = 0; }
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < total) {
+    uint32_t nz3[3] = {0, 0, 0}, mvall = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const uint64_t j = poff[i];
         const uint32_t n = W[j];
         const uint32_t r = i / 3u, p = i - 3u * r;
-        if (n <= FE_LANE_MAX) {
-            const uint32_t at = pos[(size_t)p * (nC + 1) + r];
-            uint32_t m = 0, nz = 0, mv = 0;
-            if (n == 0) {
-                O.var[p][at] = 1u;
-                st256(O.coef[p] + 4ull * at, fp::make(0));
-                m = 1; mv = 1;
-            } else if (n == 1) {
-                const fp::u256 c = fe_ld_coef(W, j + 2);
-                const uint32_t v = W[j + 1] + 1u;
-                O.var[p][at] = v;
-                st256(O.coef[p] + 4ull * at, c);
-                m = 1; mv = v; nz = !fp::is_zero(c);
-            } else {
-                jlslot::Tab t;
-                t.key = s_key + threadIdx.x; t.pay = s_pay + threadIdx.x; t.key2 = nullptr; t.pay2 = nullptr;
-                t.cap = 16; t.stride = 256;
-                jlslot::tab_init(t);
-                for (uint32_t k = 0; k < n; ++k) (void)jlslot::tab_upsert<1>(t, W[j + 1 + 9ull * k], k);
-                for (uint32_t s = 0; s < 16; ++s) {
-                    const uint32_t py = t.pay[s * 256];
-                    if (!py) continue;
-                    const uint32_t k = py - 1u, v = t.key[s * 256] + 1u;
-                    const fp::u256 c = fe_ld_coef(W, j + 2 + 9ull * k);
-                    O.var[p][at + m] = v;
-                    st256(O.coef[p] + 4ull * (at + m), c);
-                    ++m;
-                    mv = v > mv ? v : mv;
-                    nz += !fp::is_zero(c);
-                }
-                if (m < n) atomicOr(&s_dup, 1u);
+        if (n > FE_LANE_MAX) continue;
+        const uint32_t at = pos[(size_t)p * (nC + 1) + r];
+        uint32_t m = 0, nz = 0, mv = 0;
+        if (n == 0) {
+            O.var[p][at] = 1u;
+            st256(O.coef[p] + 4ull * at, fp::make(0));
+            m = 1; mv = 1;
+        } else if (n == 1) {
+            const fp::u256 c = fe_ld_coef(W, j + 2);
+            const uint32_t v = W[j + 1] + 1u;
+            O.var[p][at] = v;
+            st256(O.coef[p] + 4ull * at, c);
+            m = 1; mv = v; nz = !fp::is_zero(c);
+        } else {
+            jlslot::Tab t;
+            t.key = s_key + threadIdx.x; t.pay = s_pay + threadIdx.x; t.key2 = nullptr; t.pay2 = nullptr;
+            t.cap = 16; t.stride = 256;
+            jlslot::tab_init(t);
+            for (uint32_t k = 0; k < n; ++k) (void)jlslot::tab_upsert<1>(t, W[j + 1 + 9ull * k], k);
+            for (uint32_t s = 0; s < 16; ++s) {
+                const uint32_t py = t.pay[s * 256];
+                if (!py) continue;
+                const uint32_t k = py - 1u, v = t.key[s * 256] + 1u;
+                const fp::u256 c = fe_ld_coef(W, j + 2 + 9ull * k);
+                O.var[p][at + m] = v;
+                st256(O.coef[p] + 4ull * (at + m), c);
+                ++m;
+                mv = v > mv ? v : mv;
+                nz += !fp::is_zero(c);
             }
-            len[(size_t)p * (nC + 1) + r] = m;
-            if (nz) atomicAdd(&s_nz[p], nz);
-            atomicMax(&s_maxvar, mv);
+            if (m < n) s_dup = 1;
         }
+        len[(size_t)p * (nC + 1) + r] = m;
+        if (p == 0) nz3[0] += nz; else if (p == 1) nz3[1] += nz; else nz3[2] += nz;
+        mvall = mv > mvall ? mv : mvall;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nz3[0] += __shfl_xor(nz3[0], d, 64); nz3[1] += __shfl_xor(nz3[1], d, 64); nz3[2] += __shfl_xor(nz3[2], d, 64);
+        const uint32_t y = __shfl_xor(mvall, d, 64); mvall = y > mvall ? y : mvall;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int p = 0; p < 3; ++p) if (nz3[p]) atomicAdd(&s_nz[p], nz3[p]);
+        atomicMax(&s_maxvar, mvall);
     }
     __syncthreads();
     if (threadIdx.x < 3 && s_nz[threadIdx.x]) atomicAdd(&M->nnz[threadIdx.x], (unsigned long long)s_nz[threadIdx.x]);
     if (threadIdx.x == 3) { if (s_maxvar) atomicMax(&M->maxvar, s_maxvar); if (s_dup) atomicOr(&M->dup, 1u); }
 }
 
-// One wavefront per listed part. LDS_TABLES: tables of up to FE_MID_CAP slots in LDS (parts of 11..170 terms), else in the
-// wavefront's HBM scratch (gcap slots per buffer). Lane 0 replays the dictionary insertions; all lanes emit the slots.
-template <bool LDS_TABLES>
-__global__ __launch_bounds__(LDS_TABLES ? 64 * FE_MID_WAVES : 256) void k_fe_fill_big(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, const uint32_t* __restrict__ list,
+// One wavefront per listed part; the tables live in (dynamic) LDS (TIER 1, 2) or in the wavefront's HBM scratch (TIER 0, gcap
+// slots per buffer). Lane 0 replays the dictionary insertions; all lanes emit the slots. A part whose table outgrows its tier
+// goes to the next one's list (overflow_list / overflow_count), from the HBM tier to the host path.
+template <int TIER>
+__global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, const uint32_t* __restrict__ list,
                                                      uint32_t nlist, uint32_t nC, const uint32_t* __restrict__ pos, FeRowsOut O,
-                                                     uint32_t* __restrict__ len, FeMeta* M, uint32_t* gscratch, uint32_t gcap, uint32_t* __restrict__ overflow_list) {
-    constexpr uint32_t WAVES = LDS_TABLES ? FE_MID_WAVES : 4u;
-    __shared__ uint32_t s_tab[LDS_TABLES ? FE_MID_WAVES * 4 * FE_MID_CAP : 4];
+                                                     uint32_t* __restrict__ len, FeMeta* M, uint32_t* gscratch, uint32_t gcap, uint32_t* __restrict__ overflow_list,
+                                                     uint32_t* overflow_count) {
+    constexpr bool LDS_TABLES = TIER != 0;
+    constexpr uint32_t WAVES = FeTier<TIER>::waves;
+    uint32_t* const s_tab = reinterpret_cast<uint32_t*>(ecne_dyn_lds);
     const int lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
-    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FE_MID_CAP : gscratch + (size_t)gw * 4 * gcap;
-    const uint32_t cap = LDS_TABLES ? FE_MID_CAP : gcap;
+    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FeTier<TIER>::cap : gscratch + (size_t)gw * 4 * gcap;
+    const uint32_t cap = LDS_TABLES ? FeTier<TIER>::cap : gcap;
     for (uint32_t b = gw; b < nlist; b += nw) {
         const uint32_t i = list[b];
         const uint64_t j = poff[i];
@@ -310,8 +335,8 @@ __global__ __launch_bounds__(LDS_TABLES ? 64 * FE_MID_WAVES : 256) void k_fe_fil
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
-        if (bad) {      // the table outgrew this tier: hand the part to the HBM tier, or give the file back to the host path
-            if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(&M->n_large, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
+        if (bad) {      // the table outgrew this tier: hand the part to the next one, or give the file back to the host path
+            if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(overflow_count, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
             continue;
         }
         const uint32_t* key = flipped ? base + 2 * cap : base;
@@ -395,62 +420,92 @@ struct AbsWindows {      // one batch of candidate windows
 struct AbsRowsDev { const uint64_t* ptr[3]; const uint32_t* var[3]; const uint64_t* coef[3]; };
 
 // lane per (window row, part): every non-zero entry adds its (counter, coefficient) hash to its variable's slot
+__device__ __forceinline__ void abs_sig_add(AbsWindows& Wn, const AbsPattern& P, uint32_t w, unsigned long long key, uint64_t h1, uint64_t h2) {
+    unsigned long long* wkey = Wn.wkey + (size_t)w * Wn.capW;
+    const uint32_t mask = Wn.capW - 1;
+    uint32_t s = (uint32_t)(sig_mix(key) & mask);
+    for (uint32_t probe = 0;; ++probe) {
+        if (probe > mask) { atomicOr(&Wn.status[w], 1u); return; }
+        unsigned long long cur = __hip_atomic_load(&wkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0ull) {      // (distinct variables are counted by k_abs_match, one atomic per wavefront: a counter bumped here by every
+            cur = atomicCAS(&wkey[s], 0ull, key);      //  insertion serialises 16 000 atomics per window on one word)
+            if (cur == 0ull) cur = key;
+        }
+        if (cur == key) {
+            atomicAdd(&Wn.wh1[(size_t)w * Wn.capW + s], (unsigned long long)h1);
+            atomicAdd(&Wn.wh2[(size_t)w * Wn.capW + s], (unsigned long long)h2);
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)x, d, 64), hi = __shfl_xor((uint32_t)(x >> 32), d, 64);
+        x += ((uint64_t)hi << 32) | lo;
+    }
+    return x;
+}
+// lane per (window row, part): every non-zero entry adds its (counter, coefficient) hash to its variable's slot. The constant
+// wire sits in most rows of a circuit: its appearances are summed per wavefront first (thousands of atomics on one slot serialise).
 __global__ __launch_bounds__(256) void k_abs_sig(AbsRowsDev R, AbsPattern P, AbsWindows Wn) {
     const uint32_t w = blockIdx.y;
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-    if (q >= 3u * P.nS) return;
-    const uint32_t jrow = q / 3u, p = q - 3u * jrow;
-    const uint64_t row = (uint64_t)Wn.start[w] + jrow;
-    const uint64_t k0 = R.ptr[p][row], k1 = R.ptr[p][row + 1];
-    unsigned long long* wkey = Wn.wkey + (size_t)w * Wn.capW;
-    unsigned long long* wh1 = Wn.wh1 + (size_t)w * Wn.capW;
-    unsigned long long* wh2 = Wn.wh2 + (size_t)w * Wn.capW;
-    const uint32_t mask = Wn.capW - 1;
-    uint32_t nz = 0;
-    for (uint64_t k = k0; k < k1; ++k) {
-        const uint64_t* c = R.coef[p] + 4 * k;
-        if ((c[0] | c[1] | c[2] | c[3]) == 0) continue;
-        ++nz;
-        uint64_t h1, h2;
-        sig_hash((uint64_t)q + 1ull, c, h1, h2);
-        const unsigned long long key = (unsigned long long)R.var[p][k] + 1ull;
-        uint32_t s = (uint32_t)(sig_mix(key) & mask);
-        for (uint32_t probe = 0;; ++probe) {
-            if (probe > mask) { atomicOr(&Wn.status[w], 1u); break; }
-            unsigned long long cur = __hip_atomic_load(&wkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == 0ull) {
-                if (__hip_atomic_load(&Wn.nvars[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > P.nvS) { atomicOr(&Wn.status[w], 1u); break; }
-                cur = atomicCAS(&wkey[s], 0ull, key);
-                if (cur == 0ull) { cur = key; atomicAdd(&Wn.nvars[w], 1u); }
-            }
-            if (cur == key) { atomicAdd(&wh1[s], (unsigned long long)h1); atomicAdd(&wh2[s], (unsigned long long)h2); break; }
-            s = (s + 1) & mask;
+    uint64_t one1 = 0, one2 = 0;
+    uint32_t one_n = 0;
+    if (q < 3u * P.nS) {
+        const uint32_t jrow = q / 3u, p = q - 3u * jrow;
+        const uint64_t row = (uint64_t)Wn.start[w] + jrow;
+        const uint64_t k0 = R.ptr[p][row], k1 = R.ptr[p][row + 1];
+        uint32_t nz = 0;
+        for (uint64_t k = k0; k < k1; ++k) {
+            const uint64_t* c = R.coef[p] + 4 * k;
+            if ((c[0] | c[1] | c[2] | c[3]) == 0) continue;
+            ++nz;
+            uint64_t h1, h2;
+            sig_hash((uint64_t)q + 1ull, c, h1, h2);
+            const uint32_t v = R.var[p][k];
+            if (v == 1u) { one1 += h1; one2 += h2; ++one_n; }
+            else abs_sig_add(Wn, P, w, (unsigned long long)v + 1ull, h1, h2);
         }
+        if (nz != P.part_nz[q]) atomicOr(&Wn.status[w], 1u);
     }
-    if (nz != P.part_nz[q]) atomicOr(&Wn.status[w], 1u);
+    const uint64_t any = __ballot(one_n != 0);
+    if (any) {
+        one1 = wave_sum64(one1); one2 = wave_sum64(one2);
+        if (lane_id() == 0) abs_sig_add(Wn, P, w, 2ull, one1, one2);
+    }
 }
 // lane per window-table slot: look the variable's signature hash up among the pattern's, take the next free member of its class
 __global__ __launch_bounds__(256) void k_abs_match(AbsPattern P, AbsWindows Wn) {
     const uint32_t w = blockIdx.y;
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= Wn.capW) return;
-    const unsigned long long key = Wn.wkey[(size_t)w * Wn.capW + s];
-    if (!key) return;
-    const uint64_t h1 = Wn.wh1[(size_t)w * Wn.capW + s], h2 = Wn.wh2[(size_t)w * Wn.capW + s];
-    const uint32_t pm = P.capP - 1;
-    uint32_t t = (uint32_t)(sig_mix(h1 ^ (h2 * 0x9e3779b97f4a7c15ULL)) & pm), cls = 0;
-    for (uint32_t probe = 0; probe <= pm; ++probe) {
-        const uint32_t c = P.tab_class[t];
-        if (!c) break;
-        if (P.tab_h1[t] == h1 && P.tab_h2[t] == h2) { cls = c; break; }
-        t = (t + 1) & pm;
+    const unsigned long long key = s < Wn.capW ? Wn.wkey[(size_t)w * Wn.capW + s] : 0ull;
+    bool matched = false;
+    if (key) {
+        const uint64_t h1 = Wn.wh1[(size_t)w * Wn.capW + s], h2 = Wn.wh2[(size_t)w * Wn.capW + s];
+        const uint32_t pm = P.capP - 1;
+        uint32_t t = (uint32_t)(sig_mix(h1 ^ (h2 * 0x9e3779b97f4a7c15ULL)) & pm), cls = 0;
+        for (uint32_t probe = 0; probe <= pm; ++probe) {
+            const uint32_t c = P.tab_class[t];
+            if (!c) break;
+            if (P.tab_h1[t] == h1 && P.tab_h2[t] == h2) { cls = c; break; }
+            t = (t + 1) & pm;
+        }
+        if (!cls) atomicOr(&Wn.status[w], 1u);
+        else {
+            const uint32_t c0 = P.class_start[cls - 1], c1 = P.class_start[cls];
+            const uint32_t k = atomicAdd(&Wn.ccount[(size_t)w * P.nclass + (cls - 1)], 1u);
+            if (k >= c1 - c0) atomicOr(&Wn.status[w], 1u);
+            else { Wn.phi[(size_t)w * P.nvS + P.class_members[c0 + k]] = (uint32_t)(key - 1ull); matched = true; }
+        }
     }
-    if (!cls) { atomicOr(&Wn.status[w], 1u); return; }
-    const uint32_t c0 = P.class_start[cls - 1], c1 = P.class_start[cls];
-    const uint32_t k = atomicAdd(&Wn.ccount[(size_t)w * P.nclass + (cls - 1)], 1u);
-    if (k >= c1 - c0) { atomicOr(&Wn.status[w], 1u); return; }
-    Wn.phi[(size_t)w * P.nvS + P.class_members[c0 + k]] = (uint32_t)(key - 1ull);
-    atomicAdd(&Wn.nmatched[w], 1u);
+    const uint32_t nk = (uint32_t)__popcll(__ballot(key != 0ull)), nm = (uint32_t)__popcll(__ballot(matched));
+    if (lane_id() == 0) {
+        if (nk) atomicAdd(&Wn.nvars[w], nk);
+        if (nm) atomicAdd(&Wn.nmatched[w], nm);
+    }
 }
 // lane per pattern entry: the window's part must hold (phi(variable), same coefficient). Together with equal non-zero counts
 // per part (k_abs_sig) and phi being a bijection (k_abs_match) this is an isomorphism of the two windows.
@@ -537,12 +592,15 @@ struct LayTemp {      // device scratch of the layout (pointers carved from one 
 
 // non-zero count per (part, row); largest variable id over ALL dictionary entries; parts too long for a lane
 __global__ __launch_bounds__(256) void k_lay_count(AbsRowsDev R, uint32_t nC, uint32_t* __restrict__ nzc, uint32_t* __restrict__ midlist,
-                                                   uint32_t* __restrict__ largelist, FeMeta* M) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t mv = 0, nz = 0, p = 0;
-    if (i < 3u * nC) {
-        const uint32_t r = i / 3u;
-        p = i - 3u * r;
+                                                   uint32_t* __restrict__ largelist, uint32_t* __restrict__ hugelist, FeMeta* M) {
+    __shared__ uint32_t s_nz[3], s_mv, s_mc, s_mn;
+    if (threadIdx.x < 3) s_nz[threadIdx.x] = 0;
+    if (threadIdx.x == 3) { s_mv = 0; s_mc = 0; s_mn = 0; }
+    __syncthreads();
+    uint32_t mv = 0, mc = 0, mn = 0, nz3[3] = {0, 0, 0};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < 3u * nC; i += gridDim.x * 256u) {
+        const uint32_t r = i / 3u, p = i - 3u * r;
+        uint32_t nz = 0;
         for (uint64_t k = R.ptr[p][r]; k < R.ptr[p][r + 1]; ++k) {
             const uint32_t v = R.var[p][k];
             mv = v > mv ? v : mv;
@@ -550,21 +608,30 @@ __global__ __launch_bounds__(256) void k_lay_count(AbsRowsDev R, uint32_t nC, ui
             nz += (c[0] | c[1] | c[2] | c[3]) != 0;
         }
         nzc[(size_t)p * (nC + 1) + r] = nz;
-        if (nz > FE_MID_MAX) largelist[atomicAdd(&M->n_large, 1u)] = i;
+        if (nz > FE_LARGE_MAX) hugelist[atomicAdd(&M->n_huge, 1u)] = i;
+        else if (nz > FE_MID_MAX) largelist[atomicAdd(&M->n_large, 1u)] = i;
         else if (nz > FE_LANE_MAX) midlist[atomicAdd(&M->n_mid, 1u)] = i;
-        if (nz) atomicAdd(&M->nnz[p], (unsigned long long)nz);
+        if (p == 0) nz3[0] += nz; else if (p == 1) nz3[1] += nz; else { nz3[2] += nz; mc = nz > mc ? nz : mc; }
+        mn = nz > mn ? nz : mn;
     }
-    uint32_t mc = p == 2 ? nz : 0u, mn = nz;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         uint32_t y = __shfl_xor(mv, d, 64); mv = y > mv ? y : mv;
         y = __shfl_xor(mc, d, 64); mc = y > mc ? y : mc;
         y = __shfl_xor(mn, d, 64); mn = y > mn ? y : mn;
+        nz3[0] += __shfl_xor(nz3[0], d, 64); nz3[1] += __shfl_xor(nz3[1], d, 64); nz3[2] += __shfl_xor(nz3[2], d, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (mv) atomicMax(&M->maxvar, mv);
-        if (mc) atomicMax(&M->maxlenC, mc);
-        if (mn) atomicMax(&M->maxn, mn);
+        atomicMax(&s_mv, mv); atomicMax(&s_mc, mc); atomicMax(&s_mn, mn);
+        for (int p = 0; p < 3; ++p) if (nz3[p]) atomicAdd(&s_nz[p], nz3[p]);
+    }
+    __syncthreads();
+    // one device atomic per workgroup and word (millions of lanes adding to three words cost 10 ms)
+    if (threadIdx.x < 3 && s_nz[threadIdx.x]) atomicAdd(&M->nnz[threadIdx.x], (unsigned long long)s_nz[threadIdx.x]);
+    if (threadIdx.x == 3) {
+        if (s_mv) atomicMax(&M->maxvar, s_mv);
+        if (s_mc) atomicMax(&M->maxlenC, s_mc);
+        if (s_mn) atomicMax(&M->maxn, s_mn);
     }
 }
 
@@ -627,16 +694,17 @@ __global__ __launch_bounds__(256) void k_lay_order_small(AbsRowsDev R, uint32_t 
     sum[(size_t)p * nC + r] = S;
 }
 // ... and for longer parts: one wavefront per part (lane 0 replays the Set insertions, all lanes emit the slots)
-template <bool LDS_TABLES>
-__global__ __launch_bounds__(LDS_TABLES ? 64 * FE_MID_WAVES : 256) void k_lay_order_big(AbsRowsDev R, uint32_t nC, const uint32_t* __restrict__ rp, LayCsr L, PartSum* __restrict__ sum,
+template <int TIER>
+__global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsRowsDev R, uint32_t nC, const uint32_t* __restrict__ rp, LayCsr L, PartSum* __restrict__ sum,
                                                        uint8_t* __restrict__ nontrivial, const uint32_t* __restrict__ list, uint32_t nlist, FeMeta* M,
-                                                       uint32_t* gscratch, uint32_t gcap, uint32_t* __restrict__ overflow_list) {
-    constexpr uint32_t WAVES = LDS_TABLES ? FE_MID_WAVES : 4u;
-    __shared__ uint32_t s_tab[LDS_TABLES ? FE_MID_WAVES * 4 * FE_MID_CAP : 4];
+                                                       uint32_t* gscratch, uint32_t gcap, uint32_t* __restrict__ overflow_list, uint32_t* overflow_count) {
+    constexpr bool LDS_TABLES = TIER != 0;
+    constexpr uint32_t WAVES = FeTier<TIER>::waves;
+    uint32_t* const s_tab = reinterpret_cast<uint32_t*>(ecne_dyn_lds);
     const int lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
-    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FE_MID_CAP : gscratch + (size_t)gw * 4 * gcap;
-    const uint32_t cap = LDS_TABLES ? FE_MID_CAP : gcap;
+    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FeTier<TIER>::cap : gscratch + (size_t)gw * 4 * gcap;
+    const uint32_t cap = LDS_TABLES ? FeTier<TIER>::cap : gcap;
     for (uint32_t b = gw; b < nlist; b += nw) {
         const uint32_t i = list[b];
         const uint32_t r = i / 3u, p = i - 3u * r;
@@ -671,7 +739,7 @@ __global__ __launch_bounds__(LDS_TABLES ? 64 * FE_MID_WAVES : 256) void k_lay_or
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
         if (bad) {
-            if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(&M->n_large, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
+            if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(overflow_count, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
             continue;
         }
         const uint32_t* key = flipped ? base + 2 * cap : base;
@@ -872,18 +940,29 @@ __global__ __launch_bounds__(256) void k_lay_pairs(uint32_t nC, const uint32_t* 
     const uint64_t off = p == 0 ? 0ull : p == 1 ? off1 : off2;
     for (uint32_t k = rp[q]; k < rp[q + 1]; ++k) pairs[off + k] = ((uint64_t)L.col[p][k] << 32) | r;
 }
-__global__ __launch_bounds__(256) void k_lay_uniq_flag(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ f_uniq, uint32_t* __restrict__ deg) {
+__global__ __launch_bounds__(256) void k_lay_uniq_flag(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ f_uniq) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint64_t x = sorted[i];
-    const bool first = i == 0 || sorted[i - 1] != x;
-    f_uniq[i] = first ? 1u : 0u;
-    if (first) atomicAdd(&deg[(uint32_t)(x >> 32)], 1u);
+    f_uniq[i] = (i == 0 || sorted[i - 1] != sorted[i]) ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void k_lay_fo_rows(const uint64_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ f_uniq, uint32_t* __restrict__ fo_rows) {
+// fo_rows = the rows of the distinct pairs in sorted order; fo_ptr[v] = number of distinct pairs of variables below v, written at
+// the run boundaries of the sorted list (no per-variable atomics: the constant wire alone has 10^5 rows). nvar1 = entries of fo_ptr.
+__global__ __launch_bounds__(256) void k_lay_fo_rows(const uint64_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ f_uniq, uint32_t* __restrict__ fo_rows,
+                                                     uint32_t* __restrict__ fo_ptr, uint32_t nvar1) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n || f_uniq[i + 1] == f_uniq[i]) return;
-    fo_rows[f_uniq[i]] = (uint32_t)sorted[i];
+    if (i >= n) return;
+    const uint32_t q = f_uniq[i];
+    const uint64_t x = sorted[i];
+    const uint32_t v = (uint32_t)(x >> 32);
+    if (i == n - 1) {
+        const uint32_t tot = f_uniq[n];
+        for (uint32_t u = v + 1u; u < nvar1; ++u) fo_ptr[u] = tot;
+    }
+    if (f_uniq[i + 1] == q) return;      // a repeat of the pair before it
+    fo_rows[q] = (uint32_t)x;
+    const uint32_t vprev = i == 0 ? 0xFFFFFFFFu : (uint32_t)(sorted[i - 1] >> 32);
+    if (i == 0 || vprev != v)
+        for (uint32_t u = vprev + 1u; u <= v && u < nvar1; ++u) fo_ptr[u] = q;      // v's first pair: v and the unused ids below it start here
 }
 // row records and inline fan-out lists (chain executor / fast rounds, engine_types.hpp)
 __global__ __launch_bounds__(256) void k_lay_rec(uint32_t nC, const uint32_t* __restrict__ rp, LayCsr L, uint32_t* __restrict__ rec) {

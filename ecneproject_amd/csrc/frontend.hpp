@@ -5,7 +5,7 @@
 //   readR1CS                 /root/reference/src/ParseR1CS.jl:50-124      -> fe::parse_on_device
 //   abstraction              /root/reference/src/R1CSConstraintSolver.jl:237-395 -> fe::abstract_on_device
 //   the per-solve set-up of SolveConstraintsSymbolic that only depends on the rows (nzk_a/b/c :698-700,
-//   variable_to_indices :628-633, the shape tests the rules repeat on every visit)   -> fe::layout_count / layout_fill
+//   variable_to_indices :628-633, the shape tests the rules repeat on every visit)   -> fe::layout_on_device
 // The host implementations of the same three steps (host_model.hpp, build_layout in ecne_engine.hip) stay: they serve small
 // files, the lazily built host views (ecne_system_rows, the report orders) and every case the device path hands back
 // (FE_FALLBACK); tests/test_gpu_frontend.py compares the two array by array.
@@ -43,11 +43,10 @@ struct ParseStats {
     double upload_ms = 0, offsets_ms = 0, fill_ms = 0, total_ms = 0;
     uint64_t file_bytes = 0;
 };
-// `cons` = host pointer to the first byte of the first constraint, `len` = bytes from there to the end of the FILE (the reader
-// walks n_cons rows from the section start and is bounded by the file, not by the section size). K_OK, K_EFORMAT (the walk
-// leaves the file), K_ENODEVICE, or FE_FALLBACK (input the device path does not take: 4 GiB and more, parts of 2^18 terms and more,
-// a hash table that grows past its scratch).
-int parse_on_device(const uint8_t* cons, size_t len, uint32_t n_cons, int device, std::shared_ptr<DevRows>& out, ParseStats& st);
+// `file` = the mapped file, `cons_off` = offset of the first constraint (the reader walks n_cons rows from the section start and is
+// bounded by the end of the FILE, not by the section size). K_OK, K_EFORMAT (the walk leaves the file), K_ENODEVICE, or FE_FALLBACK
+// (input the device path does not take: 4 GiB and more, parts of 2^18 terms and more, a hash table that grows past its scratch).
+int parse_on_device(const uint8_t* file, size_t file_size, size_t cons_off, uint32_t n_cons, int device, std::shared_ptr<DevRows>& out, ParseStats& st);
 int download_rows(const DevRows& D, Rows& out);
 
 struct AbstractDevStats {

@@ -150,10 +150,10 @@ def test_many_rows_with_repeated_wire_ids(tmp_path):
     import ecneproject_amd as E
     from test_fuzz import _many_block_rows
     rng = random.Random(99)
-    n_vars = 3000
+    n_vars = 9000
     rows = _many_block_rows(7000, 400, 4242)
-    for i in range(0, 7000, 500):      # parts of 11..170 terms (tables in LDS) and beyond (tables in HBM), some with repeats
-        for n in (12, 43, 90, 171, 700, 1100):
+    for i in range(0, 7000, 500):      # parts of 11..170 terms, 171..2730 (tables in LDS) and beyond (tables in HBM), some with repeats
+        for n in (12, 43, 90, 171, 700, 1100, 3500):
             terms = [(rng.randint(1, n_vars), rng.choice([0, 1, 2, orc.P - 1, orc.P + 3, rng.getrandbits(250)])) for _ in range(n)]
             if rng.random() < 0.5:
                 terms[rng.randrange(1, n)] = (terms[0][0], 7)
