@@ -351,6 +351,7 @@ def SolveConstraintsSymbolic(constraints, special_constraints=None, known_variab
     who edits them expects; None keeps the handle's. `num_variables` has to be the handle's nVars (or -1): the state
     arrays are sized by it (:681) and it cannot be changed after parsing."""
     global last_result
+    t_begin = time.time()
     system = constraints if isinstance(constraints, System) else System(constraints)
     if num_variables not in (-1, None) and int(num_variables) != int(system.info.n_vars):
         raise ValueError("num_variables=%d differs from the system's %d" % (num_variables, system.info.n_vars))
@@ -364,18 +365,23 @@ def SolveConstraintsSymbolic(constraints, special_constraints=None, known_variab
         sp = [(str(c[0]), [int(x) for x in c[1]], [int(x) for x in c[2]]) for c in special_constraints]
         if sp != system.specials():
             system.set_specials(sp)
+    system.info                                              # the flat arrays (the reference's per-solve set-up, :593-703)
+    print("setup solver %d milliseconds" % int((time.time() - t_begin) * 1000))   # :704 (always printed)
     res = solve_batch([system], secp_solve=secp_solve, device=device)[0]
     last_result = res
     res.raise_for_status()
     s = res.summary
-    # what the reference always prints (:1565-1571, :1586-1592) and its report (:1599-1643)
-    print("Solved for %d variables out of %d total variables" % (s.unique_nontrivial, s.n_nontrivial))
-    print("Solved for %d target variables out of %d total target variables" % (s.unique_targets, s.n_targets))
     from . import report
+    # what the reference always prints (:1565-1571, :1586-1592), the state dump of debug=true between the two (:1573-1577),
+    # and its report (:1599-1643)
+    print("Solved for %d variables out of %d total variables" % (s.unique_nontrivial, s.n_nontrivial))
+    if debug:
+        print(report.debug_states(system, res), end="")
+    print("Solved for %d target variables out of %d total target variables" % (s.unique_targets, s.n_targets))
     sym = report.read_sym(input_sym) if input_sym and os.path.exists(input_sym) else None
-    if input_sym and input_sym != "default.sym" and sym is None:
-        raise FileNotFoundError(input_sym)                  # CSV.File(input_sym) (:1603) on a missing file
-    print(report.render(system, res, sym, debug=debug), end="")
+    if input_sym and sym is None:
+        raise FileNotFoundError(input_sym)                  # CSV.File(input_sym) (:1603) on a missing file -- "default.sym" included
+    print(report.render(system, res, sym), end="")
     return res.function_good
 
 
@@ -397,8 +403,8 @@ def solveWithTrustedFunctions(input_r1cs, input_r1cs_name, trusted_r1cs=(), trus
         if printRes:
             print("called abstraction")
         system.abstract(f, name)
-    if abstractionOnly:                                                        # :546-549
-        print(system.specials())
+    if abstractionOnly:                                                        # :546-549: println(specials)
+        print("Any[" + ", ".join('("%s", %s, %s)' % (n, list(i), list(o)) for n, i, o in system.specials()) + "]")
         return True
     print("time to prep inputs %d milliseconds" % int((time.time() - a) * 1000))   # :551
     result = SolveConstraintsSymbolic(system, None, None, debug, None, -1, input_sym if input_sym else "", secp_solve, device=device)

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <set>
 #include <string>
@@ -137,6 +138,7 @@ struct DeviceImage {
     double classify_ms = 0;
 };
 
+static uint64_t next_system_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1, std::memory_order_relaxed); }
 struct ecne_system {
     // dictionary order, current rows: the parsed file's own arrays until the first abstraction (no copy;
     // `base` keeps them alive after ecne_r1cs_free), `reduced` afterwards. A system that came through the device front-end
@@ -152,6 +154,7 @@ struct ecne_system {
     int64_t n_vars = 0, n_rows_main = 0;
     bool laid_out = false;
     uint64_t generation = 0;   // bumped by every solve
+    const uint64_t uid = next_system_uid();   // process-unique: a result made from a freed system never matches a new one at the same address
     Layout L;
     DeviceImage dev;
     std::vector<int64_t> order_buf;   // ecne_system_report_order
@@ -193,7 +196,7 @@ struct ecne_result {
     // per-variable state is downloaded from HBM on first request (ecne_result_states /
     // ecne_result_bad_rows), and only while `sys` has not been solved again (generation check)
     ecne_system* sys = nullptr;
-    uint64_t generation = 0;
+    uint64_t generation = 0, sys_uid = 0;
     bool have_states = false;
     std::vector<uint8_t> flags, nvalues;
     std::vector<uint64_t> lb, ub, values;
@@ -217,7 +220,8 @@ static int guarded(F&& f) {
 
 // One multi-workgroup solve at a time per device inside this process: its workgroups meet at a hand-rolled barrier and
 // have to be resident together (two such launches on one device could each hold CUs the other one waits for).
-static std::mutex& device_launch_mutex(int device) { static std::mutex m[64]; return m[(unsigned)device & 63u]; }
+// (single-workgroup launches share the device with each other; a launch that holds a multi-workgroup job, or a batch, has it alone)
+static std::shared_mutex& device_launch_mutex(int device) { static std::shared_mutex m[64]; return m[(unsigned)device & 63u]; }
 
 // launch scratch of the calling thread (job descriptors, workgroup table, events): kept between solves
 struct LaunchScratch {
@@ -862,7 +866,7 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
 // download the per-variable state of a finished solve (lazy; see ecne_result)
 static int fetch_states(ecne_result* r) {
     if (r->have_states) return K_OK;
-    if (!r->sys || !system_is_live(r->sys) || r->sys->generation != r->generation || !r->sys->dev.arena) return K_EINVAL;
+    if (!r->sys || !system_is_live(r->sys) || r->sys->uid != r->sys_uid || r->sys->generation != r->generation || !r->sys->dev.arena) return K_EINVAL;
     ecne_system& S = *r->sys;
     const Layout& L = S.L;
     const Job& J = S.dev.job;
@@ -1125,6 +1129,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
     if (ecne_device_count() <= o.device) return ECNE_ENODEVICE;   // never falls back to a CPU path
+    struct RestoreDevice { int prev; ~RestoreDevice() { (void)hipSetDevice(prev); } } restore{current_device()};      // the caller's current device is left as it was
     HIP_TRY(hipSetDevice(o.device));
     hipStream_t stream = (hipStream_t)o.stream;
     for (size_t i = 0; i < n; ++i) {
@@ -1147,6 +1152,12 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             if (st != K_OK) { rc = st; break; }
             hj[i] = sys[i]->dev.job;
             hj[i].secp_solve = o.secp_solve ? 1u : 0u;
+            {   // barrier wait without progress: 0.2 s + 2 us per row (a long sequential stretch on a huge system is not a hang), or
+                // ECNE_BARRIER_TIMEOUT_MS
+                uint64_t tmo = 200 + (uint64_t)hj[i].nC / 500;
+                if (const char* e = getenv("ECNE_BARRIER_TIMEOUT_MS")) tmo = (uint64_t)std::max(1L, atol(e));
+                hj[i].bar_timeout_ms = (uint32_t)std::min<uint64_t>(tmo, 3600000);
+            }
             hj[i].queue_mode = (uint32_t)o.queue_mode;
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
@@ -1187,8 +1198,12 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             // a launch that holds a multi-workgroup job must have the device to itself (its workgroups meet at a barrier)
             bool any_multi = false;
             for (size_t i = 0; i < n; ++i) any_multi |= hj[i].nwg > 1;
-            std::unique_lock<std::mutex> device_lock(device_launch_mutex(o.device), std::defer_lock);
-            if (any_multi || n > 1) device_lock.lock();
+            std::unique_lock<std::shared_mutex> exclusive_lock(device_launch_mutex(o.device), std::defer_lock);
+            std::shared_lock<std::shared_mutex> shared_lock(device_launch_mutex(o.device), std::defer_lock);
+            if (any_multi || n > 1) exclusive_lock.lock(); else shared_lock.lock();
+            int coop_attr = 0;
+            const bool coop_ok = !getenv("ECNE_NO_COOPERATIVE") && hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, o.device) == hipSuccess && coop_attr != 0;
+            bool refused = false;
             (void)hipEventRecord(e0, stream);
             std::vector<WgDesc> descs;
             WgDesc* const d_descs = scratch.d_descs;
@@ -1201,10 +1216,23 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                     ++i;
                 }
                 if (hipMemcpyAsync(d_descs, descs.data(), sizeof(WgDesc) * descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) { fail = true; break; }
-                hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                // the workgroups of a multi-workgroup job meet at a barrier of their own: launched cooperatively, the runtime either
+                // makes the whole grid resident together or refuses the launch (no 0.2 s wait for workgroups that never start)
+                bool launched = false;
+                if (any_multi && coop_ok) {
+                    const Job* a0 = d_jobs;
+                    const WgDesc* a1 = d_descs;
+                    void* kargs[2] = {(void*)&a0, (void*)&a1};
+                    const hipError_t ce = hipLaunchCooperativeKernel((const void*)k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), kargs, dyn_lds, stream);
+                    if (ce == hipSuccess) launched = true;
+                    else if (ce == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); refused = true; fail = true; break; }
+                    else (void)hipGetLastError();      // (not available on this stack: the plain launch below, with the barrier's own time bound)
+                }
+                if (!launched) hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
                 if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
             }
             (void)hipEventRecord(e1, stream);
+            if (refused) { rc = ECNE_ETIMEOUT; break; }      // the device cannot hold the job's workgroups together right now
             if (fail || hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
         float ms = 0;
@@ -1218,6 +1246,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             S.generation++;
             r->sys = &S;
             r->generation = S.generation;
+            r->sys_uid = S.uid;
             ecne_summary& s = r->sum;
             std::memset(&s, 0, sizeof s);
             s.status = (c.err_key != ~0ull && (c.err_key & 0xFFu) != 0) ? -(int)(c.err_key & 0xFFu) : c.error;   // (the pop the sequential run dies on)
@@ -1584,7 +1613,7 @@ const char* ecne_strerror(int st) {
         case ECNE_ENODEVICE: return "no usable HIP device (the engine has no CPU fallback)";
         case ECNE_EINVAL: return "invalid argument";
         case ECNE_ECAPACITY: return "internal device table overflow (or out of memory)";
-        case ECNE_ETIMEOUT: return "the workgroups of the solve did not meet within 0.2 s: is another process using this device?";
+        case ECNE_ETIMEOUT: return "the workgroups of the solve cannot run together (cooperative launch refused, or they did not meet in time): is another process using this device?";
         default: return "unknown status";
     }
 }

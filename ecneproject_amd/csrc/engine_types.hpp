@@ -113,6 +113,7 @@ struct Counters {   // one per job, device memory
 struct Job {
     // sizes
     uint32_t nC, nV, nSp, nKnown, nTarget, nP4, nP5, qmask, htmask, secp_solve, queue_mode, hotcap;
+    uint32_t bar_timeout_ms; // how long the workgroups of the job wait at their barrier WITHOUT progress before they give up (K_ETIMEOUT)
     uint32_t warm_bytes;     // bytes of static arrays (from rpA on) a single-workgroup job streams once to warm its XCD's L2; 0 = off
     uint32_t lds_bytes;      // dynamic LDS of the launch: a single-workgroup job keeps as much of its mutable state there as fits (k_solve)
     uint32_t nwg, nBigCls;   // nBigCls: rows with more than 8 entries in C (classified one wavefront each)   // workgroups cooperating on this job (1 = the master alone)

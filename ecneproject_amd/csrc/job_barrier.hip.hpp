@@ -76,8 +76,9 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                     __hip_atomic_store(&c->bar_gen, ((g + 1u) << 1) | (e != 0 ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // the wait is bounded by wall-clock time (0.2 s of the 100 MHz counter): the workgroups of a job are resident
-            // together unless something else occupies the device (include/ecne.h: one solver process per device)
+            // the wait is bounded by wall-clock time (J.bar_timeout_ms of the 100 MHz counter; the host scales it with the system:
+            // 0.2 s + 2 us per row): the workgroups of a job are launched co-resident (cooperative launch) unless something else
+            // occupies the device (include/ecne.h: one solver process per device)
             // (helpers legitimately wait for as long as the master works alone -- a deep chain can take many milliseconds --
             //  so the clock restarts whenever the master's heartbeat word has moved: the bound is on time WITHOUT progress)
             unsigned spins = 0, w;
@@ -89,7 +90,7 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                     const unsigned long long now = wall_clock64();
                     const unsigned hb2 = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (hb2 != hb) { hb = hb2; t_wait0 = now; }
-                    else if (now - t_wait0 > 20000000ull) { raise(J, K_ETIMEOUT); w = 1; break; }
+                    else if (now - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) { raise(J, K_ETIMEOUT); w = 1; break; }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -98,7 +98,16 @@ def all_variables_report(system, result, names):
     return lines
 
 
-def render(system, result, names=None, debug=False):
+def debug_states(system, result):
+    """debug=true: printState of every non-trivial variable, in the iteration order of the reference's Set, between the two
+    "Solved for" lines (:1573-1577; the constant wire included, no signal names)."""
+    lines = []
+    for v in _order(system, 0):
+        lines.extend(state_text(result, v))
+    return "".join(l + "\n" for l in lines)
+
+
+def render(system, result, names=None):
     """Everything SolveConstraintsSymbolic prints after its two count lines (:1599-1643). `names` = read_sym(input_sym), or
     None when input_sym == "" (then only the header is printed, as in the reference)."""
     out = ["------ Bad Constraints ------", ""]

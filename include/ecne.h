@@ -43,8 +43,8 @@ typedef enum ecne_status {
     ECNE_ENODEVICE = -8,  /* no usable HIP device: the engine never falls back to the CPU           */
     ECNE_EINVAL = -9,
     ECNE_ECAPACITY = -10, /* internal device table overflow (reported, never silently truncated)    */
-    ECNE_ETIMEOUT = -11   /* the workgroups of a solve did not meet at their barrier within 0.2 s: something else
-                             occupies the device (see ecne_solve: one solver process per device)          */
+    ECNE_ETIMEOUT = -11   /* the workgroups of a solve cannot run together: the cooperative launch was refused, or they did not
+                             meet at their barrier in time -- something else occupies the device (see ecne_solve)        */
 } ecne_status;
 
 typedef struct ecne_r1cs ecne_r1cs;     /* a parsed .r1cs file                                   */
@@ -174,9 +174,12 @@ typedef struct ecne_summary {
 /* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is
  * usable. ecne_solve_batch runs n independent systems in one launch (one workgroup per system, more for large
  * ones). The workgroups of a large system meet at a barrier of their own and therefore have to be resident on
- * the device together: the library takes at most (CUs - 8) workgroups per launch and serialises its own launches
- * per device inside the process, but it cannot see other processes -- run ONE solver process per device. A solve
- * whose workgroups do not meet within 0.2 s returns ECNE_ETIMEOUT instead of hanging.
+ * the device together: such a launch is made COOPERATIVELY (hipLaunchCooperativeKernel: the runtime keeps the grid
+ * resident together or refuses the launch -> ECNE_ETIMEOUT at once), holds at most (CUs - 8) workgroups, and has the
+ * device to itself inside the process (single-workgroup solves share it with each other). Other PROCESSES on the
+ * device are not visible to the library -- run ONE solver process per device; as a last line of defence a barrier wait
+ * WITHOUT PROGRESS is bounded (0.2 s + 2 us per row, ECNE_BARRIER_TIMEOUT_MS overrides; the master workgroup's heartbeat
+ * restarts the clock) and ends in ECNE_ETIMEOUT instead of a hang. The caller's current HIP device is left as it was.
  * Out-of-range ids (malformed input): a known id above n_vars raises ECNE_EBOUNDS as the reference's setup does
  * (:682), a target id above n_vars at the verdict (:1580); a ROW that mentions an id above n_vars is solved with the
  * state arrays widened (the reference raises BoundsError at the first rule that reads that state). */

@@ -132,6 +132,22 @@ function print_report(sys::EcneSystem, res::Ptr{Cvoid}, input_sym::String)
     end
 end
 
+# debug=true: printState of every non-trivial variable between the two "Solved for" lines (:1573-1577), in the reference's Set order
+function print_debug_states(sys::EcneSystem, res::Ptr{Cvoid})
+    fl = Ref{Ptr{UInt8}}(C_NULL); lb = Ref{Ptr{UInt64}}(C_NULL); ub = Ref{Ptr{UInt64}}(C_NULL)
+    abz = Ref{Ptr{Int32}}(C_NULL); nv = Ref{Ptr{UInt8}}(C_NULL); vals = Ref{Ptr{UInt64}}(C_NULL)
+    check(ccall((:ecne_result_states, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{UInt8}}, Ref{Ptr{UInt64}}, Ref{Ptr{UInt64}}, Ref{Ptr{Int32}}, Ref{Ptr{UInt8}}, Ref{Ptr{UInt64}}),
+                res, fl, lb, ub, abz, nv, vals))
+    for v in report_order(sys, 0)
+        println("Uniquely Determined: ", (unsafe_load(fl[], v) & 1) == 1)
+        l, u = limbs(lb[], v - 1), limbs(ub[], v - 1)
+        (l == 0 && u == P_BJJ - 1) ? println("Bounds: None") : println("Bounds: [", l, ", ", u, "]")
+        n = Int(unsafe_load(nv[], v))
+        n > 0 && println("All possible values: ", sort!(BigInt[limbs(vals[], 2 * (v - 1) + k) for k in 0:n-1]))
+        println()
+    end
+end
+
 function readR1CS(filename::String)                  # -> (equations, known, outputs, nVars)
     f = EcneR1CS(filename)
     kn = Ref{Ptr{Int64}}(C_NULL); nk = Ref{Csize_t}(0); tg = Ref{Ptr{Int64}}(C_NULL); nt = Ref{Csize_t}(0)
@@ -145,6 +161,7 @@ end
 function SolveConstraintsSymbolic(constraints, special_constraints=nothing, known_variables=nothing,
                                   debug::Bool=false, target_variables=nothing, num_variables::Int=-1,
                                   input_sym::String="default.sym", secp_solve::Bool=false; device::Int=0)
+    time_begin_solve = time()
     sys = constraints isa EcneSystem ? constraints : EcneSystem(constraints)
     # the reference takes these lists as arguments: what the caller passes REPLACES what the handle carries
     # (the file's lists, the specials abstraction() produced); `nothing` keeps the handle's
@@ -166,6 +183,8 @@ function SolveConstraintsSymbolic(constraints, special_constraints=nothing, know
             end
         end
     end
+    system_specials(sys)                                                     # lays the system out: the reference's per-solve set-up (:593-703)
+    println("setup solver ", round(Int, (time() - time_begin_solve) * 1000), " milliseconds")      # :704 (always printed)
     opts = Ref(EcneOpts(device, secp_solve, 0, 0, C_NULL))
     res = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:ecne_solve, LIB), Cint, (Ptr{Cvoid}, Ref{EcneOpts}, Ref{Ptr{Cvoid}}), sys.h, opts, res))
@@ -174,8 +193,9 @@ function SolveConstraintsSymbolic(constraints, special_constraints=nothing, know
     try
         check(s[].status)
         println("Solved for ", s[].unique_nontrivial, " variables out of ", s[].n_nontrivial, " total variables")           # :1565
+        debug && print_debug_states(sys, res[])                                                                             # :1573-1577
         println("Solved for ", s[].unique_targets, " target variables out of ", s[].n_targets, " total target variables")  # :1586
-        print_report(sys, res[], input_sym == "default.sym" && !isfile(input_sym) ? "" : input_sym)                        # :1599-1643
+        print_report(sys, res[], input_sym)                      # :1599-1643 (a missing file throws, "default.sym" included, as CSV.File does)
     finally
         ccall((:ecne_result_free, LIB), Cvoid, (Ptr{Cvoid},), res[])
     end
@@ -185,6 +205,7 @@ end
 function solveWithTrustedFunctions(input_r1cs::String, input_r1cs_name::String;
         trusted_r1cs::Vector{String}=String[], trusted_r1cs_names::Vector{String}=String[], debug::Bool=false,
         printRes::Bool=true, abstractionOnly::Bool=false, input_sym::String="", secp_solve::Bool=false)
+    a = time()
     @assert length(trusted_r1cs) == length(trusted_r1cs_names)
     main, _, _, _ = readR1CS(input_r1cs)
     fl = [(trusted_r1cs_names[i], EcneR1CS(trusted_r1cs[i])) for i in 1:length(trusted_r1cs)]
@@ -195,7 +216,11 @@ function solveWithTrustedFunctions(input_r1cs::String, input_r1cs_name::String;
         printRes && println("called abstraction")
         check(ccall((:ecne_abstract, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cstring), sys.h, f.h, name))
     end
-    abstractionOnly && return true
+    if abstractionOnly                                                      # :546-549
+        println(Any[(n, i, o) for (n, i, o) in system_specials(sys)[1]])
+        return true
+    end
+    println("time to prep inputs ", round(Int, (time() - a) * 1000), " milliseconds")       # :551 (always printed)
     result = SolveConstraintsSymbolic(sys, nothing, nothing, debug, nothing, -1, input_sym, secp_solve)
     if result
         if !isempty(fl)

@@ -77,6 +77,33 @@ def test_full_report_division(capsys):
     assert "R1CS function division has potentially unsound constraints" in out
 
 
+def test_always_on_prints_debug_dump_and_missing_sym(capsys):
+    """the lines the reference prints whatever the flags ("time to prep inputs" :551, "setup solver" :704), the printState dump of
+    debug=true between the two count lines (:1573-1577), println(specials) of abstractionOnly (:547), and CSV.File on a missing
+    .sym (:1603) -- "default.sym", SolveConstraintsSymbolic's own default, included"""
+    import re
+    import ecneproject_amd as E
+    ok = E.solveWithTrustedFunctions(fixtures.path("target/division.r1cs"), "division", debug=True)
+    out = capsys.readouterr().out
+    assert ok is False
+    assert re.search(r"^time to prep inputs \d+ milliseconds$", out, re.M) and re.search(r"^setup solver \d+ milliseconds$", out, re.M)
+    assert out.index("time to prep inputs") < out.index("setup solver") < out.index("Solved for 5 variables")
+    a, b = out.index("Solved for 5 variables out of 7 total variables"), out.index("Solved for 0 target variables")
+    dump = out[a:b]
+    assert dump.count("Uniquely Determined: true") == 5 and dump.count("Uniquely Determined: false") == 2
+    assert "main." not in dump                                   # printState only, no signal names
+    assert out.rstrip().endswith("R1CS function division has potentially unsound constraints")
+    assert E.solveWithTrustedFunctions(fixtures.path("secp256k1.r1cs"), "secp", trusted_r1cs=[fixtures.path("biglessthan.r1cs")],
+                                       trusted_r1cs_names=["BigLessThan"], abstractionOnly=True) is True
+    out = capsys.readouterr().out
+    assert out.startswith("called abstraction\nAny[(\"BigLessThan\", [") and out.count("BigLessThan") == 4
+    s = E.System(E.R1CS(fixtures.path("target/division.r1cs")))
+    with pytest.raises(FileNotFoundError):
+        E.SolveConstraintsSymbolic(s)                             # input_sym defaults to "default.sym"
+    with pytest.raises(FileNotFoundError):
+        E.SolveConstraintsSymbolic(s, None, None, False, None, -1, "/nonexistent/x.sym")
+
+
 def test_result_states_after_free_or_resolve_is_einval():
     """a result's per-variable state can only be fetched while its system is alive and has not been solved again"""
     import ctypes as C
