@@ -39,9 +39,10 @@ def parse_args():
     ap.add_argument("--cpu-sample-S", type=int, default=26, help="strides of the CPU-baseline sample (26 = the whole workload: ~13 s solve + ~4 s parse / abstraction on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queue-mode", type=int, default=0)
-    ap.add_argument("--workload", choices=["ecdsa", "suite"], default="ecdsa",
-                    help="ecdsa = BASELINE.json config 5 (the metric's configuration); suite = config 4, the 67 circomlib files "
-                         "sharded file-per-GPU (ecneproject_amd/jobs.py)")
+    ap.add_argument("--workload", choices=["ecdsa", "suite", "poseidon", "secp", "dag"], default="ecdsa",
+                    help="ecdsa = BASELINE.json config 5 (the metric's configuration, one circuit: replicas at N > 1); suite = config 4, the 67 "
+                         "circomlib files sharded file-per-GPU; poseidon = config 2; secp = config 3; dag = config 5's trusted-subcircuit "
+                         "verification DAG as four sharded jobs (ecneproject_amd/jobs.py)")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads for parse / abstraction / layout (0 = the cores present, at most 32)")
     return ap.parse_args()
 
@@ -60,14 +61,74 @@ def probe_julia():
     return {"julia": v, "note": "julia found; timing the reference needs an instantiated Ecne checkout (ECNE_REFERENCE_DIR), see julia/dump_unique.jl"}
 
 
-def run_suite(args, torch, dist, rank, local_rank, world):
-    """BASELINE.json config 4: the 67 ecne_circomlib_tests files, one batch launch per rank, one all-reduce of the verdict word."""
-    import ecneproject_amd as E
+def workload_jobs(name, args):
+    """The job lists of the BASELINE.json configurations that are batches of independent solves (ecneproject_amd.jobs.Job)."""
+    import ecdsa_like
     import fixtures
     from ecneproject_amd import jobs as J
+    fx = fixtures.path
+    if name == "suite":        # config 4
+        rels = fixtures.circomlib_suite()
+        return [J.Job(fx(r), r) for r in rels], "ecne_circomlib_tests/*.r1cs (BASELINE.json config 4), sharded file-per-GPU, one batch launch per rank", "reference fixtures (67 circom outputs)"
+    if name == "poseidon":     # config 2
+        r = "ecne_circomlib_tests/Poseidon@poseidon.r1cs"
+        return [J.Job(fx(r), r)], "ecne_circomlib_tests/Poseidon@poseidon.r1cs (BASELINE.json config 2)", "reference fixture"
+    secp = J.Job(fx("secp256k1.r1cs"), "secp256k1", [(fx("bigmultmodp.r1cs"), "BigMultModP"), (fx("biglessthan.r1cs"), "BigLessThan")], True)
+    if name == "secp":         # config 3
+        return [secp], "secp256k1.r1cs + trusted bigmultmodp.r1cs, biglessthan.r1cs, secp_solve=true (BASELINE.json config 3)", "reference fixtures"
+    if name == "dag":          # config 5's trusted-subcircuit verification DAG (SURVEY.md 8e): four solves, verdicts AND-ed
+        main = ecdsa_like.cached(args.S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid())
+        return ([J.Job(main, "ecdsa_like(%d)" % args.S, [(fx("secp256k1.r1cs"), "Secp256k1AddUnequal")]), secp,
+                 J.Job(fx("bigmultmodp.r1cs"), "bigmultmodp"), J.Job(fx("biglessthan.r1cs"), "biglessthan")],
+                "config-5 verification DAG: ecdsa_like(S=%d) <- secp256k1; secp256k1 <- bigmultmodp, biglessthan; bigmultmodp; biglessthan "
+                "(four independent solves sharded job-per-GPU, verdicts AND-ed by the all-reduce)" % args.S,
+                "synthetic ecdsa_like + reference fixtures")
+    raise SystemExit("unknown workload " + name)
+
+
+def _oracle_job(t):
+    """(worker of the CPU baseline) one job through the sequential oracle; returns (rows of the main file, t_solve, pops, alg bytes)"""
+    import orc
+    path, trusted, names, secp = t
+    o = orc.run(path, trusted, names, secp, want_states=False)
+    s = o.summary
+    return int(s.n_rows_main), float(s.t_solve), int(s.pops), int(o.alg_bytes()), float(s.t_read + s.t_abstract)
+
+
+def cpu_baseline_jobs(jobs, label):
+    """the sequential restatement on ONE core, job after job -- and the same jobs file-parallel, one process per
+    job over the host cores (core count stated)."""
+    import multiprocessing as mp
+    items = [(j.r1cs, [f for f, _ in j.trusted], [n for _, n in j.trusted], j.secp_solve) for j in jobs]
+    t0 = time.perf_counter()
+    seq = [_oracle_job(t) for t in items]
+    wall_seq = time.perf_counter() - t0
+    rows, t_solve = sum(r[0] for r in seq), sum(r[1] for r in seq)
+    out = {"value": rows / max(t_solve, 1e-9), "unit": "constraints/s", "cores": 1, "kind": "port",
+           "sample": "%s: the whole workload, %d job(s), %d rows, sequential oracle solve %.3f s in total (parse + abstraction %.3f s excluded, "
+                     "as for the GPU); longest single job %.3f s" % (label, len(jobs), rows, t_solve, sum(r[4] for r in seq), max(r[1] for r in seq)),
+           "host_cores_available": os.cpu_count(), "reference_probe": probe_julia(), "wall_s_one_core_incl_parse": round(wall_seq, 3)}
+    if len(items) > 1:
+        ncore = min(len(items), os.cpu_count() or 1)
+        order = sorted(range(len(items)), key=lambda i: -seq[i][1])          # longest first
+        with mp.get_context("fork").Pool(ncore) as pool:
+            t0 = time.perf_counter()
+            par = pool.map(_oracle_job, [items[i] for i in order], chunksize=1)
+            wall = time.perf_counter() - t0
+        out["file_parallel"] = {"value": rows / max(wall, 1e-9), "unit": "constraints/s", "cores": ncore, "wall_s": round(wall, 4),
+                                "longest_job_solve_s": round(max(r[1] for r in par), 4),
+                                "note": "one process per job over %d of the %d host cores; wall clock includes parse + abstraction of every file" % (ncore, os.cpu_count() or 1)}
+    return out
+
+
+def run_jobs_workload(args, torch, dist, rank, local_rank, world):
+    """Configs 2, 3, 4 and the config-5 DAG: independent jobs, LPT-packed onto the ranks, one batch launch per rank and step, one
+    all-reduce (MIN) of the verdict word. One step = every job of the workload solved once."""
+    import ecneproject_amd as E
+    from ecneproject_amd import jobs as J
+    from ecneproject_amd import sharding
     E.set_host_threads(args.host_threads)
-    rels = fixtures.circomlib_suite()
-    jl = [J.Job(fixtures.path(r), r) for r in rels]
+    jl, label, data = workload_jobs(args.workload, args)
     runner = J.Runner(jl, rank, world, local_rank, dist if world > 1 else None)
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(max(args.warmup, 1)):
@@ -79,28 +140,60 @@ def run_suite(args, torch, dist, rank, local_rank, world):
     for _ in range(args.steps):
         res, ok = runner.run(stream=stream)
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    rows = torch.tensor([runner.rows_main], dtype=torch.int64, device="cuda")
-    good = torch.tensor([sum(int(r.function_good) for r in res)], dtype=torch.int64, device="cuda")
+    # per-job figures of this rank: rows, device ms, pops, algorithmic bytes (from the solve's own counters -- equal
+    # to the oracle's by the parity tests)
+    mine = []
+    for i, r in zip(runner.mine, res):
+        s, inf = r.summary, runner.systems[runner.mine.index(i)].info
+        nnz = int(inf.nnz[0] + inf.nnz[1] + inf.nnz[2])
+        b_alg = 20 * int(s.pops) + 40 * int(s.pop_nnz) + (3 * int(s.outer_iterations) + 1) * (12 * int(inf.n_rows) + 40 * nnz)
+        mine.append({"job": jl[i].name, "rows_main": int(inf.n_rows_main), "device_ms": float(s.device_ms), "pops": int(s.pops), "alg_bytes": b_alg,
+                     "verdict": bool(r.function_good), "status": int(r.status), "outer_iterations": int(s.outer_iterations)})
+    per_rank = [{"rank": rank, "ms_per_step": t_rank * 1e3 / max(args.steps, 1), "jobs": mine}]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        dist.all_reduce(rows)
-        dist.all_reduce(good)
-    if rank == 0:
-        dev = max((r.summary.device_ms for r in res), default=0.0)
-        print(json.dumps({
-            "metric": "constraints resolved/sec (wall-clock to fixed point), circomlib suite",
-            "value": int(rows.item()) * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / max(args.steps, 1), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u64x4 (BN254 Fp limbs) + u8/u32 flags", "data": "reference fixtures (67 circom outputs)",
-            "config": {"workload": "ecne_circomlib_tests/*.r1cs (BASELINE.json config 4), sharded file-per-GPU, one batch launch per rank",
-                       "files": len(rels), "rows": int(rows.item()), "files_rank0": len(runner.mine), "verdicts_true": int(good.item()),
-                       "all_ran": bool(ok), "rank0_kernel_ms": dev,
-                       "note": "latency-bound: the batch takes as long as its longest dependency chain (EdDSAMiMCSponge)"}}))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    if rank != 0:
+        return
+    alljobs = [j for pr in per_rank for j in pr["jobs"]]
+    rows = sum(j["rows_main"] for j in alljobs)
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    b_alg = sum(j["alg_bytes"] for j in alljobs)
+    longest = max(alljobs, key=lambda j: j["pops"])       # (device_ms is the batch launch's time, the same for every job of a rank)
+    # the dominant kernel is k_solve: one launch per rank and step; its duration = the batch's longest job on that rank
+    k_ms = max(max((j["device_ms"] for j in pr["jobs"]), default=0.0) for pr in per_rank)
+    loads = [sum(runner.weights[i] for i in part) for part in sharding.assign(runner.weights, world)]
+    achieved = b_alg / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": "constraints resolved/sec (wall-clock to fixed point), %s" % args.workload,
+        "value": rows * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64x4 (BN254 Fp limbs) + u8/u32 flags", "data": data,
+        "config": {"workload": label, "jobs": len(jl), "rows": rows, "verdicts_true": sum(int(j["verdict"]) for j in alljobs),
+                   "all_ran": bool(ok),
+                   "per_rank": [{"rank": pr["rank"], "ms_per_step": round(pr["ms_per_step"], 3), "jobs": [j["job"] for j in pr["jobs"]],
+                                 "longest_job_ms": round(max((j["device_ms"] for j in pr["jobs"]), default=0.0), 3)} for pr in per_rank],
+                   "lpt": {"weights": "non-zeros of the main file", "rank_loads": loads, "imbalance": (max(loads) / max(sum(loads) / len(loads), 1e-9)) if loads else None},
+                   "predicted_bound": {"ms_per_step_at_any_n": round(k_ms if world == 1 else longest["device_ms"], 3), "job": longest["job"],
+                                       "note": "a batch takes as long as its longest job: more GPUs cannot go below it (strong scaling saturates at the number of jobs that take about that long)"}},
+        "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                     "alg_bytes_per_step": b_alg, "kernel_ms": k_ms,
+                     "latency_model": {"longest_job": longest["job"], "pops": longest["pops"], "outer_iterations": longest["outer_iterations"],
+                                       "us_per_pop_on_the_longest_chain": 1e3 * longest["device_ms"] / max(longest["pops"], 1),
+                                       "model": "cache-resident and dependency-depth bound: t ~ pops of the longest chain x us per sequential pop (+ rounds where the frontier is wide)"},
+                     "note": "the working set of these circuits (<= 12 MB) lives in L2 / Infinity Cache; the HBM fraction is reported for completeness, the latency model is the bound"},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_jobs(jl, args.workload)
+    print(json.dumps(out))
 
 
 def main():
@@ -118,8 +211,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    if args.workload == "suite":
-        run_suite(args, torch, dist, rank, local_rank, world)
+    if args.workload != "ecdsa":
+        run_jobs_workload(args, torch, dist, rank, local_rank, world)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -135,6 +228,7 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     main_file = E.R1CS(path)
+    parse_stats = E.frontend_stats()
     trusted = E.R1CS(fixtures.path("secp256k1.r1cs"))
     t_parse = time.time() - t0
     t0 = time.time()
@@ -156,6 +250,9 @@ def main():
 
     _shape, classify_ms_cold, classify_bytes = E.classify(system, device=local_rank)     # first launch: code object load, cold caches
     res = step()                       # first solve: layout upload + classification happen here (untimed)
+    frontend_stats = E.frontend_stats()                 # (abstraction and layout of this system; the parse figures are the main file's)
+    for k in ("parse_device", "upload_ms", "offsets_ms", "fill_ms", "parse_ms", "file_bytes"):
+        frontend_stats[k] = parse_stats[k]
     for _ in range(max(args.warmup - 1, 0)):
         res = step()
     if world > 1:
@@ -228,7 +325,8 @@ def main():
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6,
                                            "frac_of_hbm_peak": classify_bytes / max(classify_ms, 1e-9) / 1e6 / 8000.0,
                                            "note": "HIP events around the launch; ms = median of 7 warm launches, ms_best their minimum; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
-                       "abstraction": abstract_stats},
+                       "abstraction": abstract_stats,
+                       "frontend": {"mode": {0: "host", 1: "device", 2: "auto"}[E.set_frontend()], **{k: round(v, 3) for k, v in frontend_stats.items()}}},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,

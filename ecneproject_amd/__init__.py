@@ -192,6 +192,10 @@ class System:
         tg = (C.c_int64 * max(len(target_variables), 1))(*target_variables)
         _check(_lib.lib().ecne_system_set_io(self._h, kn, len(known_variables), tg, len(target_variables)), "set_io")
 
+    def set_secp_solve(self, flag):
+        """this system's kwarg secp_solve inside a batch launch (True / False; None = what solve_batch is called with)"""
+        _check(_lib.lib().ecne_system_set_secp_solve(self._h, -1 if flag is None else int(bool(flag))))
+
     def set_specials(self, special_constraints):
         """special_constraints: [(name, inputs, outputs), ...] as abstraction builds them (:388)"""
         L = _lib.lib()

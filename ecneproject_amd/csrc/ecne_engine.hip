@@ -152,6 +152,7 @@ struct ecne_system {
     std::vector<Special> specials;
     std::vector<int64_t> knowns, targets;
     int64_t n_vars = 0, n_rows_main = 0;
+    int secp_solve_override = -1;      // ecne_system_set_secp_solve: this system's kwarg secp_solve inside a batch (-1: the launch's opts decide)
     bool laid_out = false;
     uint64_t generation = 0;   // bumped by every solve
     const uint64_t uid = next_system_uid();   // process-unique: a result made from a freed system never matches a new one at the same address
@@ -1151,7 +1152,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             int st = classify_system(*sys[i], stream, d_jobs);
             if (st != K_OK) { rc = st; break; }
             hj[i] = sys[i]->dev.job;
-            hj[i].secp_solve = o.secp_solve ? 1u : 0u;
+            hj[i].secp_solve = (sys[i]->secp_solve_override >= 0 ? sys[i]->secp_solve_override != 0 : o.secp_solve != 0) ? 1u : 0u;
             {   // barrier wait without progress: 0.2 s + 2 us per row (a long sequential stretch on a huge system is not a hang), or
                 // ECNE_BARRIER_TIMEOUT_MS
                 uint64_t tmo = 200 + (uint64_t)hj[i].nC / 500;
@@ -1542,6 +1543,11 @@ int ecne_system_set_io(ecne_system* sys, const int64_t* known, size_t nk, const 
         system_changed(sys);
         return (int)ECNE_OK;
     });
+}
+int ecne_system_set_secp_solve(ecne_system* sys, int flag) {
+    if (!sys) return ECNE_EINVAL;
+    sys->secp_solve_override = flag < 0 ? -1 : (flag != 0);
+    return ECNE_OK;
 }
 int ecne_system_clear_specials(ecne_system* sys) {
     if (!sys) return ECNE_EINVAL;

@@ -60,14 +60,20 @@ class Runner:
     def run(self, stream=None, fetch_states=False, device_for_word="cuda"):
         """one pass over this rank's jobs; returns (results of this rank, all verdicts good on every rank)"""
         E = self.E
-        res = [None] * len(self.systems)
-        for flag in (False, True):                       # jobs that need secp_solve (:511) form their own launch
-            idx = [k for k, f in enumerate(self.secp) if f == flag]
-            if idx:
-                out = E.solve_batch([self.systems[k] for k in idx], secp_solve=flag, device=self.device, stream=stream,
-                                    fetch_states=fetch_states)
-                for k, r in zip(idx, out):
-                    res[k] = r
+        if hasattr(self.systems[0] if self.systems else None, "set_secp_solve"):
+            # one launch for the whole share: every system carries its own secp_solve (:511)
+            for s, f in zip(self.systems, self.secp):
+                s.set_secp_solve(f)
+            res = E.solve_batch(self.systems, device=self.device, stream=stream, fetch_states=fetch_states) if self.systems else []
+        else:
+            res = [None] * len(self.systems)
+            for flag in (False, True):                   # (an engine without per-system flags: one launch per flag value)
+                idx = [k for k, f in enumerate(self.secp) if f == flag]
+                if idx:
+                    out = E.solve_batch([self.systems[k] for k in idx], secp_solve=flag, device=self.device, stream=stream,
+                                        fetch_states=fetch_states)
+                    for k, r in zip(idx, out):
+                        res[k] = r
         ok = all(r.status == 0 for r in res)
         if self.dist is not None:
             ok = sharding.allreduce_verdict(ok, self.dist, device=device_for_word)

@@ -133,6 +133,9 @@ int ecne_debug_static_array(ecne_system* sys, int device, int which, const void*
  * that edits them says so here (ids 1-based; copied). Changing them invalidates the device image of the system. */
 int ecne_system_set_io(ecne_system* sys, const int64_t* known, size_t n_known, const int64_t* targets, size_t n_targets);
 int ecne_system_clear_specials(ecne_system* sys);
+/* kwarg secp_solve (:511) of THIS system when it is solved as part of a batch whose jobs do not all want the same (0 / 1; -1 = what
+ * the launch's ecne_opts says, the default). */
+int ecne_system_set_secp_solve(ecne_system* sys, int flag);
 int ecne_system_add_special(ecne_system* sys, const char* name, const int64_t* inputs, size_t n_inputs,
                             const int64_t* outputs, size_t n_outputs);
 int ecne_system_io(const ecne_system* sys, const int64_t** known, size_t* n_known, const int64_t** targets, size_t* n_targets);

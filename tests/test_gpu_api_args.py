@@ -131,3 +131,20 @@ def test_result_states_after_free_or_resolve_is_einval():
     assert L.ecne_result_summary(r3, C.byref(sm)) == 0 and sm.n_rows == 3
     for r in (r1, r2, r3):
         L.ecne_result_free(r)
+
+
+def test_per_system_secp_solve_in_one_batch():
+    """jobs that want different secp_solve values in ONE launch (ecne_system_set_secp_solve): config 3 needs it (:762), the secp256k1
+    adder without trusted functions must not get it, and a system with BigMultModP x BigLessThan pairs but the flag off raises UndefVarError"""
+    import ecneproject_amd as E
+    tr, names = ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"]
+    a, b, c = build_system("secp256k1.r1cs", tr, names), build_system("target/division.r1cs"), build_system("secp256k1.r1cs", tr, names)
+    a.set_secp_solve(True); b.set_secp_solve(False); c.set_secp_solve(False)
+    ra, rb, rc = E.solve_batch([a, b, c], secp_solve=False)
+    assert_bit_exact("secp+trusted", ra, orc.run(fixtures.path("secp256k1.r1cs"), [fixtures.path(t) for t in tr], names, True))
+    assert_bit_exact("division", rb, orc.run(fixtures.path("target/division.r1cs")))
+    assert rc.status == -4                                      # UndefVarError: dsu
+    for s in (a, b, c):
+        s.set_secp_solve(None)
+    ra2, rb2, rc2 = E.solve_batch([a, b, c], secp_solve=True)   # back to "what the launch says"
+    assert ra2.status == 0 and ra2.function_good and rc2.status == 0 and rc2.function_good and rb2.status == 0

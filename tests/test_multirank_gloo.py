@@ -114,3 +114,80 @@ def test_two_rank_job_runner(tmp_path):
     assert sorted(res["names"]) == sorted(rels) and res["ok"] is True and min(res["rows"]) > 0
     want = {r: orc.run(fixtures.path(r), want_states=False).verdict for r in rels}
     assert dict(zip(res["names"], res["verdicts"])) == want
+
+
+DAG_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch, torch.distributed as dist
+import fixtures, orc, ecdsa_like
+import ecneproject_amd as E
+from ecneproject_amd import jobs as J
+
+
+class TracedSystem(E.System):
+    def __init__(self, r1cs):
+        super().__init__(r1cs)
+        self.trusted_log = []
+
+    def abstract(self, f, name):
+        self.trusted_log.append((f.path, name))
+        super().abstract(f, name)
+
+    def set_secp_solve(self, flag):
+        self.secp = bool(flag)
+        super().set_secp_solve(flag)
+
+
+class OracleEngine:
+    """the product's reader / abstraction / job runner / sharding / all-reduce run for real; solve_batch is answered by the oracle"""
+    R1CS, System = E.R1CS, TracedSystem
+
+    @staticmethod
+    def solve_batch(systems, secp_solve=False, device=0, stream=None, fetch_states=False):
+        out = []
+        for s in systems:
+            o = orc.run(s.main.path, [t for t, _ in s.trusted_log], [n for _, n in s.trusted_log], s.secp, want_states=False)
+            assert [tuple(x) for x in s.specials()] == [tuple(x) for x in o.specials]
+            out.append(type("R", (), {"status": o.status, "function_good": o.verdict, "summary": o.summary})())
+        return out
+
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+fx = fixtures.path
+main = ecdsa_like.cached(2, 10)
+jl = [J.Job(main, "ecdsa_like(2)", [(fx("secp256k1.r1cs"), "Secp256k1AddUnequal")]),
+      J.Job(fx("secp256k1.r1cs"), "secp256k1", [(fx("bigmultmodp.r1cs"), "BigMultModP"), (fx("biglessthan.r1cs"), "BigLessThan")], True),
+      J.Job(fx("bigmultmodp.r1cs"), "bigmultmodp"), J.Job(fx("biglessthan.r1cs"), "biglessthan")]
+runner = J.Runner(jl, dist.get_rank(), dist.get_world_size(), 0, dist, E=OracleEngine)
+res, ok = runner.run(device_for_word="cpu")
+sound = all(bool(r.function_good) for r in res)
+from ecneproject_amd import sharding
+sound_all = sharding.allreduce_verdict(sound, dist, device="cpu")
+gathered = [None] * dist.get_world_size()
+dist.all_gather_object(gathered, ([jl[i].name for i in runner.mine], [bool(r.function_good) for r in res]))
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps({"ok": bool(ok), "sound_all": bool(sound_all), "names": sum([g[0] for g in gathered], []),
+                                   "verdicts": sum([g[1] for g in gathered], []), "per_rank": [g[0] for g in gathered]}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_verification_dag(tmp_path):
+    """config 5's trusted-subcircuit DAG (SURVEY.md 8e) as four jobs on two gloo ranks: ecdsa_like <- secp256k1,
+    secp256k1 <- bigmultmodp + biglessthan (secp_solve), bigmultmodp, biglessthan; each runs once, the big job sits alone on its
+    rank (LPT), abstraction finds the oracle's special constraints, the verdicts are AND-ed by the all-reduce."""
+    script = tmp_path / "dag_worker.py"
+    script.write_text(DAG_WORKER % {"root": ROOT, "tests": HERE})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert sorted(res["names"]) == ["biglessthan", "bigmultmodp", "ecdsa_like(2)", "secp256k1"] and res["ok"] is True
+    assert ["ecdsa_like(2)"] in res["per_rank"]                      # the heavy job alone on one rank
+    verdicts = dict(zip(res["names"], res["verdicts"]))
+    assert verdicts["secp256k1"] is True                             # test/runtests.jl:35
+    assert res["sound_all"] == all(verdicts.values())
