@@ -1,6 +1,7 @@
 # dump_unique.jl — for anyone who HAS Julia 1.7 and an instantiated Ecne checkout: run the reference solver itself and
 # dump, per variable, what it ended up knowing, so that the HIP engine's result can be compared with the real thing
-# (tests/tools/compare_julia_dump.py). Never needed by the test-suite: the build image has no Julia, which is why the
+# (tests/tools/compare_julia_dump.py), or dropped into tests/golden/julia/ where tests/test_julia_dumps.py picks it up and compares it
+# with the oracle and with the second reading (tests/ref2.py) on the CPU. Never needed by the test-suite: the build image has no Julia, which is why the
 # per-variable state is "parity unpinned" against the reference (DESIGN.md §2) until somebody runs this.
 #
 #   julia --project=<Ecne checkout> julia/dump_unique.jl <Ecne checkout> main.r1cs out.tsv [--secp] [trusted.r1cs Name]...
@@ -24,6 +25,7 @@ verdict = Main.R1CSConstraintSolver.solveWithTrustedFunctions(main, "dump"; trus
                                                                printRes = false, secp_solve = secp)
 st = Main.R1CSConstraintSolver.ECNE_DUMP_STATES
 open(out, "w") do io
+    println(io, "# input\t", basename(main), "\t", Int(secp), "\t", join([basename(t) * "=" * n for (t, n) in zip(trusted, names)], ","))
     println(io, "# verdict\t", verdict)
     println(io, "# var\tunique\tis_known\tlb\tub\tabz\tvalues")
     for (i, s) in enumerate(st)
