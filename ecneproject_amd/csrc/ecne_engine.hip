@@ -1202,8 +1202,16 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             std::unique_lock<std::shared_mutex> exclusive_lock(device_launch_mutex(o.device), std::defer_lock);
             std::shared_lock<std::shared_mutex> shared_lock(device_launch_mutex(o.device), std::defer_lock);
             if (any_multi || n > 1) exclusive_lock.lock(); else shared_lock.lock();
+            // Co-residency of a multi-workgroup job: the launch is refused unless the device can hold the whole grid at once
+            // (occupancy query: workgroups of k_solve per CU with this much dynamic LDS x CUs). ECNE_COOPERATIVE=1 additionally makes
+            // the launch through hipLaunchCooperativeKernel (the runtime checks the same thing and uses its cooperative queue) -- not
+            // the default: rocprofv3 of ROCm 7.2 crashes at process exit when the application used the cooperative queue.
             int coop_attr = 0;
-            const bool coop_ok = !getenv("ECNE_NO_COOPERATIVE") && hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, o.device) == hipSuccess && coop_attr != 0;
+            const bool coop_ok = getenv("ECNE_COOPERATIVE") && atoi(getenv("ECNE_COOPERATIVE")) != 0 &&
+                                 hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, o.device) == hipSuccess && coop_attr != 0;
+            int wg_per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k_solve, ECNE_WG, dyn_lds) != hipSuccess) { wg_per_cu = 1; (void)hipGetLastError(); }
+            const size_t resident_cap = (size_t)std::max(wg_per_cu, 0) * (size_t)n_cu;
             bool refused = false;
             (void)hipEventRecord(e0, stream);
             std::vector<WgDesc> descs;
@@ -1220,6 +1228,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 // the workgroups of a multi-workgroup job meet at a barrier of their own: launched cooperatively, the runtime either
                 // makes the whole grid resident together or refuses the launch (no 0.2 s wait for workgroups that never start)
                 bool launched = false;
+                if (any_multi && descs.size() > resident_cap) { refused = true; fail = true; break; }
                 if (any_multi && coop_ok) {
                     const Job* a0 = d_jobs;
                     const WgDesc* a1 = d_descs;

@@ -77,7 +77,7 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                 }
             }
             // the wait is bounded by wall-clock time (J.bar_timeout_ms of the 100 MHz counter; the host scales it with the system:
-            // 0.2 s + 2 us per row): the workgroups of a job are launched co-resident (cooperative launch) unless something else
+            // 0.2 s + 2 us per row): the launch was checked to fit the device as a whole (ecne_engine.hip) -- they all run unless something else
             // occupies the device (include/ecne.h: one solver process per device)
             // (helpers legitimately wait for as long as the master works alone -- a deep chain can take many milliseconds --
             //  so the clock restarts whenever the master's heartbeat word has moved: the bound is on time WITHOUT progress)

@@ -177,9 +177,10 @@ typedef struct ecne_summary {
 /* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is
  * usable. ecne_solve_batch runs n independent systems in one launch (one workgroup per system, more for large
  * ones). The workgroups of a large system meet at a barrier of their own and therefore have to be resident on
- * the device together: such a launch is made COOPERATIVELY (hipLaunchCooperativeKernel: the runtime keeps the grid
- * resident together or refuses the launch -> ECNE_ETIMEOUT at once), holds at most (CUs - 8) workgroups, and has the
- * device to itself inside the process (single-workgroup solves share it with each other). Other PROCESSES on the
+ * the device together: such a launch is refused at once (ECNE_ETIMEOUT) unless the device can hold its whole grid
+ * (occupancy query; with ECNE_COOPERATIVE=1 in the environment it also goes through hipLaunchCooperativeKernel), holds at
+ * most (CUs - 8) workgroups, and has the device to itself inside the process (single-workgroup solves share it with each
+ * other). Other PROCESSES on the
  * device are not visible to the library -- run ONE solver process per device; as a last line of defence a barrier wait
  * WITHOUT PROGRESS is bounded (0.2 s + 2 us per row, ECNE_BARRIER_TIMEOUT_MS overrides; the master workgroup's heartbeat
  * restarts the clock) and ends in ECNE_ETIMEOUT instead of a hang. The caller's current HIP device is left as it was.

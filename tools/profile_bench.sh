@@ -14,7 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -- $CMD > /dev/null 2> $O/
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $O/sq -- $CMD > /dev/null 2> $O/sq.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace -d $O/insts -- $CMD > /dev/null 2> $O/insts.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $O/tcc -- $CMD > /dev/null 2> $O/tcc.err
-rocprofv3 --kernel-trace --stats -d $O/suite -- python bench.py --workload suite --steps 5 --warmup 2 > $O/bench_suite_under_rocprof.json 2> $O/suite.err
+rocprofv3 --kernel-trace --stats -d $O/suite -- python bench.py --workload suite --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_suite_under_rocprof.json 2> $O/suite.err
 for d in trace fetch write sq insts tcc suite; do python tools/rocpd_summary.py $(find $O/$d -name "*.db") > $O/$d.txt 2>&1; done
 tail -1 $O/bench_under_rocprof.json | head -c 300; echo
 for d in trace fetch write sq insts tcc suite; do echo "== $d"; head -14 $O/$d.txt; done
