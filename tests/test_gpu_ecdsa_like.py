@@ -1,7 +1,7 @@
 """BASELINE.json config 5 on the GPU: the synthetic ecdsa_like(S) circuit (tests/ecdsa_like.py) with
 secp256k1.r1cs trusted.  Small S: bit-exact against the oracle.  Full size (S = 26, 1.09 M rows):
 size-independent properties and the whole per-variable state against the oracle (~20 s of CPU; ECNE_FULL_ORACLE=0
-skips that part)."""
+skips that part; ECNE_FULL_ORACLE=2 adds ecdsa_like(104), 4.4 M rows, minutes of oracle)."""
 import os
 
 import numpy as np
@@ -73,3 +73,20 @@ def test_mid_size_bit_exact(force_nwg):
     g = E.solve_batch([s], force_nwg=force_nwg)[0]
     o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
     assert_bit_exact("ecdsa_like(6,10) nwg=%d" % force_nwg, g, o)
+
+
+@pytest.mark.skipif(os.environ.get("ECNE_FULL_ORACLE", "1") != "2", reason="ECNE_FULL_ORACLE=2 switches the 4.4 M-row comparison on (oracle: 3-7 minutes on one core)")
+def test_scale_out_full_state_parity():
+    """ecdsa_like(104): 4.4 M rows -- the only case beyond the 256 MiB Infinity Cache -- through the device front-end, the whole
+    per-variable state against the oracle; plus one million-row input of a different shape (1 400 Poseidon copies side by side)."""
+    import multi_copy
+    path = ecdsa_like.cached(104, 10)
+    s = build_system(None, *TRUSTED, path=path)
+    assert E.frontend_stats()["layout_device"] in (0.0, 1.0)
+    g = E.solve_batch([s])[0]
+    o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
+    assert o.verdict is True
+    assert_bit_exact("ecdsa_like(104,10)", g, o)
+    p2 = multi_copy.cached("ecne_circomlib_tests/Poseidon@poseidon.r1cs", 1400)
+    s2 = build_system(None, path=p2)
+    assert_bit_exact("1400 x Poseidon", E.solve_batch([s2])[0], orc.run(p2))
