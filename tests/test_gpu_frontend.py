@@ -234,3 +234,72 @@ def test_ecdsa_like_small_through_both_frontends():
     g = E.solve_batch([sd])[0]
     o = orc.run(p, [tr], ["Secp256k1AddUnequal"], False)
     assert_bit_exact("ecdsa_like(3)", g, o)
+
+
+def test_paths_the_device_hands_back(tmp_path, monkeypatch):
+    """(1) a trusted function whose mapped inputs share their appearance signature (out = a + b, t = (a + b)^2: a and b tie; the reference breaks the
+    tie by hash-table order of the window's variables) goes through the host path as a whole; (2) with ECNE_FE_FORCE_HOST_VERIFY every
+    window the device accepts is verified again by the host code on a downloaded copy (the path a 128-bit signature collision would
+    take); (3) a file whose constraint section does not start on a word boundary (field size 33) is uploaded from the odd address;
+    (4) a file without constraints. Results: the host front-end's and the oracle's."""
+    import struct
+    import ecneproject_amd as E
+    import r1cs_py
+    P = orc.P
+    # (1) ties: sub = { out = a + b ; t = (a + b)^2 } x main with three renamed copies
+    sub = str(tmp_path / "tie_sub.r1cs")
+    r1cs_py.write(sub, 4, 1, 2, 0, [([], [], [(2, 1), (3, P - 1), (4, P - 1)]), ([(3, 1), (4, 1)], [(3, 1), (4, 1)], [(5, 1)])])
+    rows = []
+    for c in range(3):
+        o_, a_, b_, t_ = 10 + 4 * c, 11 + 4 * c, 12 + 4 * c, 13 + 4 * c
+        rows += [([], [], [(o_, 1), (a_, P - 1), (b_, P - 1)]), ([(a_, 1), (b_, 1)], [(a_, 1), (b_, 1)], [(t_, 1)])]
+        rows.append(([(2, 1)], [(3, 1)], [(4 + c, 1)]))
+    main = str(tmp_path / "tie_main.r1cs")
+    r1cs_py.write(main, 24, 1, 2, 0, rows)
+    outs = []
+    for mode in (E.FRONTEND_HOST, E.FRONTEND_DEVICE):
+        E.set_frontend(mode)
+        s = E.System(E.R1CS(main))
+        s.abstract(E.R1CS(sub), "T")
+        outs.append((s.specials(), len(s), s))
+    assert E.frontend_stats()["abstract_device"] == 0.0          # the tie sent it to the host path
+    o = orc.run(main, [sub], ["T"], want_states=False)
+    assert outs[0][:2] == outs[1][:2] and outs[1][0] == o.specials and len(o.specials) == 3
+    _same_dict_rows("ties", outs[0][2], outs[1][2])
+    # (2) forced host verification of device-accepted windows
+    monkeypatch.setenv("ECNE_FE_FORCE_HOST_VERIFY", "1")
+    _mh, sh = _system(E, E.FRONTEND_HOST, "secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"])
+    _md, sd = _system(E, E.FRONTEND_DEVICE, "secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"])
+    st = E.frontend_stats()
+    assert st["abstract_device"] == 1.0 and st["matched"] >= 1e6          # (+ 1e6 per window re-verified on the host)
+    assert sh.specials() == sd.specials() and len(sh) == len(sd)
+    _same_dict_rows("forced host verify", sh, sd)
+    monkeypatch.delenv("ECNE_FE_FORCE_HOST_VERIFY")
+    # (3) field size 33, section 1 first: the constraints start at an odd address
+    rows3 = [([(2, 3)], [(3, 1)], [(4, 1), (1, 5)]), ([], [], [(4, 1), (2, P - 1)]), ([(3, 1), (1, P - 1)], [(3, 1)], [])]
+    body2 = bytearray()
+    for parts in rows3:
+        for terms in parts:
+            body2 += struct.pack("<I", len(terms))
+            for v, c in terms:
+                body2 += struct.pack("<I", v - 1) + int(c).to_bytes(32, "little")
+    body1 = struct.pack("<I", 33) + P.to_bytes(33, "little") + struct.pack("<IIII", 3, 1, 1, 1) + struct.pack("<QI", 3, len(rows3))
+    body3 = b"".join(struct.pack("<Q", i) for i in range(3))
+    odd = str(tmp_path / "odd.r1cs")
+    with open(odd, "wb") as f:
+        f.write(b"r1cs" + struct.pack("<II", 1, 3) + struct.pack("<IQ", 1, len(body1)) + body1 + struct.pack("<IQ", 2, len(body2)) + bytes(body2) +
+                struct.pack("<IQ", 3, len(body3)) + body3)
+    assert orc.read_info(odd)[0] == 0
+    mh, sh = _system(E, E.FRONTEND_HOST, path=odd)
+    md, sd = _system(E, E.FRONTEND_DEVICE, path=odd)
+    assert E.frontend_stats()["parse_device"] == 1.0 and list(mh.info.nnz) == list(md.info.nnz)
+    _same_dict_rows("odd", sh, sd)
+    _same_static_arrays("odd", sh, sd)
+    # (4) no constraints at all
+    empty = str(tmp_path / "empty.r1cs")
+    r1cs_py.write(empty, 3, 1, 1, 1, [])
+    mh, sh = _system(E, E.FRONTEND_HOST, path=empty)
+    md, sd = _system(E, E.FRONTEND_DEVICE, path=empty)
+    assert len(md) == 0 and len(sd) == 0
+    from gpu_common import assert_bit_exact
+    assert_bit_exact("empty", E.solve_batch([sd])[0], orc.run(empty))
