@@ -1,0 +1,399 @@
+// drain.hip.hpp — the drain round: a window of the queue executed in DATAFLOW order by all workgroups of the job.
+// Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
+//
+// A round of queue_round_multi commits the longest prefix of pairwise independent rows and hands the rest back: the reference
+// pops one row at a time (/root/reference/src/R1CSConstraintSolver.jl:805-1349), so a row that depends on an earlier one of the
+// window ends the round -- and a circuit whose independent blocks sit one behind the other in the FIFO (52 multiplexers of an
+// ECDSA circuit: decoder sum, its 4 096 dependents, next decoder sum, ...) is then worked off one block per three rounds although
+// the blocks have nothing to do with each other (tools/dataflow_depth.py: ecdsa_like(26) needs 165 dataflow levels, the
+// prefix schedule took 692 rounds).
+//
+// The drain round executes the WHOLE window, level by level: at every level each pending row looks at the pending rows of LOWER
+// rank only and runs as soon as none of them can still touch what it touches. That is the sequential result: a row then reads
+// exactly the state all earlier pops leave (every earlier row that could write it has run, none that runs later writes it), no
+// earlier pending row reads or writes what it writes, and the pops of a window all precede the pops of anything the window pushes
+// (FIFO). The pushes are resolved ONCE, after the window has drained, in (rank, emission, fan-out) order with the reference's
+// in_queue rule -- multi_finish, the same code as after a prefix round.
+//
+// Hazard test of one level (three planes of per-variable marks, U and B class each, lowest rank wins; epoch-keyed so that
+// nothing is ever reset):
+//   X   exact writes: what the row would write if it ran on the state as it is now (every pending row marks)
+//   A   all accesses: what the row can read or write in ANY state it may still see (static sets minus final variables)
+//   C   conservative writes of UNSTABLE rows -- rows that found a lower X mark on something they access: their inputs may still
+//       change, so what they will write is not known; they mark everything they could
+//   P1 mark X, A | P2 unstable? -> mark C | P3 the others: a lower C mark on what they access demotes them (their lowest rank
+//   becomes the level's cut: rows above it cannot tell which lower rows are trustworthy and wait), a lower A mark on what they
+//   write makes them wait a level (an earlier row still has to read or write that state) | run the rest.
+// The lowest pending row always runs, so the window drains; the window size follows the levels a drain needed (rounds.hip.hpp).
+// Long rows (plain ones, as in every round) are taken by their workgroup as a whole; a long row of another shape, or one the
+// workgroup has no slot for, ends the window BEFORE anything has run (level 1 only).
+#pragma once
+
+namespace ecne {
+
+enum : int { DX_U = 0, DX_B = 1, DA_U = 2, DA_B = 3, DC_U = 4, DC_B = 5 };
+#define ECNE_DRAIN_EPOCH_MAX 32766u
+
+__device__ __forceinline__ uint32_t dr_key(uint32_t epoch, uint32_t rank) { return (epoch << 17) | (0x1FFFFu - rank); }
+__device__ __forceinline__ void dr_mark(uint32_t* plane, uint32_t v, uint32_t key) {
+    if (ld_agent(&plane[v]) < key) atomicMax(&plane[v], key);
+}
+// a mark of the current epoch with a LOWER rank than key's (older epochs are smaller than every key of this one)
+__device__ __forceinline__ bool dr_lower(const uint32_t* plane, uint32_t v, uint32_t key) { return ld_agent(&plane[v]) > key; }
+
+// ---- a small row on the general path (no record decision): the access-set walk of schedule.hip.hpp, four times per level at most
+__device__ __noinline__ void dr_gen_mark(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop) {
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
+        const uint32_t acc = rd | wrc;
+        if (acc & 1) dr_mark(J.dmk[DA_U], v, key);
+        if (acc & 2) dr_mark(J.dmk[DA_B], v, key);
+        if (!noop) {
+            if (wr & 1) dr_mark(J.dmk[DX_U], v, key);
+            if (wr & 2) dr_mark(J.dmk[DX_B], v, key);
+        }
+    });
+}
+__device__ __noinline__ bool dr_gen_unstable(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
+    bool u = false;
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
+        const uint32_t acc = rd | wrc;
+        if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) u = true;
+        if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) u = true;
+    });
+    return u;
+}
+__device__ __noinline__ void dr_gen_mark_c(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
+        if (wrc & 1) dr_mark(J.dmk[DC_U], v, key);
+        if (wrc & 2) dr_mark(J.dmk[DC_B], v, key);
+    });
+}
+// bit 0: demoted, bit 1: has to wait a level
+__device__ __noinline__ uint32_t dr_gen_p3(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop) {
+    uint32_t r = 0;
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
+        const uint32_t acc = rd | wrc;
+        if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) r |= 1u;
+        if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) r |= 1u;
+        if (!noop) {
+            if ((wr & 1) && dr_lower(J.dmk[DA_U], v, key)) r |= 2u;
+            if ((wr & 2) && dr_lower(J.dmk[DA_B], v, key)) r |= 2u;
+        }
+    });
+    return r;
+}
+
+// ---- the registered long rows of this workgroup (S.bl_*, S.dr_st[k]: bit 0 pending, 1 unstable, 2 demoted, 3 waiting, 4 ran
+// in this level). All threads of the workgroup, uniform control flow. Sets: reads U of every non-final variable and B of C's
+// non-unique ones, may write U of C's non-final ones (exact = conservative: R1 / R7 / R8 decide on the whole row).
+__device__ __noinline__ void dr_big_p1(const Job& J, ChunkShared& S, uint32_t epoch) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        if (!(S.dr_st[k] & 1u)) continue;
+        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
+        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DA_U], v, key); }
+        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DA_U], v, key); }
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            const uint8_t f = J.flags[v];
+            if ((f & 3) != 3) { dr_mark(J.dmk[DA_U], v, key); dr_mark(J.dmk[DX_U], v, key); }
+            if (!(f & 1)) dr_mark(J.dmk[DA_B], v, key);
+        }
+    }
+}
+__device__ __noinline__ void dr_big_p2(const Job& J, ChunkShared& S, uint32_t epoch) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        if (!(S.dr_st[k] & 1u)) continue;
+        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
+        bool u = false;
+        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true; }
+        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true; }
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            const uint8_t f = J.flags[v];
+            if ((f & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true;
+            if (!(f & 1) && dr_lower(J.dmk[DX_B], v, key)) u = true;
+        }
+        if (u) atomicOr(&S.dr_st[k], 2u);
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        if ((S.dr_st[k] & 3u) != 3u) continue;
+        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) { const uint32_t v = J.colC[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DC_U], v, key); }
+    }
+}
+__device__ __noinline__ void dr_big_p3(const Job& J, ChunkShared& S, uint32_t epoch) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        if ((S.dr_st[k] & 3u) != 1u) continue;       // pending and not unstable
+        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
+        uint32_t r = 0;
+        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
+        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            const uint8_t f = J.flags[v];
+            if ((f & 3) != 3) { if (dr_lower(J.dmk[DC_U], v, key)) r |= 4u; if (dr_lower(J.dmk[DA_U], v, key)) r |= 8u; }
+            if (!(f & 1) && dr_lower(J.dmk[DC_B], v, key)) r |= 4u;
+        }
+        if (r) atomicOr(&S.dr_st[k], r);
+        if (r & 4u) atomicMin(&S.dcut, S.bl_rank[k]);
+    }
+}
+__device__ __noinline__ void dr_big_exec(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t dcut) {
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        const uint32_t st = S.dr_st[k];
+        if (!(st & 1u)) continue;
+        const bool ready = !(st & (2u | 4u | 8u)) && S.bl_rank[k] < dcut;      // uniform
+        if (ready) exec_big_row_wg(J, S, S.bl_row[k], big_ev(J, wgrank, k), &S.bl_nev[k]);
+        __syncthreads();
+        if (threadIdx.x == 0) S.dr_st[k] = ready ? 16u : 1u;
+    }
+    __syncthreads();
+}
+
+// All workgroups of the job. n <= J.nwg * ECNE_WG rows (one per lane). Returns nonzero on error; *out_c = rows that left the
+// queue (the window, or what is in front of a long row the round does not take), *out_levels = levels the drain needed.
+__device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t head, uint32_t tail,
+                                             uint32_t n, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err,
+                                             uint32_t* out_c, uint32_t* out_tail, uint32_t* out_levels) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    Counters* const ctr = J.ctr;
+    const uint32_t g = wgrank * ECNE_WG + tid;
+    const uint32_t r0 = ((uint32_t)w * J.nwg + wgrank) * 64u + (uint32_t)lane;     // ranks dealt out wavefront by wavefront, as in queue_round_multi
+    unsigned long long mt_last = wall_clock64();
+    int err;
+    uint32_t row[2] = {0, 0}, nev[2] = {0, 0};
+    uint32_t shape = 0, xv = 0;
+    bool live = false, pending = r0 < n;
+    if (pending) {
+        row[0] = J.queue[(head + r0) & J.qmask];
+        const RowInfo ri = J.rinfo[row[0]];
+        shape = ri.shape;
+        xv = ri.x;
+        live = !J.solved[row[0]];
+    }
+    // the row's record (if it has one): loaded once, the flag bytes again at every level
+    FastIn fin;
+    bool rec_ok = false;
+    if (pending && live && !(shape & SH_BIG)) {
+        const ECNE_GLOBAL u32x4* const rec = as_global(reinterpret_cast<const u32x4*>(J.rec));
+        const RowInfo ri = J.rinfo[row[0]];
+        u32x4 w4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[i] = rec[4u * row[0] + (uint32_t)i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fin.w[4 * i] = w4[i].x; fin.w[4 * i + 1] = w4[i].y; fin.w[4 * i + 2] = w4[i].z; fin.w[4 * i + 3] = w4[i].w; }
+        fin.shape = ri.shape; fin.rx = ri.x; fin.kpos = ri.kpos; fin.kneg = ri.kneg; fin.k1 = ri.k1; fin.k2 = ri.k2;
+        fin.nA = fin.w[0] & 0xFFu; fin.nB = (fin.w[0] >> 8) & 0xFFu; fin.nE = fin.nA + fin.nB + ((fin.w[0] >> 16) & 0xFFu);
+        fin.xy = (ri.shape & (SH_R5 | SH_R4_T | SH_R4_T2 | SH_R3)) == (SH_R5 | SH_R4_T | SH_R4_T2);
+        const bool f1 = (ri.shape & SH_HAS_AB) && !(ri.shape & SH_C_EMPTY);
+        fin.f2 = (ri.shape & SH_C_EMPTY) != 0;
+        fin.f4 = !(ri.shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
+        fin.live = true; fin.bigsum = false;
+        rec_ok = (fin.w[0] >> 24) != 0 && (fin.xy || f1 || fin.f2 || fin.f4);
+    }
+    const ECNE_GLOBAL uint8_t* const Fg = as_global(J.flags);
+    if (tid == 0) { S.cut = 0xFFFFFFFFu; S.dcut = 0xFFFFFFFFu; }
+    if (tid < ECNE_BIGK) S.dr_st[tid] = 0;
+    __syncthreads();
+    uint32_t epoch = S.depoch;
+    uint32_t n_eff = n, mycand = 0, bigsl = 0, level = 0;
+    int myslot = -1;               // my row is a long row registered in this slot
+    for (;;) {
+        ++level;
+        if (epoch >= ECNE_DRAIN_EPOCH_MAX) {
+            // the epoch field is used up (once per 32 766 levels): wipe the planes; the marks of this round start over
+            const uint32_t T = J.nwg * ECNE_WG;
+            for (int p = 0; p < 6; ++p)
+                for (uint32_t v = g; v <= J.nV; v += T) J.dmk[p][v] = 0;
+            epoch = 0;
+            if ((err = job_barrier(J, s_err))) return err;
+        }
+        ++epoch;
+        const uint32_t key = dr_key(epoch, r0);
+        const uint32_t par = level & 1u;
+        // ------------------------------------------------------------------ P1: decide on the state as it is, mark X and A
+        uint32_t kind = 0;          // 0 nothing to look at (dead / final no-op), 1 record decision, 2 general walk, 3 general walk of a no-op, 4 long row
+        uint32_t fz_wva = 0, fz_wvb = 0, fz_cls = 0;
+        if (pending) {
+            if (shape & SH_BIG) {
+                kind = live ? 4u : 0u;
+                if (live && level == 1) {
+                    if (!big_plain(shape) || !big_register(S, row[0], r0)) atomicMin(&S.cut, r0);
+                }
+            } else if (live) {
+                bool fz = false;
+                if (rec_ok) {
+                    fin.flip_in = J.flip3[row[0]];
+                    const bool walk = !fin.xy && !fin.f2;
+#pragma unroll
+                    for (uint32_t e = 0; e < 15; ++e) fin.fl[e] = (walk && e < fin.nE) ? Fg[fin.w[1 + e]] : (uint8_t)3;
+                    fin.fa = fin.fb = fin.fx = 3;
+                    if (fin.xy) { fin.fa = Fg[fin.k1]; fin.fb = Fg[fin.k2]; }
+                    if (fin.f2 && (fin.shape & SH_R2)) fin.fx = Fg[fin.rx];
+                    FastOut D;
+                    fast_decide(J, fin, D);
+                    if (!D.slow) {
+                        fz = true;
+                        fz_wva = D.wva; fz_wvb = D.wvb;
+                        const uint8_t ia = fin.xy ? fin.fa : fin.f2 ? fin.fx : (uint8_t)(D.wfa & ~3u), ib = fin.fb;     // flag bytes before (products / sums only set bits 0, 1)
+                        if (D.wa) fz_cls |= (((D.wfa ^ ia) & 3u) ? 1u : 0u) | ((((D.wfa ^ ia) & ~3u) || D.a01 || D.xa_w || D.r2) ? 2u : 0u);
+                        if (D.wb) fz_cls |= (((D.wfb ^ ib) & 3u) ? 4u : 0u) | ((((D.wfb ^ ib) & ~3u) || D.b01 || D.xb_w) ? 8u : 0u);
+                    }
+                }
+                if (fz) kind = 1;
+                else {
+                    const RowInfo ri = J.rinfo[row[0]];
+                    bool nb = false;
+                    if (row_is_noop(J, row[0], ri, nb)) kind = nb ? 3u : 0u;
+                    else kind = 2;
+                }
+            }
+        }
+        // the sets of a record row: f(variable, classes it can access, classes it writes now, classes it could ever write)
+        auto fz_each = [&](auto f) {
+            if (fin.xy) { f(fin.k1, 3u, fz_cls & 3u, 3u); f(fin.k2, 3u, (fz_cls >> 2) & 3u, 3u); }
+            else if (fin.f2) { if (fin.shape & SH_R2) f(fin.rx, 3u, fz_cls & 3u, 3u); }
+            else {
+                const uint32_t acc = fin.f4 ? 3u : 1u;
+#pragma unroll
+                for (uint32_t e = 0; e < 15; ++e)
+                    if (e < fin.nE && (fin.fl[e] & 3) != 3) {
+                        const uint32_t v = fin.w[1 + e];
+                        f(v, acc, ((fz_cls & 3u) && v == fz_wva) ? (fz_cls & 3u) : 0u, e >= fin.nA + fin.nB ? 1u : 0u);
+                    }
+            }
+        };
+        if (kind == 1)
+            fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
+                if (acc & 1) dr_mark(J.dmk[DA_U], v, key);
+                if (acc & 2) dr_mark(J.dmk[DA_B], v, key);
+                if (wx & 1) dr_mark(J.dmk[DX_U], v, key);
+                if (wx & 2) dr_mark(J.dmk[DX_B], v, key);
+            });
+        else if (kind == 2 || kind == 3) dr_gen_mark(J, row[0], shape, xv, key, kind == 3);
+        __syncthreads();
+        if (level == 1) {
+            if (tid == 0 && S.cut != 0xFFFFFFFFu) atomicMin(&ctr->q_cut, S.cut);
+            if (tid < ECNE_BIGK && S.bl_rank[tid] != 0xFFFFFFFFu) S.dr_st[tid] = 1u;
+            __syncthreads();
+            if (kind == 4) myslot = big_slot_of(S, r0);
+        }
+        if (S.bl_any) dr_big_p1(J, S, epoch);
+        if ((err = job_barrier(J, s_err))) return err;
+        if (level == 1) {
+            const uint32_t qc = ld_agent(&ctr->q_cut);
+            if (qc < n_eff) n_eff = qc;           // the window ends in front of a long row the round does not take (nothing has run yet)
+            if (r0 >= n_eff) { pending = false; kind = 0; }
+            if (tid < ECNE_BIGK && S.bl_rank[tid] != 0xFFFFFFFFu && S.bl_rank[tid] >= n_eff) { S.dr_st[tid] = 0; S.bl_rank[tid] = 0xFFFFFFFFu; }
+            __syncthreads();
+        }
+        // ------------------------------------------------------------------ P2: unstable rows mark what they could ever write
+        bool unstable = false;
+        if (kind == 1) {
+            fz_each([&](uint32_t v, uint32_t acc, uint32_t, uint32_t) {
+                if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) unstable = true;
+                if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) unstable = true;
+            });
+            if (unstable)
+                fz_each([&](uint32_t v, uint32_t, uint32_t, uint32_t wc) {
+                    if (wc & 1) dr_mark(J.dmk[DC_U], v, key);
+                    if (wc & 2) dr_mark(J.dmk[DC_B], v, key);
+                });
+        } else if (kind == 2 || kind == 3) {
+            unstable = dr_gen_unstable(J, row[0], shape, xv, key);
+            if (unstable) dr_gen_mark_c(J, row[0], shape, xv, key);
+        }
+        if (tid == 0) S.dcut = 0xFFFFFFFFu;
+        if (S.bl_any) dr_big_p2(J, S, epoch);
+        if ((err = job_barrier(J, s_err))) return err;
+        // ------------------------------------------------------------------ P3: demoted (-> the level's cut) / waiting
+        uint32_t p3 = 0;
+        if (!unstable) {
+            if (kind == 1)
+                fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
+                    if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) p3 |= 1u;
+                    if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) p3 |= 1u;
+                    if ((wx & 1) && dr_lower(J.dmk[DA_U], v, key)) p3 |= 2u;
+                    if ((wx & 2) && dr_lower(J.dmk[DA_B], v, key)) p3 |= 2u;
+                });
+            else if (kind == 2 || kind == 3) p3 = dr_gen_p3(J, row[0], shape, xv, key, kind == 3);
+        }
+        { const uint32_t wm = wave_min((p3 & 1u) ? r0 : 0xFFFFFFFFu); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.dcut, wm); }
+        if (S.bl_any) dr_big_p3(J, S, epoch);
+        __syncthreads();
+        if (tid == 0 && S.dcut != 0xFFFFFFFFu) atomicMin(&ctr->d_cut[par], S.dcut);
+        if (g == 0) { ctr->d_cut[par ^ 1u] = 0xFFFFFFFFu; }
+        if ((err = job_barrier(J, s_err))) return err;
+        const uint32_t dcut = ld_agent(&ctr->d_cut[par]);
+        // ------------------------------------------------------------------ run what is ready
+        if (pending && kind != 4 && !unstable && !p3 && r0 < dcut) {
+            pending = false;
+            J.inq[row[0]] = (uint16_t)2;
+            J.prank[row[0]] = r0;
+            my_pops++;
+            uint32_t* ev = J.evbuf + (size_t)r0 * ECNE_EVCAP;
+            if (kind == 1) {
+                my_nnz += fin.nE;
+                FastOut D;
+                fast_decide(J, fin, D);      // the decision again: its inputs are what they were (the row is stable)
+                if (D.wa) J.flags[D.wva] = D.wfa;
+                if (D.wb) J.flags[D.wvb] = D.wfb;
+                if (D.a01) { st256(J.lb + 4ull * D.wva, fp::make(0)); st256(J.ub + 4ull * D.wva, fp::make(1)); }
+                if (D.b01) { st256(J.lb + 4ull * D.wvb, fp::make(0)); st256(J.ub + 4ull * D.wvb, fp::make(1)); }
+                if (D.xa_w) { st256(J.lb + 4ull * D.wva, D.xlb0); st256(J.ub + 4ull * D.wva, D.xub0); }
+                if (D.xb_w) { st256(J.lb + 4ull * D.wvb, D.xlb1); st256(J.ub + 4ull * D.wvb, D.xub1); }
+                if (D.r2) {        // make_values (:921-927)
+                    const uint32_t validx = J.rinfo[row[0]].validx;
+                    st256(J.values + 8ull * fin.rx, ld256(J.vals + 4ull * validx));
+                    st256(J.values + 8ull * fin.rx + 4, ld256(J.vals + 4ull * (validx + 1)));
+                    J.nvalues[fin.rx] = 2;
+                    J.abz[fin.rx] = -1;
+                    J.solved[row[0]] = 1;
+                }
+                if (D.flip_w) J.flip3[row[0]] = D.flip_new;
+                C.steps += D.d_steps; C.nuniq += D.d_nuniq;
+                C.hits[0] += D.d_h0; C.hits[1] += D.d_h1; C.hits[3] += D.d_h3; C.hits[4] += D.d_h4;
+                nev[0] = D.nev;
+#pragma unroll
+                for (uint32_t e = 0; e < 5; ++e) if (e < D.nev) { ev[e] = D.ev[e]; mycand += J.fo_ptr[D.ev[e] + 1] - J.fo_ptr[D.ev[e]]; }
+            } else {
+                my_nnz += (J.rpA[row[0] + 1] - J.rpA[row[0]]) + (J.rpB[row[0] + 1] - J.rpB[row[0]]) + (J.rpC[row[0] + 1] - J.rpC[row[0]]);
+                if (live) {
+                    if (kind == 2) { C.rank = head + r0; exec_row_lane(J, row[0], ev, nev[0], C); }
+                    else if ((shape & SH_R4_T) && (shape & SH_R4_T2)) J.flip3[row[0]] ^= 1;      // a no-op pop of an x == y row: its R4 orientation flips
+                }
+                for (uint32_t e = 0; e < nev[0]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
+            }
+            ev[ECNE_EVCAP - 1] = nev[0];    // for the sequential replay fallback
+        }
+        if (S.bl_any) {
+            dr_big_exec(J, S, wgrank, dcut);
+            if (pending && kind == 4 && myslot >= 0 && (S.dr_st[myslot] & 16u)) {
+                pending = false;
+                bigsl = 1u;
+                J.inq[row[0]] = (uint16_t)2;
+                J.prank[row[0]] = r0;
+                my_pops++;
+                my_nnz += (J.rpA[row[0] + 1] - J.rpA[row[0]]) + (J.rpB[row[0] + 1] - J.rpB[row[0]]) + (J.rpC[row[0] + 1] - J.rpC[row[0]]);
+            }
+            __syncthreads();
+            if (tid < ECNE_BIGK && (S.dr_st[tid] & 16u)) S.dr_st[tid] = 0;
+        }
+        {
+            const int left = __syncthreads_count(pending ? 1 : 0);
+            if (tid == 0 && left) atomicAdd(&ctr->d_pend[par], (unsigned int)left);
+            if (g == 0) ctr->d_pend[par ^ 1u] = 0;
+        }
+        if ((err = job_barrier(J, s_err))) return err;
+        if (ld_agent(&ctr->d_pend[par]) == 0) break;
+    }
+    if (tid == 0) S.depoch = epoch;
+    if (g == 0) { ctr->d_cut[level & 1u] = 0xFFFFFFFFu; S.mt[6] += level; S.mt[7] += 1; }     // (everybody read the last level's cut before its last barrier)
+    __syncthreads();
+    *out_levels = level;
+    MTICK(0);
+    return multi_finish(J, S, wgrank, head, tail, n_eff, 1u, r0, row, nev, bigsl, mycand, false, mt_last, s_err, out_c, out_tail);
+}
+
+}  // namespace ecne

@@ -707,6 +707,8 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_htlist = c.take(4ull * ((size_t)nC + (size_t)ECNE_MAX_NWG * 2049 + 64));
     size_t o_hot = c.take(4ull * hotcap), o_fired = c.take((size_t)nC + nSp + 1), o_events = c.take(4ull * nev);
+    size_t o_dmk[6];
+    for (int p = 0; p < 6; ++p) o_dmk[p] = c.take(4ull * (nV + 1));       // mark planes of the drain rounds (drain.hip.hpp)
     size_t o_wmark = c.take(4ull * (nV + 1)), o_wmarkB = c.take(4ull * (nV + 1)), o_best = c.take(4ull * std::max<size_t>(nC, 1)), o_prank = c.take(4ull * std::max<size_t>(nC, 1));
     // one event slot list per rank of a round: single-workgroup rounds examine <= 4 * 512 queue entries,
     // multi-workgroup rounds <= min(rows, ECNE_MAX_NWG workgroups * 512 lanes * 2)
@@ -821,6 +823,8 @@ static int upload_system(ecne_system& S, int device) {
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
     J.ht_list = (uint32_t*)(base + o_htlist);
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
+    for (int p = 0; p < 6; ++p) J.dmk[p] = (uint32_t*)(base + o_dmk[p]);
+    J.drain = 0;
     J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best); J.prank = (uint32_t*)(base + o_prank);
     J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
     J.candcap = (uint32_t)std::max<size_t>(ECNE_CANDCAP, 8ull * nC);
@@ -1160,6 +1164,10 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 hj[i].bar_timeout_ms = (uint32_t)std::min<uint64_t>(tmo, 3600000);
             }
             hj[i].queue_mode = (uint32_t)o.queue_mode;
+            {   // rounds on all workgroups: drain rounds (drain.hip.hpp) unless queue_mode 3 / ECNE_DRAIN=0 ask for the prefix rounds
+                static const bool drain_env = []() { const char* e = getenv("ECNE_DRAIN"); return !(e && atoi(e) == 0); }();
+                hj[i].drain = (o.queue_mode == 3 || !drain_env) ? 0u : 1u;
+            }
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
         if (rc != ECNE_OK) break;

@@ -55,6 +55,175 @@ __device__ uint32_t team_exclusive_scan_any(const Job& J, ChunkShared& S, uint32
     return team_exclusive_scan(J, S, wgrank, x, 0, total, s_err, err_out);
 }
 
+#ifdef ECNE_FINE_TICKS
+#define MTICK(slot) do { if (g == 0) { unsigned long long t_ = wall_clock64(); S.mt[slot] += t_ - mt_last; mt_last = t_; } } while (0)
+#else
+#define MTICK(slot) do { } while (0)
+#endif
+// Second half of a round on all workgroups, shared by queue_round_multi and queue_round_drain (drain.hip.hpp): the rows at ranks
+// < c have been executed (events in evbuf / the long rows' pool slots, candidate counts in mycand) -- except, with big_exec, the
+// registered long rows of the prefix, which are executed here first. REQUEUE resolution in sequential order: job-wide scan of the
+// candidate counts, expansion, winners, queue write (4 job barriers, 2 of them carrying a scan; 2 when nobody re-queues anything).
+__device__ __noinline__ int multi_finish(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t head, uint32_t tail, uint32_t c,
+                                        uint32_t rpl, uint32_t r0, const uint32_t (&row)[2], uint32_t (&nev)[2], uint32_t bigsl,
+                                        uint32_t mycand, bool big_exec, unsigned long long& mt_last, int* s_err,
+                                        uint32_t* out_c, uint32_t* out_tail) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    Counters* const ctr = J.ctr;
+    const uint32_t T = J.nwg * ECNE_WG, g = wgrank * ECNE_WG + tid;
+    int err;
+    if (S.bl_any) {   // (uniform per workgroup) long rows of the prefix: execute, then candidate offsets of their events
+        if (big_exec) big_rows_exec(J, S, c, wgrank);
+        for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+            if (S.bl_rank[k] >= c) continue;
+            const uint32_t* ev = big_ev(J, wgrank, k);
+            uint32_t* off = big_off(J, wgrank, k);
+            const uint32_t ne = S.bl_nev[k];
+            uint32_t run = 0;
+            for (uint32_t eb = 0; eb < ne; eb += ECNE_WG) {          // (uniform trip count)
+                const uint32_t e = eb + tid;
+                uint32_t d = 0;
+                if (e < ne) { const uint32_t v = ev[e]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+                uint32_t tot;
+                const uint32_t o = wg_exclusive_scan(d, S.scan, &tot);
+                if (e < ne) off[e] = run + o;
+                run += tot;
+            }
+            if (tid == 0) {
+                S.bl_deg[k] = run;
+                // the rank's regular slot only says where the events are (for the sequential replay fallback)
+                uint32_t* slot = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
+                slot[ECNE_EVCAP - 1] = 0x80000000u | (wgrank * ECNE_BIGK + k);
+                slot[ECNE_EVCAP - 2] = ne;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl)
+            if (bigsl & (1u << sl)) {
+                const int k = big_slot_of(S, r0 + sl);
+                nev[sl] = S.bl_nev[k];
+                mycand += S.bl_deg[k];
+            }
+    }
+    uint32_t M;
+    const uint32_t cbase = team_block_scan(J, wgrank, mycand, 0, &M, s_err, &err);   // candidates in rank order
+    MTICK(2);
+    if (err) return err;
+    if (M == 0) {
+        // nobody re-queues anything (a block of empty pops -- the rows a multiplexer's sum re-queued, say): the rows of the prefix
+        // leave the queue and that is all; the expansion, the winners' scan and two of the barriers drop out
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl)
+            if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
+        if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
+        if (tid == 0) big_reset(S);
+        if ((err = job_barrier(J, s_err))) return err;
+        MTICK(5);
+        *out_c = c;
+        *out_tail = tail;
+        return 0;
+    }
+    if (M > J.candcap) {
+        // a variable with a huge fan-out: the master replays all events sequentially (rare)
+        if (wgrank == 0) {
+            if (w == 0) {
+                QState qq;
+                qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                // event counts live in the executing lanes' registers: recount from the fan-out lists is not
+                // possible, so each rank's count was also stored behind its events (slot ECNE_EVCAP - 1)
+                for (uint32_t r = 0; r < c; ++r) {
+                    const uint32_t rr = J.queue[(head + r) & J.qmask];
+                    if (lane == 0) J.inq[rr] = 0;
+                    wg_fence();
+                    uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
+                    const uint32_t* evs = J.evbuf + (size_t)r * ECNE_EVCAP;
+                    if (ne & 0x80000000u) {   // a long row: its events are in the pool
+                        evs = J.bigpool + (size_t)(ne & 0x7FFFFFFFu) * J.bigstride;
+                        ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 2];
+                    }
+                    for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, evs[e]);
+                }
+                if (lane == 0) { ctr->q_tail_out = qq.tail; ctr->q_c_out = c; ctr->q_cut = 0xFFFFFFFFu; }
+            }
+            __syncthreads();
+        }
+        if ((err = job_barrier(J, s_err))) return err;
+        *out_c = c;
+        *out_tail = ld_agent(&ctr->q_tail_out);
+        return 0;
+    }
+    // ---- expansion of my own events: candidate index = cbase + running offset
+    {
+        if (tid == 0) S.nbigev = 0;
+        __syncthreads();
+        uint32_t j = cbase;
+#pragma unroll
+        for (uint32_t sl = 0; sl < 2; ++sl) {
+            if (sl >= rpl || r0 + sl >= c) continue;
+            const uint32_t a = r0 + sl;
+            if (bigsl & (1u << sl)) {   // a long row's events are expanded by the whole workgroup, below
+                const int k = big_slot_of(S, a);
+                S.bl_base[k] = j;
+                j += S.bl_deg[k];
+                continue;
+            }
+            const uint32_t* ev = J.evbuf + (size_t)a * ECNE_EVCAP;
+            for (uint32_t e = 0; e < nev[sl]; ++e) {
+                const uint32_t v = ev[e];
+                expand_event(J, S, v, a, j, true);
+                j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+            }
+        }
+        if (S.bl_any) {
+            __syncthreads();
+            for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+                if (S.bl_rank[k] >= c) continue;
+                const uint32_t* ev = big_ev(J, wgrank, k);
+                const uint32_t* off = big_off(J, wgrank, k);
+                for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) expand_event(J, S, ev[e], S.bl_rank[k], S.bl_base[k] + off[e], true);
+            }
+        }
+        expand_big_events(J, S, true);
+    }
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(3);
+    // ---- the prefix rows leave the queue (tags no longer needed); then winners in candidate order
+#pragma unroll
+    for (uint32_t sl = 0; sl < 2; ++sl)
+        if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
+    const uint32_t per = (M + T - 1) / T;
+    const uint32_t j0 = g * per < M ? g * per : M, j1 = (g + 1) * per < M ? (g + 1) * per : M;
+    uint32_t nwin = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t cw = J.cand[j];
+        const uint32_t t = cw & 0x7FFFFFFFu;
+        const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
+        J.cand[j] = t | (win ? 0x80000000u : 0u);
+        nwin += win;
+    }
+    uint32_t W;
+    const uint32_t wbase = team_exclusive_scan(J, S, wgrank, nwin, 1, &W, s_err, &err);
+    MTICK(4);
+    if (err) return err;
+    {
+        uint32_t o = tail + wbase;
+        for (uint32_t j = j0; j < j1; ++j) {
+            const uint32_t cw = J.cand[j];
+            const uint32_t t = cw & 0x7FFFFFFFu;
+            if (cw & 0x80000000u) { J.queue[o & J.qmask] = t; J.inq[t] = 1; ++o; }
+            J.best[t] = 0xFFFFFFFFu;
+        }
+    }
+    if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
+    if (tid == 0) big_reset(S);
+    if ((err = job_barrier(J, s_err))) return err;
+    MTICK(5);
+    *out_c = c;
+    *out_tail = tail + W;
+    return 0;
+}
+
 __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t head, uint32_t tail,
                                              uint32_t n, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err,
                                              uint32_t* out_c, uint32_t* out_tail) {
@@ -67,11 +236,6 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
     uint32_t live = 0, noop = 0, noop_b = 0;
     int err;
     unsigned long long mt_last = wall_clock64();
-#ifdef ECNE_FINE_TICKS
-#define MTICK(slot) do { if (g == 0) { unsigned long long t_ = wall_clock64(); S.mt[slot] += t_ - mt_last; mt_last = t_; } } while (0)
-#else
-#define MTICK(slot) do { } while (0)
-#endif
 #pragma unroll
     for (uint32_t sl = 0; sl < 2; ++sl) {
         row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
@@ -255,157 +419,12 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
         ev[ECNE_EVCAP - 1] = nev[sl];    // for the sequential replay fallback
     }
-    if (S.bl_any) {   // (uniform per workgroup) long rows of the prefix: execute, then candidate offsets of their events
-        big_rows_exec(J, S, c, wgrank);
-        for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
-            if (S.bl_rank[k] >= c) continue;
-            const uint32_t* ev = big_ev(J, wgrank, k);
-            uint32_t* off = big_off(J, wgrank, k);
-            const uint32_t ne = S.bl_nev[k];
-            uint32_t run = 0;
-            for (uint32_t eb = 0; eb < ne; eb += ECNE_WG) {          // (uniform trip count)
-                const uint32_t e = eb + tid;
-                uint32_t d = 0;
-                if (e < ne) { const uint32_t v = ev[e]; d = J.fo_ptr[v + 1] - J.fo_ptr[v]; }
-                uint32_t tot;
-                const uint32_t o = wg_exclusive_scan(d, S.scan, &tot);
-                if (e < ne) off[e] = run + o;
-                run += tot;
-            }
-            if (tid == 0) {
-                S.bl_deg[k] = run;
-                // the rank's regular slot only says where the events are (for the sequential replay fallback)
-                uint32_t* slot = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
-                slot[ECNE_EVCAP - 1] = 0x80000000u | (wgrank * ECNE_BIGK + k);
-                slot[ECNE_EVCAP - 2] = ne;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t sl = 0; sl < 2; ++sl)
-            if (bigsl & (1u << sl)) {
-                const int k = big_slot_of(S, r0 + sl);
-                nev[sl] = S.bl_nev[k];
-                mycand += S.bl_deg[k];
-            }
-    }
-    uint32_t M;
-    const uint32_t cbase = team_block_scan(J, wgrank, mycand, 0, &M, s_err, &err);   // candidates in rank order
-    MTICK(2);
-    if (err) return err;
-    if (M == 0) {
-        // nobody re-queues anything (a block of empty pops -- the rows a multiplexer's sum re-queued, say): the rows of the prefix
-        // leave the queue and that is all; the expansion, the winners' scan and two of the barriers drop out
-#pragma unroll
-        for (uint32_t sl = 0; sl < 2; ++sl)
-            if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
-        if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
-        if (tid == 0) big_reset(S);
-        if ((err = job_barrier(J, s_err))) return err;
-        MTICK(5);
-        *out_c = c;
-        *out_tail = tail;
-        return 0;
-    }
-    if (M > J.candcap) {
-        // a variable with a huge fan-out: the master replays all events sequentially (rare)
-        if (wgrank == 0) {
-            if (w == 0) {
-                QState qq;
-                qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
-                // event counts live in the executing lanes' registers: recount from the fan-out lists is not
-                // possible, so each rank's count was also stored behind its events (slot ECNE_EVCAP - 1)
-                for (uint32_t r = 0; r < c; ++r) {
-                    const uint32_t rr = J.queue[(head + r) & J.qmask];
-                    if (lane == 0) J.inq[rr] = 0;
-                    wg_fence();
-                    uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
-                    const uint32_t* evs = J.evbuf + (size_t)r * ECNE_EVCAP;
-                    if (ne & 0x80000000u) {   // a long row: its events are in the pool
-                        evs = J.bigpool + (size_t)(ne & 0x7FFFFFFFu) * J.bigstride;
-                        ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 2];
-                    }
-                    for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, evs[e]);
-                }
-                if (lane == 0) { ctr->q_tail_out = qq.tail; ctr->q_c_out = c; ctr->q_cut = 0xFFFFFFFFu; }
-            }
-            __syncthreads();
-        }
-        if ((err = job_barrier(J, s_err))) return err;
-        *out_c = c;
-        *out_tail = ld_agent(&ctr->q_tail_out);
-        return 0;
-    }
-    // ---- expansion of my own events: candidate index = cbase + running offset
-    {
-        if (tid == 0) S.nbigev = 0;
-        __syncthreads();
-        uint32_t j = cbase;
-#pragma unroll
-        for (uint32_t sl = 0; sl < 2; ++sl) {
-            if (sl >= rpl || r0 + sl >= c) continue;
-            const uint32_t a = r0 + sl;
-            if (bigsl & (1u << sl)) {   // a long row's events are expanded by the whole workgroup, below
-                const int k = big_slot_of(S, a);
-                S.bl_base[k] = j;
-                j += S.bl_deg[k];
-                continue;
-            }
-            const uint32_t* ev = J.evbuf + (size_t)a * ECNE_EVCAP;
-            for (uint32_t e = 0; e < nev[sl]; ++e) {
-                const uint32_t v = ev[e];
-                expand_event(J, S, v, a, j, true);
-                j += J.fo_ptr[v + 1] - J.fo_ptr[v];
-            }
-        }
-        if (S.bl_any) {
-            __syncthreads();
-            for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
-                if (S.bl_rank[k] >= c) continue;
-                const uint32_t* ev = big_ev(J, wgrank, k);
-                const uint32_t* off = big_off(J, wgrank, k);
-                for (uint32_t e = tid; e < S.bl_nev[k]; e += ECNE_WG) expand_event(J, S, ev[e], S.bl_rank[k], S.bl_base[k] + off[e], true);
-            }
-        }
-        expand_big_events(J, S, true);
-    }
-    if ((err = job_barrier(J, s_err))) return err;
-    MTICK(3);
-    // ---- the prefix rows leave the queue (tags no longer needed); then winners in candidate order
-#pragma unroll
-    for (uint32_t sl = 0; sl < 2; ++sl)
-        if (sl < rpl && r0 + sl < c) J.inq[row[sl]] = 0;
-    const uint32_t per = (M + T - 1) / T;
-    const uint32_t j0 = g * per < M ? g * per : M, j1 = (g + 1) * per < M ? (g + 1) * per : M;
-    uint32_t nwin = 0;
-    for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t cw = J.cand[j];
-        const uint32_t t = cw & 0x7FFFFFFFu;
-        const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == j;
-        J.cand[j] = t | (win ? 0x80000000u : 0u);
-        nwin += win;
-    }
-    uint32_t W;
-    const uint32_t wbase = team_exclusive_scan(J, S, wgrank, nwin, 1, &W, s_err, &err);
-    MTICK(4);
-    if (err) return err;
-    {
-        uint32_t o = tail + wbase;
-        for (uint32_t j = j0; j < j1; ++j) {
-            const uint32_t cw = J.cand[j];
-            const uint32_t t = cw & 0x7FFFFFFFu;
-            if (cw & 0x80000000u) { J.queue[o & J.qmask] = t; J.inq[t] = 1; ++o; }
-            J.best[t] = 0xFFFFFFFFu;
-        }
-    }
-    if (g == 0) ctr->q_cut = 0xFFFFFFFFu;     // ready for the next multi round
-    if (tid == 0) big_reset(S);
-    if ((err = job_barrier(J, s_err))) return err;
-    MTICK(5);
-    *out_c = c;
-    *out_tail = tail + W;
-    return 0;
+    return multi_finish(J, S, wgrank, head, tail, c, rpl, r0, row, nev, bigsl, mycand, true, mt_last, s_err, out_c, out_tail);
 }
+
+}  // namespace ecne
+#include "drain.hip.hpp"
+namespace ecne {
 
 // ------------------------------------------------------------------------------- wavefront round
 // The same round as in queue_phase_chunked for a window of at most 64 queue entries, executed by ONE
@@ -660,6 +679,19 @@ __device__ __forceinline__ uint32_t multi_min(const Job& J) { return fast_wg_ok(
 // the adaptive single-workgroup window has to have grown this far (rounds committing everything they looked at, doubling
 // it) before a round goes to all workgroups: with the fast round a multi-workgroup round pays from ~500 committed rows
 __device__ __forceinline__ uint32_t multi_window_min(const Job& J) { return fast_wg_ok(J) ? ECNE_V2WG_WINDOW : fast_wave_ok(J) ? ECNE_V2_WINDOW : ECNE_MULTI_MIN; }
+// drain rounds (drain.hip.hpp) instead of prefix rounds on all workgroups: the job has row records and the host did not switch them off
+__device__ __forceinline__ bool drain_ok(const Job& J) { return J.drain != 0 && J.rec != nullptr; }
+__device__ __forceinline__ uint32_t multi_cap(const Job& J) { return J.nwg * ECNE_WG * (drain_ok(J) ? 1u : 2u); }
+#ifndef ECNE_DRAIN_GROW
+#define ECNE_DRAIN_GROW 6      // a drain that needed at most this many levels doubles the next window ...
+#endif
+#ifndef ECNE_DRAIN_SHRINK
+#define ECNE_DRAIN_SHRINK 16   // ... one that needed more than this many halves it (a dependency chain inside the window: every level pays four job barriers)
+#endif
+__device__ __forceinline__ void drain_window_update(uint32_t levels, uint32_t nm, uint32_t cap_n, uint32_t& mwindow) {
+    if (levels <= ECNE_DRAIN_GROW) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
+    else if (levels > ECNE_DRAIN_SHRINK) mwindow = nm / 2 > 1024u ? nm / 2 : 1024u;
+}
 // ---- chained multi-workgroup rounds
 // After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
 // decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
@@ -692,7 +724,7 @@ __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head
     const uint32_t row0 = J.queue[head & J.qmask];
     const uint32_t shape0 = J.rinfo[row0].shape;
     if ((shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0)) return 0;   // a long row that is popped alone
-    const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+    const uint32_t cap_n = multi_cap(J);
     uint32_t nm = avail < cap_n ? avail : cap_n;
     if (nm > mwindow) nm = mwindow;
     return nm;
@@ -913,7 +945,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (!S.fallback && want_multi) {
             declined_wide = false;
             // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
-            const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+            const uint32_t cap_n = multi_cap(J);
+            const bool drain = drain_ok(J);
             uint32_t nm = avail < cap_n ? avail : cap_n;
             if (nm > mwindow) nm = mwindow;
             if (tid == 0) {
@@ -924,8 +957,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (job_barrier(J, s_err)) { helpers_released = true; break; }
             bool failed = false;
             for (uint32_t chain = 1;; ++chain) {       // chained rounds, see multi_chain_next
-                uint32_t cm = 0, ntm = q.tail;
-                if (queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { failed = true; break; }
+                uint32_t cm = 0, ntm = q.tail, levels = 0;
+                if (drain ? queue_round_drain(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm, &levels)
+                          : queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { failed = true; break; }
                 q.head += cm;
                 q.tail = ntm;
                 pops_total += cm;
@@ -934,11 +968,12 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
                 if (tid == 0) S.sd[cm < 64 ? 13 : cm < 4096 ? 14 : 15] += 1;   // schedule diagnostics: multi rounds by rows committed
 #ifdef ECNE_ROUNDLOG
-                if (tid == 0) { printf("RL multi avail %u n %u c %u dt %llu\n", avail, nm, cm, wall_clock64() - qt_last); qt_last = wall_clock64();
+                if (tid == 0) { printf("RL multi avail %u n %u c %u dt %llu levels %u\n", avail, nm, cm, wall_clock64() - qt_last, levels); qt_last = wall_clock64();
                     if (cm < nm) for (uint32_t k_ = 0; k_ < 3; ++k_) { const uint32_t r_ = J.queue[(q.head + k_) & J.qmask]; printf("CUT+%u row %u shape %x nA %u nB %u nC %u solved %d\n", k_, r_, J.rinfo[r_].shape, J.rpA[r_ + 1] - J.rpA[r_], J.rpB[r_ + 1] - J.rpB[r_], J.rpC[r_ + 1] - J.rpC[r_], (int)J.solved[r_]); } }
 #endif
                 streak = cm == nm ? streak + cm : 0;
-                multi_window_update(cm, nm, cap_n, mwindow, window);
+                if (drain && cm == nm) drain_window_update(levels, nm, cap_n, mwindow);
+                else multi_window_update(cm, nm, cap_n, mwindow, window);
                 nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow, cm, nm) : 0;
                 if (!nm) break;
             }
@@ -1233,14 +1268,17 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
         if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
         uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
         uint32_t window = ld_agent(&J.ctr->q_cmd[4]), mwindow = ld_agent(&J.ctr->q_cmd[5]);
-        const uint32_t cap_n = J.nwg * ECNE_WG * 2;
+        const uint32_t cap_n = multi_cap(J);
+        const bool drain = drain_ok(J);
         bool failed = false;
         for (uint32_t chain = 1;; ++chain) {           // the master's chain, derived here (see multi_chain_next)
-            uint32_t c = 0, nt = tail;
-            if (queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) { failed = true; break; }
+            uint32_t c = 0, nt = tail, levels = 0;
+            if (drain ? queue_round_drain(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt, &levels)
+                      : queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) { failed = true; break; }
             head += c;
             tail = nt;
-            multi_window_update(c, n, cap_n, mwindow, window);
+            if (drain && c == n) drain_window_update(levels, n, cap_n, mwindow);
+            else multi_window_update(c, n, cap_n, mwindow, window);
             n = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, head, tail, window, mwindow, c, n) : 0;
             if (!n) break;
         }

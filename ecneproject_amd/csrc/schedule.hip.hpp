@@ -13,12 +13,15 @@ namespace ecne {
 //     linear row                  : reads and may write U and B of C                          (R1, R3..R8)
 // U-class state of a variable is FINAL once both bits are set (they are only ever set), so U-class
 // accesses to such variables are dropped: no row can change them and every reader sees the same value.
+// for_row_sets4 also hands out the CONSERVATIVE write mask wrc (4th argument): what the row could write in ANY later state
+// reachable before it is popped (finality of U-class state is monotone, so final variables stay dropped) -- the write set of a
+// row whose inputs may still change (drain rounds, drain.hip.hpp). wr is a subset of wrc, wrc a subset of what rd | wrc covers.
 template <class F>
-__device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_t shape, uint32_t x, F f) {
+__device__ __forceinline__ void for_row_sets4(const Job& J, uint32_t row, uint32_t shape, uint32_t x, F f) {
     if (shape & SH_C_EMPTY) {
         if (shape & SH_R2) {
             const bool fin = (J.flags[x] & 3) == 3;
-            f(x, fin ? 0u : 1u, fin ? 2u : 3u);
+            f(x, fin ? 0u : 1u, fin ? 2u : 3u, fin ? 2u : 3u);
         }
         return;
     }
@@ -60,7 +63,7 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
             }
 #pragma unroll
             for (uint32_t i = 0; i < 12; ++i)
-                if ((fl[i] & 3) != 3) f(v[i], 1u, (i >= 8 && may_write && !(one_batch && (fl[i] & 1))) ? 1u : 0u);
+                if ((fl[i] & 3) != 3) f(v[i], 1u, (i >= 8 && may_write && !(one_batch && (fl[i] & 1))) ? 1u : 0u, i >= 8 ? 1u : 0u);
         }
         return;
     }
@@ -77,12 +80,13 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
         const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
         const uint32_t wb = (fp::eq(l1, l2) & fp::eq(u1, u2)) ? 0u : 2u;
         const uint32_t o1 = ((f1 & 3) == 3) ? 0u : 1u, o2 = ((f2 & 3) == 3) ? 0u : 1u;
-        f(ri.k1, o1 | 2u, o1 | wb);
-        f(ri.k2, o2 | 2u, o2 | wb);
+        f(ri.k1, o1 | 2u, o1 | wb, o1 | 2u);
+        f(ri.k2, o2 | 2u, o2 | wb, o2 | 2u);
         return;
     }
     const bool touch1 = (shape & SH_TOUCH1) != 0;
     uint32_t wb0 = 0xFFFFFFFFu, wb1 = 0xFFFFFFFFu, wb2 = 0xFFFFFFFFu;   // variables whose B-state may be written
+    uint32_t wc0 = 0xFFFFFFFFu, wc1 = 0xFFFFFFFFu, wc2 = 0xFFFFFFFFu;   // ... in any later state
     if (shape & SH_R3) {
         const RowInfo ri = J.rinfo[row];
         const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
@@ -91,6 +95,7 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
         const fp::u256 va = ld256(J.values + 8ull * x), lbx = ld256(J.lb + 4ull * x), ubx = ld256(J.ub + 4ull * x);
         const bool same = (nv == 1) & fp::eq(va, tv) & fp::eq(lbx, tv) & fp::eq(ubx, tv);
         if (!same) wb0 = x;
+        wc0 = x;
     }
     if (shape & (SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6)) {
         const RowInfo ri = J.rinfo[row];
@@ -99,11 +104,13 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
             const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
             const bool eqb = fp::eq(l1, l2) & fp::eq(u1, u2);
             if (!eqb || wb0 != 0xFFFFFFFFu) { wb1 = ri.k1; wb2 = ri.k2; }   // R3 may first move x's bounds
+            wc1 = ri.k1; wc2 = ri.k2;
         } else {
             // binary-decomposition row: only the pivot's bounds can be written
             if ((shape & SH_R4_T) && (shape & SH_R4_T2)) { wb1 = ri.kpos; wb2 = ri.kneg; }
             else if (shape & SH_R4_T2) wb1 = ri.kneg;
             else wb1 = ri.kpos;
+            wc1 = wb1; wc2 = wb2;
         }
     }
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
@@ -119,9 +126,14 @@ __device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_
             if (v[i] == 0xFFFFFFFFu || (v[i] == 1 && !touch1)) continue;
             const uint32_t u = ((fl[i] & 3) == 3) ? 0u : 1u;
             const uint32_t wb = (v[i] == wb0 || v[i] == wb1 || v[i] == wb2) ? 2u : 0u;
-            f(v[i], u | 2u, u | wb);
+            const uint32_t wc = (v[i] == wc0 || v[i] == wc1 || v[i] == wc2) ? 2u : 0u;
+            f(v[i], u | 2u, u | wb, u | wc);
         }
     }
+}
+template <class F>
+__device__ __forceinline__ void for_row_sets(const Job& J, uint32_t row, uint32_t shape, uint32_t x, F f) {
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t) { f(v, rd, wr); });
 }
 
 // Exact "this pop changes no variable" test against the current state, for rows all of whose
@@ -249,6 +261,7 @@ struct ChunkShared {   // LDS of the chunked queue phase
     // checked and executed by the whole workgroup, lanes across the row's entries
     uint32_t bl_n, bl_any, bl_rank[ECNE_BIGK], bl_row[ECNE_BIGK], bl_nev[ECNE_BIGK], bl_deg[ECNE_BIGK], bl_base[ECNE_BIGK];
     uint32_t bl_tmp[8];
+    uint32_t dr_st[ECNE_BIGK], depoch, dcut;   // drain rounds: state of the registered long rows, this workgroup's copy of the mark epoch, lowest demoted rank
     uint32_t hasbig;
     unsigned long long sd[16];  // schedule diagnostics (ecne_summary.sched)
     unsigned long long mt[8];   // diagnostics of multi-workgroup rounds (master only)

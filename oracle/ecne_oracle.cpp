@@ -504,9 +504,17 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
     }
     int64_t successful_steps = 0, prev_successful_steps = -1, num_unique = 0;
 
+    // developer aid (tools/dataflow_depth.py): ECNE_ORACLE_TRACE=<file> logs (tag, value) int64 pairs -- 0 outer iteration,
+    // 1 row popped, 2 variable re-queued, 3 rows that re-queue pushed
+    FILE* trace = nullptr;
+    if (const char* tp = std::getenv("ECNE_ORACLE_TRACE")) trace = std::fopen(tp, "wb");
+    auto tlog = [&](int64_t tag, int64_t val) { if (trace) { int64_t r[2] = {tag, val}; std::fwrite(r, 8, 2, trace); } };
+    struct TraceCloser { FILE*& f; ~TraceCloser() { if (f) std::fclose(f); } } trace_closer{trace};
     auto requeue = [&](int64_t v) {   // the verbatim idiom at :739-744 etc.
+        int64_t pushed = 0;
         for (int64_t cons : v2i(v))
-            if (!in_queue[cons - 1]) { q.push_back(cons); in_queue[cons - 1] = 1; }
+            if (!in_queue[cons - 1]) { q.push_back(cons); in_queue[cons - 1] = 1; if (trace) { tlog(3, cons); ++pushed; } }
+        if (trace) tlog(2, v);
     };
 
     // --- outer loop :706-1556
@@ -514,6 +522,7 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
         if (prev_successful_steps == successful_steps) break;            // :708-711
         prev_successful_steps = successful_steps;
         R.outer_iterations += 1;
+        tlog(0, R.outer_iterations);
 
         // P1 :718-747
         for (size_t i = 0; i < special_constraints.size(); ++i) {
@@ -576,6 +585,7 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
             q.pop_front();
             in_queue[lead - 1] = 0;
             R.pops += 1;
+            tlog(1, lead);
             R.alg_bytes_pops += 20 + 40 * row_nnz[lead - 1];
             if (equation_solved[lead - 1]) continue;                     // :820-822
             Eq* te = &constraints[lead - 1];
