@@ -53,14 +53,20 @@ __device__ __noinline__ void dr_gen_mark(const Job& J, uint32_t row, uint32_t sh
         }
     });
 }
-__device__ __noinline__ bool dr_gen_unstable(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
-    bool u = false;
+// bit 0: unstable (a lower row writes, as things stand, something this one accesses), bit 1: has to wait a level (a lower pending row
+// still accesses what this one writes)
+__device__ __noinline__ uint32_t dr_gen_p2(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop) {
+    uint32_t r = 0;
     for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
         const uint32_t acc = rd | wrc;
-        if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) u = true;
-        if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) u = true;
+        if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) r |= 1u;
+        if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) r |= 1u;
+        if (!noop) {
+            if ((wr & 1) && dr_lower(J.dmk[DA_U], v, key)) r |= 2u;
+            if ((wr & 2) && dr_lower(J.dmk[DA_B], v, key)) r |= 2u;
+        }
     });
-    return u;
+    return r;
 }
 __device__ __noinline__ void dr_gen_mark_c(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
     for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
@@ -68,19 +74,15 @@ __device__ __noinline__ void dr_gen_mark_c(const Job& J, uint32_t row, uint32_t 
         if (wrc & 2) dr_mark(J.dmk[DC_B], v, key);
     });
 }
-// bit 0: demoted, bit 1: has to wait a level
-__device__ __noinline__ uint32_t dr_gen_p3(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop) {
-    uint32_t r = 0;
+// a lower UNSTABLE row could still write something this one accesses
+__device__ __noinline__ bool dr_gen_demoted(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
+    bool d = false;
     for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
         const uint32_t acc = rd | wrc;
-        if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) r |= 1u;
-        if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) r |= 1u;
-        if (!noop) {
-            if ((wr & 1) && dr_lower(J.dmk[DA_U], v, key)) r |= 2u;
-            if ((wr & 2) && dr_lower(J.dmk[DA_B], v, key)) r |= 2u;
-        }
+        if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) d = true;
+        if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) d = true;
     });
-    return r;
+    return d;
 }
 
 // ---- the registered long rows of this workgroup (S.bl_*, S.dr_st[k]: bit 0 pending, 1 unstable, 2 demoted, 3 waiting, 4 ran
@@ -104,16 +106,17 @@ __device__ __noinline__ void dr_big_p2(const Job& J, ChunkShared& S, uint32_t ep
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         if (!(S.dr_st[k] & 1u)) continue;
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
-        bool u = false;
+        bool u = false, wt = false;
         for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true; }
         for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true; }
         for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colC[e];
             const uint8_t f = J.flags[v];
-            if ((f & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true;
+            if ((f & 3) != 3) { if (dr_lower(J.dmk[DX_U], v, key)) u = true; if (dr_lower(J.dmk[DA_U], v, key)) wt = true; }
             if (!(f & 1) && dr_lower(J.dmk[DX_B], v, key)) u = true;
         }
         if (u) atomicOr(&S.dr_st[k], 2u);
+        else if (wt) atomicOr(&S.dr_st[k], 8u);
     }
     __syncthreads();
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
@@ -132,7 +135,7 @@ __device__ __noinline__ void dr_big_p3(const Job& J, ChunkShared& S, uint32_t ep
         for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colC[e];
             const uint8_t f = J.flags[v];
-            if ((f & 3) != 3) { if (dr_lower(J.dmk[DC_U], v, key)) r |= 4u; if (dr_lower(J.dmk[DA_U], v, key)) r |= 8u; }
+            if ((f & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u;
             if (!(f & 1) && dr_lower(J.dmk[DC_B], v, key)) r |= 4u;
         }
         if (r) atomicOr(&S.dr_st[k], r);
@@ -281,6 +284,7 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
         }
         if (S.bl_any) dr_big_p1(J, S, epoch);
         if ((err = job_barrier(J, s_err))) return err;
+        MTICK(0);
         if (level == 1) {
             const uint32_t qc = ld_agent(&ctr->q_cut);
             if (qc < n_eff) n_eff = qc;           // the window ends in front of a long row the round does not take (nothing has run yet)
@@ -288,12 +292,15 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             if (tid < ECNE_BIGK && S.bl_rank[tid] != 0xFFFFFFFFu && S.bl_rank[tid] >= n_eff) { S.dr_st[tid] = 0; S.bl_rank[tid] = 0xFFFFFFFFu; }
             __syncthreads();
         }
-        // ------------------------------------------------------------------ P2: unstable rows mark what they could ever write
-        bool unstable = false;
+        // ------------------------------------------------------------------ P2: unstable rows mark what they could ever write;
+        // the others see whether an earlier pending row still has to read or write what they write (-> they wait a level)
+        bool unstable = false, waiting = false;
         if (kind == 1) {
-            fz_each([&](uint32_t v, uint32_t acc, uint32_t, uint32_t) {
+            fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
                 if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) unstable = true;
                 if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) unstable = true;
+                if ((wx & 1) && dr_lower(J.dmk[DA_U], v, key)) waiting = true;
+                if ((wx & 2) && dr_lower(J.dmk[DA_B], v, key)) waiting = true;
             });
             if (unstable)
                 fz_each([&](uint32_t v, uint32_t, uint32_t, uint32_t wc) {
@@ -301,33 +308,50 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
                     if (wc & 2) dr_mark(J.dmk[DC_B], v, key);
                 });
         } else if (kind == 2 || kind == 3) {
-            unstable = dr_gen_unstable(J, row[0], shape, xv, key);
+            const uint32_t r = dr_gen_p2(J, row[0], shape, xv, key, kind == 3);
+            unstable = (r & 1u) != 0; waiting = (r & 2u) != 0;
             if (unstable) dr_gen_mark_c(J, row[0], shape, xv, key);
         }
         if (tid == 0) S.dcut = 0xFFFFFFFFu;
-        if (S.bl_any) dr_big_p2(J, S, epoch);
-        if ((err = job_barrier(J, s_err))) return err;
-        // ------------------------------------------------------------------ P3: demoted (-> the level's cut) / waiting
-        uint32_t p3 = 0;
-        if (!unstable) {
-            if (kind == 1)
-                fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
-                    if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) p3 |= 1u;
-                    if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) p3 |= 1u;
-                    if ((wx & 1) && dr_lower(J.dmk[DA_U], v, key)) p3 |= 2u;
-                    if ((wx & 2) && dr_lower(J.dmk[DA_B], v, key)) p3 |= 2u;
-                });
-            else if (kind == 2 || kind == 3) p3 = dr_gen_p3(J, row[0], shape, xv, key, kind == 3);
+        if (S.bl_any) {
+            dr_big_p2(J, S, epoch);
+            __syncthreads();
+            if (pending && kind == 4 && myslot >= 0) { const uint32_t st = S.dr_st[myslot]; unstable = (st & 2u) != 0; waiting = (st & 8u) != 0; }
         }
-        { const uint32_t wm = wave_min((p3 & 1u) ? r0 : 0xFFFFFFFFu); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.dcut, wm); }
-        if (S.bl_any) dr_big_p3(J, S, epoch);
-        __syncthreads();
-        if (tid == 0 && S.dcut != 0xFFFFFFFFu) atomicMin(&ctr->d_cut[par], S.dcut);
-        if (g == 0) { ctr->d_cut[par ^ 1u] = 0xFFFFFFFFu; }
+        {
+            // one word per workgroup and kind: does anybody have to be looked at again (P3)? how many rows cannot run in this level?
+            const int any_unst = __syncthreads_or(pending && unstable ? 1 : 0);
+            const int notready = __syncthreads_count(pending && (unstable || waiting) ? 1 : 0);
+            if (tid == 0) {
+                if (any_unst) atomicOr(&ctr->d_flag[par], 1u);
+                if (notready) atomicAdd(&ctr->d_pend[par], (unsigned int)notready);
+            }
+            if (g == 0) { ctr->d_flag[par ^ 1u] = 0; ctr->d_pend[par ^ 1u] = 0; ctr->d_pend2[par ^ 1u] = 0; ctr->d_cut[par ^ 1u] = 0xFFFFFFFFu; }
+        }
         if ((err = job_barrier(J, s_err))) return err;
-        const uint32_t dcut = ld_agent(&ctr->d_cut[par]);
+        MTICK(1);
+        const bool slow_level = ld_agent(&ctr->d_flag[par]) != 0;      // somebody is unstable: its conservative marks have to be looked at
+        uint32_t dcut = 0xFFFFFFFFu;
+        bool demoted = false;
+        if (slow_level) {
+            // -------------------------------------------------------------- P3: a lower unstable row could still write what this one accesses -> demoted
+            if (pending && !unstable) {
+                if (kind == 1)
+                    fz_each([&](uint32_t v, uint32_t acc, uint32_t, uint32_t) {
+                        if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) demoted = true;
+                        if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) demoted = true;
+                    });
+                else if (kind == 2 || kind == 3) demoted = dr_gen_demoted(J, row[0], shape, xv, key);
+            }
+            { const uint32_t wm = wave_min(demoted ? r0 : 0xFFFFFFFFu); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.dcut, wm); }
+            if (S.bl_any) dr_big_p3(J, S, epoch);
+            __syncthreads();
+            if (tid == 0 && S.dcut != 0xFFFFFFFFu) atomicMin(&ctr->d_cut[par], S.dcut);
+            if ((err = job_barrier(J, s_err))) return err;
+            dcut = ld_agent(&ctr->d_cut[par]);
+        }
         // ------------------------------------------------------------------ run what is ready
-        if (pending && kind != 4 && !unstable && !p3 && r0 < dcut) {
+        if (pending && kind != 4 && !unstable && !waiting && !demoted && r0 < dcut) {
             pending = false;
             J.inq[row[0]] = (uint16_t)2;
             J.prank[row[0]] = r0;
@@ -380,19 +404,27 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             __syncthreads();
             if (tid < ECNE_BIGK && (S.dr_st[tid] & 16u)) S.dr_st[tid] = 0;
         }
+        if (!slow_level) {
+            // nobody was unstable, so nobody was demoted: everything that did not have to wait has run. Nothing left -> the window
+            // has drained (multi_finish's first barrier orders these stores before anybody reads them)
+            if (ld_agent(&ctr->d_pend[par]) == 0) break;
+            if ((err = job_barrier(J, s_err))) return err;
+            continue;
+        }
         {
             const int left = __syncthreads_count(pending ? 1 : 0);
-            if (tid == 0 && left) atomicAdd(&ctr->d_pend[par], (unsigned int)left);
-            if (g == 0) ctr->d_pend[par ^ 1u] = 0;
+            if (tid == 0 && left) atomicAdd(&ctr->d_pend2[par], (unsigned int)left);
         }
         if ((err = job_barrier(J, s_err))) return err;
-        if (ld_agent(&ctr->d_pend[par]) == 0) break;
+        if (ld_agent(&ctr->d_pend2[par]) == 0) {
+            if (g == 0) { ctr->d_flag[par] = 0; ctr->d_pend[par] = 0; ctr->d_cut[par] = 0xFFFFFFFFu; }     // (all read before this level's last barrier)
+            break;
+        }
     }
     if (tid == 0) S.depoch = epoch;
-    if (g == 0) { ctr->d_cut[level & 1u] = 0xFFFFFFFFu; S.mt[6] += level; S.mt[7] += 1; }     // (everybody read the last level's cut before its last barrier)
+    if (g == 0) { S.mt[6] += level; S.mt[7] += 1; }
     __syncthreads();
     *out_levels = level;
-    MTICK(0);
     return multi_finish(J, S, wgrank, head, tail, n_eff, 1u, r0, row, nev, bigsl, mycand, false, mt_last, s_err, out_c, out_tail);
 }
 

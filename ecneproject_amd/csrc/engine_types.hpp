@@ -24,7 +24,7 @@ namespace ecne {
 #define ECNE_SMALL_ROW 64   // rows with more entries than this are "long": handled by a whole workgroup
 #endif
 #ifndef ECNE_MAX_NWG
-#define ECNE_MAX_NWG 96      // workgroups one system can get (q_part[][128] and the scratch sizes follow it)
+#define ECNE_MAX_NWG 248     // workgroups one system can get (q_part[][256] and the scratch sizes follow it)
 #endif
 #ifndef ECNE_ROWS_PER_WG
 #define ECNE_ROWS_PER_WG 8192    // measured on ecdsa_like(26), round 2 (rows mostly on the record path): 85 workgroups 22.2 ms, 57: 22.5, 43: 23.0, 22: 26.7, 11: 31.1
@@ -105,8 +105,8 @@ struct Counters {   // one per job, device memory
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
     unsigned int q_cmd[8];          // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
-    unsigned int d_cut[2], d_pend[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows still pending
-    unsigned int q_part[2][128];
+    unsigned int d_cut[2], d_pend[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows that cannot run in the level, rows left after it, "somebody is unstable"
+    unsigned int q_part[2][256];
     unsigned int q_blk[2][ECNE_MAX_NWG * 8];   // per-wavefront totals of the block-order scan (team_block_scan)
     unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };

@@ -87,9 +87,10 @@ __device__ __forceinline__ void for_row_sets4(const Job& J, uint32_t row, uint32
     const bool touch1 = (shape & SH_TOUCH1) != 0;
     uint32_t wb0 = 0xFFFFFFFFu, wb1 = 0xFFFFFFFFu, wb2 = 0xFFFFFFFFu;   // variables whose B-state may be written
     uint32_t wc0 = 0xFFFFFFFFu, wc1 = 0xFFFFFFFFu, wc2 = 0xFFFFFFFFu;   // ... in any later state
+    fp::u256 tv = fp::make(0);
     if (shape & SH_R3) {
         const RowInfo ri = J.rinfo[row];
-        const fp::u256 tv = ld256(J.vals + 4ull * ri.validx);
+        tv = ld256(J.vals + 4ull * ri.validx);
         // (all four loads first: a short-circuit chain would wait for them one after the other)
         const uint8_t nv = J.nvalues[x];
         const fp::u256 va = ld256(J.values + 8ull * x), lbx = ld256(J.lb + 4ull * x), ubx = ld256(J.ub + 4ull * x);
@@ -103,7 +104,17 @@ __device__ __forceinline__ void for_row_sets4(const Job& J, uint32_t row, uint32
             const fp::u256 l1 = ld256(J.lb + 4ull * ri.k1), l2 = ld256(J.lb + 4ull * ri.k2);
             const fp::u256 u1 = ld256(J.ub + 4ull * ri.k1), u2 = ld256(J.ub + 4ull * ri.k2);
             const bool eqb = fp::eq(l1, l2) & fp::eq(u1, u2);
-            if (!eqb || wb0 != 0xFFFFFFFFu) { wb1 = ri.k1; wb2 = ri.k2; }   // R3 may first move x's bounds
+            // x = c written against the constant wire (x - 1 = 0: the R3 and the x == y shapes at once; every "<== 1" of a circuit is
+            // one): R3 moves x to [c, c], and when the constant wire already has exactly these bounds (after the first such pop) and
+            // no [0,1] class, R4 and R5 find nothing to do (fast_decide's r3x case, fastrow.hip.hpp) -- only x is written. Without
+            // this every such row counts as a writer of the constant wire's bounds and they run one behind the other.
+            bool partner_settled = false;
+            if ((shape & SH_R3) && (shape & SH_R5) && wb0 != 0xFFFFFFFFu && x != 1u && (ri.k1 == x ? ri.k2 : ri.k1) == 1u && (ri.k1 == x || ri.k2 == x)) {
+                const uint8_t f1w = J.flags[1];
+                const bool k1_is_x = ri.k1 == x;
+                partner_settled = (f1w & 3) == 3 && !(f1w & 4) && fp::eq(k1_is_x ? l2 : l1, tv) && fp::eq(k1_is_x ? u2 : u1, tv);
+            }
+            if ((!eqb || wb0 != 0xFFFFFFFFu) && !partner_settled) { wb1 = ri.k1; wb2 = ri.k2; }   // R3 may first move x's bounds
             wc1 = ri.k1; wc2 = ri.k2;
         } else {
             // binary-decomposition row: only the pivot's bounds can be written

@@ -20,13 +20,15 @@ for n, f in fl:
 for mode in ([int(m) for m in sys.argv[2:]] or [0]):
     best = None
     for rep in range(3):
-        r = E.solve_batch([s], secp_solve=True, fetch_states=False, queue_mode=mode)[0]
+        r = E.solve_batch([s], secp_solve=True, fetch_states=False, queue_mode=mode, force_nwg=int(os.environ.get('FORCE_NWG', '0')))[0]
         if best is None or r.summary.device_ms < best.summary.device_ms:
             best = r
     sm = best.summary
     print(rel, "mode", mode, "rows", len(s), "status", best.status, "dev_ms %.3f" % sm.device_ms, "pops", sm.pops, "outer", sm.outer_iterations,
           "rounds", sm.rule_hits[13], "alone", sm.rule_hits[14] & 0xFFFF, "\n   phases[setup,P1+P2+queue,P3,P4,P5,verdict]", [round(x, 3) for x in sm.phase_ms[:6]], "P3 passes", int(sm.phase_ms[6]),
           "\n   queue[head,mark,check,exec,flatten,resolve,alone+bursts+wave,multi]", [round(x, 3) for x in sm.queue_ms[:8]], "\n   hits", list(sm.rule_hits[:13]))
+    mm = list(sm.multi_ms)
+    print("   multi[mark,check,exec+scan,expand,count+scan,write]", [round(x, 3) for x in mm[:6]], "drain levels %d rounds %d" % (round(mm[6] * 1e5), round(mm[7] * 1e5)))
     sd = list(sm.sched)
     print("   fast rounds %d rows %d ms %.3f | general wave rounds %d rows %d ms %.3f | declines[norec/big, other shape, R2 err, xy slow, xy R7/R8, sum R7/R8] %s solo pops (long row lists) %d | multi rounds by rows [<64, <4096, more] %s"
           % (sd[0], sd[1], sd[2] * 1e-5, sd[3], sd[4], sd[5] * 1e-5, sd[6:12], sd[12], sd[13:16]))
