@@ -1165,8 +1165,8 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             }
             hj[i].queue_mode = (uint32_t)o.queue_mode;
             {   // rounds on all workgroups: drain rounds (drain.hip.hpp) unless queue_mode 3 / ECNE_DRAIN=0 ask for the prefix rounds
-                static const bool drain_env = []() { const char* e = getenv("ECNE_DRAIN"); return !(e && atoi(e) == 0); }();
-                hj[i].drain = (o.queue_mode == 3 || !drain_env) ? 0u : 1u;
+                static const int drain_env = []() { const char* e = getenv("ECNE_DRAIN"); return e ? atoi(e) : 1; }();      // 2: test hook (every frontier is drained)
+                hj[i].drain = o.queue_mode == 3 ? 0u : o.queue_mode == 4 ? 2u : drain_env <= 0 ? 0u : (uint32_t)std::min(drain_env, 2);
             }
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }

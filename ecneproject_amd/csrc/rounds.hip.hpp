@@ -681,6 +681,9 @@ __device__ __forceinline__ uint32_t multi_min(const Job& J) { return fast_wg_ok(
 __device__ __forceinline__ uint32_t multi_window_min(const Job& J) { return fast_wg_ok(J) ? ECNE_V2WG_WINDOW : fast_wave_ok(J) ? ECNE_V2_WINDOW : ECNE_MULTI_MIN; }
 // drain rounds (drain.hip.hpp) instead of prefix rounds on all workgroups: the job has row records and the host did not switch them off
 __device__ __forceinline__ bool drain_ok(const Job& J) { return J.drain != 0 && J.rec != nullptr; }
+// test hook (ECNE_DRAIN=2): every frontier of two rows and more goes to a drain round, whatever the streak -- the level logic then
+// sees the dependency chains and narrow windows the schedule normally keeps away from it
+__device__ __forceinline__ bool drain_eager(const Job& J) { return J.drain == 2 && J.rec != nullptr && J.nwg > 1; }
 __device__ __forceinline__ uint32_t multi_cap(const Job& J) { return J.nwg * ECNE_WG * (drain_ok(J) ? 1u : 2u); }
 #ifndef ECNE_DRAIN_GROW
 #define ECNE_DRAIN_GROW 6      // a drain that needed at most this many levels doubles the next window ...
@@ -720,7 +723,8 @@ __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head
     if (fast_wave_ok(J) && c_last != n_last) return 0;
     const uint32_t avail = tail - head;
     const uint32_t n = avail < window ? avail : window;
-    if (n <= 64 || avail < multi_min(J) || window < multi_window_min(J)) return 0;
+    if (drain_eager(J)) { if (avail < 2) return 0; }
+    else if (n <= 64 || avail < multi_min(J) || window < multi_window_min(J)) return 0;
     const uint32_t row0 = J.queue[head & J.qmask];
     const uint32_t shape0 = J.rinfo[row0].shape;
     if ((shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0)) return 0;   // a long row that is popped alone
@@ -828,7 +832,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             n = avail < cap_ ? avail : cap_;
         }
         if (v2wg && J.nwg == 1 && n > ECNE_WG) n = ECNE_WG;
-        if (n <= 64 && !declined_wide) {
+        const bool eager = drain_eager(J) && avail >= 2;
+        if (n <= 64 && !declined_wide && !eager) {
             // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
             if (w == 0) {
                 uint32_t nt = q.tail, nx = n;
@@ -922,7 +927,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         uint32_t live = 0, noop = 0, noop_b = 0;                    // bit s = slot s
         // (a frontier that goes to all workgroups anyway: only the row at the head matters here -- is it a long row that has to be
         //  popped alone? -- the round loads its rows itself)
-        const bool want_multi = J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide);
+        const bool want_multi = eager || (J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide));
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
             row[sl] = 0; shape[sl] = 0; xv[sl] = 0;

@@ -146,8 +146,12 @@ typedef struct ecne_opts {
     int32_t device;      /* HIP device ordinal                                                       */
     int32_t secp_solve;  /* kwarg secp_solve (:511): defines `dsu`, required when P2 has work (:762)  */
     int32_t debug;       /* test hook: > 0 forces that many cooperating workgroups per system        */
-    int32_t queue_mode;  /* 0 = default (chunk-parallel) schedule; 1 = strictly sequential pops on one
-                            wavefront: the reference's schedule verbatim, for debugging and parity   */
+    int32_t queue_mode;  /* 0 = default schedule (rounds; wide frontiers of large systems as drain rounds on all
+                            workgroups); 1 = strictly sequential pops on one wavefront: the reference's schedule
+                            verbatim, for debugging and parity; 2 = the same on the chain executor; 3 = default
+                            schedule with prefix rounds instead of drain rounds (round 2's schedule, for A/B runs);
+                            4 = test hook: every frontier of two rows and more is drained. All modes give the same
+                            results, bit for bit.                                                    */
     void* stream;        /* hipStream_t to launch on, or NULL for the device's default stream         */
 } ecne_opts;
 
