@@ -5,7 +5,7 @@
 // pops one row at a time (/root/reference/src/R1CSConstraintSolver.jl:805-1349), so a row that depends on an earlier one of the
 // window ends the round -- and a circuit whose independent blocks sit one behind the other in the FIFO (52 multiplexers of an
 // ECDSA circuit: decoder sum, its 4 096 dependents, next decoder sum, ...) is then worked off one block per three rounds although
-// the blocks have nothing to do with each other (tools/dataflow_depth.py: ecdsa_like(26) needs 165 dataflow levels, the
+// the blocks have nothing to do with each other (tests/tools/dataflow_depth.py: ecdsa_like(26) needs 165 dataflow levels, the
 // prefix schedule took 692 rounds).
 //
 // The drain round executes the WHOLE window, level by level: at every level each pending row looks at the pending rows of LOWER

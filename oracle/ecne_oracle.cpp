@@ -504,7 +504,7 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
     }
     int64_t successful_steps = 0, prev_successful_steps = -1, num_unique = 0;
 
-    // developer aid (tools/dataflow_depth.py): ECNE_ORACLE_TRACE=<file> logs (tag, value) int64 pairs -- 0 outer iteration,
+    // developer aid (tests/tools/dataflow_depth.py): ECNE_ORACLE_TRACE=<file> logs (tag, value) int64 pairs -- 0 outer iteration,
     // 1 row popped, 2 variable re-queued, 3 rows that re-queue pushed
     FILE* trace = nullptr;
     if (const char* tp = std::getenv("ECNE_ORACLE_TRACE")) trace = std::fopen(tp, "wb");

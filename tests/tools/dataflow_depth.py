@@ -1,11 +1,11 @@
 """Developer aid (CPU only): ideal dataflow depth of a solve, from the sequential oracle's pop trace.
-  python tools/dataflow_depth.py [S [stride]]        (ecdsa_like(S, stride) + trusted secp256k1.r1cs)
+  python tests/tools/dataflow_depth.py [S [stride]]        (ecdsa_like(S, stride) + trusted secp256k1.r1cs)
 Every pop gets a level = 1 + max(level of the pop that pushed its row, level of the last writer of any variable it mentions
 (RAW), level of the last reader of any variable it writes (WAR)); writes = the variables the pop re-queued. The number of
 distinct levels is what a perfect level-synchronous schedule would need; the engine's rounds are prefixes of the FIFO order."""
 import collections, os, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np
 import ecneproject_amd as E, ecdsa_like, fixtures, orc
 
