@@ -17,13 +17,16 @@
 //
 // Hazard test of one level (three planes of per-variable marks, U and B class each, lowest rank wins; epoch-keyed so that
 // nothing is ever reset):
-//   X   exact writes: what the row would write if it ran on the state as it is now (every pending row marks)
-//   A   all accesses: what the row can read or write in ANY state it may still see (static sets minus final variables)
-//   C   conservative writes of UNSTABLE rows -- rows that found a lower X mark on something they access: their inputs may still
+//   X   exact writes: what the row would write if it ran on the state as it is now (every pending row marks, P1)
+//   A   accesses that matter: a row that finds a HIGHER X mark on something it accesses (a later row wants to write it) says so
+//       here, and an unstable row marks everything it can access in any state it may still see -- so a writer finds every
+//       earlier pending row that still has to read or write its target, and nobody pays an atomic for an access nobody contests
+//   C   conservative writes of UNSTABLE rows -- rows that found a LOWER X mark on something they access: their inputs may still
 //       change, so what they will write is not known; they mark everything they could
-//   P1 mark X, A | P2 unstable? -> mark C | P3 the others: a lower C mark on what they access demotes them (their lowest rank
-//   becomes the level's cut: rows above it cannot tell which lower rows are trustworthy and wait), a lower A mark on what they
-//   write makes them wait a level (an earlier row still has to read or write that state) | run the rest.
+//   P1 mark X | P2 look at X: unstable? -> mark C and A; contested access -> mark A | P3 (only if somebody marked): a lower C mark
+//   on what a row accesses demotes it (the lowest demoted rank becomes the level's cut: rows above it cannot tell which lower rows
+//   are trustworthy and wait), a lower A mark on what it writes makes it wait a level | run the rest.
+// A level in which nobody marked A or C is two job barriers, and the window has drained after it.
 // The lowest pending row always runs, so the window drains; the window size follows the levels a drain needed (rounds.hip.hpp).
 // Long rows (plain ones, as in every round) are taken by their workgroup as a whole; a long row of another shape, or one the
 // workgroup has no slot for, ends the window BEFORE anything has run (level 1 only).
@@ -38,51 +41,59 @@ __device__ __forceinline__ uint32_t dr_key(uint32_t epoch, uint32_t rank) { retu
 __device__ __forceinline__ void dr_mark(uint32_t* plane, uint32_t v, uint32_t key) {
     if (ld_agent(&plane[v]) < key) atomicMax(&plane[v], key);
 }
+// (P1: the exact write marks are hardly ever contested -- no look before the atomic, one round trip less)
+__device__ __forceinline__ void dr_mark_now(uint32_t* plane, uint32_t v, uint32_t key) { atomicMax(&plane[v], key); }
 // a mark of the current epoch with a LOWER rank than key's (older epochs are smaller than every key of this one)
 __device__ __forceinline__ bool dr_lower(const uint32_t* plane, uint32_t v, uint32_t key) { return ld_agent(&plane[v]) > key; }
+// 1: a lower rank marked, 2: a higher rank did (and no lower one), 0: nobody else
+__device__ __forceinline__ uint32_t dr_see(const uint32_t* plane, uint32_t v, uint32_t key) {
+    const uint32_t k = ld_agent(&plane[v]);
+    return k > key ? 1u : (k < key && (k >> 17) == (key >> 17)) ? 2u : 0u;
+}
 
-// ---- a small row on the general path (no record decision): the access-set walk of schedule.hip.hpp, four times per level at most
-__device__ __noinline__ void dr_gen_mark(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop) {
+// ---- a small row on the general path (no record decision): the access-set walk of schedule.hip.hpp, up to four times per level
+__device__ __noinline__ void dr_gen_mark(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
     for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
-        const uint32_t acc = rd | wrc;
-        if (acc & 1) dr_mark(J.dmk[DA_U], v, key);
-        if (acc & 2) dr_mark(J.dmk[DA_B], v, key);
-        if (!noop) {
-            if (wr & 1) dr_mark(J.dmk[DX_U], v, key);
-            if (wr & 2) dr_mark(J.dmk[DX_B], v, key);
-        }
+        if (wr & 1) dr_mark_now(J.dmk[DX_U], v, key);
+        if (wr & 2) dr_mark_now(J.dmk[DX_B], v, key);
     });
 }
-// bit 0: unstable (a lower row writes, as things stand, something this one accesses), bit 1: has to wait a level (a lower pending row
-// still accesses what this one writes)
-__device__ __noinline__ uint32_t dr_gen_p2(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop) {
+// bit 0: unstable (a lower row writes, as things stand, something this one accesses), bit 1: it marked a contested access in A
+__device__ __noinline__ uint32_t dr_gen_p2(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
     uint32_t r = 0;
     for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
         const uint32_t acc = rd | wrc;
-        if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) r |= 1u;
-        if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) r |= 1u;
+        if (acc & 1) { const uint32_t s = dr_see(J.dmk[DX_U], v, key); if (s == 1) r |= 1u; else if (s == 2) { dr_mark(J.dmk[DA_U], v, key); r |= 2u; } }
+        if (acc & 2) { const uint32_t s = dr_see(J.dmk[DX_B], v, key); if (s == 1) r |= 1u; else if (s == 2) { dr_mark(J.dmk[DA_B], v, key); r |= 2u; } }
+    });
+    return r;
+}
+// an unstable row: everything it could write goes to C, everything it can access to A
+__device__ __noinline__ void dr_gen_mark_unstable(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
+        const uint32_t acc = rd | wrc;
+        if (wrc & 1) dr_mark(J.dmk[DC_U], v, key);
+        if (wrc & 2) dr_mark(J.dmk[DC_B], v, key);
+        if (acc & 1) dr_mark(J.dmk[DA_U], v, key);
+        if (acc & 2) dr_mark(J.dmk[DA_B], v, key);
+    });
+}
+// bit 0: demoted (a lower UNSTABLE row could still write something this one accesses; looked at only when somebody is unstable),
+// bit 1: has to wait a level (a lower pending row still accesses what this one writes)
+__device__ __noinline__ uint32_t dr_gen_p3(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key, bool noop, bool look_c) {
+    uint32_t r = 0;
+    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
+        const uint32_t acc = rd | wrc;
+        if (look_c) {
+            if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) r |= 1u;
+            if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) r |= 1u;
+        }
         if (!noop) {
             if ((wr & 1) && dr_lower(J.dmk[DA_U], v, key)) r |= 2u;
             if ((wr & 2) && dr_lower(J.dmk[DA_B], v, key)) r |= 2u;
         }
     });
     return r;
-}
-__device__ __noinline__ void dr_gen_mark_c(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
-    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
-        if (wrc & 1) dr_mark(J.dmk[DC_U], v, key);
-        if (wrc & 2) dr_mark(J.dmk[DC_B], v, key);
-    });
-}
-// a lower UNSTABLE row could still write something this one accesses
-__device__ __noinline__ bool dr_gen_demoted(const Job& J, uint32_t row, uint32_t shape, uint32_t x, uint32_t key) {
-    bool d = false;
-    for_row_sets4(J, row, shape, x, [&](uint32_t v, uint32_t rd, uint32_t wr, uint32_t wrc) {
-        const uint32_t acc = rd | wrc;
-        if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) d = true;
-        if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) d = true;
-    });
-    return d;
 }
 
 // ---- the registered long rows of this workgroup (S.bl_*, S.dr_st[k]: bit 0 pending, 1 unstable, 2 demoted, 3 waiting, 4 ran
@@ -92,51 +103,56 @@ __device__ __noinline__ void dr_big_p1(const Job& J, ChunkShared& S, uint32_t ep
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         if (!(S.dr_st[k] & 1u)) continue;
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) { const uint32_t v = J.colC[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DX_U], v, key); }
+    }
+}
+// returns (to every thread) bit 1 if some long row of this workgroup marked a contested access
+__device__ __noinline__ uint32_t dr_big_p2(const Job& J, ChunkShared& S, uint32_t epoch) {
+    bool am = false;
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        if (!(S.dr_st[k] & 1u)) continue;
+        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
+        bool u = false;
+        auto look = [&](int px, int pa, uint32_t v) { const uint32_t s = dr_see(J.dmk[px], v, key); if (s == 1) u = true; else if (s == 2) { dr_mark(J.dmk[pa], v, key); am = true; } };
+        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3) look(DX_U, DA_U, v); }
+        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3) look(DX_U, DA_U, v); }
+        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
+            const uint32_t v = J.colC[e];
+            const uint8_t f = J.flags[v];
+            if ((f & 3) != 3) look(DX_U, DA_U, v);
+            if (!(f & 1)) look(DX_B, DA_B, v);
+        }
+        if (u) atomicOr(&S.dr_st[k], 2u);
+    }
+    const int any_am = __syncthreads_or(am ? 1 : 0);
+    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
+        if ((S.dr_st[k] & 3u) != 3u) continue;       // unstable: C (what it could write) and A (what it can access)
+        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
         for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DA_U], v, key); }
         for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DA_U], v, key); }
         for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colC[e];
             const uint8_t f = J.flags[v];
-            if ((f & 3) != 3) { dr_mark(J.dmk[DA_U], v, key); dr_mark(J.dmk[DX_U], v, key); }
+            if ((f & 3) != 3) { dr_mark(J.dmk[DC_U], v, key); dr_mark(J.dmk[DA_U], v, key); }
             if (!(f & 1)) dr_mark(J.dmk[DA_B], v, key);
         }
     }
+    return any_am ? 2u : 0u;
 }
-__device__ __noinline__ void dr_big_p2(const Job& J, ChunkShared& S, uint32_t epoch) {
-    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
-        if (!(S.dr_st[k] & 1u)) continue;
-        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
-        bool u = false, wt = false;
-        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true; }
-        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DX_U], v, key)) u = true; }
-        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
-            const uint32_t v = J.colC[e];
-            const uint8_t f = J.flags[v];
-            if ((f & 3) != 3) { if (dr_lower(J.dmk[DX_U], v, key)) u = true; if (dr_lower(J.dmk[DA_U], v, key)) wt = true; }
-            if (!(f & 1) && dr_lower(J.dmk[DX_B], v, key)) u = true;
-        }
-        if (u) atomicOr(&S.dr_st[k], 2u);
-        else if (wt) atomicOr(&S.dr_st[k], 8u);
-    }
-    __syncthreads();
-    for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
-        if ((S.dr_st[k] & 3u) != 3u) continue;
-        const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
-        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) { const uint32_t v = J.colC[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DC_U], v, key); }
-    }
-}
-__device__ __noinline__ void dr_big_p3(const Job& J, ChunkShared& S, uint32_t epoch) {
+__device__ __noinline__ void dr_big_p3(const Job& J, ChunkShared& S, uint32_t epoch, bool look_c) {
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         if ((S.dr_st[k] & 3u) != 1u) continue;       // pending and not unstable
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
         uint32_t r = 0;
-        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
-        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
+        if (look_c) {
+            for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
+            for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
+        }
         for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
             const uint32_t v = J.colC[e];
             const uint8_t f = J.flags[v];
-            if ((f & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u;
-            if (!(f & 1) && dr_lower(J.dmk[DC_B], v, key)) r |= 4u;
+            if ((f & 3) != 3) { if (look_c && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; if (dr_lower(J.dmk[DA_U], v, key)) r |= 8u; }
+            if (look_c && !(f & 1) && dr_lower(J.dmk[DC_B], v, key)) r |= 4u;
         }
         if (r) atomicOr(&S.dr_st[k], r);
         if (r & 4u) atomicMin(&S.dcut, S.bl_rank[k]);
@@ -268,13 +284,11 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             }
         };
         if (kind == 1)
-            fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
-                if (acc & 1) dr_mark(J.dmk[DA_U], v, key);
-                if (acc & 2) dr_mark(J.dmk[DA_B], v, key);
-                if (wx & 1) dr_mark(J.dmk[DX_U], v, key);
-                if (wx & 2) dr_mark(J.dmk[DX_B], v, key);
+            fz_each([&](uint32_t v, uint32_t, uint32_t wx, uint32_t) {
+                if (wx & 1) dr_mark_now(J.dmk[DX_U], v, key);
+                if (wx & 2) dr_mark_now(J.dmk[DX_B], v, key);
             });
-        else if (kind == 2 || kind == 3) dr_gen_mark(J, row[0], shape, xv, key, kind == 3);
+        else if (kind == 2) dr_gen_mark(J, row[0], shape, xv, key);
         __syncthreads();
         if (level == 1) {
             if (tid == 0 && S.cut != 0xFFFFFFFFu) atomicMin(&ctr->q_cut, S.cut);
@@ -292,63 +306,74 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             if (tid < ECNE_BIGK && S.bl_rank[tid] != 0xFFFFFFFFu && S.bl_rank[tid] >= n_eff) { S.dr_st[tid] = 0; S.bl_rank[tid] = 0xFFFFFFFFu; }
             __syncthreads();
         }
-        // ------------------------------------------------------------------ P2: unstable rows mark what they could ever write;
-        // the others see whether an earlier pending row still has to read or write what they write (-> they wait a level)
-        bool unstable = false, waiting = false;
+        // ------------------------------------------------------------------ P2: look at X. A lower mark on something the row accesses: unstable
+        // (marks what it could ever write in C, what it can access in A); a higher one: the access is contested, the row says so in A
+        bool unstable = false, amark = false;
         if (kind == 1) {
-            fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
-                if ((acc & 1) && dr_lower(J.dmk[DX_U], v, key)) unstable = true;
-                if ((acc & 2) && dr_lower(J.dmk[DX_B], v, key)) unstable = true;
-                if ((wx & 1) && dr_lower(J.dmk[DA_U], v, key)) waiting = true;
-                if ((wx & 2) && dr_lower(J.dmk[DA_B], v, key)) waiting = true;
+            fz_each([&](uint32_t v, uint32_t acc, uint32_t, uint32_t) {
+                if (acc & 1) { const uint32_t s = dr_see(J.dmk[DX_U], v, key); if (s == 1) unstable = true; else if (s == 2) { dr_mark(J.dmk[DA_U], v, key); amark = true; } }
+                if (acc & 2) { const uint32_t s = dr_see(J.dmk[DX_B], v, key); if (s == 1) unstable = true; else if (s == 2) { dr_mark(J.dmk[DA_B], v, key); amark = true; } }
             });
             if (unstable)
-                fz_each([&](uint32_t v, uint32_t, uint32_t, uint32_t wc) {
+                fz_each([&](uint32_t v, uint32_t acc, uint32_t, uint32_t wc) {
                     if (wc & 1) dr_mark(J.dmk[DC_U], v, key);
                     if (wc & 2) dr_mark(J.dmk[DC_B], v, key);
+                    if (acc & 1) dr_mark(J.dmk[DA_U], v, key);
+                    if (acc & 2) dr_mark(J.dmk[DA_B], v, key);
                 });
         } else if (kind == 2 || kind == 3) {
-            const uint32_t r = dr_gen_p2(J, row[0], shape, xv, key, kind == 3);
-            unstable = (r & 1u) != 0; waiting = (r & 2u) != 0;
-            if (unstable) dr_gen_mark_c(J, row[0], shape, xv, key);
+            const uint32_t r = dr_gen_p2(J, row[0], shape, xv, key);
+            unstable = (r & 1u) != 0; amark = (r & 2u) != 0;
+            if (unstable) dr_gen_mark_unstable(J, row[0], shape, xv, key);
         }
         if (tid == 0) S.dcut = 0xFFFFFFFFu;
+        uint32_t big_am = 0;
         if (S.bl_any) {
-            dr_big_p2(J, S, epoch);
+            big_am = dr_big_p2(J, S, epoch);
             __syncthreads();
-            if (pending && kind == 4 && myslot >= 0) { const uint32_t st = S.dr_st[myslot]; unstable = (st & 2u) != 0; waiting = (st & 8u) != 0; }
+            if (pending && kind == 4 && myslot >= 0) unstable = (S.dr_st[myslot] & 2u) != 0;
         }
         {
-            // one word per workgroup and kind: does anybody have to be looked at again (P3)? how many rows cannot run in this level?
+            // two bits per workgroup: is anybody unstable (then C has to be looked at, P3)? did anybody mark A (then writers look at it)?
             const int any_unst = __syncthreads_or(pending && unstable ? 1 : 0);
-            const int notready = __syncthreads_count(pending && (unstable || waiting) ? 1 : 0);
-            if (tid == 0) {
-                if (any_unst) atomicOr(&ctr->d_flag[par], 1u);
-                if (notready) atomicAdd(&ctr->d_pend[par], (unsigned int)notready);
-            }
-            if (g == 0) { ctr->d_flag[par ^ 1u] = 0; ctr->d_pend[par ^ 1u] = 0; ctr->d_pend2[par ^ 1u] = 0; ctr->d_cut[par ^ 1u] = 0xFFFFFFFFu; }
+            const int any_am = __syncthreads_or(pending && (amark || unstable) ? 1 : 0) | (int)big_am;
+            if (tid == 0 && (any_unst || any_am)) atomicOr(&ctr->d_flag[par], (any_unst ? 1u : 0u) | (any_am ? 2u : 0u));
+            if (g == 0) { ctr->d_flag[par ^ 1u] = 0; ctr->d_pend2[par ^ 1u] = 0; ctr->d_cut[par ^ 1u] = 0xFFFFFFFFu; }
         }
         if ((err = job_barrier(J, s_err))) return err;
         MTICK(1);
-        const bool slow_level = ld_agent(&ctr->d_flag[par]) != 0;      // somebody is unstable: its conservative marks have to be looked at
+        const uint32_t lflag = ld_agent(&ctr->d_flag[par]);
+        const bool slow_level = (lflag & 1u) != 0;      // somebody is unstable: its conservative marks have to be looked at
         uint32_t dcut = 0xFFFFFFFFu;
-        bool demoted = false;
-        if (slow_level) {
-            // -------------------------------------------------------------- P3: a lower unstable row could still write what this one accesses -> demoted
+        bool demoted = false, waiting = false;
+        if (lflag) {
+            // -------------------------------------------------------------- P3: demoted by a lower unstable row / waiting for a lower accessor
             if (pending && !unstable) {
+                uint32_t r = 0;
                 if (kind == 1)
-                    fz_each([&](uint32_t v, uint32_t acc, uint32_t, uint32_t) {
-                        if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) demoted = true;
-                        if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) demoted = true;
+                    fz_each([&](uint32_t v, uint32_t acc, uint32_t wx, uint32_t) {
+                        if (slow_level) {
+                            if ((acc & 1) && dr_lower(J.dmk[DC_U], v, key)) r |= 1u;
+                            if ((acc & 2) && dr_lower(J.dmk[DC_B], v, key)) r |= 1u;
+                        }
+                        if ((wx & 1) && dr_lower(J.dmk[DA_U], v, key)) r |= 2u;
+                        if ((wx & 2) && dr_lower(J.dmk[DA_B], v, key)) r |= 2u;
                     });
-                else if (kind == 2 || kind == 3) demoted = dr_gen_demoted(J, row[0], shape, xv, key);
+                else if (kind == 2 || kind == 3) r = dr_gen_p3(J, row[0], shape, xv, key, kind == 3, slow_level);
+                demoted = (r & 1u) != 0; waiting = (r & 2u) != 0;
             }
-            { const uint32_t wm = wave_min(demoted ? r0 : 0xFFFFFFFFu); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.dcut, wm); }
-            if (S.bl_any) dr_big_p3(J, S, epoch);
-            __syncthreads();
-            if (tid == 0 && S.dcut != 0xFFFFFFFFu) atomicMin(&ctr->d_cut[par], S.dcut);
-            if ((err = job_barrier(J, s_err))) return err;
-            dcut = ld_agent(&ctr->d_cut[par]);
+            if (S.bl_any) {
+                dr_big_p3(J, S, epoch, slow_level);
+                __syncthreads();
+                if (pending && kind == 4 && myslot >= 0) waiting = (S.dr_st[myslot] & 8u) != 0;
+            }
+            if (slow_level) {
+                { const uint32_t wm = wave_min(demoted ? r0 : 0xFFFFFFFFu); if (lane == 0 && wm != 0xFFFFFFFFu) atomicMin(&S.dcut, wm); }
+                __syncthreads();
+                if (tid == 0 && S.dcut != 0xFFFFFFFFu) atomicMin(&ctr->d_cut[par], S.dcut);
+                if ((err = job_barrier(J, s_err))) return err;
+                dcut = ld_agent(&ctr->d_cut[par]);
+            }
         }
         // ------------------------------------------------------------------ run what is ready
         if (pending && kind != 4 && !unstable && !waiting && !demoted && r0 < dcut) {
@@ -404,20 +429,16 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             __syncthreads();
             if (tid < ECNE_BIGK && (S.dr_st[tid] & 16u)) S.dr_st[tid] = 0;
         }
-        if (!slow_level) {
-            // nobody was unstable, so nobody was demoted: everything that did not have to wait has run. Nothing left -> the window
-            // has drained (multi_finish's first barrier orders these stores before anybody reads them)
-            if (ld_agent(&ctr->d_pend[par]) == 0) break;
-            if ((err = job_barrier(J, s_err))) return err;
-            continue;
-        }
+        // nobody marked A or C: nobody was unstable, demoted or made to wait -- everything has run, the window has drained
+        // (multi_finish's first barrier orders these stores before anybody reads them)
+        if (!lflag) break;
         {
             const int left = __syncthreads_count(pending ? 1 : 0);
             if (tid == 0 && left) atomicAdd(&ctr->d_pend2[par], (unsigned int)left);
         }
         if ((err = job_barrier(J, s_err))) return err;
         if (ld_agent(&ctr->d_pend2[par]) == 0) {
-            if (g == 0) { ctr->d_flag[par] = 0; ctr->d_pend[par] = 0; ctr->d_cut[par] = 0xFFFFFFFFu; }     // (all read before this level's last barrier)
+            if (g == 0) { ctr->d_flag[par] = 0; ctr->d_cut[par] = 0xFFFFFFFFu; }     // (all read before this level's last barrier)
             break;
         }
     }

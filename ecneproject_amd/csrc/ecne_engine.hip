@@ -1166,7 +1166,9 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             hj[i].queue_mode = (uint32_t)o.queue_mode;
             {   // rounds on all workgroups: drain rounds (drain.hip.hpp) unless queue_mode 3 / ECNE_DRAIN=0 ask for the prefix rounds
                 static const int drain_env = []() { const char* e = getenv("ECNE_DRAIN"); return e ? atoi(e) : 1; }();      // 2: test hook (every frontier is drained)
-                hj[i].drain = o.queue_mode == 3 ? 0u : o.queue_mode == 4 ? 2u : drain_env <= 0 ? 0u : (uint32_t)std::min(drain_env, 2);
+                static const bool solo_off = []() { const char* e = getenv("ECNE_SOLO"); return e && atoi(e) == 0; }();
+                hj[i].drain = o.queue_mode == 3 ? 0u : o.queue_mode == 4 ? 3u : drain_env <= 0 ? 0u : drain_env >= 2 ? 3u : 1u;      // bit 0: drain rounds, bit 1: every frontier, bit 2: no solo drains
+                if (hj[i].drain && solo_off) hj[i].drain |= 4u;
             }
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }

@@ -105,7 +105,7 @@ struct Counters {   // one per job, device memory
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
     unsigned int q_cmd[8];          // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
-    unsigned int d_cut[2], d_pend[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows that cannot run in the level, rows left after it, "somebody is unstable"
+    unsigned int d_cut[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows left after the level, bit 0 "somebody is unstable" / bit 1 "somebody marked A"
     unsigned int q_part[2][256];
     unsigned int q_blk[2][ECNE_MAX_NWG * 8];   // per-wavefront totals of the block-order scan (team_block_scan)
     unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
@@ -173,7 +173,7 @@ struct Job {
     // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
     uint32_t *wmarkU, *wmarkB;
     uint32_t* dmk[6];          // drain rounds (drain.hip.hpp): epoch-keyed mark planes X / A / C, U and B class each; multi-workgroup jobs only
-    uint32_t drain;            // 1 = rounds on all workgroups are drain rounds (0: prefix rounds, queue_round_multi)
+    uint32_t drain;            // bit 0: rounds on all workgroups are drain rounds (0: prefix rounds, queue_round_multi); bit 1: test hook, every frontier is drained; bit 2: no solo drains
     uint32_t* best;            // per row: lowest candidate index that wants to push it
     uint32_t* prank;           // per row: its rank while it is being popped in a multi-workgroup round
     uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
             if ((J.rec[16ull * r] >> 24) == 0) const_cast<uint32_t*>(J.rec)[16ull * r + 1] = 0xFFFFFFFFu;
     for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
     for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
-    if (master && tid == 0) { ctr->err_key = ~0ull; ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; ctr->d_cut[0] = ctr->d_cut[1] = 0xFFFFFFFFu; ctr->d_pend[0] = ctr->d_pend[1] = 0; ctr->d_pend2[0] = ctr->d_pend2[1] = 0; ctr->d_flag[0] = ctr->d_flag[1] = 0; }
+    if (master && tid == 0) { ctr->err_key = ~0ull; ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; ctr->d_cut[0] = ctr->d_cut[1] = 0xFFFFFFFFu; ctr->d_pend2[0] = ctr->d_pend2[1] = 0; ctr->d_flag[0] = ctr->d_flag[1] = 0; }
     job_barrier(J, &s_err);
     for (uint32_t i = gtid; i < J.nLong; i += gstride) J.rdead[J.long_list[i]] = 2;   // bit 1: a long row (P3 evaluates it on a wavefront)
     for (uint32_t i = gtid; i < J.nKnown; i += gstride) {

@@ -683,7 +683,7 @@ __device__ __forceinline__ uint32_t multi_window_min(const Job& J) { return fast
 __device__ __forceinline__ bool drain_ok(const Job& J) { return J.drain != 0 && J.rec != nullptr; }
 // test hook (ECNE_DRAIN=2): every frontier of two rows and more goes to a drain round, whatever the streak -- the level logic then
 // sees the dependency chains and narrow windows the schedule normally keeps away from it
-__device__ __forceinline__ bool drain_eager(const Job& J) { return J.drain == 2 && J.rec != nullptr && J.nwg > 1; }
+__device__ __forceinline__ bool drain_eager(const Job& J) { return (J.drain & 2u) && J.rec != nullptr && J.nwg > 1; }
 __device__ __forceinline__ uint32_t multi_cap(const Job& J) { return J.nwg * ECNE_WG * (drain_ok(J) ? 1u : 2u); }
 #ifndef ECNE_DRAIN_GROW
 #define ECNE_DRAIN_GROW 6      // a drain that needed at most this many levels doubles the next window ...
@@ -764,6 +764,14 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     uint32_t declined_run = 0;
     const uint32_t burst_c = chain ? ECNE_CHAIN_BURST_C : ECNE_BURST_C, burst_avail = chain ? 0xFFFFFFFFu : 64u, burst_max = chain ? 4096u : 512u;
     uint32_t mwindow = 16384;        // window of multi-workgroup rounds (adaptive like `window`)
+    // Solo drain rounds: the master of a large job drains up to 512 rows by itself (queue_round_drain on a team of one: its job
+    // barriers are workgroup barriers) when fast rounds keep committing a few rows of a full window -- many dependency chains side
+    // by side, each with several rows queued (45 copies of a chained circuit in one file: ~5 of 64 rows per fast round).
+    Job Js = J;
+    Js.nwg = 1;
+    const bool solo_ok = drain_ok(J) && J.nwg > 1 && !(J.drain & 4u);       // (multi-workgroup jobs: their state lives in device memory; ECNE_SOLO=0 switches them off)
+    bool solo = false;
+    uint32_t solo_cool = 0;
     bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
     __syncthreads();
     while (q.head != q.tail) {
@@ -819,6 +827,31 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             __syncthreads();
             QTICK(6);
             continue;
+        }
+        if (solo) {
+            const uint32_t row0 = J.queue[q.head & J.qmask];
+            const uint32_t shape0 = J.rinfo[row0].shape;
+            const bool head_alone = (shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0);     // a long row that is popped alone
+            const uint32_t smin = (v2 && avail >= ECNE_V2_BACKLOG) ? 64u : multi_window_min(J);
+            if (avail < 2 || head_alone || (avail >= multi_min(J) && streak >= smin)) solo = false;        // (a wide independent frontier: all workgroups)
+            else {
+                const uint32_t ns = avail < (uint32_t)ECNE_WG ? avail : (uint32_t)ECNE_WG;
+                uint32_t cm = 0, nt = q.tail, levels = 0;
+                if (queue_round_drain(Js, S, 0, q.head, q.tail, ns, C, my_pops, my_nnz, s_err, &cm, &nt, &levels)) break;
+#ifdef ECNE_ROUNDLOG
+                if (tid == 0) printf("RL solo avail %u n %u c %u dt %llu levels %u\n", avail, ns, cm, wall_clock64() - qt_last, levels);
+#endif
+                q.head += cm;
+                q.tail = nt;
+                pops_total += cm;
+                hits[13]++;
+                if (tid == 0) { S.sd[3] += 1; S.sd[4] += cm; S.sd[5] += wall_clock64() - qt_last; }     // schedule diagnostics: solo drains in the "general wavefront rounds" slots
+                streak = levels <= 2 ? streak + cm : 0;
+                // a drain that runs fewer than two rows per level is a chain: back to the fast rounds and bursts for a while
+                if (cm < 2 * levels || cm < ns) { solo = false; solo_cool = 8; }
+                QTICK(6);
+                continue;
+            }
         }
         // adaptive window: examining rows that end up behind the cut is wasted work, so the window
         // follows the prefix lengths actually achieved (shrinks on short prefixes, doubles on full ones)
@@ -878,6 +911,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 hits[13]++;
                 declined_run = 0;
                 streak = cw == nx ? streak + cw : 0;
+                // a dependency cut a well-filled window short: several chains side by side -- the master drains the next windows by itself
+                if (solo_cool) --solo_cool;
+                else if (solo_ok && avail >= 32 && 8 * cw <= (avail < 64u ? avail : 64u)) solo = true;      // (whatever stopped the round: a dependency, or a row the fast round only takes at rank 0)
                 // (single-workgroup jobs: a short prefix goes to the chain executor whatever stopped it -- rows the fast round
                 //  does not take are cheap there; the master of a large job only bursts on true dependency chains)
                 if (cw < burst_c && (chain || cw < nx) && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
@@ -957,6 +993,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (tid == 0) {
                 J.ctr->q_cmd[1] = q.head; J.ctr->q_cmd[2] = q.tail; J.ctr->q_cmd[3] = nm;
                 J.ctr->q_cmd[4] = window; J.ctr->q_cmd[5] = mwindow;
+                J.ctr->q_cmd[6] = S.depoch;      // the master's solo drain rounds moved its mark epoch on: everybody continues from there
                 __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (job_barrier(J, s_err)) { helpers_released = true; break; }
@@ -1273,6 +1310,8 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
         if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
         uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
         uint32_t window = ld_agent(&J.ctr->q_cmd[4]), mwindow = ld_agent(&J.ctr->q_cmd[5]);
+        if (threadIdx.x == 0) S.depoch = ld_agent(&J.ctr->q_cmd[6]);
+        __syncthreads();
         const uint32_t cap_n = multi_cap(J);
         const bool drain = drain_ok(J);
         bool failed = false;
