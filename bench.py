@@ -307,8 +307,12 @@ def main():
         latency = {"rounds": n_rounds, "us_per_round": 1e3 * q_ms / max(n_rounds, 1),
                    "multi_workgroup_rounds": n_multi, "us_per_multi_round": 1e3 * multi_ms / max(n_multi, 1),
                    "fast_wavefront_rounds": sd[0], "rows_in_fast_rounds": sd[1], "us_per_fast_round": sd[2] * 1e-2 / max(sd[0], 1),
-                   "general_wavefront_rounds": sd[3], "outer_iterations": int(s.outer_iterations),
-                   "model": "t_solve ~ rounds x us_per_round + P-phases; %d levels at %.1f us" % (n_rounds, 1e3 * q_ms / max(n_rounds, 1))}
+                   "outer_iterations": int(s.outer_iterations),
+                   # drain rounds (csrc/drain.hip.hpp): a window executed in dataflow order, level by level, pushes resolved once per window;
+                   # a level costs 2 job barriers (nobody contested anything) to 4, the resolution 4
+                   "drain_rounds": int(round(float(s.multi_ms[7]) * 1e5)), "drain_levels": int(round(float(s.multi_ms[6]) * 1e5)),
+                   "solo_drain_rounds": sd[3], "rows_in_solo_drains": sd[4], "us_per_solo_drain": sd[5] * 1e-2 / max(sd[3], 1),
+                   "model": "t_solve ~ rounds x us_per_round + P-phases; %d rounds at %.1f us" % (n_rounds, 1e3 * q_ms / max(n_rounds, 1))}
         out = {
             "metric": "constraints resolved/sec (wall-clock to fixed point), ecdsa-scale R1CS",
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -49,6 +49,15 @@ __device__ __forceinline__ fp::u256 r7_abs(const fp::u256& c) {
     return c;
 }
 
+// exclusive prefix sum over the 64 lanes of a wavefront; *total = the sum
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t* total) {
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += y; }
+    *total = __shfl(incl, 63, 64);
+    return incl - x;
+}
+
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -722,6 +722,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_ctr = c.take(sizeof(Counters));
     char* base = nullptr;
     HIP_TRY(hipMalloc((void**)&base, c.off));
+    if (getenv("ECNE_POISON")) HIP_TRY(hipMemset(base, 0xA5, c.off));      // test hook: whatever the solve reads before writing it shows up
     S.dev.arena = base;
     S.dev.arena_bytes = c.off;
     S.dev.device = device;
@@ -1181,14 +1182,16 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
         // single-workgroup jobs keep their hot state there (k_solve, "LDS residency")
         uint32_t dyn_lds = 0;
         {
-            hipFuncAttributes fa;
+            // (two kernels, k_solve for single-workgroup jobs and k_solve_team: the same dynamic LDS for both)
+            hipFuncAttributes fa, fb;
             int lds_max = 0;
-            if (hipFuncGetAttributes(&fa, (const void*)k_solve) == hipSuccess &&
+            if (hipFuncGetAttributes(&fa, (const void*)k_solve) == hipSuccess && hipFuncGetAttributes(&fb, (const void*)k_solve_team) == hipSuccess &&
                 hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, o.device) == hipSuccess &&
-                (size_t)lds_max > fa.sharedSizeBytes + 1024) {
-                dyn_lds = ((uint32_t)lds_max - (uint32_t)fa.sharedSizeBytes - 256u) & ~255u;
+                (size_t)lds_max > std::max(fa.sharedSizeBytes, fb.sharedSizeBytes) + 1024) {
+                dyn_lds = ((uint32_t)lds_max - (uint32_t)std::max(fa.sharedSizeBytes, fb.sharedSizeBytes) - 256u) & ~255u;
                 if (const char* e = getenv("ECNE_LDS_BYTES")) dyn_lds = std::min<uint32_t>(dyn_lds, (uint32_t)atoi(e));   // test hook
-                if (dyn_lds && hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess) dyn_lds = 0;
+                if (dyn_lds && (hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess ||
+                                hipFuncSetAttribute((const void*)k_solve_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess)) dyn_lds = 0;
             }
             (void)hipGetLastError();
         }
@@ -1220,7 +1223,8 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             const bool coop_ok = getenv("ECNE_COOPERATIVE") && atoi(getenv("ECNE_COOPERATIVE")) != 0 &&
                                  hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, o.device) == hipSuccess && coop_attr != 0;
             int wg_per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k_solve, ECNE_WG, dyn_lds) != hipSuccess) { wg_per_cu = 1; (void)hipGetLastError(); }
+            const void* const kernel = any_multi ? (const void*)k_solve_team : (const void*)k_solve;      // single-workgroup jobs: the kernel without team code
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kernel, ECNE_WG, dyn_lds) != hipSuccess) { wg_per_cu = 1; (void)hipGetLastError(); }
             const size_t resident_cap = (size_t)std::max(wg_per_cu, 0) * (size_t)n_cu;
             bool refused = false;
             (void)hipEventRecord(e0, stream);
@@ -1243,12 +1247,15 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                     const Job* a0 = d_jobs;
                     const WgDesc* a1 = d_descs;
                     void* kargs[2] = {(void*)&a0, (void*)&a1};
-                    const hipError_t ce = hipLaunchCooperativeKernel((const void*)k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), kargs, dyn_lds, stream);
+                    const hipError_t ce = hipLaunchCooperativeKernel(kernel, dim3((unsigned)descs.size()), dim3(ECNE_WG), kargs, dyn_lds, stream);
                     if (ce == hipSuccess) launched = true;
                     else if (ce == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); refused = true; fail = true; break; }
                     else (void)hipGetLastError();      // (not available on this stack: the plain launch below, with the barrier's own time bound)
                 }
-                if (!launched) hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                if (!launched) {
+                    if (any_multi) hipLaunchKernelGGL(k_solve_team, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                    else hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                }
                 if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
             }
             (void)hipEventRecord(e1, stream);

@@ -39,7 +39,9 @@ struct DevMem {      // one allocation, carved
     void free_now() { if (base) (void)hipFree(base); base = nullptr; }
     int alloc(size_t bytes) {
         cap = bytes + 256;
-        return hipMalloc((void**)&base, cap) == hipSuccess ? K_OK : K_ENODEVICE;
+        if (hipMalloc((void**)&base, cap) != hipSuccess) return K_ENODEVICE;
+        if (std::getenv("ECNE_POISON") && hipMemset(base, 0xA5, cap) != hipSuccess) return K_ENODEVICE;      // test hook (see ecne_engine.hip)
+        return K_OK;
     }
     template <class T> T* take(size_t n) {
         const size_t o = off;
@@ -99,6 +101,7 @@ int alloc_rows(DevRows& D, int device, uint64_t n, const uint64_t terms[3]) {
     size_t bytes = 0;
     for (int p = 0; p < 3; ++p) bytes += DevMem::sz(n + 1, 8) + DevMem::sz(std::max<uint64_t>(terms[p], 1), 4) + DevMem::sz(std::max<uint64_t>(terms[p], 1), 32);
     FE_TRY(hipMalloc(&D.arena, bytes + 256));
+    if (std::getenv("ECNE_POISON")) FE_TRY(hipMemset(D.arena, 0xA5, bytes + 256));
     D.arena_bytes = bytes + 256;
     char* b = (char*)D.arena;
     size_t off = 0;

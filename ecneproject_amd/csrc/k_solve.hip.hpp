@@ -8,7 +8,11 @@ namespace ecne {
 // ---------------------------------------------------------------------------------------- k_solve
 struct WgDesc { uint32_t job, rank; };
 
-__global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc* wgs) {
+// TEAM = false: the kernel of single-workgroup jobs. It has no code for helper workgroups, rounds on all workgroups or drain
+// rounds: with that code in the same kernel (registers of the callee chain, 1.2 KB more scratch per lane) every phase of a
+// small solve -- setup, P3, the chain executor's bursts -- measured 4-9 % slower (tools/ab_old_new.py).
+template <bool TEAM>
+__device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs) {
     __shared__ Job J;
     __shared__ uint32_t s_scan[ECNE_NWAVES + 2];
     __shared__ uint32_t s_u32[8];
@@ -184,20 +188,26 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                     int from = 0;
                     for (;;) {
                         bool can = i < J.nSp && lane >= from && !J.fired[nC + i];   // [nC..) = special_solved
-                        if (can)
-                            for (uint32_t e = J.sp_in_ptr[i]; e < J.sp_in_ptr[i + 1] && can; ++e) can = (J.flags[J.sp_in[e]] & 1) != 0;
+                        if (can) {
+                            // (four inputs per trip, ids first, then their flag bytes: two round trips per four inputs instead of per input)
+                            const uint32_t e1 = J.sp_in_ptr[i + 1];
+                            for (uint32_t e = J.sp_in_ptr[i]; e < e1 && can; e += 4) {
+                                uint32_t vv[4];
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k) vv[k] = e + k < e1 ? J.sp_in[e + k] : 1u;       // (padding: the constant wire, always unique)
+                                uint32_t all = 1;
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k) all &= J.flags[vv[k]];
+                                can = (all & 1) != 0;
+                            }
+                        }
                         const uint64_t m = __ballot(can);
                         if (!m) break;
                         const int src = __ffsll((long long)m) - 1;
                         const uint32_t is = base + (uint32_t)src;
                         if (lane == 0) J.fired[nC + is] = 1;
                         steps++; hits[8]++;
-                        for (uint32_t e = J.sp_out_ptr[is]; e < J.sp_out_ptr[is + 1]; ++e) {
-                            uint32_t v = J.sp_out[e];
-                            if (J.flags[v] & 1) continue;
-                            mark_unique(J, v);
-                            requeue(J, q, v);
-                        }
+                        p1_fire_outputs(J, q, is);
                         from = src + 1;
                     }
                 }
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                     }
                 }
                 if (lane == 0) { s_q = q; s_steps = steps; }
+                tk[7] += wall_clock64() - t_last;      // diagnostics: P1 + P2 alone (phase_ms[7]); the slot-1 clock keeps running
             }
             __syncthreads();
             steps = s_steps;
@@ -263,12 +274,12 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
                 // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
                 unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
                 for (int i = 0; i < 16; ++i) ht2[i] = 0;
-                queue_phase_chunked(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
+                queue_phase_chunked<TEAM>(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
                 steps = st2;
                 if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
             }
         }
-        else if (!seq_mode) queue_phase_helper(J, s_chunk, me.rank, &s_err);
+        else if (!seq_mode) { if constexpr (TEAM) queue_phase_helper(J, s_chunk, me.rank, &s_err); }
         if (job_barrier(J, &s_err)) break;      // publishes the queue phase's state changes to the helpers
         if (master && J.nwg > 1 && !seq_mode) {
             // fold in what the helpers did during multi-workgroup rounds
@@ -729,5 +740,8 @@ __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc
         }
     }
 }
+
+__global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc* wgs) { k_solve_body<false>(jobs, wgs); }
+__global__ __launch_bounds__(ECNE_WG) void k_solve_team(const Job* jobs, const WgDesc* wgs) { k_solve_body<true>(jobs, wgs); }
 
 }  // namespace ecne

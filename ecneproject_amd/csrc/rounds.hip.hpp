@@ -18,32 +18,58 @@ namespace ecne {
 // except cand[] / best[] / inq[] / wmark, which are read after a barrier. Returns nonzero on error.
 __device__ uint32_t team_exclusive_scan(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t buf,
                                         uint32_t* total, int* s_err, int* err_out) {
+    static_assert(ECNE_MAX_NWG <= 256, "the scan over the workgroup totals is one wavefront with four values per lane");
     uint32_t wgtot;
     const uint32_t local = wg_exclusive_scan(x, S.scan, &wgtot);
     if (threadIdx.x == 0) __hip_atomic_store(&J.ctr->q_part[buf][wgrank], wgtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *err_out = job_barrier(J, s_err);
-    if (threadIdx.x < J.nwg) S.bases[threadIdx.x] = ld_agent(&J.ctr->q_part[buf][threadIdx.x]);
+    // prefix over the workgroups: wavefront 0, four totals per lane (a loop over J.nwg values per thread cost 7 us at 248 workgroups)
+    if (wave_id() == 0) {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t v[4], sum = 0, below = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) v[k] = 4u * lane + k < J.nwg ? ld_agent(&J.ctr->q_part[buf][4u * lane + k]) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) { if (4u * lane + k < wgrank) below += v[k]; sum += v[k]; }
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(sum, &tot);
+        if (lane == (wgrank >> 2)) S.bases[0] = ex + below;
+        if (lane == 0) S.bases[1] = tot;
+    }
     __syncthreads();
-    uint32_t pre = 0, tot = 0;
-    for (uint32_t i = 0; i < J.nwg; ++i) { const uint32_t v = S.bases[i]; if (i < wgrank) pre += v; tot += v; }
+    const uint32_t pre = S.bases[0];
+    *total = S.bases[1];
     __syncthreads();
-    *total = tot;
     return pre + local;
 }
 
 // Job-wide exclusive scan in BLOCK order: wavefront v of workgroup w owns block b = v * nwg + w (64 lanes),
 // the scan runs over blocks 0, 1, 2, ... and inside a block over the lanes. Used where the ranks of a round
 // are dealt out to the workgroups wavefront by wavefront (queue_round_multi), so that the order of the
-// scan is the order of the ranks.
-__device__ uint32_t team_block_scan(const Job& J, uint32_t wgrank, uint32_t x, uint32_t buf, uint32_t* total, int* s_err, int* err_out) {
+// scan is the order of the ranks. (Every workgroup scans all block totals, four per thread: a per-lane loop over
+// them was 31 dependent-issue loads at 248 workgroups.)
+__device__ uint32_t team_block_scan(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t x, uint32_t buf, uint32_t* total, int* s_err, int* err_out) {
+    static_assert(ECNE_MAX_NWG * ECNE_NWAVES <= 4 * ECNE_WG, "four block totals per thread");
     const uint32_t lane = (uint32_t)lane_id(), b = (uint32_t)wave_id() * J.nwg + wgrank, nblocks = J.nwg * ECNE_NWAVES;
     uint32_t wtot;
     const uint32_t local = wave_excl_scan(x, &wtot);
     if (lane == 0) __hip_atomic_store(&J.ctr->q_blk[buf][b], wtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *err_out = job_barrier(J, s_err);
-    uint32_t pre = 0, tot = 0;
-    for (uint32_t i = lane; i < nblocks; i += 64) { const uint32_t v = ld_agent(&J.ctr->q_blk[buf][i]); if (i < b) pre += v; tot += v; }
-    for (int d = 32; d >= 1; d >>= 1) { pre += __shfl_xor(pre, d, 64); tot += __shfl_xor(tot, d, 64); }
+    const uint32_t t4 = 4u * (uint32_t)threadIdx.x;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) { v[k] = t4 + k < nblocks ? ld_agent(&J.ctr->q_blk[buf][t4 + k]) : 0u; sum += v[k]; }
+    uint32_t tot;
+    uint32_t run = wg_exclusive_scan(sum, S.scan, &tot);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = t4 + k;
+        if (i < nblocks && i % J.nwg == wgrank) S.bases[i / J.nwg] = run;      // block i = wavefront (i / nwg) of this workgroup
+        run += v[k];
+    }
+    __syncthreads();
+    const uint32_t pre = S.bases[wave_id()];
+    __syncthreads();
     *total = tot;
     return pre + local;
 }
@@ -107,7 +133,7 @@ __device__ __noinline__ int multi_finish(const Job& J, ChunkShared& S, uint32_t 
             }
     }
     uint32_t M;
-    const uint32_t cbase = team_block_scan(J, wgrank, mycand, 0, &M, s_err, &err);   // candidates in rank order
+    const uint32_t cbase = team_block_scan(J, S, wgrank, mycand, 0, &M, s_err, &err);   // candidates in rank order
     MTICK(2);
     if (err) return err;
     if (M == 0) {
@@ -695,6 +721,14 @@ __device__ __forceinline__ void drain_window_update(uint32_t levels, uint32_t nm
     if (levels <= ECNE_DRAIN_GROW) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
     else if (levels > ECNE_DRAIN_SHRINK) mwindow = nm / 2 > 1024u ? nm / 2 : 1024u;
 }
+// a drain round on a team of one: the master by itself (the copy of the job lives in this frame only: queue_phase_chunked's own
+// is tight -- its sequential bursts call the chain executor thousands of times per solve and pay for every value kept alive)
+__device__ __noinline__ int queue_round_solo(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
+                                            uint32_t& my_pops, uint32_t& my_nnz, int* s_err, uint32_t* out_c, uint32_t* out_tail, uint32_t* out_levels) {
+    Job Js = J;
+    Js.nwg = 1;
+    return queue_round_drain(Js, S, 0, head, tail, n, C, my_pops, my_nnz, s_err, out_c, out_tail, out_levels);
+}
 // ---- chained multi-workgroup rounds
 // After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
 // decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
@@ -734,6 +768,7 @@ __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head
     return nm;
 }
 
+template <bool TEAM>
 __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
                                     unsigned long long& steps, unsigned long long& nuniq,
                                     unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
@@ -767,9 +802,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     // Solo drain rounds: the master of a large job drains up to 512 rows by itself (queue_round_drain on a team of one: its job
     // barriers are workgroup barriers) when fast rounds keep committing a few rows of a full window -- many dependency chains side
     // by side, each with several rows queued (45 copies of a chained circuit in one file: ~5 of 64 rows per fast round).
-    Job Js = J;
-    Js.nwg = 1;
-    const bool solo_ok = drain_ok(J) && J.nwg > 1 && !(J.drain & 4u);       // (multi-workgroup jobs: their state lives in device memory; ECNE_SOLO=0 switches them off)
+    const bool solo_ok = TEAM && drain_ok(J) && J.nwg > 1 && !(J.drain & 4u);       // (multi-workgroup jobs: their state lives in device memory; ECNE_SOLO=0 switches them off)
     bool solo = false;
     uint32_t solo_cool = 0;
     bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
@@ -828,7 +861,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             QTICK(6);
             continue;
         }
-        if (solo) {
+        if (TEAM && solo) {
             const uint32_t row0 = J.queue[q.head & J.qmask];
             const uint32_t shape0 = J.rinfo[row0].shape;
             const bool head_alone = (shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0);     // a long row that is popped alone
@@ -837,7 +870,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             else {
                 const uint32_t ns = avail < (uint32_t)ECNE_WG ? avail : (uint32_t)ECNE_WG;
                 uint32_t cm = 0, nt = q.tail, levels = 0;
-                if (queue_round_drain(Js, S, 0, q.head, q.tail, ns, C, my_pops, my_nnz, s_err, &cm, &nt, &levels)) break;
+                if constexpr (TEAM) { if (queue_round_solo(J, S, q.head, q.tail, ns, C, my_pops, my_nnz, s_err, &cm, &nt, &levels)) break; }
 #ifdef ECNE_ROUNDLOG
                 if (tid == 0) printf("RL solo avail %u n %u c %u dt %llu levels %u\n", avail, ns, cm, wall_clock64() - qt_last, levels);
 #endif
@@ -865,7 +898,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             n = avail < cap_ ? avail : cap_;
         }
         if (v2wg && J.nwg == 1 && n > ECNE_WG) n = ECNE_WG;
-        const bool eager = drain_eager(J) && avail >= 2;
+        const bool eager = TEAM && drain_eager(J) && avail >= 2;
         if (n <= 64 && !declined_wide && !eager) {
             // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
             if (w == 0) {
@@ -963,7 +996,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         uint32_t live = 0, noop = 0, noop_b = 0;                    // bit s = slot s
         // (a frontier that goes to all workgroups anyway: only the row at the head matters here -- is it a long row that has to be
         //  popped alone? -- the round loads its rows itself)
-        const bool want_multi = eager || (J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide));
+        const bool want_multi = TEAM && (eager || (J.nwg > 1 && avail >= multi_min(J) && ((v2 ? streak >= streak_min : window >= multi_window_min(J)) || declined_wide)));
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
             row[sl] = 0; shape[sl] = 0; xv[sl] = 0;

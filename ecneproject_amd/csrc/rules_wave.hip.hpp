@@ -76,6 +76,56 @@ __device__ __forceinline__ void mark_unique(const Job& J, uint32_t v) {
     wg_fence();
 }
 
+// P1 (:735-746): the outputs of special `is` that are not unique yet become unique and known and are re-queued, in order. The
+// wavefront takes up to 64 outputs at a time: ids, flag bytes and fan-out bounds in one round trip each, then all push
+// candidates of the batch in (output, fan-out position) order -- what one REQUEUE after the other leaves in the queue (a row is
+// pushed by the first candidate that finds it out of the queue). One output at a time this was six dependent round trips per
+// output, ~50 us per outer iteration on an ECDSA-scale circuit (one adder fires per iteration, six outputs).
+__device__ __noinline__ void p1_fire_outputs(const Job& J, QState& q, uint32_t is) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t o0 = J.sp_out_ptr[is], o1 = J.sp_out_ptr[is + 1];
+    for (uint32_t ob = o0; ob < o1; ob += 64) {
+        const uint32_t nb = o1 - ob < 64u ? o1 - ob : 64u;
+        const bool act = lane < nb;
+        const uint32_t v = act ? J.sp_out[ob + lane] : 1u;
+        const uint8_t f = J.flags[v];
+        const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+        bool dup = false;           // the same variable earlier in the list: that occurrence makes it unique, this one finds it so
+        for (uint32_t e = 0; e < nb; ++e) { const uint32_t ve = (uint32_t)__shfl((int)v, (int)e, 64); if (e < lane && ve == v) dup = true; }
+        const bool todo = act && !(f & 1) && !dup;
+        if (todo) J.flags[v] = (uint8_t)(f | 3);
+        const uint32_t deg = todo ? f1 - f0 : 0u;
+        uint32_t M;
+        const uint32_t cb = wave_excl_scan(deg, &M);
+        for (uint32_t jb = 0; jb < M; jb += 64) {
+            const uint32_t j = jb + lane;
+            const bool have = j < M;
+            uint32_t k = 0;
+            for (uint32_t e = 0; e < nb; ++e) {
+                const uint32_t be = (uint32_t)__shfl((int)cb, (int)e, 64), de = (uint32_t)__shfl((int)deg, (int)e, 64), fe = (uint32_t)__shfl((int)f0, (int)e, 64);
+                if (have && j >= be && j - be < de) k = fe + (j - be);
+            }
+            const uint32_t r = have ? J.fo_rows[k] : 0u;
+            bool push = have && J.inq[r] == 0;
+            const uint32_t nj = M - jb < 64u ? M - jb : 64u;
+            for (uint32_t e = 0; e + 1 < nj; ++e) {      // the same row twice in this batch: the first candidate pushes it
+                const uint32_t re = (uint32_t)__shfl((int)r, (int)e, 64);
+                const int pe = __shfl((int)push, (int)e, 64);
+                if (e < lane && pe && re == r) push = false;
+            }
+            const uint64_t m = __ballot(push);
+            if (push) {
+                const uint32_t pos = q.tail + (uint32_t)__popcll(m & lanes_below());
+                J.queue[pos & J.qmask] = r;
+                J.inq[r] = 1;
+            }
+            q.tail += (uint32_t)__popcll(m);
+            wg_fence();
+        }
+        wg_fence();
+    }
+}
+
 // walk C entries [c0,c1) in stored (= reference Set) order; every non-unique variable other than
 // `skip` becomes unique and is re-queued, in order. Returns how many.
 __device__ __noinline__ uint32_t uniq_range_and_requeue(const Job& J, QState& q, uint32_t c0, uint32_t c1, uint32_t skip) {

@@ -163,13 +163,6 @@ __device__ __forceinline__ int wg_error(const Job& J, int* s_err) {
 
 // ---- wavefront-level helpers
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t* total) {
-    uint32_t incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += y; }
-    *total = __shfl(incl, 63, 64);
-    return incl - x;
-}
 __device__ __forceinline__ uint32_t wave_min(uint32_t x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(x, d, 64); x = y < x ? y : x; }

@@ -25,7 +25,7 @@ for mode in ([int(m) for m in sys.argv[2:]] or [0]):
             best = r
     sm = best.summary
     print(rel, "mode", mode, "rows", len(s), "status", best.status, "dev_ms %.3f" % sm.device_ms, "pops", sm.pops, "outer", sm.outer_iterations,
-          "rounds", sm.rule_hits[13], "alone", sm.rule_hits[14] & 0xFFFF, "\n   phases[setup,P1+P2+queue,P3,P4,P5,verdict]", [round(x, 3) for x in sm.phase_ms[:6]], "P3 passes", int(sm.phase_ms[6]),
+          "rounds", sm.rule_hits[13], "alone", sm.rule_hits[14] & 0xFFFF, "\n   phases[setup,P1+P2+queue,P3,P4,P5,verdict]", [round(x, 3) for x in sm.phase_ms[:6]], "P3 passes", int(sm.phase_ms[6]), "P1+P2 alone %.3f" % sm.phase_ms[7],
           "\n   queue[head,mark,check,exec,flatten,resolve,alone+bursts+wave,multi]", [round(x, 3) for x in sm.queue_ms[:8]], "\n   hits", list(sm.rule_hits[:13]))
     mm = list(sm.multi_ms)
     print("   multi[mark,check,exec+scan,expand,count+scan,write]", [round(x, 3) for x in mm[:6]], "drain levels %d rounds %d" % (round(mm[6] * 1e5), round(mm[7] * 1e5)))
