@@ -826,6 +826,7 @@ static int upload_system(ecne_system& S, int device) {
     J.hot = (uint32_t*)(base + o_hot); J.fired = (uint8_t*)(base + o_fired); J.events = (uint32_t*)(base + o_events);
     for (int p = 0; p < 6; ++p) J.dmk[p] = (uint32_t*)(base + o_dmk[p]);
     J.drain = 0;
+    J.subteam = 0;
     J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best); J.prank = (uint32_t*)(base + o_prank);
     J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
     J.candcap = (uint32_t)std::max<size_t>(ECNE_CANDCAP, 8ull * nC);
@@ -1170,6 +1171,8 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 static const bool solo_off = []() { const char* e = getenv("ECNE_SOLO"); return e && atoi(e) == 0; }();
                 hj[i].drain = o.queue_mode == 3 ? 0u : o.queue_mode == 4 ? 3u : drain_env <= 0 ? 0u : drain_env >= 2 ? 3u : 1u;      // bit 0: drain rounds, bit 1: every frontier, bit 2: no solo drains
                 if (hj[i].drain && solo_off) hj[i].drain |= 4u;
+                static const bool sub_off = []() { const char* e = getenv("ECNE_SUBTEAM"); return e && atoi(e) == 0; }();      // bit 3: rounds always on all workgroups
+                if (sub_off) hj[i].drain |= 8u;
             }
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }

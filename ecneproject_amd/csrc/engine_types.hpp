@@ -98,12 +98,14 @@ struct Counters {   // one per job, device memory
     unsigned int xcd_members[8];                  // workgroups of this job resident on each XCD
     unsigned int n_xcd_active, bar_ready;
     unsigned int heartbeat;                       // bumped by the master while it works alone (bounds the barrier wait, job_barrier)
+    alignas(128) unsigned int sub_count;          // flat barrier of a sub-team (the first K workgroups of the job, rounds.hip.hpp multi_chain)
+    alignas(128) unsigned int sub_gen;
     alignas(128) unsigned int pad_after_barrier;
     unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;
     unsigned int p3_hot;   // some k >= 2 group could be complete in this pass (else nobody looks at the table)
     unsigned int p4_nfired, setup_tail;
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
-    unsigned int q_cmd[8];          // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow
+    unsigned int q_cmd[12];         // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow, mark epoch, team size K, sub-team barrier generation
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
     unsigned int d_cut[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows left after the level, bit 0 "somebody is unstable" / bit 1 "somebody marked A"
     unsigned int q_part[2][256];
@@ -173,6 +175,7 @@ struct Job {
     // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
     uint32_t *wmarkU, *wmarkB;
     uint32_t* dmk[6];          // drain rounds (drain.hip.hpp): epoch-keyed mark planes X / A / C, U and B class each; multi-workgroup jobs only
+    uint32_t subteam;          // device-side copies only: 1 = this Job stands for the first `nwg` workgroups of the job, which meet at the sub-team barrier
     uint32_t drain;            // bit 0: rounds on all workgroups are drain rounds (0: prefix rounds, queue_round_multi); bit 1: test hook, every frontier is drained; bit 2: no solo drains
     uint32_t* best;            // per row: lowest candidate index that wants to push it
     uint32_t* prank;           // per row: its rank while it is being popped in a multi-workgroup round

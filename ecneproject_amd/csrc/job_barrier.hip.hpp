@@ -22,17 +22,51 @@ __device__ __forceinline__ uint32_t my_xcc_id() {
 // What a workgroup remembers between job barriers (LDS): the generation it waits for next and, once the
 // first barrier of the launch has established them, its XCD's member count and the number of XCDs in use
 // -- so that a barrier costs one atomic per level and one polled word, no other memory round trips.
-struct BarLocal { unsigned gen, members, nxcd, ready; };
+struct BarLocal { unsigned gen, members, nxcd, ready, sgen; };
 __device__ __forceinline__ BarLocal& bar_local() {
     __shared__ BarLocal b;
     return b;
 }
 __device__ __forceinline__ void job_barrier_init() {   // thread 0, once per launch (the device words are zeroed by the host)
     BarLocal& b = bar_local();
-    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0;
+    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0; b.sgen = 0;
+}
+
+// Barrier of a SUB-TEAM: the first J.nwg workgroups of the job (J is a copy of the job with nwg = K and subteam = 1, made by
+// multi_chain in rounds.hip.hpp; the others wait at the job's own barrier for the next command). Flat -- every workgroup releases
+// and acquires, one counter, one generation word -- which costs what the hierarchical one costs up to ~48 workgroups. The local
+// generation is set from the master's command at the start of every chain (different chains have different members).
+__device__ int sub_barrier(const Job& J, int* s_err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Counters* c = J.ctr;
+        BarLocal& b = bar_local();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned g = b.sgen;
+        const unsigned arrived = __hip_atomic_fetch_add(&c->sub_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == J.nwg - 1) {
+            const int e = __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->sub_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->sub_gen, ((g + 1u) << 1) | (e != 0 ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned spins = 0, w;
+        unsigned long long t_wait0 = wall_clock64();
+        while (((w = __hip_atomic_load(&c->sub_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 1023u) == 0 && wall_clock64() - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) { raise(J, K_ETIMEOUT); w = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        b.sgen = g + 1;
+        *s_err = (w & 1u) ? __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+    __syncthreads();
+    return *s_err;
 }
 
 __device__ int job_barrier(const Job& J, int* s_err) {
+    if (J.subteam && J.nwg > 1) return sub_barrier(J, s_err);
     __syncthreads();
     if (threadIdx.x == 0) {
         Counters* c = J.ctr;
@@ -85,7 +119,9 @@ __device__ int job_barrier(const Job& J, int* s_err) {
             unsigned long long t_wait0 = wall_clock64();
             unsigned hb = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (((w = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
-                __builtin_amdgcn_s_sleep(8);
+                // (a workgroup that waits long -- outside the team of a chain of rounds, or a helper while the master works alone -- backs
+                //  off: hundreds of pollers take memory bandwidth and latency from the workgroups that work)
+                if (spins < 48) __builtin_amdgcn_s_sleep(8); else if (spins < 192) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
                 if ((++spins & 1023u) == 0) {
                     const unsigned long long now = wall_clock64();
                     const unsigned hb2 = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

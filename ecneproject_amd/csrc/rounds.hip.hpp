@@ -55,6 +55,13 @@ __device__ uint32_t team_block_scan(const Job& J, ChunkShared& S, uint32_t wgran
     const uint32_t local = wave_excl_scan(x, &wtot);
     if (lane == 0) __hip_atomic_store(&J.ctr->q_blk[buf][b], wtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *err_out = job_barrier(J, s_err);
+    if (nblocks <= 64) {       // a small team (the master by itself: 8 blocks): one value per lane, no workgroup scan
+        const uint32_t v = lane < nblocks ? ld_agent(&J.ctr->q_blk[buf][lane]) : 0u;
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(v, &tot);
+        *total = tot;
+        return (uint32_t)__shfl((int)ex, (int)b, 64) + local;
+    }
     const uint32_t t4 = 4u * (uint32_t)threadIdx.x;
     uint32_t v[4], sum = 0;
 #pragma unroll
@@ -721,14 +728,6 @@ __device__ __forceinline__ void drain_window_update(uint32_t levels, uint32_t nm
     if (levels <= ECNE_DRAIN_GROW) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
     else if (levels > ECNE_DRAIN_SHRINK) mwindow = nm / 2 > 1024u ? nm / 2 : 1024u;
 }
-// a drain round on a team of one: the master by itself (the copy of the job lives in this frame only: queue_phase_chunked's own
-// is tight -- its sequential bursts call the chain executor thousands of times per solve and pay for every value kept alive)
-__device__ __noinline__ int queue_round_solo(const Job& J, ChunkShared& S, uint32_t head, uint32_t tail, uint32_t n, LaneCtr& C,
-                                            uint32_t& my_pops, uint32_t& my_nnz, int* s_err, uint32_t* out_c, uint32_t* out_tail, uint32_t* out_levels) {
-    Job Js = J;
-    Js.nwg = 1;
-    return queue_round_drain(Js, S, 0, head, tail, n, C, my_pops, my_nnz, s_err, out_c, out_tail, out_levels);
-}
 // ---- chained multi-workgroup rounds
 // After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
 // decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
@@ -768,6 +767,41 @@ __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head
     return nm;
 }
 
+// ---- a chain of rounds on a TEAM: the first K workgroups of the job (K = J.nwg: everybody, the job's own barrier; K < J.nwg: a
+// sub-team with a flat barrier of its own, the other workgroups wait at the job barrier for the next command; K = 1: the master
+// by itself, "solo": its barriers are workgroup barriers). A frontier of 6 000 rows is 12 workgroups' worth of lanes: 248
+// workgroups meeting six times per round cost 64 us per round, 43 cost 45. The copy of the job with nwg = K lives in this frame
+// only (queue_phase_chunked's own is tight: its sequential bursts call the chain executor thousands of times per solve).
+struct ChainState { uint32_t head, tail, window, mwindow, streak, rounds, sd[3]; unsigned long long rows; };
+__device__ __noinline__ int multi_chain(const Job& J0, uint32_t K, ChunkShared& S, uint32_t wgrank, uint32_t nm, uint32_t max_rounds,
+                                       ChainState& st, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err) {
+    Job Js;
+    const Job* Jp = &J0;
+    if (K < J0.nwg) { Js = J0; Js.nwg = K; Js.subteam = 1; Jp = &Js; }
+    const Job& J = *Jp;
+    const uint32_t cap_n = multi_cap(J);
+    const bool drain = drain_ok(J);
+    for (uint32_t chain = 1;; ++chain) {       // chained rounds, see multi_chain_next
+        uint32_t cm = 0, ntm = st.tail, levels = 0;
+        if (drain ? queue_round_drain(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm, &levels)
+                  : queue_round_multi(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) return 1;
+#ifdef ECNE_ROUNDLOG
+        if (wgrank == 0 && threadIdx.x == 0) printf("RL %s avail %u n %u c %u dt %llu levels %u team %u\n", K == 1 ? "solo" : "multi", st.tail - st.head, nm, cm, 0ull, levels, K);
+#endif
+        st.head += cm;
+        st.tail = ntm;
+        st.rounds += 1;
+        st.rows += cm;
+        st.sd[cm < 64 ? 0 : cm < 4096 ? 1 : 2] += 1;
+        st.streak = (cm == nm && (!drain || levels <= 2 || K > 1)) ? st.streak + cm : 0;
+        if (drain && cm == nm) drain_window_update(levels, nm, cap_n, st.mwindow);
+        else multi_window_update(cm, nm, cap_n, st.mwindow, st.window);
+        if (K == 1 && (cm < 2 * levels || cm < nm)) return 0;      // a solo drain that runs fewer than two rows per level is a chain: back to the fast rounds
+        if (K < J0.nwg && st.tail - st.head > 2 * cap_n) return 0;  // the frontier has outgrown the team: the master commands a larger one
+        nm = chain < max_rounds ? multi_chain_next(J, st.head, st.tail, st.window, st.mwindow, cm, nm) : 0;
+        if (!nm) return 0;
+    }
+}
 template <bool TEAM>
 __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
                                     unsigned long long& steps, unsigned long long& nuniq,
@@ -869,19 +903,19 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (avail < 2 || head_alone || (avail >= multi_min(J) && streak >= smin)) solo = false;        // (a wide independent frontier: all workgroups)
             else {
                 const uint32_t ns = avail < (uint32_t)ECNE_WG ? avail : (uint32_t)ECNE_WG;
-                uint32_t cm = 0, nt = q.tail, levels = 0;
-                if constexpr (TEAM) { if (queue_round_solo(J, S, q.head, q.tail, ns, C, my_pops, my_nnz, s_err, &cm, &nt, &levels)) break; }
-#ifdef ECNE_ROUNDLOG
-                if (tid == 0) printf("RL solo avail %u n %u c %u dt %llu levels %u\n", avail, ns, cm, wall_clock64() - qt_last, levels);
-#endif
-                q.head += cm;
-                q.tail = nt;
+                ChainState st;
+                st.head = q.head; st.tail = q.tail; st.window = window; st.mwindow = mwindow; st.streak = streak; st.rounds = 0; st.rows = 0;
+                st.sd[0] = st.sd[1] = st.sd[2] = 0;
+                if constexpr (TEAM) { if (multi_chain(J, 1u, S, 0, ns, 1u, st, C, my_pops, my_nnz, s_err)) break; }
+                const uint32_t cm = st.head - q.head;
+                q.head = st.head;
+                q.tail = st.tail;
                 pops_total += cm;
                 hits[13]++;
                 if (tid == 0) { S.sd[3] += 1; S.sd[4] += cm; S.sd[5] += wall_clock64() - qt_last; }     // schedule diagnostics: solo drains in the "general wavefront rounds" slots
-                streak = levels <= 2 ? streak + cm : 0;
-                // a drain that runs fewer than two rows per level is a chain: back to the fast rounds and bursts for a while
-                if (cm < 2 * levels || cm < ns) { solo = false; solo_cool = 8; }
+                streak = st.streak;
+                // a drain that ran fewer than two rows per level (streak reset) or stopped in front of a long row: back to the fast rounds and bursts for a while
+                if (cm < ns || st.streak == 0) { solo = false; solo_cool = 8; }
                 QTICK(6);
                 continue;
             }
@@ -1018,41 +1052,45 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         QTICK(0);
         if (!S.fallback && want_multi) {
             declined_wide = false;
-            // a wide frontier: one round on all workgroups of the job (see queue_round_multi)
-            const uint32_t cap_n = multi_cap(J);
-            const bool drain = drain_ok(J);
+            // a wide frontier: a chain of rounds on a team of workgroups (multi_chain) -- all of them for a frontier that fills their
+            // lanes, the first K for a narrower one (at least 8, twice what the window needs: it may double along the chain)
+            uint32_t K = J.nwg;
+            if (J.nwg > 16 && !(J.drain & 8u)) {
+                const uint32_t per = ECNE_WG * (drain_ok(J) ? 1u : 2u);
+                const uint32_t need = (avail + per - 1) / per;       // (by what is queued, not by the window: windows drain as a whole and double)
+                uint32_t kt = (2 * need + 7u) & ~7u;
+                if (kt < 8) kt = 8;
+                if (4 * kt <= 3 * J.nwg) K = kt;
+            }
+            const uint32_t cap_n = K * ECNE_WG * (drain_ok(J) ? 1u : 2u);
             uint32_t nm = avail < cap_n ? avail : cap_n;
             if (nm > mwindow) nm = mwindow;
             if (tid == 0) {
+                const uint32_t sg = ld_agent(&J.ctr->sub_gen) >> 1;
+                bar_local().sgen = sg;
                 J.ctr->q_cmd[1] = q.head; J.ctr->q_cmd[2] = q.tail; J.ctr->q_cmd[3] = nm;
                 J.ctr->q_cmd[4] = window; J.ctr->q_cmd[5] = mwindow;
                 J.ctr->q_cmd[6] = S.depoch;      // the master's solo drain rounds moved its mark epoch on: everybody continues from there
+                J.ctr->q_cmd[7] = K; J.ctr->q_cmd[8] = sg;
                 __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (job_barrier(J, s_err)) { helpers_released = true; break; }
+            ChainState st;
+            st.head = q.head; st.tail = q.tail; st.window = window; st.mwindow = mwindow; st.streak = streak; st.rounds = 0; st.rows = 0;
+            st.sd[0] = st.sd[1] = st.sd[2] = 0;
             bool failed = false;
-            for (uint32_t chain = 1;; ++chain) {       // chained rounds, see multi_chain_next
-                uint32_t cm = 0, ntm = q.tail, levels = 0;
-                if (drain ? queue_round_drain(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm, &levels)
-                          : queue_round_multi(J, S, 0, q.head, q.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { failed = true; break; }
-                q.head += cm;
-                q.tail = ntm;
-                pops_total += cm;
-                hits[13]++;
-                hits[14] += 1u << 16;                 // diagnostics: multi rounds in the high half
-                hits[15] += (unsigned long long)cm << 8;   // and the rows they committed
-                if (tid == 0) S.sd[cm < 64 ? 13 : cm < 4096 ? 14 : 15] += 1;   // schedule diagnostics: multi rounds by rows committed
-#ifdef ECNE_ROUNDLOG
-                if (tid == 0) { printf("RL multi avail %u n %u c %u dt %llu levels %u\n", avail, nm, cm, wall_clock64() - qt_last, levels); qt_last = wall_clock64();
-                    if (cm < nm) for (uint32_t k_ = 0; k_ < 3; ++k_) { const uint32_t r_ = J.queue[(q.head + k_) & J.qmask]; printf("CUT+%u row %u shape %x nA %u nB %u nC %u solved %d\n", k_, r_, J.rinfo[r_].shape, J.rpA[r_ + 1] - J.rpA[r_], J.rpB[r_ + 1] - J.rpB[r_], J.rpC[r_ + 1] - J.rpC[r_], (int)J.solved[r_]); } }
-#endif
-                streak = cm == nm ? streak + cm : 0;
-                if (drain && cm == nm) drain_window_update(levels, nm, cap_n, mwindow);
-                else multi_window_update(cm, nm, cap_n, mwindow, window);
-                nm = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, q.head, q.tail, window, mwindow, cm, nm) : 0;
-                if (!nm) break;
+            if constexpr (TEAM) failed = multi_chain(J, K, S, 0, nm, ECNE_CHAIN_MAX, st, C, my_pops, my_nnz, s_err) != 0;
+            q.head = st.head; q.tail = st.tail; window = st.window; mwindow = st.mwindow; streak = st.streak;
+            pops_total += st.rows;
+            hits[13] += st.rounds;
+            hits[14] += (unsigned long long)st.rounds << 16;      // diagnostics: multi rounds in the high half
+            hits[15] += st.rows << 8;                             // and the rows they committed
+            if (tid == 0) { S.sd[13] += st.sd[0]; S.sd[14] += st.sd[1]; S.sd[15] += st.sd[2]; }   // schedule diagnostics: multi rounds by rows committed
+            if (failed) {
+                if (K < J.nwg) job_barrier(J, s_err);      // the workgroups outside the team wait for a command: meet them (they leave on the error snapshot)
+                helpers_released = true;
+                break;
             }
-            if (failed) { helpers_released = true; break; }
             QTICK(7);
             continue;
         }
@@ -1343,23 +1381,17 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
         if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
         uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
         uint32_t window = ld_agent(&J.ctr->q_cmd[4]), mwindow = ld_agent(&J.ctr->q_cmd[5]);
-        if (threadIdx.x == 0) S.depoch = ld_agent(&J.ctr->q_cmd[6]);
+        const uint32_t K = ld_agent(&J.ctr->q_cmd[7]);
+        if (wgrank >= K) continue;          // not on this chain's team: back to the job barrier, for the next command
+        if (threadIdx.x == 0) { S.depoch = ld_agent(&J.ctr->q_cmd[6]); bar_local().sgen = ld_agent(&J.ctr->q_cmd[8]); }
         __syncthreads();
-        const uint32_t cap_n = multi_cap(J);
-        const bool drain = drain_ok(J);
-        bool failed = false;
-        for (uint32_t chain = 1;; ++chain) {           // the master's chain, derived here (see multi_chain_next)
-            uint32_t c = 0, nt = tail, levels = 0;
-            if (drain ? queue_round_drain(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt, &levels)
-                      : queue_round_multi(J, S, wgrank, head, tail, n, C, my_pops, my_nnz, s_err, &c, &nt)) { failed = true; break; }
-            head += c;
-            tail = nt;
-            if (drain && c == n) drain_window_update(levels, n, cap_n, mwindow);
-            else multi_window_update(c, n, cap_n, mwindow, window);
-            n = chain < ECNE_CHAIN_MAX ? multi_chain_next(J, head, tail, window, mwindow, c, n) : 0;
-            if (!n) break;
+        ChainState st;
+        st.head = head; st.tail = tail; st.window = window; st.mwindow = mwindow; st.streak = 0; st.rounds = 0; st.rows = 0;
+        st.sd[0] = st.sd[1] = st.sd[2] = 0;
+        if (multi_chain(J, K, S, wgrank, n, ECNE_CHAIN_MAX, st, C, my_pops, my_nnz, s_err)) {      // the master's chain, derived here (see multi_chain_next)
+            if (K < J.nwg) job_barrier(J, s_err);          // (an error inside a sub-team: see the master's side)
+            break;
         }
-        if (failed) break;
     }
     // per-lane counters -> LDS -> ONE device atomic per counter and workgroup (22 000 lanes hitting twelve
     // words of device memory serialise at the L2 for ~90 us per outer iteration otherwise)

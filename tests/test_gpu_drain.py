@@ -30,7 +30,7 @@ def fuzz_paths(tmp_path_factory):
     return paths
 
 
-@pytest.mark.parametrize("nwg", [2, 7])
+@pytest.mark.parametrize("nwg", [2, 7, 24])      # 24: narrow frontiers go to a sub-team of 8 workgroups (rounds.hip.hpp multi_chain), error pops included
 def test_fuzz_families_all_schedules(fuzz_paths, nwg):
     oracles = [orc.run(p) for p in fuzz_paths]
     systems = [E.System(E.R1CS(p)) for p in fuzz_paths]
@@ -49,7 +49,7 @@ def test_ecdsa_like_all_schedules(S, stride):
     path = ecdsa_like.cached(S, stride)
     s = build_system(None, ["secp256k1.r1cs"], ["Secp256k1AddUnequal"], path=path)
     o = orc.run(path, [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"])
-    for nwg in (3, 16):
+    for nwg in (3, 16, 40):
         for mode in MODES:
             g = E.solve_batch([s], force_nwg=nwg, queue_mode=mode)[0]
             assert_bit_exact("ecdsa_like(%d,%d) nwg=%d mode=%d" % (S, stride, nwg, mode), g, o)
