@@ -184,7 +184,8 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
                    "lpt": {"weights": "non-zeros of the main file", "rank_loads": loads, "imbalance": (max(loads) / max(sum(loads) / len(loads), 1e-9)) if loads else None},
                    "predicted_bound": {"ms_per_step_at_any_n": round(k_ms if world == 1 else longest["device_ms"], 3), "job": longest["job"],
                                        "note": "a batch takes as long as its longest job: more GPUs cannot go below it (strong scaling saturates at the number of jobs that take about that long)"}},
-        "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+        # (two kernels since round 3: k_solve for batches of single-workgroup jobs, k_solve_team as soon as one job of the batch has a team)
+        "roofline": {"bound": "hbm", "kernel": "k_solve_team" if args.workload == "dag" else "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                      "alg_bytes_per_step": b_alg, "kernel_ms": k_ms,
                      "latency_model": {"longest_job": longest["job"], "pops": longest["pops"], "outer_iterations": longest["outer_iterations"],
                                        "us_per_pop_on_the_longest_chain": 1e3 * longest["device_ms"] / max(longest["pops"], 1),
@@ -331,7 +332,7 @@ def main():
                                            "note": "HIP events around the launch; ms = median of 7 warm launches, ms_best their minimum; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
                        "abstraction": abstract_stats,
                        "frontend": {"mode": {0: "host", 1: "device", 2: "auto"}[E.set_frontend()], **{k: round(v, 3) for k, v in frontend_stats.items()}}},
-            "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_solve_team", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
                          "latency_model": latency,

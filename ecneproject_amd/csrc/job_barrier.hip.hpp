@@ -22,14 +22,14 @@ __device__ __forceinline__ uint32_t my_xcc_id() {
 // What a workgroup remembers between job barriers (LDS): the generation it waits for next and, once the
 // first barrier of the launch has established them, its XCD's member count and the number of XCDs in use
 // -- so that a barrier costs one atomic per level and one polled word, no other memory round trips.
-struct BarLocal { unsigned gen, members, nxcd, ready, sgen; };
+struct BarLocal { unsigned gen, members, nxcd, ready, sgen, lazy; };
 __device__ __forceinline__ BarLocal& bar_local() {
     __shared__ BarLocal b;
     return b;
 }
 __device__ __forceinline__ void job_barrier_init() {   // thread 0, once per launch (the device words are zeroed by the host)
     BarLocal& b = bar_local();
-    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0; b.sgen = 0;
+    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0; b.sgen = 0; b.lazy = 0;
 }
 
 // Barrier of a SUB-TEAM: the first J.nwg workgroups of the job (J is a copy of the job with nwg = K and subteam = 1, made by
@@ -119,9 +119,10 @@ __device__ int job_barrier(const Job& J, int* s_err) {
             unsigned long long t_wait0 = wall_clock64();
             unsigned hb = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (((w = __hip_atomic_load(&c->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
-                // (a workgroup that waits long -- outside the team of a chain of rounds, or a helper while the master works alone -- backs
-                //  off: hundreds of pollers take memory bandwidth and latency from the workgroups that work)
-                if (spins < 48) __builtin_amdgcn_s_sleep(8); else if (spins < 192) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
+                // (a workgroup outside the team of the running chain of rounds backs off: hundreds of pollers take memory bandwidth and
+                //  latency from the workgroups that work. Not the helpers that wait for the master's next command between chains: waking
+                //  them late cost 0.2 ms per ecdsa-scale solve)
+                if (!b.lazy || spins < 48) __builtin_amdgcn_s_sleep(8); else if (spins < 192) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
                 if ((++spins & 1023u) == 0) {
                     const unsigned long long now = wall_clock64();
                     const unsigned hb2 = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -131,6 +132,7 @@ __device__ int job_barrier(const Job& J, int* s_err) {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             b.gen = g + 1;
+            b.lazy = 0;
             if (!hier) {   // the first barrier of the launch just completed: remember the XCD layout
                 b.members = __hip_atomic_load(&c->xcd_members[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 b.nxcd = __hip_atomic_load(&c->n_xcd_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -770,21 +770,27 @@ __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head
 // ---- a chain of rounds on a TEAM: the first K workgroups of the job (K = J.nwg: everybody, the job's own barrier; K < J.nwg: a
 // sub-team with a flat barrier of its own, the other workgroups wait at the job barrier for the next command; K = 1: the master
 // by itself, "solo": its barriers are workgroup barriers). A frontier of 6 000 rows is 12 workgroups' worth of lanes: 248
-// workgroups meeting six times per round cost 64 us per round, 43 cost 45. The copy of the job with nwg = K lives in this frame
-// only (queue_phase_chunked's own is tight: its sequential bursts call the chain executor thousands of times per solve).
+// workgroups meeting six times per round cost 64 us per round, 43 cost 45. For the time of the chain the workgroup's own copy of
+// the job (LDS, k_solve) says nwg = K, subteam = 1 -- every function of the round reads the team from there (a private copy of the
+// 700-byte Job per thread cost 17 us per chain).
 struct ChainState { uint32_t head, tail, window, mwindow, streak, rounds, sd[3]; unsigned long long rows; };
-__device__ __noinline__ int multi_chain(const Job& J0, uint32_t K, ChunkShared& S, uint32_t wgrank, uint32_t nm, uint32_t max_rounds,
+__device__ __noinline__ int multi_chain(const Job& J, uint32_t K, ChunkShared& S, uint32_t wgrank, uint32_t nm, uint32_t max_rounds,
                                        ChainState& st, LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, int* s_err) {
-    Job Js;
-    const Job* Jp = &J0;
-    if (K < J0.nwg) { Js = J0; Js.nwg = K; Js.subteam = 1; Jp = &Js; }
-    const Job& J = *Jp;
-    const uint32_t cap_n = multi_cap(J);
+    Job& Jm = const_cast<Job&>(J);           // (the kernel's __shared__ Job: not const there)
+    const uint32_t nwg_full = J.nwg;
+    const bool sub = K < nwg_full;
+    if (sub) {
+        __syncthreads();
+        if (threadIdx.x == 0) { Jm.nwg = K; Jm.subteam = 1; }
+        __syncthreads();
+    }
+    const uint32_t cap_n = K * ECNE_WG * (drain_ok(J) ? 1u : 2u);
     const bool drain = drain_ok(J);
+    int rc = 0;
     for (uint32_t chain = 1;; ++chain) {       // chained rounds, see multi_chain_next
         uint32_t cm = 0, ntm = st.tail, levels = 0;
         if (drain ? queue_round_drain(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm, &levels)
-                  : queue_round_multi(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) return 1;
+                  : queue_round_multi(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { rc = 1; break; }
 #ifdef ECNE_ROUNDLOG
         if (wgrank == 0 && threadIdx.x == 0) printf("RL %s avail %u n %u c %u dt %llu levels %u team %u\n", K == 1 ? "solo" : "multi", st.tail - st.head, nm, cm, 0ull, levels, K);
 #endif
@@ -796,11 +802,17 @@ __device__ __noinline__ int multi_chain(const Job& J0, uint32_t K, ChunkShared& 
         st.streak = (cm == nm && (!drain || levels <= 2 || K > 1)) ? st.streak + cm : 0;
         if (drain && cm == nm) drain_window_update(levels, nm, cap_n, st.mwindow);
         else multi_window_update(cm, nm, cap_n, st.mwindow, st.window);
-        if (K == 1 && (cm < 2 * levels || cm < nm)) return 0;      // a solo drain that runs fewer than two rows per level is a chain: back to the fast rounds
-        if (K < J0.nwg && st.tail - st.head > 2 * cap_n) return 0;  // the frontier has outgrown the team: the master commands a larger one
+        if (K == 1 && (cm < 2 * levels || cm < nm)) break;      // a solo drain that runs fewer than two rows per level is a chain: back to the fast rounds
+        if (sub && st.tail - st.head > 2 * cap_n) break;        // the frontier has outgrown the team: the master commands a larger one
         nm = chain < max_rounds ? multi_chain_next(J, st.head, st.tail, st.window, st.mwindow, cm, nm) : 0;
-        if (!nm) return 0;
+        if (!nm) break;
     }
+    if (sub) {
+        __syncthreads();
+        if (threadIdx.x == 0) { Jm.nwg = nwg_full; Jm.subteam = 0; }
+        __syncthreads();
+    }
+    return rc;
 }
 template <bool TEAM>
 __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
@@ -1382,7 +1394,7 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
         uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
         uint32_t window = ld_agent(&J.ctr->q_cmd[4]), mwindow = ld_agent(&J.ctr->q_cmd[5]);
         const uint32_t K = ld_agent(&J.ctr->q_cmd[7]);
-        if (wgrank >= K) continue;          // not on this chain's team: back to the job barrier, for the next command
+        if (wgrank >= K) { if (threadIdx.x == 0) bar_local().lazy = 1; continue; }          // not on this chain's team: back to the job barrier (polling lazily), for the next command
         if (threadIdx.x == 0) { S.depoch = ld_agent(&J.ctr->q_cmd[6]); bar_local().sgen = ld_agent(&J.ctr->q_cmd[8]); }
         __syncthreads();
         ChainState st;
