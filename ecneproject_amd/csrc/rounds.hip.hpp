@@ -728,6 +728,12 @@ __device__ __forceinline__ void drain_window_update(uint32_t levels, uint32_t nm
     if (levels <= ECNE_DRAIN_GROW) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
     else if (levels > ECNE_DRAIN_SHRINK) mwindow = nm / 2 > 1024u ? nm / 2 : 1024u;
 }
+#ifndef ECNE_SOLO_AVAIL
+#define ECNE_SOLO_AVAIL 32     // solo drains: from this many queued rows on, when a fast round committed less than 1 / ECNE_SOLO_RATIO of them
+#endif
+#ifndef ECNE_SOLO_RATIO
+#define ECNE_SOLO_RATIO 8
+#endif
 // ---- chained multi-workgroup rounds
 // After a multi-workgroup round every workgroup of the job knows the new head, tail and prefix length, so the
 // decision "the next round is a multi-workgroup round again, over nm rows" can be taken by every workgroup
@@ -789,10 +795,13 @@ __device__ __noinline__ int multi_chain(const Job& J, uint32_t K, ChunkShared& S
     int rc = 0;
     for (uint32_t chain = 1;; ++chain) {       // chained rounds, see multi_chain_next
         uint32_t cm = 0, ntm = st.tail, levels = 0;
+#ifdef ECNE_ROUNDLOG
+        const unsigned long long rl_t0 = wall_clock64();
+#endif
         if (drain ? queue_round_drain(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm, &levels)
                   : queue_round_multi(J, S, wgrank, st.head, st.tail, nm, C, my_pops, my_nnz, s_err, &cm, &ntm)) { rc = 1; break; }
 #ifdef ECNE_ROUNDLOG
-        if (wgrank == 0 && threadIdx.x == 0) printf("RL %s avail %u n %u c %u dt %llu levels %u team %u\n", K == 1 ? "solo" : "multi", st.tail - st.head, nm, cm, 0ull, levels, K);
+        if (wgrank == 0 && threadIdx.x == 0) printf("RL %s avail %u n %u c %u dt %llu levels %u team %u\n", K == 1 ? "solo" : "multi", st.tail - st.head, nm, cm, wall_clock64() - rl_t0, levels, K);
 #endif
         st.head += cm;
         st.tail = ntm;
@@ -992,7 +1001,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 streak = cw == nx ? streak + cw : 0;
                 // a dependency cut a well-filled window short: several chains side by side -- the master drains the next windows by itself
                 if (solo_cool) --solo_cool;
-                else if (solo_ok && avail >= 32 && 8 * cw <= (avail < 64u ? avail : 64u)) solo = true;      // (whatever stopped the round: a dependency, or a row the fast round only takes at rank 0)
+                else if (solo_ok && avail >= ECNE_SOLO_AVAIL && ECNE_SOLO_RATIO * cw <= (avail < 64u ? avail : 64u)) solo = true;      // (whatever stopped the round: a dependency, or a row the fast round only takes at rank 0)
                 // (single-workgroup jobs: a short prefix goes to the chain executor whatever stopped it -- rows the fast round
                 //  does not take are cheap there; the master of a large job only bursts on true dependency chains)
                 if (cw < burst_c && (chain || cw < nx) && avail < burst_avail) { burst = next_burst; if (next_burst < burst_max) next_burst *= 2; }
