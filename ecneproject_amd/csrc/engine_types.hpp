@@ -107,6 +107,7 @@ struct Counters {   // one per job, device memory
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
     unsigned int q_cmd[12];         // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow, mark epoch, team size K, sub-team barrier generation
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
+    unsigned int q_nhuge, q_huge[8][4];   // REQUEUE events with thousands of rows, expanded by the whole team after the expansion barrier: variable, rank, candidate base
     unsigned int d_cut[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows left after the level, bit 0 "somebody is unstable" / bit 1 "somebody marked A"
     unsigned int q_part[2][256];
     unsigned int q_blk[2][ECNE_MAX_NWG * 8];   // per-wavefront totals of the block-order scan (team_block_scan)

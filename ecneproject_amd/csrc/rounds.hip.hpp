@@ -220,6 +220,14 @@ __device__ __noinline__ int multi_finish(const Job& J, ChunkShared& S, uint32_t 
         expand_big_events(J, S, true);
     }
     if ((err = job_barrier(J, s_err))) return err;
+    {
+        const uint32_t nh = ld_agent(&ctr->q_nhuge);      // events published as huge: the whole team expands them now (rare: one more barrier)
+        if (nh) {
+            expand_huge_events(J, S, wgrank, nh);
+            if ((err = job_barrier(J, s_err))) return err;
+            if (g == 0) ctr->q_nhuge = 0;
+        }
+    }
     MTICK(3);
     // ---- the prefix rows leave the queue (tags no longer needed); then winners in candidate order
 #pragma unroll

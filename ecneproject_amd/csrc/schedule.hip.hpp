@@ -540,8 +540,18 @@ __device__ __forceinline__ void expand_candidate(const Job& J, ChunkShared& S, u
     else if (ld_agent(&J.best[t]) > j) atomicMin(&J.best[t], j);
 }
 // expand event (v, rank a, candidate base b0): small fan-outs inline, big ones go to the workgroup list
+#ifndef ECNE_HUGE_EVENT
+#define ECNE_HUGE_EVENT 4096   // REQUEUE events with at least this many rows are expanded by the whole team (rounds on teams of workgroups only)
+#endif
+#define ECNE_HUGE_SLOTS 8
 __device__ __forceinline__ void expand_event(const Job& J, ChunkShared& S, uint32_t v, uint32_t a, uint32_t b0, bool multi) {
     const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+    if (multi && J.nwg > 1 && f1 - f0 >= ECNE_HUGE_EVENT) {
+        // the constant wire's bounds move, say, and every row that mentions it is re-queued (53 250 rows of an ecdsa-scale circuit):
+        // 104 strides of ONE workgroup were 0.45 ms of one round; the team takes slices after the expansion barrier (multi_finish)
+        const uint32_t slot = atomicAdd(&J.ctr->q_nhuge, 1u);
+        if (slot < ECNE_HUGE_SLOTS) { J.ctr->q_huge[slot][0] = v; J.ctr->q_huge[slot][1] = a; J.ctr->q_huge[slot][2] = b0; return; }
+    }
     if (f1 - f0 > 48) {
         const uint32_t slot = atomicAdd(&S.nbigev, 1u);
         if (slot < 64) { S.bigev_v[slot] = v; S.bigev_a[slot] = a; S.bigev_b[slot] = b0; return; }
@@ -574,6 +584,14 @@ __device__ __forceinline__ void expand_event(const Job& J, ChunkShared& S, uint3
         }
     }
 }
+// the workgroup's minima for big target rows (S.bt, filled by expand_candidate) go to best[]; the slots are left empty again
+__device__ __forceinline__ void flush_big_targets(const Job& J, ChunkShared& S) {
+    const uint32_t nb_rows = J.nBigRows < ECNE_BIGTAB ? J.nBigRows : ECNE_BIGTAB;
+    for (uint32_t i = threadIdx.x; i < nb_rows; i += ECNE_WG) {
+        const uint32_t j = S.bt[i];
+        if (j != 0xFFFFFFFFu) { atomicMin(&J.best[J.bigrows[i]], j); S.bt[i] = 0xFFFFFFFFu; }
+    }
+}
 // all threads of the workgroup: expand the listed big events, lanes across fan-out positions
 __device__ __forceinline__ void expand_big_events(const Job& J, ChunkShared& S, bool multi) {
     __syncthreads();
@@ -585,12 +603,18 @@ __device__ __forceinline__ void expand_big_events(const Job& J, ChunkShared& S, 
     }
     __syncthreads();
     if (threadIdx.x == 0) S.nbigev = 0;
-    // the workgroup's minima for big target rows go to best[]; the slots are left empty again
-    const uint32_t nb_rows = J.nBigRows < ECNE_BIGTAB ? J.nBigRows : ECNE_BIGTAB;
-    for (uint32_t i = threadIdx.x; i < nb_rows; i += ECNE_WG) {
-        const uint32_t j = S.bt[i];
-        if (j != 0xFFFFFFFFu) { atomicMin(&J.best[J.bigrows[i]], j); S.bt[i] = 0xFFFFFFFFu; }
+    flush_big_targets(J, S);
+}
+// the team's share of the events published as huge (expand_event): every workgroup takes every (team size)-th stride of each list
+__device__ __forceinline__ void expand_huge_events(const Job& J, ChunkShared& S, uint32_t wgrank, uint32_t nh) {
+    const uint32_t T = J.nwg * ECNE_WG, g = wgrank * ECNE_WG + threadIdx.x;
+    for (uint32_t h = 0; h < nh && h < ECNE_HUGE_SLOTS; ++h) {
+        const uint32_t v = ld_agent(&J.ctr->q_huge[h][0]), a = ld_agent(&J.ctr->q_huge[h][1]), b0 = ld_agent(&J.ctr->q_huge[h][2]);
+        const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+        for (uint32_t k = f0 + g; k < f1; k += T) expand_candidate(J, S, J.fo_rows[k], b0 + (k - f0), a, true);
     }
+    __syncthreads();
+    flush_big_targets(J, S);
 }
 
 // Ordered multi-source REQUEUE by the whole workgroup. Input: a flat list of N events (variables) in
