@@ -267,7 +267,13 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
 // 64 rows per wavefront, so the field inversions of bit-check / single-variable rows run on full
 // SIMDs instead of one lane of a wave. Same results as classify_row, written serially.
 #define ECNE_CLS_LANE 8
-__device__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri) {
+#ifndef ECNE_CLS_STAGE
+#define ECNE_CLS_STAGE 1024      // C entries of 256 consecutive rows staged in LDS per workgroup (36 KB); the average row has 1.6
+#endif
+// cfC / clC: where the row's C entries are read from -- the CSR arrays themselves (cbase = 0), or the workgroup's LDS copy of the
+// entries [cbase, ...) of its 256 rows (k_classify_rows stages them with coalesced 16-byte loads: one lane walking its own row
+// through device memory is a chain of dependent round trips per entry).
+__device__ __forceinline__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri, const uint64_t* __restrict__ cfC, const uint32_t* __restrict__ clC, uint32_t cbase) {
     const uint32_t shape_in = ri.shape, kpos_in = ri.kpos, kneg_in = ri.kneg;
     // a product a * b = c (or any row with C empty that is no bit check) needs nothing from this pass
     if ((shape_in & SH_HAS_AB) && !(shape_in & SH_R2) && !((shape_in & SH_C_HAS1) && (shape_in & SH_R5))) return;
@@ -296,9 +302,9 @@ __device__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri) {
         if (shape & SH_R3) {
             fp::u256 c1v = fp::make(0), cx = fp::make(0);
             for (uint32_t k = c0; k < c1; ++k) {
-                uint32_t v = J.colC[k];
-                if (v == 1) c1v = ld256(J.coefC + 4ull * k);
-                else if (v == ri.x) cx = ld256(J.coefC + 4ull * k);
+                uint32_t v = clC[k - cbase];
+                if (v == 1) c1v = ld256(cfC + 4ull * (k - cbase));
+                else if (v == ri.x) cx = ld256(cfC + 4ull * (k - cbase));
             }
             st256(J.vals + 4ull * ri.validx, neg_div(c1v, cx));
         }
@@ -308,11 +314,11 @@ __device__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri) {
             uint32_t maskT = 0, maskT2 = 0;     // exponents seen (l <= 8: exponents 0..6)
             bool okT = true, okT2 = true;
             for (uint32_t k = c0; k < c1; ++k) {
-                const fp::u256 c = ld256(J.coefC + 4ull * k);
+                const fp::u256 c = ld256(cfC + 4ull * (k - cbase));
                 const fp::u256 nc = fp::neg(c);
                 const bool one = fp::is_one(c), mone = fp::is_one(nc);
-                if (one) { ++n_one; if (n_one == 1) kpos = J.colC[k]; }
-                if (mone) { ++n_mone; if (n_mone == 1) kneg = J.colC[k]; }
+                if (one) { ++n_one; if (n_one == 1) kpos = clC[k - cbase]; }
+                if (mone) { ++n_mone; if (n_mone == 1) kneg = clC[k - cbase]; }
                 if (!one) {
                     int e = (popc256(nc) == 1) ? ctz256(nc) : 999;
                     if (e > (int)l - 2 || (maskT >> e & 1)) okT = false; else maskT |= 1u << e;
@@ -338,7 +344,7 @@ __device__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri) {
             const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
             uint32_t idx[ECNE_CLS_LANE];
             for (uint32_t k = 0; k < l; ++k) {
-                fp::u256 c = ld256(J.coefC + 4ull * (c0 + k));
+                fp::u256 c = ld256(cfC + 4ull * (c0 + k - cbase));
                 if (negated) c = fp::neg(c);
                 c = r7_abs(c);
                 uint32_t pos = k;
@@ -366,11 +372,33 @@ __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t
     if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
     __syncthreads();
     if (blockIdx.x >= n_long_blocks) {
+        // the C entries of the workgroup's 256 rows are one contiguous stretch of the CSR arrays: staged in LDS with coalesced 16-byte
+        // loads (36 B per entry), then every lane classifies its row from there. A stretch that does not fit (a long row among the 256:
+        // its own entries alone are more than the buffer) is read from device memory as before.
+        __shared__ uint4 s_coef[2 * ECNE_CLS_STAGE];
+        __shared__ uint32_t s_col[ECNE_CLS_STAGE];
         const uint32_t nb0 = gridDim.x - n_long_blocks;
-        for (uint32_t row = (blockIdx.x - n_long_blocks) * 256 + threadIdx.x; row < sJ.nC; row += nb0 * 256)
-        {
-            const RowInfo ri = sJ.rinfo[row];
-            if (ri.lenC <= ECNE_CLS_LANE) classify_row_lane(sJ, row, ri);
+        for (uint32_t rb = (blockIdx.x - n_long_blocks) * 256; rb < sJ.nC; rb += nb0 * 256) {      // (uniform trip count: barriers inside)
+            const uint32_t rend = rb + 256 < sJ.nC ? rb + 256 : sJ.nC;
+            const uint32_t clo = sJ.rpC[rb], chi = sJ.rpC[rend];
+            const uint32_t n_ent = chi - clo;
+            const bool staged = n_ent <= ECNE_CLS_STAGE;
+            if (staged) {
+                const uint4* const src = reinterpret_cast<const uint4*>(sJ.coefC) + 2ull * clo;
+                // (plain strided loops: holding a thread's loads in registers first -- twelve in flight -- cost occupancy and was 51 us instead of 38)
+                for (uint32_t i = threadIdx.x; i < 2 * n_ent; i += 256) s_coef[i] = src[i];
+                for (uint32_t i = threadIdx.x; i < n_ent; i += 256) s_col[i] = sJ.colC[clo + i];
+            }
+            __syncthreads();
+            const uint32_t row = rb + threadIdx.x;
+            if (row < sJ.nC) {
+                const RowInfo ri = sJ.rinfo[row];
+                if (ri.lenC <= ECNE_CLS_LANE) {
+                    if (staged) classify_row_lane(sJ, row, ri, reinterpret_cast<const uint64_t*>(s_coef), s_col, clo);
+                    else classify_row_lane(sJ, row, ri, sJ.coefC, sJ.colC, 0u);
+                }
+            }
+            __syncthreads();
         }
         return;
     }
