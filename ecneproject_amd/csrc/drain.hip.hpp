@@ -414,7 +414,7 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
                 }
                 for (uint32_t e = 0; e < nev[0]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
             }
-            ev[ECNE_EVCAP - 1] = nev[0];    // for the sequential replay fallback
+            J.evcnt[r0] = nev[0];           // for the sequential replay fallback (a dense array: the last word of the rank's 800-byte event slot was a dirty line per pop)
         }
         if (S.bl_any) {
             dr_big_exec(J, S, wgrank, dcut);

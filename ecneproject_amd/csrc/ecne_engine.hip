@@ -713,6 +713,7 @@ static int upload_system(ecne_system& S, int device) {
     // one event slot list per rank of a round: single-workgroup rounds examine <= 4 * 512 queue entries,
     // multi-workgroup rounds <= min(rows, ECNE_MAX_NWG workgroups * 512 lanes * 2)
     const size_t max_ranks = std::max<size_t>((size_t)4 * ECNE_WG, std::min<size_t>((size_t)nC + 1, (size_t)ECNE_MAX_NWG * ECNE_WG * 2));
+    size_t o_evcnt = c.take(4ull * max_ranks);
     size_t o_evbuf = c.take(4ull * max_ranks * ECNE_EVCAP), o_cand = c.take(4ull * std::max<size_t>(ECNE_CANDCAP, 8ull * nC));
     const size_t flatcap = std::max<size_t>((size_t)4 * ECNE_WG * ECNE_EVCAP, 16384) + (size_t)ECNE_BIGK * (maxrowC + 8);
     size_t o_fvar = c.take(4ull * flatcap), o_frank = c.take(4ull * flatcap), o_fbase = c.take(4ull * (flatcap + 1));
@@ -828,7 +829,7 @@ static int upload_system(ecne_system& S, int device) {
     J.drain = 0;
     J.subteam = 0;
     J.wmarkU = (uint32_t*)(base + o_wmark); J.wmarkB = (uint32_t*)(base + o_wmarkB); J.best = (uint32_t*)(base + o_best); J.prank = (uint32_t*)(base + o_prank);
-    J.evbuf = (uint32_t*)(base + o_evbuf); J.cand = (uint32_t*)(base + o_cand);
+    J.evbuf = (uint32_t*)(base + o_evbuf); J.evcnt = (uint32_t*)(base + o_evcnt); J.cand = (uint32_t*)(base + o_cand);
     J.candcap = (uint32_t)std::max<size_t>(ECNE_CANDCAP, 8ull * nC);
     J.fvar = (uint32_t*)(base + o_fvar); J.frank = (uint32_t*)(base + o_frank); J.fbase = (uint32_t*)(base + o_fbase);
     J.bigev = (uint32_t*)(base + o_bigev);

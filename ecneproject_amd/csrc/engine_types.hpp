@@ -181,6 +181,7 @@ struct Job {
     uint32_t* best;            // per row: lowest candidate index that wants to push it
     uint32_t* prank;           // per row: its rank while it is being popped in a multi-workgroup round
     uint32_t* evbuf;           // per chunk rank: REQUEUE events emitted by the row popped there
+    uint32_t* evcnt;           // per chunk rank of a round on a team: how many (dense; bit 31 = a long row's events, in the pool)
     uint32_t *fvar, *frank, *fbase;   // flat event list of one resolution round: variable, rank, candidate base
     uint32_t* bigev;           // events of a big row popped alone
     uint32_t* bigpool;         // events (+ candidate offsets) of long rows executed inside rounds: ECNE_MAX_NWG * ECNE_BIGK slots

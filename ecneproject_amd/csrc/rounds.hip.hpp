@@ -126,8 +126,8 @@ __device__ __noinline__ int multi_finish(const Job& J, ChunkShared& S, uint32_t 
                 S.bl_deg[k] = run;
                 // the rank's regular slot only says where the events are (for the sequential replay fallback)
                 uint32_t* slot = J.evbuf + (size_t)S.bl_rank[k] * ECNE_EVCAP;
-                slot[ECNE_EVCAP - 1] = 0x80000000u | (wgrank * ECNE_BIGK + k);
-                slot[ECNE_EVCAP - 2] = ne;
+                J.evcnt[S.bl_rank[k]] = 0x80000000u | (wgrank * ECNE_BIGK + k);
+                slot[0] = ne;
             }
         }
         __syncthreads();
@@ -164,16 +164,16 @@ __device__ __noinline__ int multi_finish(const Job& J, ChunkShared& S, uint32_t 
                 QState qq;
                 qq.head = 0; qq.tail = tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
                 // event counts live in the executing lanes' registers: recount from the fan-out lists is not
-                // possible, so each rank's count was also stored behind its events (slot ECNE_EVCAP - 1)
+                // possible, so each rank's count was also stored (evcnt[rank]; bit 31: a long row, its events are in the pool, their number in word 0 of the rank's slot)
                 for (uint32_t r = 0; r < c; ++r) {
                     const uint32_t rr = J.queue[(head + r) & J.qmask];
                     if (lane == 0) J.inq[rr] = 0;
                     wg_fence();
-                    uint32_t ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 1];
+                    uint32_t ne = J.evcnt[r];
                     const uint32_t* evs = J.evbuf + (size_t)r * ECNE_EVCAP;
                     if (ne & 0x80000000u) {   // a long row: its events are in the pool
                         evs = J.bigpool + (size_t)(ne & 0x7FFFFFFFu) * J.bigstride;
-                        ne = J.evbuf[(size_t)r * ECNE_EVCAP + ECNE_EVCAP - 2];
+                        ne = J.evbuf[(size_t)r * ECNE_EVCAP];
                     }
                     for (uint32_t e = 0; e < ne; ++e) requeue(J, qq, evs[e]);
                 }
@@ -440,7 +440,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
             nev[0] = D.nev;
 #pragma unroll
             for (uint32_t e = 0; e < 5; ++e) if (e < D.nev) { ev[e] = D.ev[e]; mycand += J.fo_ptr[D.ev[e] + 1] - J.fo_ptr[D.ev[e]]; }
-            ev[ECNE_EVCAP - 1] = D.nev;
+            J.evcnt[r0] = D.nev;
             continue;
         }
         if ((live & (1u << sl)) && !(shape[sl] & SH_BIG) && !(noop & (1u << sl))) row_unmark_global(J, row[sl], shape[sl], xv[sl]);
@@ -458,7 +458,7 @@ __device__ __noinline__ int queue_round_multi(const Job& J, ChunkShared& S, uint
         }
         uint32_t* ev = J.evbuf + (size_t)(r0 + sl) * ECNE_EVCAP;
         for (uint32_t e = 0; e < nev[sl]; ++e) mycand += J.fo_ptr[ev[e] + 1] - J.fo_ptr[ev[e]];
-        ev[ECNE_EVCAP - 1] = nev[sl];    // for the sequential replay fallback
+        J.evcnt[r0 + sl] = nev[sl];      // for the sequential replay fallback
     }
     return multi_finish(J, S, wgrank, head, tail, c, rpl, r0, row, nev, bigsl, mycand, true, mt_last, s_err, out_c, out_tail);
 }
