@@ -1,5 +1,6 @@
 """Developer aid (CPU only): ideal dataflow depth of a solve, from the sequential oracle's pop trace.
   python tests/tools/dataflow_depth.py [S [stride]]        (ecdsa_like(S, stride) + trusted secp256k1.r1cs)
+  python tests/tools/dataflow_depth.py <fixture relpath> [trusted.r1cs:Name ...]
 Every pop gets a level = 1 + max(level of the pop that pushed its row, level of the last writer of any variable it mentions
 (RAW), level of the last reader of any variable it writes (WAR)); writes = the variables the pop re-queued. The number of
 distinct levels is what a perfect level-synchronous schedule would need; the engine's rounds are prefixes of the FIFO order."""
@@ -9,17 +10,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, o
 import numpy as np
 import ecneproject_amd as E, ecdsa_like, fixtures, orc
 
-S_ = int(sys.argv[1]) if len(sys.argv) > 1 else 26
-stride = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-path = ecdsa_like.cached(S_, stride)
 E.set_frontend(E.FRONTEND_HOST)
+if len(sys.argv) > 1 and not sys.argv[1].isdigit():      # a fixture (relative path) [+ trusted fixture:Name ...]
+    path = fixtures.path(sys.argv[1])
+    TR = [(fixtures.path(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[2:]]
+else:
+    S_ = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+    stride = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    path = ecdsa_like.cached(S_, stride)
+    TR = [(fixtures.path("secp256k1.r1cs"), "Secp256k1AddUnequal")]
 s = E.System(E.R1CS(path))
-s.abstract(E.R1CS(fixtures.path("secp256k1.r1cs")), "Secp256k1AddUnequal")
+for tp, tn in sorted(TR, key=lambda x: -len(E.R1CS(x[0]))):
+    s.abstract(E.R1CS(tp), tn)
 parts = [s.rows(p) for p in range(3)]
 n = len(s)
 tr = os.path.join(tempfile.gettempdir(), "ecne_trace_%d.bin" % os.getpid())
 os.environ["ECNE_ORACLE_TRACE"] = tr
-o = orc.run(path, [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"], want_states=False)
+o = orc.run(path, [t[0] for t in TR], [t[1] for t in TR], secp_solve=True, want_states=False)
 del os.environ["ECNE_ORACLE_TRACE"]
 T = np.fromfile(tr, dtype=np.int64).reshape(-1, 2)
 os.unlink(tr)
