@@ -80,3 +80,16 @@ def test_drain_is_the_default_for_large_systems():
     assert g0.summary.multi_ms[7] > 0 and g3.summary.multi_ms[7] == 0
     assert g0.summary.pops == g3.summary.pops and list(g0.counts()) == list(g3.counts())
     assert g0.summary.rule_hits[13] < g3.summary.rule_hits[13]
+
+
+@pytest.mark.parametrize("mode", [0, 4])
+def test_every_reference_fixture_on_teams(mode):
+    """all 89 .r1cs files of the reference, each on a team of six workgroups (so that rounds on teams, sub-team logic and -- mode 4
+    -- drain rounds on every frontier meet real circuits: long rows of every shape, error statuses, empty files), batched"""
+    rels = fixtures.all_r1cs()
+    systems = [build_system(r) for r in rels]
+    res = []
+    for i in range(0, len(systems), 30):
+        res += E.solve_batch(systems[i:i + 30], force_nwg=6, queue_mode=mode)
+    for r, g in zip(rels, res):
+        assert_bit_exact("%s nwg=6 mode=%d" % (r, mode), g, orc.run(fixtures.path(r)))
