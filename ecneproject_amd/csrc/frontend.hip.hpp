@@ -44,6 +44,11 @@ namespace fe {
 #define FE_LARGE_MAX 2730u              // up to this many: one wavefront per workgroup, tables of <= 4096 slots in 64 KB of (dynamic) LDS
 #define FE_LARGE_CAP 4096u
 // tiers of the hash-order kernels: 1 = LDS 1024 slots x 2 wavefronts, 2 = LDS 4096 slots x 1 wavefront, 0 = HBM scratch x 4 wavefronts
+// table storage of the hash-order kernels: LDS-address-space pointers for the LDS tiers (ds_read / ds_write in jlslot's walk; through
+// a generic pointer an LDS access costs what an L2 hit costs -- lane 0 replays up to 2 730 insertions, one dependent probe after the other)
+typedef __attribute__((address_space(3))) uint32_t* FeLdsPtr;
+template <bool LDS> struct FeTabPtr { typedef uint32_t* type; };
+template <> struct FeTabPtr<true> { typedef FeLdsPtr type; };
 template <int TIER> struct FeTier {
     static constexpr uint32_t cap = TIER == 1 ? FE_MID_CAP : TIER == 2 ? FE_LARGE_CAP : 0u;
     static constexpr uint32_t waves = TIER == 1 ? FE_MID_WAVES : TIER == 2 ? 1u : 4u;
@@ -266,8 +271,8 @@ __global__ __launch_bounds__(256) void k_fe_fill_small(const uint32_t* __restric
             st256(O.coef[p] + 4ull * at, c);
             m = 1; mv = v; nz = !fp::is_zero(c);
         } else {
-            jlslot::Tab t;
-            t.key = s_key + threadIdx.x; t.pay = s_pay + threadIdx.x; t.key2 = nullptr; t.pay2 = nullptr;
+            jlslot::TabT<FeLdsPtr> t;
+            t.key = (FeLdsPtr)(s_key + threadIdx.x); t.pay = (FeLdsPtr)(s_pay + threadIdx.x); t.key2 = nullptr; t.pay2 = nullptr;
             t.cap = 16; t.stride = 256;
             jlslot::tab_init(t);
             for (uint32_t k = 0; k < n; ++k) (void)jlslot::tab_upsert<1>(t, W[j + 1 + 9ull * k], k);
@@ -325,13 +330,15 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const 
         const uint32_t at = pos[(size_t)p * (nC + 1) + r];
         uint32_t sz = 0, flipped = 0, bad = 0;
         if (lane == 0) {
-            jlslot::Tab t;
-            t.key = base; t.pay = base + cap; t.key2 = base + 2 * cap; t.pay2 = base + 3 * cap;
+            typedef typename FeTabPtr<LDS_TABLES>::type TP;
+            const TP tb = (TP)base;
+            jlslot::TabT<TP> t;
+            t.key = tb; t.pay = tb + cap; t.key2 = tb + 2 * cap; t.pay2 = tb + 3 * cap;
             t.cap = cap; t.stride = 1;
             jlslot::tab_init(t);
             for (uint32_t k = 0; k < n && !bad; ++k) bad = jlslot::tab_upsert<1>(t, W[j + 1 + 9ull * k], k) != 0;
             sz = t.sz;
-            flipped = t.key != base;
+            flipped = t.key != tb;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
@@ -661,8 +668,8 @@ __global__ __launch_bounds__(256) void k_lay_order_small(AbsRowsDev R, uint32_t 
     const uint64_t k0 = R.ptr[p][r], k1 = R.ptr[p][r + 1];
     PartSum S;
     S.first_var = S.first_non1 = S.last_non1 = 0; S.bits = 0;
-    jlslot::Tab t;
-    t.key = s_key + threadIdx.x; t.pay = s_pay + threadIdx.x; t.key2 = nullptr; t.pay2 = nullptr;
+    jlslot::TabT<FeLdsPtr> t;
+    t.key = (FeLdsPtr)(s_key + threadIdx.x); t.pay = (FeLdsPtr)(s_pay + threadIdx.x); t.key2 = nullptr; t.pay2 = nullptr;
     t.cap = 16; t.stride = 256;
     if (nz > 1) jlslot::tab_init(t);
     uint32_t m = 0;
@@ -712,8 +719,10 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
         const uint32_t at = rp[q];
         const uint64_t k0 = R.ptr[p][r], k1 = R.ptr[p][r + 1];
         uint32_t sz = 0, flipped = 0, bad = 0, haskey1 = 0;
-        jlslot::Tab t;
-        t.key = base; t.pay = base + cap; t.key2 = base + 2 * cap; t.pay2 = base + 3 * cap;
+        typedef typename FeTabPtr<LDS_TABLES>::type TP;
+        const TP tb = (TP)base;
+        jlslot::TabT<TP> t;
+        t.key = tb; t.pay = tb + cap; t.key2 = tb + 2 * cap; t.pay2 = tb + 3 * cap;
         t.cap = cap; t.stride = 1;
         if (lane == 0) jlslot::tab_init(t);
         // all lanes look at 64 dictionary entries at a time (non-zero? key 1?), lane 0 inserts the non-zero ones in order
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
                 if (lane == 0 && !bad) bad = jlslot::tab_upsert<0>(t, vv, (uint32_t)(kb + src - k0)) != 0;
             }
         }
-        if (lane == 0) { sz = t.sz; flipped = t.key != base; }
+        if (lane == 0) { sz = t.sz; flipped = t.key != tb; }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
         if (bad) {

@@ -33,21 +33,27 @@ JLQ uint64_t hash64(uint64_t a) {
 // key[] holds the stored 32-bit key, pay[] = payload + 1 (0 = empty slot). Two buffers of `cap` slots each: a growth
 // re-inserts from one into the other. STRIDE: distance between consecutive slots in the arrays (per-lane tables are
 // interleaved in LDS so that the lanes of a wavefront hit different banks).
-struct Tab {
-    uint32_t *key, *pay, *key2, *pay2;
+// P: the pointer type of the storage -- plain `uint32_t*` on the host and for tables in device memory; the device front-end passes
+// LDS-address-space pointers for its LDS tables, so that the walk below is ds_read / ds_write and not flat accesses (a flat access
+// to LDS costs what an L2 hit costs, and lane 0 replays up to 1 025 insertions one dependent probe after the other).
+template <class P = uint32_t*>
+struct TabT {
+    P key, pay, key2, pay2;
     uint32_t cap;        // slots per buffer
     uint32_t stride;
     uint32_t sz, n, maxprobe;
 };
+using Tab = TabT<>;
 
-JLQ void tab_init(Tab& t) {
+template <class P>
+JLQ void tab_init(TabT<P>& t) {
     t.sz = 16; t.n = 0; t.maxprobe = 0;
     for (uint32_t i = 0; i < 16; ++i) t.pay[i * t.stride] = 0;
 }
 
 // ADD: the hashed Int64 is (stored key + ADD) -- the parser hashes wire id + 1 (which may be 2^32), everybody else the id itself
-template <int ADD>
-JLQ int tab_grow(Tab& t, uint64_t want) {
+template <int ADD, class P>
+JLQ int tab_grow(TabT<P>& t, uint64_t want) {
     uint64_t nsz = 16;
     while (nsz < want) nsz <<= 1;
     if (nsz > t.cap) return -1;
@@ -66,7 +72,7 @@ JLQ int tab_grow(Tab& t, uint64_t want) {
         t.pay2[idx * st] = p;
         t.key2[idx * st] = k;
     }
-    uint32_t* a = t.key; t.key = t.key2; t.key2 = a;
+    P a = t.key; t.key = t.key2; t.key2 = a;
     a = t.pay; t.pay = t.pay2; t.pay2 = a;
     t.sz = (uint32_t)nsz;
     t.maxprobe = mp;
@@ -75,8 +81,8 @@ JLQ int tab_grow(Tab& t, uint64_t want) {
 
 // insert `skey` with `payload`, or replace the payload of the slot that holds it already ("last wins" at the first
 // occurrence's position, ParseR1CS.jl:104-108). Returns 0, or -1 when the table would have to grow beyond `cap`.
-template <int ADD>
-JLQ int tab_upsert(Tab& t, uint32_t skey, uint32_t payload) {
+template <int ADD, class P>
+JLQ int tab_upsert(TabT<P>& t, uint32_t skey, uint32_t payload) {
     const uint64_t hk = (uint64_t)skey + (uint64_t)ADD;
     const uint32_t st = t.stride;
     for (;;) {
