@@ -233,7 +233,7 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
         const uint32_t par = level & 1u;
         // ------------------------------------------------------------------ P1: decide on the state as it is, mark X and A
         uint32_t kind = 0;          // 0 nothing to look at (dead / final no-op), 1 record decision, 2 general walk, 3 general walk of a no-op, 4 long row
-        uint32_t fz_wva = 0, fz_wvb = 0, fz_cls = 0;
+        uint32_t fz_wva = 0, fz_cls = 0;          // (x == y rows write k1 / k2, bit checks x, products and sums one variable: fz_wva)
         if (pending) {
             if (shape & SH_BIG) {
                 kind = live ? 4u : 0u;
@@ -254,7 +254,7 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
                     fast_decide(J, fin, D);
                     if (!D.slow) {
                         fz = true;
-                        fz_wva = D.wva; fz_wvb = D.wvb;
+                        fz_wva = D.wva;
                         const uint8_t ia = fin.xy ? fin.fa : fin.f2 ? fin.fx : (uint8_t)(D.wfa & ~3u), ib = fin.fb;     // flag bytes before (products / sums only set bits 0, 1)
                         if (D.wa) fz_cls |= (((D.wfa ^ ia) & 3u) ? 1u : 0u) | ((((D.wfa ^ ia) & ~3u) || D.a01 || D.xa_w || D.r2) ? 2u : 0u);
                         if (D.wb) fz_cls |= (((D.wfb ^ ib) & 3u) ? 4u : 0u) | ((((D.wfb ^ ib) & ~3u) || D.b01 || D.xb_w) ? 8u : 0u);
