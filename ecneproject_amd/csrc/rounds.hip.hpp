@@ -680,6 +680,9 @@ __device__ __noinline__ uint32_t queue_round_wave(const Job& J, ChunkShared& S, 
 #ifndef ECNE_CHAIN_AVAIL
 #define ECNE_CHAIN_AVAIL 0      // queue length up to which the chain executor pops without trying a round first (measured: wave rounds win from 3-4 rows; 0 = off)
 #endif
+#ifndef ECNE_FAST_CHAIN
+#define ECNE_FAST_CHAIN 3      // fast wavefront rounds the master of a team may run back to back in front of the one the policy looks at
+#endif
 #ifndef ECNE_CHAIN_BURST_C
 #define ECNE_CHAIN_BURST_C 12
 #endif
@@ -875,7 +878,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (tid == 0 && J.nwg > 1) __hip_atomic_store(&J.ctr->heartbeat, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "the master is alive"
         if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
         if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
-        const uint32_t avail = q.tail - q.head;
+        uint32_t avail = q.tail - q.head;
         // chain executor: a short queue is popped sequentially right away (a round over a handful of rows costs more
         // than their pops, ~0.8 us each), until the queue is empty or a frontier has built up again
         uint32_t burst_stop = 0;
@@ -967,18 +970,48 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (w == 0) {
                 uint32_t nt = q.tail, nx = n;
                 uint32_t cw = 0xFFFFFFFFu;
-                // the fast round on row records first; it declines (nothing touched) what it does not cover
-                if (v2)
-                    cw = chain ? queue_round_fast<true, false>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
-                               : queue_round_fast<false, false>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
+                // On the master of a multi-workgroup job narrow levels follow each other (the adders of ecdsa_like: seven rounds of
+                // ~10 rows per outer iteration). A round that committed its whole window and left another narrow frontier behind
+                // has only one possible sequel in the policy below -- the next fast round -- so the wavefront runs it right away,
+                // up to four in a row, without the workgroup's two barriers and the policy code in between (pre_*: what the
+                // rounds in front of the last one did; applied by every thread below).
+                uint32_t pre_cw = 0, pre_k = 0, hd = q.head, tl = q.tail, nn = n;
+                for (;;) {
+                    nt = tl; nx = nn;
+                    // the fast round on row records first; it declines (nothing touched) what it does not cover
+                    if (v2)
+                        cw = chain ? queue_round_fast<true, false>(J, S, hd, tl, nn, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
+                                   : queue_round_fast<false, false>(J, S, hd, tl, nn, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
+                    if (TEAM && J.nwg > 1 && cw < 0xFFFFFFFEu && cw == nn && nx == nn && pre_k < ECNE_FAST_CHAIN) {
+                        const uint32_t av2 = nt - (hd + cw);
+                        if (av2 >= 1u && av2 <= 64u) { pre_cw += cw; ++pre_k; hd += cw; tl = nt; nn = av2; continue; }
+                    }
+                    break;
+                }
                 const bool fast = cw < 0xFFFFFFFEu;
                 // declined at rank 0: a single-workgroup job (or a long row) takes the general wavefront round; the master of a
                 // multi-workgroup job pops that one row with the general executor (narrow level) or goes to a round on all
                 // workgroups (wide frontier), see below
-                if (cw == 0xFFFFFFFFu || (cw == 0xFFFFFFFEu && J.nwg == 1)) cw = queue_round_wave(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &hits[15]);
-                if (lane == 0) { S.nbig = cw; S.tail = nt; S.flag7 = fast ? 1u : 0u; S.bl_tmp[0] = nx; }
+                if (cw == 0xFFFFFFFFu || (cw == 0xFFFFFFFEu && J.nwg == 1)) cw = queue_round_wave(J, S, hd, tl, nn, C, my_pops, my_nnz, &nt, &hits[15]);
+                if (lane == 0) { S.nbig = cw; S.tail = nt; S.flag7 = fast ? 1u : 0u; S.bl_tmp[0] = nx; S.bl_tmp[1] = pre_cw; S.bl_tmp[2] = pre_k; S.bl_tmp[3] = tl; }
             }
             __syncthreads();
+            if (TEAM && S.bl_tmp[2]) {       // the chained rounds in front of the last one: each committed all it looked at
+                const uint32_t pre_cw = S.bl_tmp[1], pre_k = S.bl_tmp[2];
+                q.head += pre_cw;
+                q.tail = S.bl_tmp[3];
+                pops_total += pre_cw;
+                hits[13] += pre_k;
+                declined_run = 0;
+                streak += pre_cw;
+                solo_cool = solo_cool > pre_k ? solo_cool - pre_k : 0u;
+                for (uint32_t k_ = 0; k_ < pre_k; ++k_) window = (window * ECNE_WGROW < ECNE_RPL * ECNE_WG) ? window * ECNE_WGROW : ECNE_RPL * ECNE_WG;
+#ifdef ECNE_FINE_TICKS
+                if (tid == 0) { S.sd[0] += pre_k; S.sd[1] += pre_cw; }
+#endif
+                avail = q.tail - q.head;
+                n = avail;
+            }
             const uint32_t cw = S.nbig, ntw = S.tail, nx = S.bl_tmp[0] & 0x7FFFFFFFu;   // nx: rows the round examined (the fast round may stop short of n)
             // (bit 31: the round stopped in front of something it does not take, not at a dependency -- then nx == cw, and the
             //  streak below keeps counting; tried and dropped: treating short rounds of that kind like declines, 23.9 -> 25.5 ms)
