@@ -975,16 +975,26 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 // has only one possible sequel in the policy below -- the next fast round -- so the wavefront runs it right away,
                 // up to four in a row, without the workgroup's two barriers and the policy code in between (pre_*: what the
                 // rounds in front of the last one did; applied by every thread below).
-                uint32_t pre_cw = 0, pre_k = 0, hd = q.head, tl = q.tail, nn = n;
+                uint32_t pre_cw = 0, pre_k = 0, hd = q.head, tl = q.tail, nn = n, sc_ = solo_cool;
                 for (;;) {
                     nt = tl; nx = nn;
                     // the fast round on row records first; it declines (nothing touched) what it does not cover
                     if (v2)
                         cw = chain ? queue_round_fast<true, false>(J, S, hd, tl, nn, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
                                    : queue_round_fast<false, false>(J, S, hd, tl, nn, C, my_pops, my_nnz, &nt, &nx, &S.sd[6]);
-                    if (TEAM && J.nwg > 1 && cw < 0xFFFFFFFEu && cw == nn && nx == nn && pre_k < ECNE_FAST_CHAIN) {
-                        const uint32_t av2 = nt - (hd + cw);
-                        if (av2 >= 1u && av2 <= 64u) { pre_cw += cw; ++pre_k; hd += cw; tl = nt; nn = av2; continue; }
+                    // (committed everything it examined -- its whole window, or up to a row / an event it does not take, bit 31 -- and the
+                    //  policy below would not start solo drains on it)
+                    if (TEAM && J.nwg > 1 && cw < 0xFFFFFFFEu && cw != 0 && (nx & 0x7FFFFFFFu) == cw && pre_k < ECNE_FAST_CHAIN) {
+                        const uint32_t av1 = tl - hd, av2 = nt - (hd + cw);
+                        const bool to_solo = sc_ == 0 && solo_ok && av1 >= ECNE_SOLO_AVAIL && ECNE_SOLO_RATIO * cw <= (av1 < 64u ? av1 : 64u);
+                        if (!to_solo && av2 >= 1u && av2 <= 64u) {
+#ifdef ECNE_ROUNDLOG
+                            if (lane == 0) { const unsigned long long t_ = wall_clock64(); printf("RL wave avail %u n %u c %u dt %llu\n", av1, nx & 0x7FFFFFFFu, cw, t_ - qt_last); qt_last = t_; }
+#endif
+                            if (sc_) --sc_;
+                            pre_cw += cw; ++pre_k; hd += cw; tl = nt; nn = av2;
+                            continue;
+                        }
                     }
                     break;
                 }
