@@ -989,7 +989,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                         const bool to_solo = sc_ == 0 && solo_ok && av1 >= ECNE_SOLO_AVAIL && ECNE_SOLO_RATIO * cw <= (av1 < 64u ? av1 : 64u);
                         if (!to_solo && av2 >= 1u && av2 <= 64u) {
 #ifdef ECNE_ROUNDLOG
-                            if (lane == 0) { const unsigned long long t_ = wall_clock64(); printf("RL wave avail %u n %u c %u dt %llu\n", av1, nx & 0x7FFFFFFFu, cw, t_ - qt_last); qt_last = t_; }
+                            if (lane == 0) { const unsigned long long t_ = wall_clock64(); printf("RL wave avail %u n %u c %u dt %llu\n", av1, nx & 0x7FFFFFFFu, cw, t_ - qt_last); qt_last = wall_clock64(); }      // (the print itself is not the round's time)
 #endif
                             if (sc_) --sc_;
                             pre_cw += cw; ++pre_k; hd += cw; tl = nt; nn = av2;
