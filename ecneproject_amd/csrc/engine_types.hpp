@@ -104,6 +104,7 @@ struct Counters {   // one per job, device memory
     unsigned int p3_cand1, p3_nhot, p3_any, p3_fire;
     unsigned int p3_hot;   // some k >= 2 group could be complete in this pass (else nobody looks at the table)
     unsigned int p4_nfired, setup_tail;
+    unsigned int p4_live;  // outer iteration in which some P4 candidate still had an untagged, non-unique b (k_solve, P4)
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
     unsigned int q_cmd[12];         // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow, mark epoch, team size K, sub-team barrier generation
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;

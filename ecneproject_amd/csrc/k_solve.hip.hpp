@@ -373,6 +373,13 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
                 const bool any = ld_agent(&ctr->p3_any) != 0;
                 const bool hot = ld_agent(&ctr->p3_hot) != 0;
+                // Nobody reported a one-variable group or a group that could be complete: nothing can fire in this pass, and every
+                // workgroup sees that from the same two words (the master does not touch them on this path) -- the pass ends here,
+                // without the master's search and the second barrier (most passes of most circuits: 28 of 28 on ecdsa_like(26)).
+                if (!hot && ld_agent(&ctr->p3_cand1) == 0xFFFFFFFFu) {
+                    if (master && tid == 0 && any) ctr->p3_any = 0;      // (read again a whole outer iteration from now)
+                    break;
+                }
                 // phase 2: rows whose group could reach its size in this pass
                 if (hot) {
                     for (uint32_t r = f + gtid; r < nC; r += gstride) {
@@ -440,13 +447,13 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                             wg_fence();
                             if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
                         }
-                        if (lane == 0) {
-                            ctr->p3_fire = best;
-                            ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0;   // ready for the next round
-                        }
+                        if (lane == 0) ctr->p3_fire = best;
                     }
                 }
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                // ready for the next pass -- only now: the other workgroups decide from p3_hot / p3_cand1 whether this pass goes on
+                // (above) at their own pace after the first barrier; all of them have done so once they are here
+                if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; }
                 const uint32_t fire = ld_agent(&ctr->p3_fire);
                 if (fire == 0xFFFFFFFFu) break;
                 const uint32_t upto = fire + 1;
@@ -512,13 +519,19 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         // statically eligible row. A row tags b iff b is not unique, still untagged, and the row is the
         // FIRST such row of b in index order (varmin[b]).
         {
+            bool my_live = false;      // a candidate whose b is neither unique nor tagged: some row will tag in this pass
             for (uint32_t i = gtid; i < J.nP4; i += gstride) {
                 const uint32_t b = J.p4_b[i];
                 if (J.flags[b] & 1) continue;
                 if (J.p4_s[i] & 0x80000000u) { raise(J, K_EDIVZERO); continue; }
                 if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
+                if (J.abz[b] == -1) my_live = true;
             }
+            if (my_live) __hip_atomic_store(&ctr->p4_live, (unsigned)outer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (stamped with the outer iteration: never reset)
             if (job_barrier(J, &s_err)) break;
+            // No live candidate anywhere: no row can tag, nothing to re-queue -- the pass ends at this barrier (every workgroup reads the
+            // same word). The minima stay: as long as b is not unique its first candidate row is the same row.
+            if (ld_agent(&ctr->p4_live) == (unsigned)outer) {
             uint32_t my_fired = 0;
             for (uint32_t i = gtid; i < J.nP4; i += gstride) {
                 const uint32_t b = J.p4_b[i];
@@ -665,6 +678,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                     if (w == 0) hits[11] += nev;
                 }
             }
+            }      // (a live candidate)
         }
         ECNE_TICK(3);
 

@@ -93,3 +93,24 @@ def test_every_reference_fixture_on_teams(mode):
         res += E.solve_batch(systems[i:i + 30], force_nwg=6, queue_mode=mode)
     for r, g in zip(rels, res):
         assert_bit_exact("%s nwg=6 mode=%d" % (r, mode), g, orc.run(fixtures.path(r)))
+
+
+def test_sweeps_that_end_early_agree_across_workgroups(tmp_path):
+    """P3 ends at its first barrier when nobody reported a candidate, P4 when no candidate is untagged (k_solve.hip.hpp): every
+    workgroup decides that by itself from words published before the barrier, so nobody may change those words before the next one.
+    The first version let the master re-arm P3's candidate word while slower workgroups were still reading it -- they left the pass,
+    the others went on to its second barrier: one wrong state in eight runs of this batch (tests/tools/stress_fuzz.py 92000 60 4,
+    seed 92002 on five workgroups, the only system of the batch whose P3 fires). Repeated, on teams of 5 and 8, every frontier drained."""
+    paths = []
+    for seed in range(92000, 92024):
+        p = str(tmp_path / ("%d.r1cs" % seed))
+        fuzz_r1cs.write(p, fuzz_r1cs.make_wide(seed, 4))
+        paths.append(p)
+    oracles = [orc.run(p) for p in paths]
+    assert any(o.summary.rule_hits[10] for o in oracles)          # P3 fires somewhere in the batch
+    systems = [E.System(E.R1CS(p)) for p in paths]
+    for rep in range(6):
+        for nwg in (5, 8):
+            res = E.solve_batch(systems, force_nwg=nwg, queue_mode=4 if rep % 2 else 0)
+            for p, g, o in zip(paths, res, oracles):
+                assert_bit_exact("%s nwg=%d rep %d" % (os.path.basename(p), nwg, rep), g, o)
