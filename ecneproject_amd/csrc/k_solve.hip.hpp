@@ -280,17 +280,13 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             }
         }
         else if (!seq_mode) { if constexpr (TEAM) queue_phase_helper(J, s_chunk, me.rank, &s_err); }
-        if (job_barrier(J, &s_err)) break;      // publishes the queue phase's state changes to the helpers
-        if (master && J.nwg > 1 && !seq_mode) {
-            // fold in what the helpers did during multi-workgroup rounds
-            steps += ctr->q_acc[0];
-            if (w == 0) {
-                nuniq += ctr->q_acc[1]; pops += ctr->q_acc[10]; pop_nnz += ctr->q_acc[11];
-                for (int i = 0; i < 8; ++i) hits[i] += ctr->q_acc[2 + i];
-            }
-            __syncthreads();
-            if (tid < 16) ctr->q_acc[tid] = 0;
-        }
+        // A team leaves the queue phase through a job barrier of its own (the master's last command): that barrier has published the
+        // phase's state changes and left every workgroup the same snapshot of the error word -- a second barrier here would only make
+        // the helpers' counters visible, and those are folded in behind P3's first barrier instead (4.5 us per outer iteration).
+        const bool team_phase = TEAM && J.nwg > 1 && !seq_mode;
+        if (team_phase) { if (s_err) break; }
+        else if (job_barrier(J, &s_err)) break;      // (sequential modes: the helpers have been waiting here for the master's queue phase)
+        bool fold_helpers = team_phase && master;
         ECNE_TICK(1);
 
         // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
@@ -371,6 +367,17 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 if (my_any) __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (my_hot) __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
+                if (fold_helpers) {
+                    // fold in what the helpers did during the rounds on teams (their atomics came before this barrier)
+                    fold_helpers = false;
+                    steps += ctr->q_acc[0];
+                    if (w == 0) {
+                        nuniq += ctr->q_acc[1]; pops += ctr->q_acc[10]; pop_nnz += ctr->q_acc[11];
+                        for (int i = 0; i < 8; ++i) hits[i] += ctr->q_acc[2 + i];
+                    }
+                    __syncthreads();
+                    if (tid < 16) ctr->q_acc[tid] = 0;
+                }
                 const bool any = ld_agent(&ctr->p3_any) != 0;
                 const bool hot = ld_agent(&ctr->p3_hot) != 0;
                 // Nobody reported a one-variable group or a group that could be complete: nothing can fire in this pass, and every
