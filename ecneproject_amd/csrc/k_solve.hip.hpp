@@ -26,8 +26,16 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     const WgDesc me = wgs[blockIdx.x];
     if (tid < (int)(sizeof(Job) / 4)) ((uint32_t*)&J)[tid] = ((const uint32_t*)&jobs[me.job])[tid];
     __syncthreads();
-    const uint32_t nC = J.nC, nV = J.nV;
-    const bool master = me.rank == 0;
+    // (workgroup-uniform values as scalars: read from the Job in LDS or from memory they would sit in a vector register of every thread
+    //  across the whole outer loop -- and be spilled there, see the phase clocks below)
+    auto uni32 = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    auto uniptr = [](const void* p) -> uint64_t {
+        const uint64_t x = (uint64_t)p;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    };
+    const uint32_t nC = uni32(J.nC), nV = uni32(J.nV);
+    const uint32_t my_rank = uni32(me.rank);
+    const bool master = my_rank == 0;
     const bool seq_mode = J.queue_mode == 1 || J.queue_mode == 2;   // strictly sequential pops: 1 = exec_row(), 2 = the chain executor where it applies
     // ---------------- LDS residency. A job run by ONE workgroup keeps the two arrays every pop reads and writes
     // -- the unique / is_known flag bytes and the in_queue tags -- in the CU's LDS when they fit the launch's
@@ -65,13 +73,16 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
 #ifdef ECNE_POPPROF
     if (tid < 8) pop_prof().acc[tid] = 0;
 #endif
-    const uint32_t gtid = me.rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;   // job-wide thread index
-    Counters* const ctr = J.ctr;
-    const uint32_t ht_cap = (nC + J.nwg - 1) / J.nwg + 2048;   // this workgroup's share of ht_list (its rows + slack)
+    const uint32_t gtid = my_rank * ECNE_WG + tid, gstride = uni32(J.nwg) * ECNE_WG;   // job-wide thread index
+    Counters* const ctr = (Counters*)uniptr(J.ctr);
+    const uint32_t ht_cap = (nC + uni32(J.nwg) - 1) / uni32(J.nwg) + 2048;   // this workgroup's share of ht_list (its rows + slack)
     if (tid == 0) { s_htn = 0; job_barrier_init(); }
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t_last = wall_clock64();
-#define ECNE_TICK(slot) do { unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } while (0)
+    // phase clocks (ecne_summary.phase_ms): thread 0 of the master keeps them, in LDS. As eight 64-bit accumulators and a time stamp in
+    // the registers of EVERY thread they were live across the whole outer loop: 92 more register spills in this kernel, 0.46 GB of
+    // scratch write-backs per ecdsa-scale launch (each job barrier's release writes the dirty scratch lines back) and 0.4 ms.
+    __shared__ unsigned long long tk[8], t_last;
+    if (tid == 0) { for (int i = 0; i < 8; ++i) tk[i] = 0; t_last = wall_clock64(); }
+#define ECNE_TICK(slot) do { if (master && tid == 0) { const unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } } while (0)
 
     // ---------------- setup (:593-704), all workgroups
     for (uint32_t i = tid; i < ECNE_BIGTAB; i += ECNE_WG) s_chunk.bt[i] = 0xFFFFFFFFu;
@@ -111,8 +122,8 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     q.head = 0; q.tail = 0; q.evout = nullptr; q.nev = 0; q.emit = 0;
     {
         const uint32_t per = (nC + J.nwg - 1) / J.nwg;
-        const uint32_t blk0 = me.rank * per < nC ? me.rank * per : nC;
-        const uint32_t blk1 = (me.rank + 1) * per < nC ? (me.rank + 1) * per : nC;
+        const uint32_t blk0 = my_rank * per < nC ? my_rank * per : nC;
+        const uint32_t blk1 = (my_rank + 1) * per < nC ? (my_rank + 1) * per : nC;
         auto wants = [&](uint32_t r) -> uint32_t {
             uint32_t first = 0, cnt = 0;
             const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
@@ -131,7 +142,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         for (uint32_t r = blk0 + tid; r < blk1; r += ECNE_WG) mine += wants(r);
         uint32_t total_pushes = 0;
         int scan_err = 0;
-        uint32_t base = team_exclusive_scan_any(J, s_chunk, me.rank, mine, &total_pushes, &s_err, &scan_err);
+        uint32_t base = team_exclusive_scan_any(J, s_chunk, my_rank, mine, &total_pushes, &s_err, &scan_err);
         // base = pushes of all lower workgroups + of lower threads of mine; but rows are interleaved
         // across my threads, so redo my block in row order with workgroup scans from my block's base
         uint32_t wg_base = base;
@@ -165,9 +176,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         if (acc == 0x9E3779B9u && nq == 0xFFFFFFFFu) s_u32[1] = acc;   // (keeps the loads alive)
     }
     ECNE_TICK(0);
-    unsigned long long steps = 0, prev_steps = ~0ull, nuniq = 0, pops = 0, outer = 0, pop_nnz = 0;
-    unsigned long long hits[16];
-    for (int i = 0; i < 16; ++i) hits[i] = 0;
+    unsigned long long steps = 0, prev_steps = ~0ull, outer = 0;
+    // statistics only the master's wavefront 0 keeps (its lanes in lockstep: they read the same word and write the same sum): in LDS,
+    // not in the registers / scratch frame of every thread across the outer loop
+    __shared__ unsigned long long s_stat[3], hits[16];
+    unsigned long long &nuniq = s_stat[0], &pops = s_stat[1], &pop_nnz = s_stat[2];
+    if (tid < 16) hits[tid] = 0;
+    if (tid < 3) s_stat[tid] = 0;
+    __syncthreads();
     // `steps` is the loop-control value: the master publishes it in ctr->sync_steps before each barrier
 
     for (;;) {
@@ -261,7 +277,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                     }
                 }
                 if (lane == 0) { s_q = q; s_steps = steps; }
-                tk[7] += wall_clock64() - t_last;      // diagnostics: P1 + P2 alone (phase_ms[7]); the slot-1 clock keeps running
+                if (lane == 0) tk[7] += wall_clock64() - t_last;      // diagnostics: P1 + P2 alone (phase_ms[7]); the slot-1 clock keeps running
             }
             __syncthreads();
             steps = s_steps;
@@ -279,14 +295,17 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
             }
         }
-        else if (!seq_mode) { if constexpr (TEAM) queue_phase_helper(J, s_chunk, me.rank, &s_err); }
+        else if (!seq_mode) { if constexpr (TEAM) queue_phase_helper(J, s_chunk, my_rank, &s_err); }
         // A team leaves the queue phase through a job barrier of its own (the master's last command): that barrier has published the
         // phase's state changes and left every workgroup the same snapshot of the error word -- a second barrier here would only make
         // the helpers' counters visible, and those are folded in behind P3's first barrier instead (4.5 us per outer iteration).
         const bool team_phase = TEAM && J.nwg > 1 && !seq_mode;
+#ifdef ECNE_POSTQ_BARRIER
+        if (team_phase) { if (job_barrier(J, &s_err)) break; }
+#else
         if (team_phase) { if (s_err) break; }
+#endif
         else if (job_barrier(J, &s_err)) break;      // (sequential modes: the helpers have been waiting here for the master's queue phase)
-        bool fold_helpers = team_phase && master;
         ECNE_TICK(1);
 
         // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
@@ -294,7 +313,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
             bool p3_err = false;
             for (;;) {
-                tk[6]++;
+                if (master && tid == 0) tk[6]++;
                 // phase 1: evaluate rows >= f against the current state
                 // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
                 bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
@@ -322,14 +341,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                             my_any = true;
                             if (created) {   // remembered, so that only the slots in use are wiped afterwards
                                 const uint32_t pos = atomicAdd(&s_htn, 1u);
-                                if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                                if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
                             }
                         }
                     }
                 }
                 // long rows: one WAVEFRONT per row, lanes across its entries (one lane walking a 1 025-term row made
                 // its whole workgroup -- and with it every workgroup of the job -- wait ~70 us per sweep)
-                for (uint32_t li = me.rank * ECNE_NWAVES + (uint32_t)w; li < J.nLong; li += J.nwg * ECNE_NWAVES) {
+                for (uint32_t li = my_rank * ECNE_NWAVES + (uint32_t)w; li < J.nLong; li += J.nwg * ECNE_NWAVES) {
                     const uint32_t r = J.long_list[li];
                     if (r < f || (J.rdead[r] & 1)) continue;               // (wave-uniform)
                     bool nuab = false;
@@ -359,7 +378,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                             my_any = true;
                             if (created) {
                                 const uint32_t pos = atomicAdd(&s_htn, 1u);
-                                if (pos < ht_cap) J.ht_list[(size_t)me.rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                                if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
                             }
                         }
                     }
@@ -367,17 +386,6 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 if (my_any) __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (my_hot) __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
-                if (fold_helpers) {
-                    // fold in what the helpers did during the rounds on teams (their atomics came before this barrier)
-                    fold_helpers = false;
-                    steps += ctr->q_acc[0];
-                    if (w == 0) {
-                        nuniq += ctr->q_acc[1]; pops += ctr->q_acc[10]; pop_nnz += ctr->q_acc[11];
-                        for (int i = 0; i < 8; ++i) hits[i] += ctr->q_acc[2 + i];
-                    }
-                    __syncthreads();
-                    if (tid < 16) ctr->q_acc[tid] = 0;
-                }
                 const bool any = ld_agent(&ctr->p3_any) != 0;
                 const bool hot = ld_agent(&ctr->p3_hot) != 0;
                 // Nobody reported a one-variable group or a group that could be complete: nothing can fire in this pass, and every
@@ -512,12 +520,23 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             {
                 const uint32_t nmine = s_htn < ht_cap ? s_htn : ht_cap;
                 for (uint32_t i = tid; i < nmine; i += ECNE_WG) {
-                    const uint32_t s = J.ht_list[(size_t)me.rank * ht_cap + i];
+                    const uint32_t s = J.ht_list[(size_t)my_rank * ht_cap + i];
                     J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0;
                 }
                 __syncthreads();
                 if (tid == 0) s_htn = 0;
             }
+        }
+        if (team_phase && master) {
+            // fold in what the helpers did during the rounds on teams: their atomics came before P3's first barrier (here, not inside
+            // P3's loop: with the counters live across that loop the compiler spilled them, +0.27 GB of scratch writes per launch)
+            steps += ctr->q_acc[0];
+            if (w == 0) {
+                nuniq += ctr->q_acc[1]; pops += ctr->q_acc[10]; pop_nnz += ctr->q_acc[11];
+                for (int i = 0; i < 8; ++i) hits[i] += ctr->q_acc[2 + i];
+            }
+            __syncthreads();
+            if (tid < 16) ctr->q_acc[tid] = 0;
         }
         ECNE_TICK(2);
 
@@ -576,7 +595,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 uint32_t cnt = 0;
                 for (uint32_t i = i0; i < i1; ++i) cnt += J.fired[i];
                 uint32_t nev = 0;
-                uint32_t o = team_exclusive_scan(J, s_chunk, me.rank, cnt, 0, &nev, &s_err, &err);
+                uint32_t o = team_exclusive_scan(J, s_chunk, my_rank, cnt, 0, &nev, &s_err, &err);
                 if (!err) {
                     for (uint32_t i = i0; i < i1; ++i)
                         if (J.fired[i]) { J.events[o++] = J.p4_b[i]; J.fired[i] = 0; }
@@ -590,7 +609,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                     e1 = (gtid + 1) * eper < nev ? (gtid + 1) * eper : nev;
                     uint32_t deg = 0;
                     for (uint32_t e = e0; e < e1; ++e) { const uint32_t v = J.events[e]; deg += J.fo_ptr[v + 1] - J.fo_ptr[v]; }
-                    cbase = team_exclusive_scan(J, s_chunk, me.rank, deg, 1, &M, &s_err, &err);
+                    cbase = team_exclusive_scan(J, s_chunk, my_rank, deg, 1, &M, &s_err, &err);
                 }
                 if (!err && M <= J.candcap) {
                     if (tid == 0) s_chunk.nbigev = 0;
@@ -616,7 +635,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                             J.cand[jj] = t | (win ? 0x80000000u : 0u);
                             nwin += win;
                         }
-                        const uint32_t wbase = team_exclusive_scan(J, s_chunk, me.rank, nwin, 0, &W, &s_err, &err);
+                        const uint32_t wbase = team_exclusive_scan(J, s_chunk, my_rank, nwin, 0, &W, &s_err, &err);
                         if (!err) {
                             uint32_t oq = tail0 + wbase;
                             for (uint32_t jj = j0; jj < j1; ++jj) {
@@ -676,13 +695,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
                 {
                     uint32_t tl = q.tail;
+                    unsigned long long p4_fb = 0;
                     for (uint32_t eb = 0; eb < nev; eb += 4096) {
                         const uint32_t cnt = (nev - eb) < 4096u ? (nev - eb) : 4096u;
-                        tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &hits[15]);
+                        tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &p4_fb);      // (every thread counts a fallback in a copy of its own)
                     }
                     q.tail = tl;
                     steps += nev;
-                    if (w == 0) hits[11] += nev;
+                    if (w == 0) { hits[11] += nev; hits[15] += p4_fb; }
                 }
             }
             }      // (a live candidate)
