@@ -732,11 +732,24 @@ __device__ __forceinline__ uint32_t multi_cap(const Job& J) { return J.nwg * ECN
 #ifndef ECNE_DRAIN_GROW
 #define ECNE_DRAIN_GROW 6      // a drain that needed at most this many levels doubles the next window ...
 #endif
+#ifndef ECNE_DRAIN_GROW4
+#define ECNE_DRAIN_GROW4 2     // ... at most this many: it quadruples
+#endif
+#ifndef ECNE_MWINDOW0
+#define ECNE_MWINDOW0 16384   // window of the first PREFIX round on all workgroups of a queue phase (a dependency cuts it short: start small)
+#endif
+#ifndef ECNE_MWINDOW0_DRAIN
+#define ECNE_MWINDOW0_DRAIN 131072   // ... of the first DRAIN round: the whole team's worth (a drain is not cut short by a dependency, it takes more levels;
+                                     // ramping up from 16 384 cost three to five extra rounds per wide phase of ecdsa_like(26): 7.98 -> 7.50 ms)
+#endif
 #ifndef ECNE_DRAIN_SHRINK
 #define ECNE_DRAIN_SHRINK 16   // ... one that needed more than this many halves it (a dependency chain inside the window: every level pays four job barriers)
 #endif
 __device__ __forceinline__ void drain_window_update(uint32_t levels, uint32_t nm, uint32_t cap_n, uint32_t& mwindow) {
-    if (levels <= ECNE_DRAIN_GROW) mwindow = (mwindow * 2 < cap_n) ? mwindow * 2 : cap_n;
+    if (levels <= ECNE_DRAIN_GROW) {
+        const uint32_t g = levels <= ECNE_DRAIN_GROW4 ? 4u : 2u;       // (a drain of one or two levels: the frontier is wide and flat, the window goes up in two steps instead of four)
+        mwindow = (mwindow * g < cap_n) ? mwindow * g : cap_n;
+    }
     else if (levels > ECNE_DRAIN_SHRINK) mwindow = nm / 2 > 1024u ? nm / 2 : 1024u;
 }
 #ifndef ECNE_SOLO_AVAIL
@@ -864,7 +877,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     bool declined_wide = false;      // the fast wavefront round keeps declining the head row of a wide frontier
     uint32_t declined_run = 0;
     const uint32_t burst_c = chain ? ECNE_CHAIN_BURST_C : ECNE_BURST_C, burst_avail = chain ? 0xFFFFFFFFu : 64u, burst_max = chain ? 4096u : 512u;
-    uint32_t mwindow = 16384;        // window of multi-workgroup rounds (adaptive like `window`)
+    uint32_t mwindow = (TEAM && drain_ok(J)) ? ECNE_MWINDOW0_DRAIN : ECNE_MWINDOW0;        // window of multi-workgroup rounds (adaptive like `window`)
     // Solo drain rounds: the master of a large job drains up to 512 rows by itself (queue_round_drain on a team of one: its job
     // barriers are workgroup barriers) when fast rounds keep committing a few rows of a full window -- many dependency chains side
     // by side, each with several rows queued (45 copies of a chained circuit in one file: ~5 of 64 rows per fast round).
