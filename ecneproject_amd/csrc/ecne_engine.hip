@@ -19,6 +19,8 @@
 #include <mutex>
 #include <shared_mutex>
 #include <new>
+#include <array>
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -126,6 +128,11 @@ struct Layout {
     // only; the counts the arena is carved from and the small lists above are filled either way
     bool host_arrays = false;    // rp, col, coef, rinfo hold data on the host
     uint32_t n_p4 = 0, n_p5 = 0, n_cls = 0, n_long = 0, n_bigrows = 0, fo_total = 0, maxrowC = 0;
+    // secp_solve's dsu setup (:634-678) raises BoundsError on this system (`l[1]` / `l[2]` of a two-entry C whose non-zero keys are
+    // none or the constant alone, :650-656; or a root outside the dsu when ids above num_variables occur)
+    bool dsu_err = false;
+    // ids above num_variables in a row (non-zero coefficient) or a special: tables for the reference's lazy BoundsError (oob.hip.hpp)
+    std::vector<uint32_t> oob_blob;
 };
 
 struct DeviceImage {
@@ -283,6 +290,183 @@ static LaunchScratch& launch_scratch() { static thread_local LaunchScratch s; re
 
 // ------------------------------------------------------------------------------------ layout
 static void build_small_lists(ecne_system& S, uint32_t nVall, std::vector<uint32_t>* marks);
+static void row_variables_in_set_order(const Rows& R, size_t i, jl::SlotTable& set, std::vector<int64_t>& out);
+
+// IntDisjointSet as secp_solve's setup uses it (:634-678): find_root raises BoundsError outside 1..length, push! appends an element
+struct HostDsu {
+    std::vector<uint32_t> parent;      // 1-based
+    bool err = false;
+    explicit HostDsu(size_t n) : parent(n + 1) { for (size_t i = 0; i <= n; ++i) parent[i] = (uint32_t)i; }
+    size_t size() const { return parent.size() - 1; }
+    uint32_t root(int64_t x) {
+        if (x < 1 || (size_t)x > size()) { err = true; return 0; }
+        uint32_t r = (uint32_t)x;
+        while (parent[r] != r) r = parent[r];
+        for (uint32_t c = (uint32_t)x; parent[c] != r;) { const uint32_t nx = parent[c]; parent[c] = r; c = nx; }
+        return r;
+    }
+    uint32_t find(int64_t x, bool& bad) const {
+        if (x < 1 || (size_t)x > size()) { bad = true; return 0; }
+        uint32_t r = (uint32_t)x;
+        while (parent[r] != r) r = parent[r];
+        return r;
+    }
+    void unite(int64_t a, int64_t b) {
+        const uint32_t ra = root(a);
+        if (err) return;
+        const uint32_t rb = root(b);
+        if (err) return;
+        if (ra != rb) parent[rb] = ra;
+    }
+    uint32_t push() { parent.push_back((uint32_t)parent.size()); return (uint32_t)size(); }
+};
+
+// Tables for the reference's lazy BoundsError (oob.hip.hpp; format: the OOB_* words there). Host-laid systems only (the device
+// layout hands a system with such ids back to the host): per row that names one with a non-zero coefficient, the variables in
+// front of the first such id in the order each rule walks the row -- R1: B, A (nonzeroKeys order, :828-846), then C; R2 and P3:
+// getVariables order (:36-56); P5: A of row i (:1503) -- and, for secp_solve, the dsu of the setup (:634-678) with ids as they are.
+static void build_oob_tables(ecne_system& S, const std::vector<uint8_t>& a_equal_next) {
+    Layout& L = S.L;
+    const Rows& R = S.rows();
+    const uint32_t nC = L.nC;
+    const uint32_t nVref = (uint32_t)std::min<int64_t>(S.n_vars, 0x7FFFFFFF);
+    auto is_oob = [&](uint32_t v) { return v > nVref; };
+    std::vector<uint32_t> rowids, rowrec_off, recs, p5;
+    uint32_t n_p5 = 0;
+    jl::SlotTable set;
+    std::vector<int64_t> gv;
+    for (uint32_t i = 0; i < nC; ++i) {
+        bool any = false;
+        for (int p = 0; p < 3 && !any; ++p)
+            for (uint32_t e = L.rp[p][i]; e < L.rp[p][i + 1]; ++e) if (is_oob(L.col[p][e])) { any = true; break; }
+        if (!any) continue;
+        const uint32_t nA = L.rp[0][i + 1] - L.rp[0][i], nB = L.rp[1][i + 1] - L.rp[1][i], nCc = L.rp[2][i + 1] - L.rp[2][i];
+        uint32_t flags = 0;
+        std::vector<uint32_t> strict, cpart, r2, p3;
+        if (nA == 0 && nB == 0) flags |= 1u;                 // OOBF_LINEAR
+        if (nCc == 0) flags |= 4u;                           // OOBF_C_EMPTY
+        bool hit = false;
+        for (int p = 1; p >= 0 && !hit; --p)                 // B first, then A
+            for (uint32_t e = L.rp[p][i]; e < L.rp[p][i + 1]; ++e) {
+                if (is_oob(L.col[p][e])) { hit = true; break; }
+                strict.push_back(L.col[p][e]);
+            }
+        if (hit) flags |= 2u;                                // OOBF_STRICT_HAS
+        else
+            for (uint32_t e = L.rp[2][i]; e < L.rp[2][i + 1]; ++e) {
+                if (is_oob(L.col[2][e])) break;
+                cpart.push_back(L.col[2][e]);
+            }
+        gv.clear();
+        row_variables_in_set_order(R, i, set, gv);
+        for (int64_t v : gv) {
+            if (is_oob((uint32_t)v)) break;
+            if (nCc == 0) r2.push_back((uint32_t)v);
+            bool inA = false, inB = false;
+            for (uint32_t e = L.rp[0][i]; e < L.rp[0][i + 1]; ++e) inA |= L.col[0][e] == (uint32_t)v;
+            for (uint32_t e = L.rp[1][i]; e < L.rp[1][i + 1]; ++e) inB |= L.col[1][e] == (uint32_t)v;
+            if (inA && inB) p3.push_back((uint32_t)v);
+        }
+        rowids.push_back(i);
+        rowrec_off.push_back((uint32_t)recs.size());
+        recs.push_back(flags);
+        recs.push_back((uint32_t)strict.size()); recs.push_back((uint32_t)cpart.size()); recs.push_back((uint32_t)r2.size()); recs.push_back((uint32_t)p3.size());
+        recs.insert(recs.end(), strict.begin(), strict.end());
+        recs.insert(recs.end(), cpart.begin(), cpart.end());
+        recs.insert(recs.end(), r2.begin(), r2.end());
+        recs.insert(recs.end(), p3.begin(), p3.end());
+    }
+    // P5 (:1492-1550) at row i: the three counts, then A of row i while unique, then (maps equal, y, C's keys) variable_states[y]
+    for (uint32_t i = 0; i + 1 < nC; ++i) {
+        const uint32_t nc_next = L.rp[2][i + 2] - L.rp[2][i + 1], nb_next = L.rp[1][i + 2] - L.rp[1][i + 1], nc_this = L.rp[2][i + 1] - L.rp[2][i];
+        if (nc_next != 0 || nb_next != 1 || nc_this != 2) continue;
+        std::vector<uint32_t> pre;
+        bool hit = false;
+        for (uint32_t e = L.rp[0][i]; e < L.rp[0][i + 1]; ++e) {
+            if (is_oob(L.col[0][e])) { hit = true; break; }
+            pre.push_back(L.col[0][e]);
+        }
+        if (!hit) {
+            if (!a_equal_next[i]) continue;
+            const uint32_t y = L.col[1][L.rp[1][i + 1]];
+            if (y == 1 || !is_oob(y)) continue;
+            bool bad = false;
+            for (uint32_t k = L.rp[2][i]; k < L.rp[2][i + 1]; ++k) if (L.col[2][k] != 1 && L.col[2][k] != y) bad = true;
+            if (bad) continue;
+        }
+        p5.push_back(i); p5.push_back(hit ? 0u : 1u); p5.push_back((uint32_t)pre.size());
+        p5.insert(p5.end(), pre.begin(), pre.end());
+        ++n_p5;
+    }
+    // secp_solve: the dsu of the setup, with the ids as they are
+    std::vector<uint32_t> k1, k2;
+    for (uint32_t i = 0; i < S.specials.size(); ++i) { if (S.specials[i].name == "BigMultModP") k1.push_back(i); else if (S.specials[i].name == "BigLessThan") k2.push_back(i); }
+    HostDsu dsu((size_t)nVref);
+    {
+        const fp::u256 ONE = fp::make(1), PM1 = fp::pminus1();
+        std::map<std::array<uint64_t, 4>, uint32_t> const_vals;
+        for (uint32_t e = 0; e < nC && !dsu.err; ++e) {
+            if (L.rp[0][e + 1] != L.rp[0][e] || L.rp[1][e + 1] != L.rp[1][e]) continue;
+            const uint64_t d0 = R.ptr[2][e];
+            if (R.ptr[2][e + 1] - d0 != 2) continue;
+            const uint32_t c0 = L.rp[2][e], nl = L.rp[2][e + 1] - c0;      // l = nonzeroKeys(c) in Set order
+            const fp::u256 &u = R.coef[2][d0], &v = R.coef[2][d0 + 1];
+            if ((fp::eq(u, ONE) && fp::eq(v, PM1)) || (fp::eq(u, PM1) && fp::eq(v, ONE))) { dsu.unite(L.col[2][c0], L.col[2][c0 + 1]); continue; }
+            if (nl == 0) { dsu.err = true; break; }
+            bool constant_val = false;
+            for (uint32_t t = 0; t < nl; ++t) constant_val |= L.col[2][c0 + t] == 1;
+            uint32_t non_one = L.col[2][c0], pos = 0;
+            if (non_one == 1) { if (nl < 2) { dsu.err = true; break; } non_one = L.col[2][c0 + 1]; pos = 1; }
+            if (!constant_val) continue;
+            fp::u256 c1 = fp::make(0), cx = fp::make(L.coef[2][4ull * (c0 + pos)], L.coef[2][4ull * (c0 + pos) + 1], L.coef[2][4ull * (c0 + pos) + 2], L.coef[2][4ull * (c0 + pos) + 3]);
+            for (uint32_t t = 0; t < nl; ++t)
+                if (L.col[2][c0 + t] == 1) c1 = fp::make(L.coef[2][4ull * (c0 + t)], L.coef[2][4ull * (c0 + t) + 1], L.coef[2][4ull * (c0 + t) + 2], L.coef[2][4ull * (c0 + t) + 3]);
+            const fp::u256 value = fp::mul(c1, fp::inv(fp::neg(cx)));      // divexact(c[1], -c[non_one]) (:662)
+            const std::array<uint64_t, 4> key = {value.w[0], value.w[1], value.w[2], value.w[3]};
+            auto it = const_vals.find(key);
+            if (it == const_vals.end()) it = const_vals.emplace(key, dsu.push()).first;
+            dsu.unite(non_one, it->second);
+        }
+    }
+    L.dsu_err = dsu.err;
+    std::vector<uint32_t> codes(std::max<size_t>(k1.size() * k2.size(), 1), 0);
+    if (!dsu.err)
+        for (size_t a = 0; a < k1.size(); ++a)
+            for (size_t b = 0; b < k2.size(); ++b) {
+                const Special &ci = S.specials[k1[a]], &cj = S.specials[k2[b]];
+                if (ci.inputs.size() < 9 || cj.inputs.size() < 6) continue;      // (the device raises on the sizes first)
+                uint32_t code = 0;
+                bool same = true;
+                for (int k = 1; k <= 6 && !code; ++k) {
+                    bool bad = false;
+                    const uint32_t ra = dsu.find(ci.inputs[(size_t)k + 2], bad), rb = bad ? 0 : dsu.find(cj.inputs[(size_t)k - 1], bad);
+                    if (bad) code |= 1u;
+                    else if (ra != rb) same = false;
+                }
+                if (!code && same) {
+                    if (cj.outputs.empty()) code |= 1u;                                   // constraint_j[3][1]
+                    else if (cj.outputs[0] > S.n_vars) code |= 2u;
+                    else {
+                        bool o = false;
+                        for (int64_t v : ci.outputs) o |= v > S.n_vars;
+                        for (int idx : {1, 2, 3, 7, 8, 9}) o |= ci.inputs[(size_t)idx - 1] > S.n_vars;
+                        if (o) code |= 4u;
+                    }
+                }
+                codes[a * k2.size() + b] = code;
+            }
+    std::vector<uint32_t>& B = L.oob_blob;
+    B.assign(8, 0);
+    B[0] = (uint32_t)rowids.size(); B[1] = n_p5; B[2] = nVref; B[3] = (uint32_t)dsu.size();
+    B[4] = (uint32_t)B.size(); B.insert(B.end(), rowids.begin(), rowids.end());
+    B[5] = (uint32_t)B.size();
+    const uint32_t rec_base = (uint32_t)(B.size() + rowrec_off.size());
+    for (uint32_t o : rowrec_off) B.push_back(rec_base + o);
+    B.insert(B.end(), recs.begin(), recs.end());
+    B[6] = (uint32_t)B.size(); B.insert(B.end(), p5.begin(), p5.end());
+    B[7] = (uint32_t)B.size(); B.insert(B.end(), codes.begin(), codes.end());
+}
+
 static void build_layout(ecne_system& S) {
     Layout& L = S.L;
     const Rows& R = S.rows();
@@ -295,21 +479,23 @@ static void build_layout(ecne_system& S) {
     // a special or a row may mention a variable above nWires+1 only in malformed input; size state
     // arrays for the largest id seen so that indexing stays in bounds. Same pass: non-zero terms per
     // block and part, i.e. where every block of rows starts in the flat arrays.
-    std::vector<uint32_t> wmax(W, L.nV);
+    std::vector<uint32_t> wmax(W, L.nV), wmax_nz(W, 0);
+    std::vector<uint8_t> wdsu(W, 0);
     std::vector<uint64_t> blk_pos[3];
     for (int p = 0; p < 3; ++p) blk_pos[p].assign(nblk + 1, 0);
     for_chunks(nblk, [&](size_t blk, unsigned w) {
         const size_t i0 = blk * BLK, i1 = std::min(nC, i0 + BLK);
-        uint32_t mx = wmax[w];
+        uint32_t mx = wmax[w], mxnz = wmax_nz[w];
         for (int p = 0; p < 3; ++p) {
             uint64_t nz = 0;
             for (uint64_t k = R.ptr[p][i0]; k < R.ptr[p][i1]; ++k) {
                 mx = std::max(mx, R.var[p][k]);
-                nz += !fp::is_zero(R.coef[p][k]);
+                if (!fp::is_zero(R.coef[p][k])) { ++nz; mxnz = std::max(mxnz, R.var[p][k]); }
             }
             blk_pos[p][blk + 1] = nz;
         }
         wmax[w] = mx;
+        wmax_nz[w] = mxnz;
     });
     uint32_t maxv = L.nV;
     for (uint32_t m : wmax) maxv = std::max(maxv, m);
@@ -319,6 +505,14 @@ static void build_layout(ecne_system& S) {
     }
     const uint32_t nVall = maxv;   // arrays hold ids 0..nVall
     L.nV = nVall;
+    // ids above num_variables that a rule can ever read (a non-zero coefficient, a special's lists): the reference raises
+    // BoundsError at the first such read (variable_states has num_variables entries, :681) -- build_oob_tables below
+    bool oob = false;
+    for (uint32_t m : wmax_nz) oob |= (int64_t)m > S.n_vars;
+    for (auto& sp : S.specials) {
+        for (int64_t v : sp.inputs) oob |= v > S.n_vars;
+        for (int64_t v : sp.outputs) oob |= v > S.n_vars;
+    }
     for (int p = 0; p < 3; ++p) {
         for (size_t blk = 0; blk < nblk; ++blk) blk_pos[p][blk + 1] += blk_pos[p][blk];
         L.nnz[p] = blk_pos[p][nblk];
@@ -374,6 +568,10 @@ static void build_layout(ecne_system& S) {
         }
         const size_t nA = nz[0].size(), nB = nz[1].size(), nCc = nz[2].size();
         ri.lenC = (uint32_t)nCc;
+        // secp_solve's dsu setup (:634-678): a two-entry C without A and B whose non-zero keys are none (`l[1]`, :650) or the
+        // constant wire alone (`l[2]`, :652) is a BoundsError
+        if (nA == 0 && nB == 0 && R.ptr[2][i + 1] - R.ptr[2][i] == 2 && (nCc == 0 || (nCc == 1 && nz[2][0].v == 1)))
+            __atomic_store_n(&wdsu[0], (uint8_t)1, __ATOMIC_RELAXED);
         for (auto& e : nz[2]) if (e.v == 1) ri.shape |= SH_C_HAS1;
         if (nA + nB + nCc > ECNE_SMALL_ROW) ri.shape |= SH_BIG;
         if (nA || nB) ri.shape |= SH_HAS_AB;
@@ -545,6 +743,8 @@ static void build_layout(ecne_system& S) {
     L.host_arrays = true;
     L.n_p4 = (uint32_t)L.p4_list.size(); L.n_p5 = (uint32_t)L.p5_rows.size(); L.n_cls = (uint32_t)L.cls_list.size();
     L.fo_total = (uint32_t)L.fo_rows.size();
+    L.dsu_err = wdsu[0] != 0;
+    if (oob) build_oob_tables(S, a_equal_next);
     S.laid_out = true;
 }
 
@@ -601,7 +801,8 @@ static int upload_system(ecne_system& S, int device) {
             for (int64_t v : sp.inputs) min_nv = std::max<uint32_t>(min_nv, (uint32_t)v);
             for (int64_t v : sp.outputs) min_nv = std::max<uint32_t>(min_nv, (uint32_t)v);
         }
-        const int rc = fe::layout_on_device(*S.drows, (uint32_t)S.n_vars, min_nv, S.dev.lay);
+        int rc = fe::layout_on_device(*S.drows, (uint32_t)S.n_vars, min_nv, S.dev.lay);
+        if (rc == K_OK && S.dev.lay->cnt.nVall > (uint64_t)S.n_vars) { rc = fe::FE_FALLBACK; }      // ids above num_variables: the host lays the system out (build_oob_tables)
         if (rc == K_OK) {
             dev_layout = true;
             const fe::LayoutCounts& C = S.dev.lay->cnt;
@@ -611,6 +812,7 @@ static int upload_system(ecne_system& S, int device) {
             for (int p = 0; p < 3; ++p) L.nnz[p] = C.nnz[p];
             L.n_vals = C.n_vals; L.n_p4 = C.nP4; L.n_p5 = C.nP5; L.n_cls = C.nCls; L.n_long = C.nLong; L.n_bigrows = C.nBigRows;
             L.fo_total = C.fo_total; L.maxrowC = C.maxrowC;
+            L.dsu_err = C.dsu_err != 0;
             L.host_arrays = false;
             build_small_lists(S, C.nVall, &marks);
             const uint64_t nnz = L.nnz[0] + L.nnz[1] + L.nnz[2];
@@ -739,6 +941,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_bigev = c.take(4ull * ((size_t)maxrowC * 3 + 64));
     const uint32_t bigstride = 2 * (maxrowC + 8);
     size_t o_bigpool = c.take(4ull * ECNE_MAX_NWG * ECNE_BIGK * bigstride);
+    size_t o_oob = L.oob_blob.empty() ? 0 : c.take(4ull * L.oob_blob.size());
     size_t o_ctr = c.take(sizeof(Counters));
     char* base = nullptr;
     HIP_TRY(hipMalloc((void**)&base, c.off));
@@ -784,8 +987,10 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_k2, k2_list.data(), 4ull * k2_list.size()));
     HIP_TRY(up(o_knowns, L.knowns.data(), 4ull * L.knowns.size()));
     HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
+    if (!L.oob_blob.empty()) HIP_TRY(up(o_oob, L.oob_blob.data(), 4ull * L.oob_blob.size()));
     Job& J = S.dev.job;
     std::memset(&J, 0, sizeof J);
+    J.oob = L.oob_blob.empty() ? nullptr : (const uint32_t*)(base + o_oob);
     J.nC = nC; J.nV = nV; J.nSp = nSp;
     J.nKnown = (uint32_t)L.knowns.size(); J.nTarget = (uint32_t)L.targets.size();
     J.nP4 = L.n_p4; J.nP5 = L.n_p5;
@@ -1185,7 +1390,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 if (const char* e = getenv("ECNE_BARRIER_TIMEOUT_MS")) tmo = (uint64_t)std::max(1L, atol(e));
                 hj[i].bar_timeout_ms = (uint32_t)std::min<uint64_t>(tmo, 3600000);
             }
-            hj[i].queue_mode = (uint32_t)o.queue_mode;
+            hj[i].queue_mode = hj[i].oob ? 1u : (uint32_t)o.queue_mode;      // (ids above num_variables: strictly sequential pops, oob.hip.hpp)
             {   // rounds on all workgroups: drain rounds (drain.hip.hpp) unless queue_mode 3 / ECNE_DRAIN=0 ask for the prefix rounds
                 static const int drain_env = []() { const char* e = getenv("ECNE_DRAIN"); return e ? atoi(e) : 1; }();      // 2: test hook (every frontier is drained)
                 static const bool solo_off = []() { const char* e = getenv("ECNE_SOLO"); return e && atoi(e) == 0; }();
@@ -1226,6 +1431,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             const bool lds_fits = hj[i].rec && hj[i].nC <= ECNE_CHAIN_ROWS && ((size_t)hj[i].nV + 1 + 16) + (2ull * hj[i].nC + 16) + 8192 <= dyn_lds;
             if (hj[i].nC <= single_wg_rows || (lds_fits && !getenv("ECNE_SINGLE_WG_ROWS"))) want = 1;
             if (o.debug > 0) want = (uint32_t)o.debug;          // test hook: force the helper count
+            if (hj[i].oob) want = 1;
             hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
             hj[i].lds_bytes = dyn_lds;
         }
@@ -1308,7 +1514,9 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             bool known_oob = false, target_oob = false;
             for (int64_t v : S.knowns) known_oob |= v > S.n_vars;
             for (int64_t v : S.targets) target_oob |= v > S.n_vars;
-            if (known_oob) s.status = ECNE_EBOUNDS;
+            const bool secp = sys[i]->secp_solve_override >= 0 ? sys[i]->secp_solve_override != 0 : o.secp_solve != 0;
+            if (secp && L.dsu_err) s.status = ECNE_EBOUNDS;      // secp_solve's dsu setup raises before anything else (:634-678)
+            else if (known_oob) s.status = ECNE_EBOUNDS;
             else if (target_oob && s.status == 0) s.status = ECNE_EBOUNDS;
             s.unique_nontrivial = (int64_t)c.unique_nontrivial;
             s.n_nontrivial = (int64_t)c.n_nontrivial;

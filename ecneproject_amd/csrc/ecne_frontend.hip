@@ -830,7 +830,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         FE_TRY(hipMemsetAsync(f_big, 0, 4ull * ((size_t)nC + 2), s));
         FE_TRY(hipMemsetAsync(f_val, 0, 4ull * ((size_t)nC + 2), s));
         FE_TRY(hipMemsetAsync(f_p5, 0, 4ull * ((size_t)nC + 2), s));
-        hipLaunchKernelGGL(k_lay_rows, dim3(blocks(nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, (const PartSum*)sum, Dst.rinfo, f_p4, f_cls, f_big, f_val, aeq);
+        hipLaunchKernelGGL(k_lay_rows, dim3(blocks(nC)), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, (const PartSum*)sum, Dst.rinfo, f_p4, f_cls, f_big, f_val, aeq, M);
         tick("k_lay_rows");
         hipLaunchKernelGGL(k_lay_p5_flag, dim3(blocks(nC)), dim3(256), 0, s, nC, (const uint32_t*)nzc, L, (const uint8_t*)aeq, f_p5);
         scan_u32(f_p4, f_p4, nC + 1, tops, totals + 4, s);
@@ -861,6 +861,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     FE_TRY(hipGetLastError());
     tick("uniq + scans");
     if (hm.unsupported) return FE_FALLBACK;
+    C.dsu_err = hm.dsu_err;
     C.nP4 = ht[4]; C.nCls = ht[5]; C.nLong = ht[6]; C.n_vals = 2 * ht[7]; C.nP5 = ht[8]; C.fo_total = ht[9];
     C.nBigRows = std::min<uint32_t>(C.nLong, ECNE_BIGTAB);
     // ---- second allocation: the lists

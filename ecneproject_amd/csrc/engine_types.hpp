@@ -189,6 +189,9 @@ struct Job {
     uint32_t bigstride;        // u32 words per pool slot (2 * (longest C part + 8))
     uint32_t* cand;            // per push candidate: target row | eligibility bit
     uint32_t candcap;          // capacity of cand[] (single-workgroup rounds use the first ECNE_CANDCAP)
+    // rows / specials that name a variable id above num_variables (malformed input): tables for the reference's lazy BoundsError
+    // (oob.hip.hpp), or nullptr. Such a system is solved by one workgroup with strictly sequential pops.
+    const uint32_t* oob;
     Counters* ctr;
 };
 

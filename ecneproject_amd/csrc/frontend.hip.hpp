@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_fe_part_offsets(const uint32_t* __restr
 
 // ====================================================================================== 1. parse: the rows in dictionary order
 struct FeMeta {      // device-side results of the parse / layout passes (zeroed before use)
-    uint32_t n_mid, n_large, n_huge, maxn, dup, unsupported, maxvar, err_idx, maxlenC, pad_;
+    uint32_t n_mid, n_large, n_huge, maxn, dup, unsupported, maxvar, err_idx, maxlenC, dsu_err;
     unsigned long long nnz[3];
 };
 struct FeRowsOut { uint64_t* ptr[3]; uint32_t* var[3]; uint64_t* coef[3]; };
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
 // Flags out: f_p4 / f_cls / f_big / f_val (0 / 1 per row, scanned afterwards), aeq.
 __global__ __launch_bounds__(256) void k_lay_rows(AbsRowsDev R, uint32_t nC, const uint32_t* __restrict__ rp, const PartSum* __restrict__ sum,
                                                   RowInfo* __restrict__ rinfo, uint32_t* __restrict__ f_p4, uint32_t* __restrict__ f_cls,
-                                                  uint32_t* __restrict__ f_big, uint32_t* __restrict__ f_val, uint8_t* __restrict__ aeq) {
+                                                  uint32_t* __restrict__ f_big, uint32_t* __restrict__ f_val, uint8_t* __restrict__ aeq, FeMeta* __restrict__ M) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= nC) return;
     PartSum S[3];
@@ -865,6 +865,9 @@ __global__ __launch_bounds__(256) void k_lay_rows(AbsRowsDev R, uint32_t nC, con
         }
         if ((shape & (SH_R5 | SH_R6)) && ri.k1 != ri.k2 && jlslot::pair_second_first(ri.k1, ri.k2)) shape |= SH_R56_SWAP;
     }
+    // secp_solve's dsu setup (:634-678): a two-entry C without A and B whose non-zero keys are none (`l[1]`, :650) or the constant
+    // wire alone (`l[2]`, :652) raises BoundsError
+    if (n[0] == 0 && n[1] == 0 && dl[2] == 2 && (n[2] == 0 || (n[2] == 1 && (S[2].bits & 3u) == 0))) M->dsu_err = 1u;
     ri.shape = shape;
     rinfo[r] = ri;
     f_p4[r] = p4 ? 1u : 0u;

@@ -65,6 +65,7 @@ struct LayoutCounts {
     uint32_t nC = 0, nVall = 0;      // rows; largest variable id the state arrays must hold
     uint64_t nnz[3] = {0, 0, 0};
     uint32_t n_vals = 0, nP4 = 0, nP5 = 0, nCls = 0, nLong = 0, nBigRows = 0, fo_total = 0, maxrowC = 0;
+    uint32_t dsu_err = 0;            // some row makes secp_solve's dsu setup raise (:650-656)
 };
 // what the layout kernels write: the static arrays of a system that only depend on its rows (device pointers)
 struct LayoutDst {

@@ -2,6 +2,7 @@
 // Part of the gfx950 device code of libecne_hip (see kernels.hip.hpp for the overview).
 #pragma once
 #include "rounds.hip.hpp"
+#include "oob.hip.hpp"
 
 namespace ecne {
 
@@ -199,6 +200,8 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 // P1 (:718-747). 64 specials are tested at a time, one per lane; the ones whose inputs are all
                 // unique fire in index order, and after every firing the later lanes look again (its outputs
                 // may complete their inputs), which is what the one-by-one sweep would have seen.
+                if (J.oob) oob_p1(J, q, hits, steps);      // (ids above num_variables: one special at a time, oob.hip.hpp)
+                else
                 for (uint32_t base = 0; base < J.nSp; base += 64) {
                     const uint32_t i = base + lane;
                     int from = 0;
@@ -228,6 +231,8 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                     }
                 }
                 // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair, from the two index lists
+                if (J.oob) { if (!J.ctr->error) oob_p2(J, q, hits); }
+                else
                 for (uint32_t a = 0; a < J.nK1; ++a) {
                     const uint32_t i = J.k1_list[a];
                     for (uint32_t bj = 0; bj < J.nK2; ++bj) {
@@ -273,6 +278,11 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                         pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
                         if (J.solved[row]) continue;
                         ECNE_PT(1);
+                        if (J.oob) {      // a row that names an id above num_variables: BoundsError at the first read of that state, else nothing
+                            const int k = oob_pop(J, row);
+                            if (k == 2) { raise_ranked(J, q.head - 1, K_EBOUNDS); break; }
+                            if (k == 1) continue;
+                        }
                         exec_row(J, q, row, hits, steps, nuniq);
                     }
                 }
@@ -314,6 +324,9 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             bool p3_err = false;
             for (;;) {
                 if (master && tid == 0) tk[6]++;
+                // (ids above num_variables) the lowest row from f on whose visit reads such a state enters as a row that "fires": the
+                // pass then examines what comes before it, and the master raises instead of firing it (phase 3)
+                if (J.oob && master && tid == 0) { const uint32_t ro = oob_p3_first(J, f); if (ro != 0xFFFFFFFFu) atomicMin(&ctr->p3_cand1, ro); }
                 // phase 1: evaluate rows >= f against the current state
                 // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
                 bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
@@ -462,6 +475,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                             wg_fence();
                             if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
                         }
+                        if (J.oob && best != 0xFFFFFFFFu && best == oob_p3_first(J, f)) raise(J, K_EBOUNDS);      // BoundsError at that row's visit (:1365)
                         if (lane == 0) ctr->p3_fire = best;
                     }
                 }
@@ -714,6 +728,8 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             if (w == 0) {
                 // 64 candidates are tested at a time, one per lane; the ones that pass fire in index order,
                 // and after every firing the later lanes look again (its newly unique y may complete their A)
+                if (J.oob) oob_p5(J, q, hits, steps);
+                else
                 for (uint32_t base = 0; base < J.nP5; base += 64) {
                     const uint32_t i = base + lane;
                     const uint32_t r = i < J.nP5 ? J.p5_rows[i] : 0, y = i < J.nP5 ? J.p5_y[i] : 0;

@@ -1005,8 +1005,10 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
     // "Bad Constraints" :1609-1618
     for (int64_t i = 1; i <= nC; ++i) {
         bool all_unique = true;
+        // (an id above num_variables: the report loop :1609-1618 only runs when a sym file is given and would raise there;
+        //  solveWithTrustedFunctions' default input_sym="" skips it, so the run itself ends normally -- such a row is listed)
         for (int64_t v : getVariables(constraints[i - 1], ctx).ordered_keys(ctx))
-            if (!st(v).unique) all_unique = false;
+            if (v < 1 || v > num_variables || !vs[v].unique) all_unique = false;
         if (!all_unique) R.bad_rows.push_back(i);
     }
 }

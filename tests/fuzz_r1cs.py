@@ -203,6 +203,60 @@ def make_wide(seed, scale=1):
     return dict(n_wires=nv - 1, n_out=base["n_out"], n_pub=0, n_prv=base["n_prv"], rows=[rows[i] for i in order], witness=w)
 
 
+def make_oob(seed):
+    """A random system in which some rows name variable ids ABOVE num_variables (nWires + 1 .. nWires + 5): the reference sizes
+    `variable_states` by num_variables (:681) and raises BoundsError at the first rule that READS such a state -- lazily, since
+    `variable_to_indices` is a DefaultDict (:628). Which read comes first depends on the order a rule walks the row in and on its
+    early exits, so the cases are built around those: ids in A, B or C of rows that are popped at once / only later / never, behind
+    or in front of a variable that is not unique, next to rows that raise DivideError, with a zero coefficient (never read), in
+    isZero pairs, and rows whose P3 visit ends at a non-unique variable of A n B before it reaches the id (no error at all)."""
+    rng = random.Random(424243 * seed + 7)
+    base = make(seed + 70000, allow_errors=rng.random() < 0.35)
+    rows = list(base["rows"])
+    nv = base["n_wires"] + 1
+    w = dict(base["witness"])
+    W = lambda: nv + rng.randint(1, 5)                                       # noqa: E731
+    V = lambda: rng.randint(2, nv)                                           # noqa: E731
+    for k in range(1, 6):
+        w[nv + k] = rng.choice([0, 1, 5])
+    mode = rng.random()
+    if mode < 0.45 and rows:        # an existing row names such an id instead of one of its variables
+        for _ in range(rng.randint(1, 3)):
+            i = rng.randrange(len(rows))
+            parts = [list(p) for p in rows[i]]
+            cand = [p for p in range(3) if parts[p]]
+            if not cand:
+                continue
+            p = rng.choice(cand)
+            e = rng.randrange(len(parts[p]))
+            parts[p][e] = (W(), parts[p][e][1])
+            rows[i] = tuple(parts)
+    if mode >= 0.3:
+        quiet = rng.random() < 0.45     # only rows that may never be read
+        for _ in range(rng.randint(1, 4)):
+            j, k, x, ww = V(), V(), V(), W()
+            kind = rng.random()
+            if quiet:
+                kind = rng.choice([0.05, 0.5])
+            if kind < 0.25:      # j in A and B: P3's walk ends at j while j is not unique (:1366); R1 stops at B's j
+                new = [([(j, 1)], [(j, 1)], [(ww, 1)])] if rng.random() < 0.5 else [([(j, 1), (ww, 3)], [(j, 1)], [(x, 1)])]
+            elif kind < 0.4:     # the id behind other factors
+                new = [([(j, 1), (ww, 1)], [(k, 1)], [(x, 1)])]
+            elif kind < 0.55:    # zero coefficient: never read
+                new = [([], [], [(x, 1), (ww, 0), (1, (-w[x]) % P)])]
+            elif kind < 0.7:     # C empty: R2 walks getVariables until the second variable that is not known
+                new = [([(ww, 1)], [(j, 1)], [])] if rng.random() < 0.5 else [([(j, 1)], [(j, 1), (ww, 2)], [])]
+            elif kind < 0.85:    # linear rows
+                new = [([], [], [(ww, 1), (x, P - 1)])] if rng.random() < 0.5 else [([], [], [(x, 1), (j, 2), (ww, 4), (k, 8)])]
+            else:                # isZero pair with the id as y, or in the shared A
+                a = [(j, 1), (ww, 1)] if rng.random() < 0.5 else [(j, 1)]
+                y = ww if len(a) == 1 or rng.random() < 0.3 else x
+                new = [(a, [(k, 1)], [(1, 1), (y, P - 1)]), (a, [(y, 1)], [])]
+            pos = rng.randint(0, len(rows))
+            rows[pos:pos] = new
+    return dict(n_wires=base["n_wires"], n_out=base["n_out"], n_pub=base["n_pub"], n_prv=base["n_prv"], rows=rows, witness=w)
+
+
 def write(path, spec):
     rows = []
     for A, B, C in spec["rows"]:

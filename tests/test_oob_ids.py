@@ -1,0 +1,165 @@
+"""Rows and specials that name a variable id ABOVE num_variables (malformed input). The reference sizes `variable_states` by
+num_variables (src/R1CSConstraintSolver.jl:681) while `variable_to_indices` is a DefaultDict (:628): setup does not raise, the run
+dies with BoundsError at the FIRST rule that reads such a state (:829, :835, :841, :881, :1365, :1503, ...) -- or never, when every
+walk over such a row ends before it reaches the id. tests/fuzz_r1cs.py::make_oob builds systems around those walks.
+
+CPU part: the oracle against the independent second reading (tests/ref2.py) -- status and, where the run ends normally, the whole
+state. GPU part: the HIP engine against the oracle through the C ABI (status; whole state where the run ends normally), with and
+without secp_solve (its dsu setup :634-678 calls find_root on such ids), through the host and the device front-end, plus specials
+that name such ids (P1 :723-733, P2 :762-798)."""
+import os
+
+import pytest
+
+import fuzz_r1cs
+import orc
+
+N_SEEDS = 300
+
+
+@pytest.fixture(scope="module")
+def oob_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("oob")
+    for seed in range(N_SEEDS):
+        fuzz_r1cs.write(str(d / ("%d.r1cs" % seed)), fuzz_r1cs.make_oob(seed))
+    return d
+
+
+def test_oracle_and_second_reading_agree(oob_dir):
+    import ref2
+    from test_ref2 import differences
+    statuses = {}
+    for seed in range(0, N_SEEDS, 2):
+        p = str(oob_dir / ("%d.r1cs" % seed))
+        for secp in (False, True):
+            o = orc.run(p, secp_solve=secp)
+            r = ref2.run(p, secp_solve=secp)
+            assert differences(r, o) == [], (seed, secp)
+            statuses[o.status] = statuses.get(o.status, 0) + 1
+    # most runs die with BoundsError; some never read the id (normal end) and a few die earlier with DivideError
+    assert set(statuses) <= {0, -2, -3, -10}
+    assert statuses.get(-2, 0) > 100 and statuses.get(0, 0) >= 10
+
+
+# hand-made cases: (nwires, nout, npub, nprv, rows, expected status) -- variable ids are 1-based, nVars = nwires + 1
+P = orc.P
+HAND = {
+    # product of two inputs = id 7 (nVars = 5): R1 reaches C's only variable at the first pop (:841)
+    "r1_reaches_c": (4, 1, 2, 1, [([(3, 1)], [(4, 1)], [(7, 1)])], -2),
+    # B's first variable (5, private... not an input here: nprv = 0) is not unique: R1 stops there (:829), R2 is off (C non-empty); P3's walk
+    # reaches 7 -- unless 5 sits in A and B and comes first in Set order (then it ends there, :1366)
+    "p3_reaches": (4, 1, 2, 0, [([(5, 1)], [(3, 1)], [(7, 1)])], -2),
+    # zero coefficient: the id is never a key of nonzeroKeys -- never read
+    "zero_coefficient": (4, 1, 2, 1, [([], [], [(2, 1), (7, 0), (3, P - 1)])], 0),
+    # linear row: R7 reads `unique` of every C variable (:1240)
+    "linear_row": (4, 1, 2, 1, [([], [], [(2, 1), (5, 1), (7, 1), (3, P - 1)])], -2),
+}
+
+
+@pytest.fixture(scope="module")
+def hand_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("oob_hand")
+    for name, (nw, no, npub, nprv, rows, _st) in HAND.items():
+        fuzz_r1cs.write_raw(str(d / (name + ".r1cs")), nw, no, npub, nprv, rows)
+    return d
+
+
+@pytest.mark.parametrize("name", sorted(HAND))
+def test_hand_cases_oracle(hand_dir, name):
+    import ref2
+    p = str(hand_dir / (name + ".r1cs"))
+    assert orc.run(p).status == HAND[name][5] == ref2.run(p).status
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("secp", [False, True])
+@pytest.mark.parametrize("frontend", ["host", "device"])
+def test_gpu_oob_parity(oob_dir, hand_dir, secp, frontend):
+    import ecneproject_amd as E
+    from gpu_common import assert_bit_exact
+    paths = [str(oob_dir / ("%d.r1cs" % seed)) for seed in range(N_SEEDS)] + [str(hand_dir / (n + ".r1cs")) for n in sorted(HAND)]
+    prev = E.set_frontend(-1)
+    E.set_frontend(E.FRONTEND_DEVICE if frontend == "device" else E.FRONTEND_HOST)
+    try:
+        systems = [E.System(E.R1CS(p)) for p in paths]
+        results = []
+        for i in range(0, len(systems), 100):
+            results += E.solve_batch(systems[i:i + 100], secp_solve=secp)
+    finally:
+        E.set_frontend(prev)
+    n_ok = 0
+    for p, g in zip(paths, results):
+        o = orc.run(p, secp_solve=secp)
+        assert_bit_exact("ids above nVars %s secp=%s %s" % (os.path.basename(p), secp, frontend), g, o)
+        n_ok += o.status == 0
+    assert n_ok >= 10
+
+
+def _ref2_status(path, specials, secp):
+    """SolveConstraintsSymbolic with the caller's special_constraints, by the second reading (tests/ref2.py)"""
+    import ref2
+    eqs, knowns, outs, nv = ref2.read_r1cs(path)
+    try:
+        return ref2.solve(eqs, [(n, list(i), list(o)) for n, i, o in specials], knowns, outs, nv, secp).status
+    except (ref2.BoundsError, ref2.DivideError, ref2.UndefVarError, ref2.Watchdog) as e:
+        return e.status
+
+
+SPECIAL_CASES = [
+    ([], False),
+    ([("F", [3, 4], [7])], False),                       # fires, in range
+    ([("F", [3, 11], [7])], False),                      # input above nVars, reached (3 is unique)
+    ([("F", [7, 11], [8])], False),                      # 7 is not unique: the walk ends before 11
+    ([("F", [3, 4], [7, 12])], False),                   # fires: every output is read
+    ([("F", [7], [12])], False),                         # never fires
+    ([("F", [3, 4], [7]), ("G", [7, 9], [8])], False),   # G's walk reaches 9 once F has fired (same sweep)
+    ([("BigMultModP", [3, 4, 5, 3, 4, 5, 3, 4, 5], [7]), ("BigLessThan", [3, 4, 5, 3, 4, 5], [8])], True),
+    ([("BigMultModP", [3, 4, 5, 3, 4, 5, 3, 4, 5], [7]), ("BigLessThan", [8, 4, 13, 3, 4, 5], [8])], True),    # find_root(13): outside the dsu
+    ([("BigMultModP", [3, 4, 5, 3, 4, 5, 3, 4, 5], [7]), ("BigLessThan", [8, 4, 13, 3, 4, 5], [8])], False),   # UndefVarError `dsu` first
+    ([("BigMultModP", [8, 4, 5, 3, 4, 5, 3, 4, 5], [7]), ("BigLessThan", [8, 10, 5, 3, 4, 5], [8])], True),    # k-loop fine (ids 4..9 / 1..6 in range?) then [2][1:3]
+    ([("BigMultModP", [8, 4, 5, 3, 3, 3, 3, 3, 3], [7]), ("BigLessThan", [3, 3, 3, 3, 3, 3], [12])], True),    # same_set: constraint_j[3][1] = 12 is read
+    ([("BigMultModP", [8, 4, 5, 3, 3, 3, 3, 3, 3], [12]), ("BigLessThan", [3, 3, 3, 3, 3, 3], [2])], True),    # same_set: read only if values(2) == [1]
+]
+
+
+def test_special_cases_have_the_expected_spread(tmp_path):
+    p = str(tmp_path / "base.r1cs")
+    fuzz_r1cs.write_raw(p, 7, 1, 2, 1, [([(3, 1)], [(4, 1)], [(6, 1)]), ([(6, 1)], [(5, 1)], [(2, 1)])])
+    st = [_ref2_status(p, sp, secp) for sp, secp in SPECIAL_CASES]
+    assert st[0] == 0 and st[2] == -2 and st[3] == 0 and st[4] == -2 and st[5] == 0 and st[8] == -2 and st[9] == -4
+    assert set(st) == {0, -2, -4}
+
+
+@pytest.mark.gpu
+def test_gpu_oob_ids_in_specials(tmp_path):
+    """P1 reads a special's inputs in order until the first one that is not unique (:723-728) and every output of a special that
+    fires (:733); P2 reads constraint_j[2][1:3] (:785) after the dsu roots of the k-loop (:762) and what `same_set` guards (:766-784).
+    The caller's lists are honoured as they are (SolveConstraintsSymbolic's special_constraints argument), ids above num_variables
+    included. Checked against the second reading (tests/ref2.py), which takes the same lists."""
+    import random
+    import ecneproject_amd as E
+    p = str(tmp_path / "base.r1cs")
+    # nVars = 8; inputs 3, 4 (public), 5 (private); 2 = output
+    fuzz_r1cs.write_raw(p, 7, 1, 2, 1, [([(3, 1)], [(4, 1)], [(6, 1)]), ([(6, 1)], [(5, 1)], [(2, 1)])])
+    f = E.R1CS(p)
+    cases = list(SPECIAL_CASES)
+    rng = random.Random(5)
+    ids = [1, 2, 3, 4, 5, 6, 7, 8, 9, 11]
+    for _ in range(120):      # random lists, mostly in range
+        sp = []
+        for _k in range(rng.randint(1, 3)):
+            name = rng.choice(["F", "BigMultModP", "BigLessThan"])
+            nin = 9 if name == "BigMultModP" else 6 if name == "BigLessThan" else rng.randint(1, 3)
+            pick = lambda: rng.choice(ids) if rng.random() < 0.25 else rng.choice([3, 4, 5, 6, 2])      # noqa: E731
+            sp.append((name, [pick() for _i in range(nin)], [pick() for _o in range(rng.randint(1, 2))]))
+        cases.append((sp, rng.random() < 0.7))
+    systems = []
+    for sp, secp in cases:
+        s = E.System(f)
+        s.set_specials(sp)
+        s.set_secp_solve(secp)
+        systems.append(s)
+    got = [g.status for g in E.solve_batch(systems)]
+    want = [_ref2_status(p, sp, secp) for sp, secp in cases]
+    assert got == want, [(c, g, w) for c, g, w in zip(cases, got, want) if g != w][:5]
+    assert len(set(want)) >= 3
