@@ -47,6 +47,29 @@ def parse_args():
     return ap.parse_args()
 
 
+def csrc_sha16():
+    """sha256 over the library's sources (ecneproject_amd/csrc/*, include/ecne.h), first 16 hex digits: profiles/traffic_latest.json
+    carries the value of the build its PMC passes were taken on; a line printed by another build drops `roofline.traffic`"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(HERE, "ecneproject_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    with open(os.path.join(HERE, "include", "ecne.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def step_invariants(r):
+    """what every timed step must reproduce exactly (a schedule may change the time of a solve, never its result)"""
+    s = r.summary
+    return (int(r.status), bool(r.function_good), int(s.pops), int(s.successful_steps), int(s.num_unique), int(s.outer_iterations),
+            int(s.unique_nontrivial), int(s.n_nontrivial), int(s.unique_targets), int(s.n_targets), tuple(int(x) for x in list(s.rule_hits)[:13]))
+
+
 def probe_julia():
     """the reference itself can only be timed where Julia 1.7 and an instantiated Ecne checkout exist."""
     import shutil
@@ -87,12 +110,12 @@ def workload_jobs(name, args):
 
 
 def _oracle_job(t):
-    """(worker of the CPU baseline) one job through the sequential oracle; returns (rows of the main file, t_solve, pops, alg bytes)"""
+    """(worker of the CPU baseline) one job through the sequential oracle; returns (rows of the main file, t_solve, pops, alg bytes, ...)"""
     import orc
     path, trusted, names, secp = t
     o = orc.run(path, trusted, names, secp, want_states=False)
     s = o.summary
-    return int(s.n_rows_main), float(s.t_solve), int(s.pops), int(o.alg_bytes()), float(s.t_read + s.t_abstract)
+    return int(s.n_rows_main), float(s.t_solve), int(s.pops), int(o.alg_bytes()), float(s.t_read + s.t_abstract), int(o.status), bool(o.verdict)
 
 
 def cpu_baseline_jobs(jobs, label):
@@ -107,7 +130,8 @@ def cpu_baseline_jobs(jobs, label):
     out = {"value": rows / max(t_solve, 1e-9), "unit": "constraints/s", "cores": 1, "kind": "port",
            "sample": "%s: the whole workload, %d job(s), %d rows, sequential oracle solve %.3f s in total (parse + abstraction %.3f s excluded, "
                      "as for the GPU); longest single job %.3f s" % (label, len(jobs), rows, t_solve, sum(r[4] for r in seq), max(r[1] for r in seq)),
-           "host_cores_available": os.cpu_count(), "reference_probe": probe_julia(), "wall_s_one_core_incl_parse": round(wall_seq, 3)}
+           "host_cores_available": os.cpu_count(), "reference_probe": probe_julia(), "wall_s_one_core_incl_parse": round(wall_seq, 3),
+           "_per_job": {j.name: (r[5], r[6], r[2]) for j, r in zip(jobs, seq)}}
     if len(items) > 1:
         ncore = min(len(items), os.cpu_count() or 1)
         order = sorted(range(len(items)), key=lambda i: -seq[i][1])          # longest first
@@ -137,10 +161,15 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    inv = []
     for _ in range(args.steps):
         res, ok = runner.run(stream=stream)
+        inv.append(res)
     torch.cuda.synchronize()
     t_rank = time.perf_counter() - t0
+    inv = [[step_invariants(r) for r in step] for step in inv]           # (after the timed region)
+    if any(step != inv[0] for step in inv):
+        raise SystemExit("bench.py: the timed steps did not reproduce the same result (verdicts / counts / counters differ between steps)")
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -192,8 +221,16 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
                                        "model": "cache-resident and dependency-depth bound: t ~ pops of the longest chain x us per sequential pop (+ rounds where the frontier is wide)"},
                      "note": "the working set of these circuits (<= 12 MB) lives in L2 / Infinity Cache; the HBM fraction is reported for completeness, the latency model is the bound"},
     }
+    out["config"]["invariants"] = {"steps_identical": True, "checked": "status, verdict, pops, successful_steps, num_unique, outer_iterations, the four printed counts, rule hits -- every job, every timed step"}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_jobs(jl, args.workload)
+        # the oracle leg doubles as a check of the timed steps' counters (cpu_baseline_jobs keeps the oracle's per job)
+        want = out["cpu_baseline"].pop("_per_job")
+        got = {j["job"]: (j["status"], j["verdict"], j["pops"]) for j in alljobs}
+        bad = [n for n, w in want.items() if got.get(n) != w]
+        if bad:
+            raise SystemExit("bench.py: the solve disagrees with the sequential oracle on %r" % bad[:5])
+        out["config"]["invariants"]["matches_oracle"] = "status, verdict, pops of every job equal the sequential oracle's"
     print(json.dumps(out))
 
 
@@ -260,14 +297,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dev_ms = []
+    dev_ms, timed = [], []
     for _ in range(args.steps):
         res = step()
         dev_ms.append(res.summary.device_ms)
+        timed.append(res)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    inv = [step_invariants(r) for r in timed]                             # (after the timed region)
+    if any(x != inv[0] for x in inv):
+        raise SystemExit("bench.py: the timed steps did not reproduce the same result: %r" % (sorted(set(inv))[:2],))
     # k_classify_rows, warm (after the timed steps: clocks up, the same resident rows; the kernel is idempotent)
     warm = sorted(E.classify(system, device=local_rank)[1] for _ in range(7))
     classify_ms, classify_ms_best = warm[len(warm) // 2], warm[0]                             # the figure reported: their median
@@ -296,7 +337,10 @@ def main():
         if os.path.exists(tj) and args.S == 26 and args.stride == 10 and world == 1:
             with open(tj) as f:
                 t = json.load(f)
-            traffic, traffic_src = t.get("k_solve_bytes_per_launch"), t.get("source")
+            if t.get("csrc_sha16") == csrc_sha16():
+                traffic, traffic_src = t.get("k_solve_bytes_per_launch"), t.get("source")
+            else:      # the PMC passes were taken on another build of the library: not this line's traffic
+                traffic_src = "stale: profiles/traffic_latest.json was measured on csrc %s, this build is %s (re-run tools/profile_r04.sh)" % (t.get("csrc_sha16"), csrc_sha16())
         achieved = b_alg / (k_ms * 1e-3) / 1e9
         # latency model: the solve is rounds x time per round; a round is one dependency level of the
         # queue schedule (or a P-phase pass)
@@ -325,6 +369,7 @@ def main():
                        "parallelism": "replicas x%d, RCCL all-reduce of the verdict word" % world if world > 1 else "1 GPU",
                        "verdict": bool(res.function_good), "status": int(res.status),
                        "outer_iterations": int(s.outer_iterations), "pops": int(s.pops),
+                       "invariants": {"steps_identical": True, "checked": "status, verdict, pops, successful_steps, num_unique, outer_iterations, the four printed counts, rule hits -- every timed step"},
                        "host_prep_s": {"generate": round(t_gen, 3), "parse": round(t_parse, 3), "abstract": round(t_abstract, 3)},
                        "classify_kernel": {"ms": classify_ms, "ms_best": classify_ms_best, "ms_first_call": classify_ms_cold, "bytes": classify_bytes,
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6,
@@ -346,6 +391,13 @@ def main():
             import orc
             sp = ecdsa_like.cached(args.cpu_sample_S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid())
             o = orc.run(sp, [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"], want_states=False)
+            if args.cpu_sample_S == args.S:      # the oracle leg doubles as a check of the timed steps (same workload)
+                os_ = o.summary
+                want = (int(o.status), bool(o.verdict), int(os_.pops), int(os_.successful_steps), int(os_.num_unique), int(os_.outer_iterations),
+                        int(os_.unique_nontrivial), int(os_.n_nontrivial), int(os_.unique_targets), int(os_.n_targets), tuple(int(x) for x in list(os_.rule_hits)[:13]))
+                if want != inv[0]:
+                    raise SystemExit("bench.py: the timed solve disagrees with the sequential oracle: %r vs %r" % (inv[0], want))
+                out["config"]["invariants"]["matches_oracle"] = "the same tuple equals the sequential oracle's on this workload"
             out["cpu_baseline"] = {"value": o.summary.n_rows_main / max(o.summary.t_solve, 1e-9), "unit": "constraints/s",
                                    "cores": 1, "kind": "port",
                                    "sample": "ecdsa_like(S=%d,stride=%d): %d rows, sequential oracle solve %.2f s "

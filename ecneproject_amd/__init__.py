@@ -262,6 +262,14 @@ class SolveResult:
         self.summary = s
         self.status = int(s.status)
         self.function_good = bool(s.function_good)
+        self.digest = None
+        if fetch_states in ("digest", "both"):      # the device-side digest of the per-variable state (instead of / next to the state itself)
+            d = (C.c_uint64 * 2)()
+            _check(L.ecne_result_digest(handle, d))
+            self.digest = (int(d[0]), int(d[1]))
+            if fetch_states == "digest":
+                L.ecne_result_free(handle)
+                return
         if not fetch_states:
             L.ecne_result_free(handle)
             return

@@ -45,7 +45,7 @@ EXPORTS = [
     "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_states",
     "ecne_result_bad_rows", "ecne_result_free", "ecne_classify", "ecne_fp_selftest", "ecne_fp_sqrt",
     "ecne_device_count", "ecne_strerror", "ecne_version",
-    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve",
+    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve", "ecne_result_digest",
 ]
 
 _L = None
@@ -84,6 +84,7 @@ def lib():
                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64))]
     L.ecne_result_bad_rows.argtypes = [vp, C.POINTER(i64p), C.POINTER(C.c_size_t)]
+    L.ecne_result_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ecne_result_free.argtypes = [vp]
     L.ecne_result_free.restype = None
     L.ecne_classify.argtypes = [vp, C.POINTER(Opts), vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

@@ -220,6 +220,7 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
     int myslot = -1;               // my row is a long row registered in this slot
     for (;;) {
         ++level;
+        if (wgrank == 0 && (level & 15u) == 0) job_heartbeat(J);      // (a window of dependent rows drains one row per level: thousands of levels in one round)
         if (epoch >= ECNE_DRAIN_EPOCH_MAX) {
             // the epoch field is used up (once per 32 766 levels): wipe the planes; the marks of this round start over
             const uint32_t T = J.nwg * ECNE_WG;

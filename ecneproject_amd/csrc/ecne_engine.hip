@@ -62,6 +62,22 @@ static bool frontend_wants_device(uint64_t n_rows) {
     if (m == 2 && n_rows < ECNE_FRONTEND_DEVICE_ROWS) return false;
     return ecne_device_count() > 0;
 }
+// A device front-end step that failed for want of device memory or capacity (the parse needs 5-6x the file size in temporaries,
+// the layout a sort scratch) is not an error of the INPUT: the host front-end takes over, as it does for FE_FALLBACK. What is
+// propagated: the reference's own exceptions (format, KeyError) -- a genuinely faulted device makes the solve fail later anyway.
+static bool fe_falls_back(int rc) {
+    if (rc == fe::FE_FALLBACK) return true;
+    if (rc == K_ENODEVICE || rc == K_ECAPACITY) { (void)hipGetLastError(); return true; }
+    return false;
+}
+// every entry point that switches the HIP device leaves the caller's current device as it found it (include/ecne.h)
+struct RestoreDevice {
+    int prev = -1;
+    RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+    RestoreDevice(const RestoreDevice&) = delete;
+    RestoreDevice& operator=(const RestoreDevice&) = delete;
+};
 static int current_device() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) d = 0;
@@ -83,11 +99,14 @@ struct AbiTick {
 struct FrontendStats { fe::ParseStats parse; fe::AbstractDevStats abs; double layout_ms = 0; int parse_dev = 0, abs_dev = 0, layout_dev = 0; };
 static thread_local FrontendStats g_fe_stats;
 
-// host rows of a file that was parsed on the device only
+// host rows of a file that was parsed on the device only (the file object is shared with the systems made from it: one lock for
+// every lazy fetch of host rows, here and in sys_host_rows)
+static std::mutex g_lazy_rows_mu;
 static int ensure_host_rows(const ecne_r1cs* h) {
     R1CSFile& f = const_cast<ecne_r1cs*>(h)->f;
+    std::lock_guard<std::mutex> g(g_lazy_rows_mu);
     if (f.host_rows) return K_OK;
-    if (!f.path.empty()) {      // from the file again where it still is (a download into fresh pageable memory costs more than parsing a small file)
+    if (!f.path.empty() && !(h->drows && f.n_cons >= 4096)) {      // small files: from the file again where it still is (cheaper than a download); a file that changed on disk since is caught by the counts only, so anything larger comes from the resident rows
         FileView fv(f.path.c_str());
         R1CSFile again;
         size_t cons_off = 0;
@@ -177,7 +196,6 @@ struct ecne_system {
     }
 };
 // host copy of the system's current rows (lazily: a device-front-end system downloads them on first use)
-static std::mutex g_lazy_rows_mu;
 static int sys_host_rows(ecne_system& S) {
     if (S.cur) return K_OK;
     std::lock_guard<std::mutex> g(g_lazy_rows_mu);
@@ -242,6 +260,31 @@ __global__ __launch_bounds__(256) void k_gather_results(const Job* jobs, unsigne
     if (threadIdx.x < ECNE_RESULT_BYTES / 4) dst[threadIdx.x] = src[threadIdx.x];
 }
 
+// ecne_result_digest: per variable a splitmix64 chain over its state, summed over the variables (commutative: any thread order)
+__device__ __forceinline__ unsigned long long dg_mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_state_digest(Job J, uint32_t n_vars, unsigned long long* out) {
+    unsigned long long s0 = 0, s1 = 0;
+    for (uint32_t v = 1 + blockIdx.x * 256u + threadIdx.x; v <= n_vars; v += gridDim.x * 256u) {
+        unsigned long long h = dg_mix(v);
+        const uint32_t nvl = J.nvalues[v];
+        h = dg_mix(h ^ (unsigned long long)(J.flags[v] & 3u));
+        h = dg_mix(h ^ (unsigned long long)(uint32_t)J.abz[v]);
+        h = dg_mix(h ^ (unsigned long long)nvl);
+        for (int k = 0; k < 4; ++k) h = dg_mix(h ^ J.lb[4ull * v + k]);
+        for (int k = 0; k < 4; ++k) h = dg_mix(h ^ J.ub[4ull * v + k]);
+        for (uint32_t k = 0; k < 4u * (nvl < 2u ? nvl : 2u); ++k) h = dg_mix(h ^ J.values[8ull * v + k]);
+        s0 += h;
+        s1 += dg_mix(h ^ 0xA5A5A5A5A5A5A5A5ull);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s0); atomicAdd(&out[1], s1); }
+}
+
 // launch scratch of the calling thread (job descriptors, workgroup table, events): kept between solves
 struct LaunchScratch {
     int device = -1;
@@ -251,6 +294,7 @@ struct LaunchScratch {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     void release() {
         if (device < 0) return;
+        RestoreDevice restore;
         (void)hipSetDevice(device);
         if (d_res) (void)hipFree(d_res);
         if (d_jobs) (void)hipFree(d_jobs);
@@ -820,7 +864,7 @@ static int upload_system(ecne_system& S, int device) {
             S.laid_out = true;
             g_fe_stats.layout_ms = S.dev.lay->ms;
             g_fe_stats.layout_dev = 1;
-        } else if (rc != fe::FE_FALLBACK) return rc;
+        } else if (!fe_falls_back(rc)) return rc;
         else S.dev.lay.reset();
     }
     if (!dev_layout) {
@@ -945,10 +989,10 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_ctr = c.take(sizeof(Counters));
     char* base = nullptr;
     HIP_TRY(hipMalloc((void**)&base, c.off));
+    // (the image is published -- S.dev.arena set -- only once it is complete: a failed step below frees the arena, so the next
+    //  call starts over instead of launching on a half-filled image)
+    struct ArenaGuard { char* p; ecne_system& S; bool done = false; ~ArenaGuard() { if (!done) { (void)hipFree(p); S.dev = DeviceImage(); } } } arena_guard{base, S};
     if (getenv("ECNE_POISON")) HIP_TRY(hipMemset(base, 0xA5, c.off));      // test hook: whatever the solve reads before writing it shows up
-    S.dev.arena = base;
-    S.dev.arena_bytes = c.off;
-    S.dev.device = device;
     auto up = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
         return hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
@@ -1063,6 +1107,10 @@ static int upload_system(ecne_system& S, int device) {
     // (the L2 warm-up streams one contiguous range: the arena's static part; a device-laid system's static arrays are elsewhere)
     J.warm_bytes = (!dev_layout && (static_end - o_rp[0]) <= (7u << 19)) ? (uint32_t)(static_end - o_rp[0]) : 0u;   // fits one XCD's 4 MB L2 beside the state
     S.dev.classified = false;
+    S.dev.arena = base;
+    S.dev.arena_bytes = c.off;
+    S.dev.device = device;
+    arena_guard.done = true;
     return K_OK;
 }
 
@@ -1102,6 +1150,7 @@ static int fetch_states(ecne_result* r) {
     ecne_system& S = *r->sys;
     const Layout& L = S.L;
     const Job& J = S.dev.job;
+    RestoreDevice restore;
     HIP_TRY(hipSetDevice(S.dev.device));
     const size_t nv = (size_t)S.n_vars;
     std::vector<uint8_t> flags(L.nV + 1), nvals(L.nV + 1);
@@ -1158,7 +1207,8 @@ static int ecne_r1cs_load_impl(const char* path, ecne_r1cs** out) {
             for (int p = 0; p < 3; ++p) r->f.nnz[p] = r->drows->nnz[p];
             g_fe_stats.parse_dev = 1;
             done = true;
-        } else if (st != fe::FE_FALLBACK) return st;
+        } else if (!fe_falls_back(st)) return st;
+        else r->drows.reset();
         tick("load: parse_on_device");
     }
     if (!done) {
@@ -1246,7 +1296,7 @@ static int ecne_abstract_impl(ecne_system* sys, const ecne_r1cs* trusted, const 
             tick("abstract: handle update");
             return K_OK;
         }
-        if (rc != fe::FE_FALLBACK) return rc;
+        if (!fe_falls_back(rc)) return rc;
     }
     { const int rc = sys_host_rows(*sys); if (rc != K_OK) return rc; }
     Rows red;
@@ -1323,19 +1373,22 @@ static int ecne_system_rows_impl(ecne_system* sys, int part, const uint32_t** ro
         // laid out on the device: fetch the three CSR parts (once)
         if (!sys->dev.lay) return ECNE_EINVAL;
         const fe::LayoutDst& D = sys->dev.lay->dst;
-        const int prev = current_device();
+        RestoreDevice restore;
         HIP_TRY(hipSetDevice(sys->dev.lay->device));
+        // (fetched into temporaries: the handle's arrays count as fetched by their size, so they only change once every copy has succeeded)
+        std::vector<uint32_t, RawAlloc<uint32_t>> rp[3], col[3];
+        std::vector<uint64_t, RawAlloc<uint64_t>> coef[3];
         for (int p = 0; p < 3; ++p) {
-            L.rp[p].resize((size_t)L.nC + 1);
-            L.col[p].resize(L.nnz[p]);
-            L.coef[p].resize(4 * L.nnz[p]);
-            HIP_TRY(hipMemcpy(L.rp[p].data(), D.rp[p], 4ull * ((size_t)L.nC + 1), hipMemcpyDeviceToHost));
+            rp[p].resize((size_t)L.nC + 1);
+            col[p].resize(L.nnz[p]);
+            coef[p].resize(4 * L.nnz[p]);
+            HIP_TRY(hipMemcpy(rp[p].data(), D.rp[p], 4ull * ((size_t)L.nC + 1), hipMemcpyDeviceToHost));
             if (L.nnz[p]) {
-                HIP_TRY(hipMemcpy(L.col[p].data(), D.col[p], 4ull * L.nnz[p], hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(L.coef[p].data(), D.coef[p], 32ull * L.nnz[p], hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(col[p].data(), D.col[p], 4ull * L.nnz[p], hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(coef[p].data(), D.coef[p], 32ull * L.nnz[p], hipMemcpyDeviceToHost));
             }
         }
-        (void)hipSetDevice(prev);
+        for (int p = 0; p < 3; ++p) { L.rp[p].swap(rp[p]); L.col[p].swap(col[p]); L.coef[p].swap(coef[p]); }
     }
     if (rowptr) *rowptr = L.rp[part].data();
     if (col) *col = L.col[part].data();
@@ -1361,7 +1414,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
     if (ecne_device_count() <= o.device) return ECNE_ENODEVICE;   // never falls back to a CPU path
-    struct RestoreDevice { int prev; ~RestoreDevice() { (void)hipSetDevice(prev); } } restore{current_device()};      // the caller's current device is left as it was
+    RestoreDevice restore;      // the caller's current device is left as it was
     HIP_TRY(hipSetDevice(o.device));
     hipStream_t stream = (hipStream_t)o.stream;
     for (size_t i = 0; i < n; ++i) {
@@ -1575,6 +1628,25 @@ static int ecne_result_bad_rows_impl(const ecne_result* r, const int64_t** rows,
     if (n) *n = r->bad_rows.size();
     return ECNE_OK;
 }
+static int ecne_result_digest_impl(const ecne_result* r, uint64_t* out) {
+    if (!r || !out) return ECNE_EINVAL;
+    if (!r->sys || !system_is_live(r->sys) || r->sys->uid != r->sys_uid || r->sys->generation != r->generation || !r->sys->dev.arena) return ECNE_EINVAL;
+    const ecne_system& S = *r->sys;
+    RestoreDevice restore;
+    HIP_TRY(hipSetDevice(S.dev.device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 16));
+    int rc = ECNE_OK;
+    const uint32_t nv = (uint32_t)std::min<int64_t>(S.n_vars, (int64_t)S.L.nV);
+    if (hipMemset(d, 0, 16) != hipSuccess) rc = ECNE_ENODEVICE;
+    if (rc == ECNE_OK) {
+        hipLaunchKernelGGL(k_state_digest, dim3(std::max(1u, std::min(2048u, (nv + 255u) / 256u))), dim3(256), 0, 0, S.dev.job, nv, d);
+        if (hipMemcpy(out, d, 16, hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess) rc = ECNE_ENODEVICE;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+int ecne_result_digest(const ecne_result* r, uint64_t out[2]) { return guarded([&] { return ecne_result_digest_impl(r, out); }); }
 void ecne_result_free(ecne_result* r) { delete r; }
 
 static int ecne_classify_impl(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, double* kernel_ms, uint64_t* bytes) {
@@ -1583,6 +1655,7 @@ static int ecne_classify_impl(ecne_system* sys, const ecne_opts* opts, uint32_t*
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
     if (ecne_device_count() <= o.device) return ECNE_ENODEVICE;
+    RestoreDevice restore;
     HIP_TRY(hipSetDevice(o.device));
     int st = upload_system(*sys, o.device);
     if (st != K_OK) return st;
@@ -1607,6 +1680,7 @@ static int ecne_classify_impl(ecne_system* sys, const ecne_opts* opts, uint32_t*
 
 static int ecne_fp_selftest_impl(int device, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
     if (ecne_device_count() <= device) return ECNE_ENODEVICE;
+    RestoreDevice restore;
     HIP_TRY(hipSetDevice(device));
     uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc((void**)&da, 32 * n + 32));
@@ -1633,6 +1707,7 @@ static void system_changed_rows(ecne_system* sys) {
     sys->generation++;
     sys->laid_out = false;
     if (sys->dev.arena) {
+        RestoreDevice restore;
         (void)hipSetDevice(sys->dev.device);
         (void)hipFree(sys->dev.arena);
         sys->dev = DeviceImage();

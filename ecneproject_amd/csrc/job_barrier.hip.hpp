@@ -27,6 +27,12 @@ __device__ __forceinline__ BarLocal& bar_local() {
     __shared__ BarLocal b;
     return b;
 }
+// "the job is alive": thread 0 of a workgroup that works while others wait at the JOB barrier (the master between two commands, the
+// master of a sub-team during its chain of rounds, the sweeps' master-only stretches) moves this word; a waiter's clock restarts
+// whenever it has moved, so the barrier's time bound is on time WITHOUT progress, however long a legitimate sequential stretch is.
+__device__ __forceinline__ void job_heartbeat(const Job& J) {
+    if (threadIdx.x == 0 && (J.nwg > 1 || J.subteam)) __hip_atomic_fetch_add(&J.ctr->heartbeat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void job_barrier_init() {   // thread 0, once per launch (the device words are zeroed by the host)
     BarLocal& b = bar_local();
     b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0; b.sgen = 0; b.lazy = 0;

@@ -205,6 +205,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 for (uint32_t base = 0; base < J.nSp; base += 64) {
                     const uint32_t i = base + lane;
                     int from = 0;
+                    job_heartbeat(J);
                     for (;;) {
                         bool can = i < J.nSp && lane >= from && !J.fired[nC + i];   // [nC..) = special_solved
                         if (can) {
@@ -430,6 +431,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                         if (nhot > J.hotcap) { raise(J, K_ECAPACITY); nhot = 0; }
                         uint32_t best = ld_agent(&ctr->p3_cand1);   // k == 1: first arrival of a one-variable group always fires
                         for (uint32_t a = 0; a < nhot; ++a) {
+                            if ((a & 63u) == 0) job_heartbeat(J);      // (up to hotcap candidates, examined by the master alone)
                             uint32_t t = J.hot[a];
                             if (t >= best) continue;
                             uint32_t k = J.p3k[t];
@@ -734,6 +736,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                     const uint32_t i = base + lane;
                     const uint32_t r = i < J.nP5 ? J.p5_rows[i] : 0, y = i < J.nP5 ? J.p5_y[i] : 0;
                     int from = 0;            // lanes below `from` are done
+                    if ((base & 4095u) == 0) job_heartbeat(J);
                     for (;;) {
                         bool can = i < J.nP5 && lane >= from && !(J.flags[y] & 1);
                         if (can)

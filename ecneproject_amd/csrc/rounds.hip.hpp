@@ -827,6 +827,7 @@ __device__ __noinline__ int multi_chain(const Job& J, uint32_t K, ChunkShared& S
 #ifdef ECNE_ROUNDLOG
         if (wgrank == 0 && threadIdx.x == 0) printf("RL %s avail %u n %u c %u dt %llu levels %u team %u\n", K == 1 ? "solo" : "multi", st.tail - st.head, nm, cm, wall_clock64() - rl_t0, levels, K);
 #endif
+        if (wgrank == 0) job_heartbeat(J);      // (the workgroups outside a sub-team wait at the job barrier for the whole chain)
         st.head += cm;
         st.tail = ntm;
         st.rounds += 1;
@@ -888,7 +889,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     __syncthreads();
     while (q.head != q.tail) {
         // the error word is polled every 8th round (a raised error only has to stop the solve soon)
-        if (tid == 0 && J.nwg > 1) __hip_atomic_store(&J.ctr->heartbeat, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "the master is alive"
+        job_heartbeat(J);   // "the master is alive"
         if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
         if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
         uint32_t avail = q.tail - q.head;

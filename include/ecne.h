@@ -202,6 +202,12 @@ int ecne_result_states(const ecne_result* r, const uint8_t** flags, const uint64
                        const int32_t** abz, const uint8_t** nvalues, const uint64_t** values);
 /* rows that still contain a non-uniquely-determined variable ("Bad Constraints", :1609-1618), 1-based */
 int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n);
+/* 128-bit digest of the whole per-variable state of a finished solve (unique / is_known, lb, ub, abz, the candidate values of
+ * variables 1..n_vars), computed ON THE DEVICE from the resident state -- two 64-bit sums over the variables of a splitmix64
+ * chain over (v, flags & 3, abz, nvalues, lb, ub, values[0..nvalues)) -- so that repeated solves can be compared with each other
+ * (run-to-run determinism, soak tests) without moving ~150 bytes per variable to the host. Same validity rule as
+ * ecne_result_states. tests/test_gpu_soak.py restates the digest in numpy and checks it against fetched states. */
+int ecne_result_digest(const ecne_result* r, uint64_t out[2]);
 void ecne_result_free(ecne_result* r);
 
 /* k_classify_rows output for tests/profiling: per-row shape word (see ecne_engine.hip SH_*) */

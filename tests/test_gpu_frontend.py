@@ -79,6 +79,69 @@ def test_parse_and_layout_all_fixtures():
         _same_static_arrays(rel, sh, sd)
 
 
+def _rows_against_second_reading(tag, sysm, path):
+    """dictionary-order rows of a system (host or device reader) against tests/ref2.py's reader -- an independent parser with its
+    own model of Julia's Dict: same keys in the same iteration order, same values (reduced mod p, last value of a repeated wire id
+    at the first occurrence's position, explicit zeros kept, {1 => 0} for an empty part; ParseR1CS.jl:96-115)"""
+    import ref2
+    eqs, _kn, _out, _nv = ref2.read_r1cs(path)
+    parts = [sysm.dict_rows(p) for p in range(3)]
+    assert all(len(parts[p][0]) == len(eqs) + 1 for p in range(3)), (tag, "row count")
+    for p in range(3):
+        ptr, var, coef = parts[p]
+        ints = orc.limbs_to_int(coef) if len(coef) else []
+        for i, eq in enumerate(eqs):
+            d = (eq.a, eq.b, eq.c)[p]
+            keys = list(d.keys())
+            a, b = int(ptr[i]), int(ptr[i + 1])
+            assert var[a:b].tolist() == keys, (tag, "keys of row %d part %d" % (i + 1, p), var[a:b].tolist(), keys)
+            assert ints[a:b] == [d[k] for k in keys], (tag, "values of row %d part %d" % (i + 1, p))
+
+
+def test_both_readers_against_the_second_reading(tmp_path):
+    """every fixture, the fuzz family (values >= p, repeated ids, explicit zeros), ids above nVars and the three section orders:
+    rows of the DEVICE reader and of the host reader, each row by row against an independent parser (not only against each other)"""
+    import ecneproject_amd as E
+    n_rows = 0
+    for rel in fixtures.all_r1cs():
+        _md, sd = _system(E, E.FRONTEND_DEVICE, rel)
+        assert E.frontend_stats()["parse_device"] == 1.0, rel
+        _rows_against_second_reading(rel, sd, fixtures.path(rel))
+        if len(sd) <= 4000:
+            _mh, sh = _system(E, E.FRONTEND_HOST, rel)
+            _rows_against_second_reading(rel + " (host)", sh, fixtures.path(rel))
+        n_rows += len(sd)
+    assert n_rows > 150000
+    for seed in range(0, 120):
+        p = str(tmp_path / ("f%d.r1cs" % seed))
+        fuzz_r1cs.write(p, fuzz_r1cs.make(seed) if seed % 4 else fuzz_r1cs.make_oob(seed))
+        for mode in (E.FRONTEND_DEVICE, E.FRONTEND_HOST):
+            _m, s = _system(E, mode, path=p)
+            _rows_against_second_reading((seed, mode), s, p)
+    rows = [([(2, 0), (2, 5), (4, orc.P + 2)], [], [(3, 5), (2, 1), (3, 7), (1, orc.P - 9), (2, 0)])]
+    for order in ((2, 1, 3), (1, 2, 3), (3, 1, 2), (3, 2, 1)):
+        p = str(tmp_path / ("o%d%d%d.r1cs" % order))
+        fuzz_r1cs.write_raw(p, 3, 1, 0, 1, rows, section_order=order)
+        for mode in (E.FRONTEND_DEVICE, E.FRONTEND_HOST):
+            _m, s = _system(E, mode, path=p)
+            _rows_against_second_reading((order, mode), s, p)
+    # long parts in every tier of the device reader (tables in LDS / HBM), with repeats
+    from test_fuzz import _many_block_rows
+    rng = random.Random(7)
+    rows = _many_block_rows(600, 300, 99)
+    for i, n in enumerate((12, 43, 90, 171, 700, 1100, 3500)):
+        terms = [(rng.randint(1, 5000), rng.choice([0, 1, 2, orc.P - 1, orc.P + 3, rng.getrandbits(250)])) for _ in range(n)]
+        terms[rng.randrange(1, n)] = (terms[0][0], 7)
+        a = list(rows[40 * i + 3])
+        a[i % 3] = terms
+        rows[40 * i + 3] = tuple(a)
+    p = str(tmp_path / "tiers.r1cs")
+    fuzz_r1cs.write_raw(p, 4999, 1, 1, 4997, rows)
+    for mode in (E.FRONTEND_DEVICE, E.FRONTEND_HOST):
+        _m, s = _system(E, mode, path=p)
+        _rows_against_second_reading(("tiers", mode), s, p)
+
+
 def test_abstraction_reference_configs():
     import ecneproject_amd as E
     for rel, trusted, names, _secp, _verdict in fixtures.REFERENCE_ASSERTED:

@@ -1,0 +1,89 @@
+"""The batch front-end (ecneproject_amd/jobs.py: the job queue that stands in for src/Ecne.jl:9-37 and src/Server.jl:6-30) on a
+real device, world size 1: LPT share, reader + abstraction per job, ONE batch launch with every system's own secp_solve, the
+verdict word -- and every result compared bit for bit with the oracle (whole per-variable state, counts, counters), on
+BASELINE config 4 (the 67 circomlib files) and on the four-job verification DAG of config 5 (mixed secp_solve)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import fixtures
+import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _oracle(job):
+    return orc.run(job.r1cs, [f for f, _n in job.trusted], [n for _f, n in job.trusted], job.secp_solve)
+
+
+@pytest.mark.gpu
+def test_runner_suite_bit_exact():
+    """config 4: ecne_circomlib_tests/*.r1cs as one batch launch through jobs.Runner"""
+    import ecneproject_amd as E
+    from ecneproject_amd import jobs as J
+    from gpu_common import assert_bit_exact
+    rels = fixtures.circomlib_suite()
+    assert len(rels) == 67
+    jl = [J.Job(fixtures.path(r), r) for r in rels]
+    runner = J.Runner(jl, rank=0, world=1, device=0, dist=None)
+    assert runner.mine == list(range(len(jl)))
+    assert runner.rows_main == sum(len(E.R1CS(j.r1cs)) for j in jl)
+    oracles = [_oracle(j) for j in jl]
+    for rep in range(2):      # a Runner is built once and run many times (bench.py does): the second pass must not differ
+        res, ok = runner.run(fetch_states=True)
+        assert len(res) == len(jl)
+        for j, g, o in zip(jl, res, oracles):
+            assert_bit_exact("jobs.Runner suite %s pass %d" % (j.name, rep), g, o)
+        assert ok == all(o.status == 0 for o in oracles)
+
+
+@pytest.mark.gpu
+def test_runner_verification_dag_bit_exact():
+    """config 5's DAG: ecdsa_like <- secp256k1, secp256k1 <- bigmultmodp + biglessthan (secp_solve=true), bigmultmodp,
+    biglessthan; one launch holds all four, each with its own secp_solve; the verdicts are what the oracle says"""
+    import ecdsa_like
+    from ecneproject_amd import jobs as J
+    from gpu_common import assert_bit_exact
+    fx = fixtures.path
+    main = ecdsa_like.cached(3, 10)
+    jl = [J.Job(main, "ecdsa_like(3)", [(fx("secp256k1.r1cs"), "Secp256k1AddUnequal")]),
+          J.Job(fx("secp256k1.r1cs"), "secp256k1", [(fx("bigmultmodp.r1cs"), "BigMultModP"), (fx("biglessthan.r1cs"), "BigLessThan")], True),
+          J.Job(fx("bigmultmodp.r1cs"), "bigmultmodp"), J.Job(fx("biglessthan.r1cs"), "biglessthan"),
+          # the same main file WITHOUT secp_solve next to the one with it: UndefVarError `dsu` (:762) for this job only
+          J.Job(fx("secp256k1.r1cs"), "secp256k1 without secp_solve", [(fx("bigmultmodp.r1cs"), "BigMultModP"), (fx("biglessthan.r1cs"), "BigLessThan")], False)]
+    runner = J.Runner(jl, rank=0, world=1, device=0, dist=None)
+    res, ok = runner.run(fetch_states=True)
+    oracles = [_oracle(j) for j in jl]
+    for j, g, o in zip(jl, res, oracles):
+        assert_bit_exact("jobs.Runner dag %s" % j.name, g, o)
+        if o.status == 0:
+            assert [tuple(x) for x in runner.systems[jl.index(j)].specials()] == [tuple(x) for x in o.specials], j.name
+    assert [o.status for o in oracles] == [0, 0, 0, 0, -4]
+    assert ok is False                                   # one job raised
+    assert res[1].function_good is True or res[1].function_good == 1      # test/runtests.jl:35
+
+
+@pytest.mark.gpu
+def test_jobs_cli_one_process(tmp_path):
+    """python -m ecneproject_amd.jobs jobs.json on one GPU: one JSON line per job + the summary line"""
+    fx = fixtures.path
+    spec = [{"r1cs": fx("target/division.r1cs"), "name": "division"},
+            {"r1cs": fx("secp256k1.r1cs"), "name": "secp", "trusted": [[fx("bigmultmodp.r1cs"), "BigMultModP"], [fx("biglessthan.r1cs"), "BigLessThan"]], "secp_solve": True},
+            {"r1cs": fx("ecne_circomlib_tests/Poseidon@poseidon.r1cs"), "name": "poseidon"}]
+    p = tmp_path / "jobs.json"
+    p.write_text(json.dumps(spec))
+    out = subprocess.run([sys.executable, "-m", "ecneproject_amd.jobs", str(p)], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    by = {l["job"]: l for l in lines if "job" in l}
+    for s in spec:
+        o = orc.run(s["r1cs"], [t for t, _ in s.get("trusted", [])], [n for _, n in s.get("trusted", [])], s.get("secp_solve", False), want_states=False)
+        assert by[s["name"]]["status"] == o.status == 0
+        assert by[s["name"]]["sound"] == o.verdict
+        assert (by[s["name"]]["unique"], by[s["name"]]["of"]) == (o.summary.unique_nontrivial, o.summary.n_nontrivial)
+    assert [l for l in lines if "jobs" in l][0] == {"jobs": 3, "n_gpus": 1, "all_ran": True, "wall_s": [l for l in lines if "jobs" in l][0]["wall_s"]}

@@ -53,6 +53,10 @@ HAND = {
     "zero_coefficient": (4, 1, 2, 1, [([], [], [(2, 1), (7, 0), (3, P - 1)])], 0),
     # linear row: R7 reads `unique` of every C variable (:1240)
     "linear_row": (4, 1, 2, 1, [([], [], [(2, 1), (5, 1), (7, 1), (3, P - 1)])], -2),
+    # ids in range; secp_solve's dsu setup (:634-678) indexes `l[2]` of a two-entry C whose only non-zero key is the constant
+    # (:652): BoundsError under secp_solve, a normal run without (the GPU test runs both)
+    "dsu_const_only": (4, 1, 2, 1, [([(3, 1)], [(4, 1)], [(2, 1)]), ([], [], [(1, 5), (3, 0)])], 0),
+    "dsu_fine": (4, 1, 2, 1, [([(3, 1)], [(4, 1)], [(2, 1)]), ([], [], [(5, 5), (3, 0)])], 0),
 }
 
 
@@ -69,6 +73,7 @@ def test_hand_cases_oracle(hand_dir, name):
     import ref2
     p = str(hand_dir / (name + ".r1cs"))
     assert orc.run(p).status == HAND[name][5] == ref2.run(p).status
+    assert orc.run(p, secp_solve=True).status == ref2.run(p, secp_solve=True).status == (-2 if name != "dsu_fine" and name != "zero_coefficient" else 0)
 
 
 @pytest.mark.gpu
