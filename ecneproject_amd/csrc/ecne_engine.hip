@@ -1451,6 +1451,8 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 if (hj[i].drain && solo_off) hj[i].drain |= 4u;
                 static const bool sub_off = []() { const char* e = getenv("ECNE_SUBTEAM"); return e && atoi(e) == 0; }();      // bit 3: rounds always on all workgroups
                 if (sub_off) hj[i].drain |= 8u;
+                static const bool lv_off = []() { const char* e = getenv("ECNE_LEVEL"); return e && atoi(e) == 0; }();      // level rounds (level.hip.hpp) off: A/B runs
+                hj[i].lv_off = lv_off ? 1u : 0u;
             }
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }

@@ -3,7 +3,7 @@
 #pragma once
 #include "job_barrier.hip.hpp"
 #include "chain.hip.hpp"
-#include "wave2.hip.hpp"
+#include "level.hip.hpp"
 
 namespace ecne {
 
@@ -873,6 +873,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     // more rows to be worth its latency, whatever the queue length; bursts grow further while the chain lasts.
     const bool chain = chain_ok(J);
     const bool v2 = fast_wave_ok(J);
+    const bool lv_ok = chain && v2 && level_rounds_on(J);      // level rounds: LDS-resident state, row records, the fast round's LDS block
+    uint32_t lv_burst = 1;
+    bool lv_wide = false, lv_chain = false;      // lv_chain: the burst that follows pops rows the level rounds declined (chain executor)
     const bool v2wg = v2 && fast_wg_ok(J);
     uint32_t streak = 0;             // rows committed in a row without a dependency cutting a round short (evidence for a wide independent frontier)
     bool declined_wide = false;      // the fast wavefront round keeps declining the head row of a wide frontier
@@ -897,6 +900,37 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // than their pops, ~0.8 us each), until the queue is empty or a frontier has built up again
         uint32_t burst_stop = 0;
         if (chain && !burst && avail <= ECNE_CHAIN_AVAIL) { burst = 1u << 20; burst_stop = 2 * ECNE_CHAIN_AVAIL; }
+        // ---- level rounds (level.hip.hpp): a single-workgroup job with LDS-resident state takes every frontier of up to 192 rows
+        // level by level on wavefront 0, without coming back here between two levels. It returns in front of a row it does not
+        // take (the chain executor pops that one; more of them in a row: longer bursts) or when the frontier has grown wide.
+        if (lv_ok && (lv_wide || (!burst && avail <= ECNE_LV_EXIT_AVAIL))) {
+            // (lv_wide: a round on the workgroup was cut short by a dependency with many rows queued -- chains side by side; the level
+            //  rounds work the queue off 64 rows at a time for as many rounds as the burst would have had pops)
+            const uint32_t lv_max = lv_wide ? burst : (1u << 20);
+            const bool wide = lv_wide;
+            lv_wide = false; if (wide) burst = 0;
+            if (w == 0) {
+                uint32_t hd = q.head, tl = q.tail, nr = 0;
+                const uint32_t why = level_rounds(J, hd, tl, lv_max, wide, C, my_pops, my_nnz, &nr, &S.sd[0]);
+                if (lane == 0) { S.head = hd; S.tail = tl; S.nbig = why; S.bl_tmp[0] = nr; }
+            }
+            __syncthreads();
+            const uint32_t why = S.nbig, nr = S.bl_tmp[0], done = S.head - q.head;
+#if defined(ECNE_FINE_TICKS) && !defined(ECNE_LVPROF)
+            if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: level rounds in the fast rounds' slots
+#endif
+            pops_total += done;
+            hits[13] += nr;
+            q.head = S.head; q.tail = S.tail;
+            __syncthreads();
+            if (why == LV_DECLINED) { burst = lv_burst; lv_chain = true; if (nr < 2 && lv_burst < 64u) lv_burst *= 2; else if (nr >= 2) lv_burst = 1; }
+            QTICK(6);
+            if (why == LV_REFILL) lv_wide = true, burst = lv_max > nr ? lv_max - nr : 1u;      // (the mirrored part is used up: the same call again)
+            if (why != LV_WIDE) continue;
+            avail = q.tail - q.head;
+        }
+        if (lv_ok && burst > 1 && !lv_chain) { lv_wide = true; continue; }      // what would be a burst of the chain executor: level rounds instead
+        lv_chain = false;
         if (burst) {
             // The last chunk round committed only a handful of rows (a dependency chain): pop the next
             // `burst` rows strictly sequentially on wave 0 (cheaper per pop than a round), then look again.
