@@ -147,29 +147,41 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         // unrolled over the record's 15 slots and ends, for the whole wavefront, at the longest row of the window.
         const bool walk = live && !slow && !xy && !f2;
         const uint32_t maxE = max4(nE, walk);
-        bool nuab = false, notknown = false;
-        uint32_t cnt = 0, u = 0, nonfinal = 0;
-        uint8_t uf = 0;
+        // (written with masks and arithmetic, not with branches: the compiler turns a chain of small `if`s on per-lane conditions into
+        //  exec-mask bookkeeping on the scalar unit, ~40 instructions and four branches per entry; this is ~20 straight-line VALU ones)
+        const uint32_t nEw = walk ? nE : 0u, nAB = nA + nB;
+        uint32_t cnt = 0, u = 0, uf32 = 0, nonfinal = 0, nuab32 = 0, notk32 = 0;
 #pragma unroll
         for (uint32_t g = 0; g < 4; ++g) {          // four entries per step: their flag bytes are in flight together
             if (4 * g >= maxE) break;
-            uint8_t fg[4];
+            uint32_t fg[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) { const uint32_t e = 4 * g + t; fg[t] = (e < 15) ? F[(walk && e < nE) ? w[1 + (e < 15 ? e : 0)] : 0u] : (uint8_t)3; }
+            for (uint32_t t = 0; t < 4; ++t) {
+                const uint32_t e = 4 * g + t;
+                if (e >= 15) { fg[t] = 3; continue; }
+                const uint32_t on = (uint32_t)((int32_t)(e - nEw) >> 31);            // all ones iff e < nEw
+                fg[t] = F[w[1 + e] & on];
+            }
 #pragma unroll
             for (uint32_t t = 0; t < 4; ++t) {
                 const uint32_t e = 4 * g + t;
                 if (e >= 15) continue;
-                const uint8_t f = fg[t];
-                if (walk && e < nE) {
-                    if ((f & 3) != 3) nonfinal |= 1u << e;
-                    if (!(f & 1)) {
-                        if (e < nA + nB) nuab = true;
-                        else { if (!cnt) { u = w[1 + e]; uf = f; } ++cnt; if (!(f & 2)) notknown = true; }
-                    }
-                }
+                const uint32_t f = fg[t];
+                const uint32_t on = (uint32_t)((int32_t)(e - nEw) >> 31);
+                const uint32_t inC = ~(uint32_t)((int32_t)(e - nAB) >> 31);           // all ones iff e >= nA + nB
+                nonfinal |= (((((f & 3u) ^ 3u) + 3u) >> 2) & on & 1u) << e;
+                const uint32_t nu = ~f & on & 1u;                                     // not unique
+                nuab32 |= nu & ~inC;
+                const uint32_t cn = nu & inC;
+                const uint32_t m = 0u - (cn & ((cnt - 1u) >> 31));                    // the first non-unique variable of C
+                u = (u & ~m) | (w[1 + e] & m);
+                uf32 = (uf32 & ~m) | (f & m);
+                cnt += cn;
+                notk32 |= cn & ((f >> 1) ^ 1u);
             }
         }
+        const bool nuab = nuab32 != 0, notknown = (notk32 & 1u) != 0;
+        const uint8_t uf = (uint8_t)uf32;
         FastOut D;
         D.slow = slow; D.reason = 7;
         if (walk) {
@@ -230,15 +242,22 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                 if (c2) blocked = m0 < rank;
                 if (cxy) blocked = m0 < rank || m1 < rank;
             }
+            const uint32_t cw_ = (cand && walk) ? nonfinal : 0u;
+            uint32_t blk = 0;
 #pragma unroll
             for (uint32_t g = 0; g < 4; ++g) {
                 if (4 * g >= maxE) break;
                 uint32_t mg[4];
 #pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) { const uint32_t e = 4 * g + t; mg[t] = (e < 15) ? wm[wslot((cand && walk && ((nonfinal >> e) & 1u)) ? w[1 + (e < 15 ? e : 0)] : 0u)] : 0xFFFFFFFFu; }
+                for (uint32_t t = 0; t < 4; ++t) {
+                    const uint32_t e = 4 * g + t;
+                    if (e >= 15) { mg[t] = 0xFFFFFFFFu; continue; }
+                    mg[t] = wm[wslot(w[1 + e] & (0u - ((cw_ >> e) & 1u)))];
+                }
 #pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) { const uint32_t e = 4 * g + t; if (e < 15 && cand && walk && ((nonfinal >> e) & 1u) && mg[t] < rank) blocked = true; }
+                for (uint32_t t = 0; t < 4; ++t) { const uint32_t e = 4 * g + t; if (e < 15) blk |= (mg[t] < rank ? 1u : 0u) & (cw_ >> e); }
             }
+            if (blk & 1u) blocked = true;
             const uint64_t m = __ballot(blocked);
             if (m) { const uint32_t fb_ = (uint32_t)(__ffsll((long long)m) - 1); if (fb_ < c) c = fb_; }      // >= 1: rank 0 is never blocked
             if (ma) wm[sa] = 0xFFFFFFFFu;       // (marks are the round's: the writers take them back)
