@@ -32,8 +32,8 @@ namespace ecne {
 #define ECNE_LV_QM 256u         // mirror of the queue ring: positions head .. head + 255
 #define ECNE_LV_CAND 960u       // dense list of eligible candidates of one round (64 rows x 15)
 static_assert(4u * (ECNE_LV_MARKS + ECNE_LV_QM + ECNE_LV_CAND) <= ECNE_W2_BYTES, "the level rounds' tables live in the fast wavefront round's LDS block");
-#ifndef ECNE_LV_EXIT_AVAIL
-#define ECNE_LV_EXIT_AVAIL 192u   // more rows than this queued: a wide frontier, the round schedule's business
+#ifndef ECNE_LV_WIDE_AVAIL
+#define ECNE_LV_WIDE_AVAIL 192u   // more rows than this queued: a wide frontier, the round schedule's business (unless it asks for level rounds: wide_ok)
 #endif
 
 __device__ __forceinline__ bool level_rounds_on(const Job& J) { return J.lv_off == 0; }
@@ -110,7 +110,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
     };
     while (head != tail) {
         const uint32_t avail = tail - head;
-        if (!wide_ok && avail > ECNE_LV_EXIT_AVAIL) { why = LV_WIDE; break; }
+        if (!wide_ok && avail > ECNE_LV_WIDE_AVAIL) { why = LV_WIDE; break; }      // a wide frontier: the rounds on the whole workgroup first
         if (rounds >= max_rounds) { why = LV_ROUNDS; break; }
         uint32_t n = avail < 64u ? avail : 64u;
         if (head + n > mtop) {                       // the window reaches beyond the mirror
@@ -142,7 +142,21 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         const bool f2 = (shape & SH_C_EMPTY) != 0;
         const bool f4 = !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R4_T | SH_R4_T2 | SH_R5 | SH_R6));
         const bool live = mine && !is_solved;
-        bool slow = mine && (norec || (shape & SH_BIG) || (!is_solved && !(xy || f1 || f2 || f4)));
+        // A long linear row (no record: the 1 025-term sum of a decoder, the 88 bits of a decomposition) is re-queued by each of its
+        // terms and nearly all of those pops do nothing; words 1 and 2 of its record line hold the watched pair that says why
+        // (long_row_walk, fastrow.hip.hpp). While the pair still does, the pop is settled here from two flag bytes, at any rank.
+        const uint32_t lenC = ri4[1].w;
+        const bool lr4 = long_r4(shape);
+        const bool biglin = live && norec && (f4 || lr4) && lenC > 15;
+        bool bl_nop = false, watched = false;
+        if (__ballot(biglin)) {
+            const uint32_t h0 = w[1], h1 = w[2];
+            watched = biglin && h0 < 0xFFFFFFFEu;
+            const uint8_t g0 = F[watched ? h0 : 0u], g1 = F[watched ? h1 : 0u];
+            bl_nop = (biglin && h0 == 0xFFFFFFFEu && f4) || (watched && long_watch_holds(g0, g1, lr4));
+            watched = watched && bl_nop;
+        }
+        bool slow = mine && !bl_nop && (norec || (shape & SH_BIG) || (!is_solved && !(xy || f1 || f2 || f4)));
         // ---- 3: products and plain sums walk their entries (R1, :827-873): flag bytes from LDS, counted on the fly. The loop is
         // unrolled over the record's 15 slots and ends, for the whole wavefront, at the longest row of the window.
         const bool walk = live && !slow && !xy && !f2;
@@ -258,6 +272,11 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                 for (uint32_t t = 0; t < 4; ++t) { const uint32_t e = 4 * g + t; if (e < 15) blk |= (mg[t] < rank ? 1u : 0u) & (cw_ >> e); }
             }
             if (blk & 1u) blocked = true;
+            if (__ballot(cand && watched)) {       // the watched pair of a long row is what its empty pop has read
+                const bool on = cand && watched;
+                const uint32_t m0 = wm[wslot(on ? w[1] : 0u)], m1 = wm[wslot(on ? w[2] : 0u)];
+                if (on && (m0 < rank || m1 < rank)) blocked = true;
+            }
             const uint64_t m = __ballot(blocked);
             if (m) { const uint32_t fb_ = (uint32_t)(__ffsll((long long)m) - 1); if (fb_ < c) c = fb_; }      // >= 1: rank 0 is never blocked
             if (ma) wm[sa] = 0xFFFFFFFFu;       // (marks are the round's: the writers take them back)
@@ -297,7 +316,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         // ---- 6: commit the prefix: every lane its own pop; the rows of the prefix carry 2 + rank while the pushes are resolved
         if (in) {
             c_pops++;
-            c_nnz += nE;
+            c_nnz += bl_nop ? lenC : nE;
             Q[row] = (uint16_t)(2u + rank);
         }
         if (inl) {

@@ -903,7 +903,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // ---- level rounds (level.hip.hpp): a single-workgroup job with LDS-resident state takes every frontier of up to 192 rows
         // level by level on wavefront 0, without coming back here between two levels. It returns in front of a row it does not
         // take (the chain executor pops that one; more of them in a row: longer bursts) or when the frontier has grown wide.
-        if (lv_ok && (lv_wide || (!burst && avail <= ECNE_LV_EXIT_AVAIL))) {
+        if (lv_ok && (lv_wide || (!burst && avail <= ECNE_LV_WIDE_AVAIL))) {
             // (lv_wide: a round on the workgroup was cut short by a dependency with many rows queued -- chains side by side; the level
             //  rounds work the queue off 64 rows at a time for as many rounds as the burst would have had pops)
             const uint32_t lv_max = lv_wide ? burst : (1u << 20);
@@ -918,6 +918,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             const uint32_t why = S.nbig, nr = S.bl_tmp[0], done = S.head - q.head;
 #if defined(ECNE_FINE_TICKS) && !defined(ECNE_LVPROF)
             if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: level rounds in the fast rounds' slots
+#endif
+#ifdef ECNE_ROUNDLOG
+            if (tid == 0) printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, wall_clock64() - qt_last);
 #endif
             pops_total += done;
             hits[13] += nr;

@@ -7,8 +7,9 @@ import ecneproject_amd as E, fixtures
 from gpu_common import build_system
 names = ["entry", "record + descriptor", "flag bytes", "decisions", "marks + check", "fan-out lists", "commit", "push resolution"]
 for rel in sys.argv[1:]:
-    s = build_system(rel)
-    for _ in range(3): r = E.solve_batch([s], fetch_states=False)[0]
+    secp = rel == "secp"
+    s = build_system("secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"]) if secp else build_system(rel)
+    for _ in range(3): r = E.solve_batch([s], secp_solve=secp, fetch_states=False)[0]
     sm = r.summary
     sd = list(sm.sched)
     n = sm.rule_hits[13]
