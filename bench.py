@@ -39,10 +39,12 @@ def parse_args():
     ap.add_argument("--cpu-sample-S", type=int, default=26, help="strides of the CPU-baseline sample (26 = the whole workload: ~13 s solve + ~4 s parse / abstraction on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queue-mode", type=int, default=0)
-    ap.add_argument("--workload", choices=["ecdsa", "suite", "poseidon", "secp", "dag"], default="ecdsa",
+    ap.add_argument("--copies", type=int, default=8, help="--workload many: copies of every mid-depth circomlib file (8 -> 504 jobs of 63 files)")
+    ap.add_argument("--workload", choices=["ecdsa", "suite", "poseidon", "secp", "dag", "many"], default="ecdsa",
                     help="ecdsa = BASELINE.json config 5 (the metric's configuration, one circuit: replicas at N > 1); suite = config 4, the 67 "
                          "circomlib files sharded file-per-GPU; poseidon = config 2; secp = config 3; dag = config 5's trusted-subcircuit "
-                         "verification DAG as four sharded jobs (ecneproject_amd/jobs.py)")
+                         "verification DAG as four sharded jobs (ecneproject_amd/jobs.py); many = hundreds of mid-depth circuits (the suite without "
+                         "its four long chains, --copies times): the job mix DESIGN.md section 6 predicts to scale over GPUs")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads for parse / abstraction / layout (0 = the cores present, at most 32)")
     return ap.parse_args()
 
@@ -84,6 +86,9 @@ def probe_julia():
     return {"julia": v, "note": "julia found; timing the reference needs an instantiated Ecne checkout (ECNE_REFERENCE_DIR), see julia/dump_unique.jl"}
 
 
+MANY_EXCLUDES = ("EdDSAMiMCSpongeVerifier", "EdDSAMiMCVerifier", "EdDSAPoseidonVerifier", "BabyPbk")      # the suite's four long dependency chains (14-24 k rows each)
+
+
 def workload_jobs(name, args):
     """The job lists of the BASELINE.json configurations that are batches of independent solves (ecneproject_amd.jobs.Job)."""
     import ecdsa_like
@@ -96,6 +101,13 @@ def workload_jobs(name, args):
     if name == "poseidon":     # config 2
         r = "ecne_circomlib_tests/Poseidon@poseidon.r1cs"
         return [J.Job(fx(r), r)], "ecne_circomlib_tests/Poseidon@poseidon.r1cs (BASELINE.json config 2)", "reference fixture"
+    if name == "many":         # not a BASELINE configuration: a batch that DOES scale over GPUs -- many circuits of similar depth
+        rels = [r for r in fixtures.circomlib_suite() if not any(k in r for k in MANY_EXCLUDES)]
+        copies = max(1, int(getattr(args, "copies", 8)))
+        return ([J.Job(fx(r), "%s#%d" % (r, c)) for c in range(copies) for r in rels],
+                "many mid-depth circuits: ecne_circomlib_tests/*.r1cs without the four long chains (%s), %d copies of each = %d independent jobs, "
+                "LPT-packed job-per-GPU, batch launches of up to 248 single-workgroup jobs" % (", ".join(MANY_EXCLUDES), copies, copies * len(rels)),
+                "reference fixtures, replicated")
     secp = J.Job(fx("secp256k1.r1cs"), "secp256k1", [(fx("bigmultmodp.r1cs"), "BigMultModP"), (fx("biglessthan.r1cs"), "BigLessThan")], True)
     if name == "secp":         # config 3
         return [secp], "secp256k1.r1cs + trusted bigmultmodp.r1cs, biglessthan.r1cs, secp_solve=true (BASELINE.json config 3)", "reference fixtures"
@@ -210,7 +222,13 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
                    "all_ran": bool(ok),
                    "per_rank": [{"rank": pr["rank"], "ms_per_step": round(pr["ms_per_step"], 3), "jobs": [j["job"] for j in pr["jobs"]],
                                  "longest_job_ms": round(max((j["device_ms"] for j in pr["jobs"]), default=0.0), 3)} for pr in per_rank],
-                   "lpt": {"weights": "non-zeros of the main file", "rank_loads": loads, "imbalance": (max(loads) / max(sum(loads) / len(loads), 1e-9)) if loads else None},
+                   "lpt": {"weights": "non-zeros of the main file", "rank_loads": loads, "imbalance": (max(loads) / max(sum(loads) / len(loads), 1e-9)) if loads else None,
+                           # what the packing alone says about N = 1, 2, 4, 8 (no run needed): the heaviest rank's share of the weight, and the
+                           # time model t(N) ~ t(1) x that share, never below the share of the heaviest single job
+                           "predicted_scaling": {str(nn): {"max_rank_share": round(max(sum(runner.weights[i] for i in part) for part in sharding.assign(runner.weights, nn)) / max(sum(runner.weights), 1), 4),
+                                                           "imbalance": round(max(sum(runner.weights[i] for i in part) for part in sharding.assign(runner.weights, nn)) * nn / max(sum(runner.weights), 1), 3)}
+                                                 for nn in (1, 2, 4, 8)},
+                           "heaviest_job_share": round(max(runner.weights) / max(sum(runner.weights), 1), 4)},
                    "predicted_bound": {"ms_per_step_at_any_n": round(k_ms if world == 1 else longest["device_ms"], 3), "job": longest["job"],
                                        "note": "a batch takes as long as its longest job: more GPUs cannot go below it (strong scaling saturates at the number of jobs that take about that long)"}},
         # (two kernels since round 3: k_solve for batches of single-workgroup jobs, k_solve_team as soon as one job of the batch has a team)
@@ -334,11 +352,14 @@ def main():
         # --pmc WRITE_SIZE, separate runs; summaries under profiles/). Not measurable from inside this process.
         traffic, traffic_src = None, None
         tj = os.path.join(HERE, "profiles", "traffic_latest.json")
-        if os.path.exists(tj) and args.S == 26 and args.stride == 10 and world == 1:
+        if os.path.exists(tj) and args.stride == 10 and world == 1:
             with open(tj) as f:
                 t = json.load(f)
-            if t.get("csrc_sha16") == csrc_sha16():
-                traffic, traffic_src = t.get("k_solve_bytes_per_launch"), t.get("source")
+            ts = t.get("by_S", {}).get(str(args.S))          # one entry per workload size the PMC passes were taken on (26: the headline, 104: beyond the Infinity Cache)
+            if ts is None:
+                traffic_src = "no PMC passes on file for S = %d (tools/profile_r04.sh %d)" % (args.S, args.S)
+            elif t.get("csrc_sha16") == csrc_sha16():
+                traffic, traffic_src = ts.get("k_solve_bytes_per_launch"), ts.get("source")
             else:      # the PMC passes were taken on another build of the library: not this line's traffic
                 traffic_src = "stale: profiles/traffic_latest.json was measured on csrc %s, this build is %s (re-run tools/profile_r04.sh)" % (t.get("csrc_sha16"), csrc_sha16())
         achieved = b_alg / (k_ms * 1e-3) / 1e9
@@ -363,7 +384,8 @@ def main():
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64x4 (BN254 Fp limbs) + u8/u32 flags", "data": "synthetic",
-            "config": {"workload": "ecdsa_like(S=%d,stride=%d) + trusted secp256k1.r1cs (config 5; ecdsa.r1cs absent from the reference)" % (args.S, args.stride),
+            "config": {"workload": ("ecdsa_like(S=%d,stride=%d) + trusted secp256k1.r1cs (config 5; ecdsa.r1cs absent from the reference)" % (args.S, args.stride)) if args.S == 26 else
+                                   ("ecdsa_like(S=%d,stride=%d) + trusted secp256k1.r1cs: the SCALE-OUT variant of config 5 (%d strides instead of 26) whose static arrays and state exceed the 256 MiB Infinity Cache -- the HBM-true roofline line, not the headline" % (args.S, args.stride, args.S)),
                        "rows_main": n_main, "rows_reduced": int(info.n_rows), "nnz_reduced": nnz,
                        "specials": int(info.n_specials), "n_vars": int(info.n_vars),
                        "parallelism": "replicas x%d, RCCL all-reduce of the verdict word" % world if world > 1 else "1 GPU",
@@ -374,6 +396,8 @@ def main():
                        "classify_kernel": {"ms": classify_ms, "ms_best": classify_ms_best, "ms_first_call": classify_ms_cold, "bytes": classify_bytes,
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6,
                                            "frac_of_hbm_peak": classify_bytes / max(classify_ms, 1e-9) / 1e6 / 8000.0,
+                                           "resident": ("infinity cache: the %d MB this pass streams fit the 256 MiB MALL and the launches are warm -- the fraction is of the HBM peak, the data does not come from HBM (see --S 104)" % (classify_bytes >> 20))
+                                                       if classify_bytes < (256 << 20) else "hbm: %d MB per pass, beyond the 256 MiB Infinity Cache" % (classify_bytes >> 20),
                                            "note": "HIP events around the launch; ms = median of 7 warm launches, ms_best their minimum; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
                        "abstraction": abstract_stats,
                        "frontend": {"mode": {0: "host", 1: "device", 2: "auto"}[E.set_frontend()], **{k: round(v, 3) for k, v in frontend_stats.items()}}},

@@ -191,3 +191,65 @@ def test_two_rank_verification_dag(tmp_path):
     verdicts = dict(zip(res["names"], res["verdicts"]))
     assert verdicts["secp256k1"] is True                             # test/runtests.jl:35
     assert res["sound_all"] == all(verdicts.values())
+
+
+MANY_WORKER = r'''
+import os, sys, json, argparse
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch, torch.distributed as dist
+import fixtures, orc
+import bench
+import ecneproject_amd as E
+from ecneproject_amd import jobs as J, sharding
+
+
+class OracleEngine:
+    """reader / job runner / sharding / all-reduce run for real; solve_batch is answered by the oracle (no GPU here)"""
+    R1CS, System = E.R1CS, E.System
+    cache = {}
+
+    @classmethod
+    def solve_batch(cls, systems, secp_solve=False, device=0, stream=None, fetch_states=False):
+        out = []
+        for s in systems:
+            if s.main.path not in cls.cache:
+                o = orc.run(s.main.path, want_states=False)
+                cls.cache[s.main.path] = type("R", (), {"status": o.status, "function_good": o.verdict, "summary": o.summary})()
+            out.append(cls.cache[s.main.path])
+        return out
+
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+jl, label, data = bench.workload_jobs("many", argparse.Namespace(copies=2, S=26, stride=10))
+runner = J.Runner(jl, dist.get_rank(), dist.get_world_size(), 0, dist, E=OracleEngine)
+res, ok = runner.run(device_for_word="cpu")
+loads = [sum(runner.weights[i] for i in part) for part in sharding.assign(runner.weights, dist.get_world_size())]
+gathered = [None] * dist.get_world_size()
+dist.all_gather_object(gathered, ([jl[i].name for i in runner.mine], [bool(r.function_good) for r in res], runner.rows_main))
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps({"ok": bool(ok), "n_jobs": len(jl), "names": sum([g[0] for g in gathered], []), "rows": [g[2] for g in gathered],
+                                   "verdicts_true": sum(sum(g[1]) for g in gathered), "loads": loads}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_many_workload(tmp_path):
+    """bench.py --workload many (hundreds of mid-depth circuits: the job mix that scales over GPUs, DESIGN.md section 6) on two gloo
+    ranks: every job runs exactly once, the LPT loads differ by less than the heaviest job, rows add up."""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / "many_worker.py"
+    script.write_text(MANY_WORKER % {"root": ROOT, "tests": HERE})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29536")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29536", str(script)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    jl, _label, _data = bench.workload_jobs("many", argparse.Namespace(copies=2, S=26, stride=10))
+    assert res["n_jobs"] == len(jl) == 126 and sorted(res["names"]) == sorted(j.name for j in jl)
+    assert not any(k in n for n in res["names"] for k in bench.MANY_EXCLUDES)
+    assert min(res["rows"]) > 0 and abs(res["loads"][0] - res["loads"][1]) <= max(res["loads"]) * 0.05      # balanced: no job dominates
+    assert res["ok"] is True and 0 < res["verdicts_true"] < len(jl)
