@@ -282,6 +282,14 @@ def main():
     t0 = time.time()
     path = ecdsa_like.cached(args.S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid())
     t_gen = time.time() - t0
+    # The first host-to-device copy of a process sets up the HIP runtime's copy path: ~100 ms with torch's code objects loaded, 27 ms
+    # without (tools/fe_first_upload.py) -- whoever copies first pays it. One 64 MB torch copy up front, so that `config.frontend`
+    # below reports the library's front-end and not the runtime's start-up (reported here, untimed like all of the preparation).
+    t0 = time.perf_counter()
+    _warm = torch.empty(64 << 20, dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    runtime_warmup_ms = (time.perf_counter() - t0) * 1e3
+    del _warm
     t0 = time.time()
     main_file = E.R1CS(path)
     parse_stats = E.frontend_stats()
@@ -305,7 +313,10 @@ def main():
         return r
 
     _shape, classify_ms_cold, classify_bytes = E.classify(system, device=local_rank)     # first launch: code object load, cold caches
+    t_first = time.perf_counter()
     res = step()                       # first solve: layout upload + classification happen here (untimed)
+    torch.cuda.synchronize()
+    first_call = {"wall_ms": round((time.perf_counter() - t_first) * 1e3, 3), "kernel_ms": round(float(res.summary.device_ms), 3)}
     frontend_stats = E.frontend_stats()                 # (abstraction and layout of this system; the parse figures are the main file's)
     for k in ("parse_device", "upload_ms", "offsets_ms", "fill_ms", "parse_ms", "file_bytes"):
         frontend_stats[k] = parse_stats[k]
@@ -393,12 +404,14 @@ def main():
                        "outer_iterations": int(s.outer_iterations), "pops": int(s.pops),
                        "invariants": {"steps_identical": True, "checked": "status, verdict, pops, successful_steps, num_unique, outer_iterations, the four printed counts, rule hits -- every timed step"},
                        "host_prep_s": {"generate": round(t_gen, 3), "parse": round(t_parse, 3), "abstract": round(t_abstract, 3)},
+                       "runtime_warmup": {"ms": round(runtime_warmup_ms, 1), "what": "one 64 MB torch host-to-device copy before the front-end: the process's first copy initialises the HIP runtime's copy path; without it that time shows up as the first file's upload_ms"},
                        "classify_kernel": {"ms": classify_ms, "ms_best": classify_ms_best, "ms_first_call": classify_ms_cold, "bytes": classify_bytes,
                                            "GBps": classify_bytes / max(classify_ms, 1e-9) / 1e6,
                                            "frac_of_hbm_peak": classify_bytes / max(classify_ms, 1e-9) / 1e6 / 8000.0,
                                            "resident": ("infinity cache: the %d MB this pass streams fit the 256 MiB MALL and the launches are warm -- the fraction is of the HBM peak, the data does not come from HBM (see --S 104)" % (classify_bytes >> 20))
                                                        if classify_bytes < (256 << 20) else "hbm: %d MB per pass, beyond the 256 MiB Infinity Cache" % (classify_bytes >> 20),
                                            "note": "HIP events around the launch; ms = median of 7 warm launches, ms_best their minimum; the first call of a process also loads the code object (that was round 1's 1.3 ms)"},
+                       "solve_first_call": dict(first_call, note="the first solve of the process: layout upload + classification + the runtime growing the device's scratch memory for k_solve_team; the timed steps follow it"),
                        "abstraction": abstract_stats,
                        "frontend": {"mode": {0: "host", 1: "device", 2: "auto"}[E.set_frontend()], **{k: round(v, 3) for k, v in frontend_stats.items()}}},
             "roofline": {"bound": "hbm", "kernel": "k_solve_team", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

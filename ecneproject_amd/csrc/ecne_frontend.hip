@@ -5,6 +5,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -184,6 +185,9 @@ int parse_on_device(const uint8_t* file, size_t file_size, size_t cons_off, uint
     Tick tick("parse");
     tick("alloc scratch");
     const auto t_up = std::chrono::steady_clock::now();
+    // (measured, tools/fe_first_upload.py: touching the fresh mapping with the host workers first does not pay -- 27 -> 32 ms for the
+    //  first file of a process, 3 ms either way afterwards; the 90-150 ms a first upload shows in a process that has torch loaded is the
+    //  HIP runtime setting up its copy path -- a 64 MB torch copy costs the same 98 ms -- and goes away with any earlier copy)
     FE_TRY(hipMemsetAsync(W + (NW - 1), 0, 4 * 17, s));           // the last (partial) word and the pad
     if (head) FE_TRY(hipMemcpy(Wbuf, file, file_size, hipMemcpyHostToDevice));
     else FE_TRY(hipMemcpy(W, cons, len, hipMemcpyHostToDevice));
