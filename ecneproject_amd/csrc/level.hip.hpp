@@ -36,12 +36,20 @@ static_assert(4u * (ECNE_LV_MARKS + ECNE_LV_QM + ECNE_LV_CAND) <= ECNE_W2_BYTES,
 #define ECNE_LV_WIDE_AVAIL 192u   // more rows than this queued: a wide frontier, the round schedule's business (unless it asks for level rounds: wide_ok)
 #endif
 
+#ifndef ECNE_SOLO_RATIO
+#define ECNE_SOLO_RATIO 8       // (rounds.hip.hpp: solo drains when a narrow round committed less than 1 / ECNE_SOLO_RATIO of a well-filled window)
+#endif
 __device__ __forceinline__ bool level_rounds_on(const Job& J) { return J.lv_off == 0; }
-enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_REFILL = 4 };
+enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_REFILL = 4, LV_CUT = 5 };
 
 // Wavefront 0 of a single-workgroup job whose flags / in_queue tags are LDS-resident (chain_ok). head / tail: the queue cursors, in
 // and out. Returns why it stopped (LV_*); *n_rounds = rounds run.
-__device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, uint32_t& tail_io, uint32_t max_rounds, bool wide_ok, LaneCtr& C,
+// LDS = false: the master of a multi-workgroup job (flags / tags in device memory; level rounds in place of its fast wavefront rounds):
+// tags are read before anything is stored in a round (a prefix row's rank comes from the window in registers, not from its tag), a
+// round resolves at most 64 candidates, stores are fenced at the end of every round; cut_exit: a well-filled window whose prefix a
+// dependency cut to an eighth returns LV_CUT (chains side by side: the caller's solo drain rounds take those).
+template <bool LDS>
+__device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, uint32_t& tail_io, uint32_t max_rounds, bool wide_ok, bool cut_exit, LaneCtr& C,
                                               uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, unsigned long long* prof) {
     const uint32_t lane = (uint32_t)lane_id();
     auto uni = [](const void* p) -> uint64_t {
@@ -54,9 +62,15 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
     ECNE_GLOBAL uint32_t* const queue = (ECNE_GLOBAL uint32_t*)uni(J.queue);
     const uint32_t qmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.qmask);
     ECNE_GLOBAL uint8_t* const solved = (ECNE_GLOBAL uint8_t*)uni(J.solved);
-    uint8_t* const F = (uint8_t*)(ecne_dyn_lds + J.lds_flags_off);
-    uint16_t* const Q = (uint16_t*)(ecne_dyn_lds + J.lds_inq_off);
-    const bool flip_lds = J.lds_flip_off != 0xFFFFFFFFu;
+    uint8_t* const Fl = (uint8_t*)(ecne_dyn_lds + (LDS ? J.lds_flags_off : 0u));
+    uint16_t* const Ql = (uint16_t*)(ecne_dyn_lds + (LDS ? J.lds_inq_off : 0u));
+    ECNE_GLOBAL uint8_t* const Fg = LDS ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flags);
+    ECNE_GLOBAL uint16_t* const Qg = LDS ? (ECNE_GLOBAL uint16_t*)nullptr : (ECNE_GLOBAL uint16_t*)uni(J.inq);
+    auto ldF = [&](uint32_t v) -> uint8_t { if constexpr (LDS) return Fl[v]; else return Fg[v]; };
+    auto stF = [&](uint32_t v, uint8_t f) { if constexpr (LDS) Fl[v] = f; else Fg[v] = f; };
+    auto ldQ = [&](uint32_t r) -> uint32_t { if constexpr (LDS) return Ql[r]; else return Qg[r]; };
+    auto stQ = [&](uint32_t r, uint32_t x) { if constexpr (LDS) Ql[r] = (uint16_t)x; else Qg[r] = (uint16_t)x; };
+    const bool flip_lds = LDS && J.lds_flip_off != 0xFFFFFFFFu;
     uint8_t* const flipL = (uint8_t*)(ecne_dyn_lds + (flip_lds ? J.lds_flip_off : 0u));
     ECNE_GLOBAL uint8_t* const flipG = flip_lds ? (ECNE_GLOBAL uint8_t*)nullptr : (ECNE_GLOBAL uint8_t*)uni(J.flip3);
     uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + J.lds_w2_off);
@@ -152,7 +166,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         if (__ballot(biglin)) {
             const uint32_t h0 = w[1], h1 = w[2];
             watched = biglin && h0 < 0xFFFFFFFEu;
-            const uint8_t g0 = F[watched ? h0 : 0u], g1 = F[watched ? h1 : 0u];
+            const uint8_t g0 = ldF(watched ? h0 : 0u), g1 = ldF(watched ? h1 : 0u);
             bl_nop = (biglin && h0 == 0xFFFFFFFEu && f4) || (watched && long_watch_holds(g0, g1, lr4));
             watched = watched && bl_nop;
         }
@@ -174,7 +188,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                 const uint32_t e = 4 * g + t;
                 if (e >= 15) { fg[t] = 3; continue; }
                 const uint32_t on = (uint32_t)((int32_t)(e - nEw) >> 31);            // all ones iff e < nEw
-                fg[t] = F[w[1 + e] & on];
+                fg[t] = ldF(w[1 + e] & on);
             }
 #pragma unroll
             for (uint32_t t = 0; t < 4; ++t) {
@@ -211,7 +225,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         if (__ballot(oth)) {
             uint8_t fa = 3, fb = 3, fx = 3;
             const bool on_xy = oth && xy, on_x = oth && f2 && (shape & SH_R2);
-            const uint8_t a_ = F[on_xy ? k1 : 0u], b_ = F[on_xy ? k2 : 0u], x_ = F[on_x ? rx : 0u];
+            const uint8_t a_ = ldF(on_xy ? k1 : 0u), b_ = ldF(on_xy ? k2 : 0u), x_ = ldF(on_x ? rx : 0u);
             if (on_xy) { fa = a_; fb = b_; }
             if (on_x) fx = x_;
             FastIn fin;
@@ -311,17 +325,31 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                 cb = wave_excl_scan(ncand, &M);
             }
         }
+        if constexpr (!LDS) {
+            if (M > 64u) {                           // device-memory tags: one block of 64 candidates per round (all tags are read before any is stored)
+                const uint64_t m = __ballot(rank < c && cb + ncand > 64u);
+                if (m) {
+                    const uint32_t f0 = (uint32_t)(__ffsll((long long)m) - 1);
+                    if (f0 == 0) { why = LV_DECLINED; LVCOUNT(14); break; }
+                    if (f0 < c) c = f0;
+                }
+                if (rank >= c) ncand = 0;
+                cb = wave_excl_scan(ncand, &M);
+            }
+            // chains side by side: a well-filled window cut to an eighth by a dependency -- the caller's solo drain rounds take those
+            if (cut_exit && n >= 32u && ECNE_SOLO_RATIO * c <= n && c < cmax) { why = LV_CUT; break; }
+        }
         const bool in = mine && rank < c;
         const bool inl = in && live;
         // ---- 6: commit the prefix: every lane its own pop; the rows of the prefix carry 2 + rank while the pushes are resolved
         if (in) {
             c_pops++;
             c_nnz += bl_nop ? lenC : nE;
-            Q[row] = (uint16_t)(2u + rank);
+            if constexpr (LDS) stQ(row, 2u + rank);
         }
         if (inl) {
-            if (D.wa) F[D.wva] = D.wfa;
-            if (D.wb) F[D.wvb] = D.wfb;
+            if (D.wa) stF(D.wva, D.wfa);
+            if (D.wb) stF(D.wvb, D.wfb);
             if (D.a01) { st256(J.lb + 4ull * D.wva, fp::make(0)); st256(J.ub + 4ull * D.wva, fp::make(1)); }
             if (D.b01) { st256(J.lb + 4ull * D.wvb, fp::make(0)); st256(J.ub + 4ull * D.wvb, fp::make(1)); }
             if (D.r2) {        // make_values (:921-927)
@@ -338,6 +366,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         LVT(6);        // commit
         // ---- REQUEUE resolution in sequential order (rank, emission index, position in the variable's row list)
         uint32_t new_tail = tail;
+        bool requeued = false;
         if (M) {
             // the candidate list: rank << 24 | target row, in candidate order
             uint32_t base = cb;
@@ -366,8 +395,14 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                 const uint32_t jj = b0 + lane;
                 const uint32_t pk = cl[jj < M ? jj : 0u];
                 const uint32_t t = pk & 0xFFFFFFu, rk = pk >> 24;
-                const uint32_t st = Q[t];
-                const bool el = jj < M && (st == 0u || (st >= 2u && st - 2u <= rk));
+                const uint32_t st = ldQ(t);
+                bool el;
+                if constexpr (LDS) el = jj < M && (st == 0u || (st >= 2u && st - 2u <= rk));
+                else {
+                    uint32_t prk = 0xFFFFFFFFu;                       // the target's own rank if it is a row of the prefix (registers: the window's rows)
+                    for (uint32_t k = 0; k < c; ++k) { const uint32_t rowk = rdlane(row, k); if (rowk == t) prk = k; }
+                    el = jj < M && (prk != 0xFFFFFFFFu ? prk <= rk : st == 0u);
+                }
                 const uint64_t em = __ballot(el);
                 bool dup = false;
                 for (uint64_t mm = em & (em - 1) ? em : 0ull; mm; mm &= mm - 1) {      // (one eligible candidate: nothing to compare)
@@ -381,7 +416,10 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                     // into the mirror while it holds everything queued and has room (256 positions from the new head on), else to the ring
                     const uint32_t pos = new_tail + (uint32_t)__popcll(wmask & lanes_below());
                     if (mtop == new_tail && pos - (head + c) < ECNE_LV_QM) qm[pos & (ECNE_LV_QM - 1)] = t; else queue[pos & qmask] = t;
-                    Q[t] = 1;
+                    stQ(t, 1u);
+                }
+                if constexpr (!LDS) {                 // (one block) a row of the prefix that a winner re-queued keeps its tag
+                    for (uint64_t mm = wmask; mm; mm &= mm - 1) { const uint32_t tw = rdlane(t, (uint32_t)(__ffsll((long long)mm) - 1)); if (in && tw == row) requeued = true; }
                 }
                 {
                     const uint32_t nw = (uint32_t)__popcll(wmask);
@@ -391,7 +429,12 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
             }
         }
         // rows of the prefix that nobody re-queued are out of the queue now
-        if (in && Q[row] >= 2u) Q[row] = 0;
+        if constexpr (LDS) { if (in && ldQ(row) >= 2u) stQ(row, 0u); }
+        else {
+            if (in && !requeued) stQ(row, 0u);
+            wg_fence();                               // the round's stores have landed before the next round's loads
+            if ((rounds & 63u) == 63u) job_heartbeat(J);
+        }
         head += c;
         tail = new_tail;
         ++rounds;

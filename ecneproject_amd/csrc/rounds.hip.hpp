@@ -873,6 +873,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     // more rows to be worth its latency, whatever the queue length; bursts grow further while the chain lasts.
     const bool chain = chain_ok(J);
     const bool v2 = fast_wave_ok(J);
+    const bool lvg_ok = TEAM && J.nwg > 1 && v2 && level_rounds_on(J) && !drain_eager(J);      // ... and on the master of a team (device-memory state)
+    uint32_t lvg_hold = 0;
     const bool lv_ok = chain && v2 && level_rounds_on(J);      // level rounds: LDS-resident state, row records, the fast round's LDS block
     uint32_t lv_burst = 1;
     bool lv_wide = false, lv_chain = false;      // lv_chain: the burst that follows pops rows the level rounds declined (chain executor)
@@ -911,7 +913,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             lv_wide = false; if (wide) burst = 0;
             if (w == 0) {
                 uint32_t hd = q.head, tl = q.tail, nr = 0;
-                const uint32_t why = level_rounds(J, hd, tl, lv_max, wide, C, my_pops, my_nnz, &nr, &S.sd[0]);
+                const uint32_t why = level_rounds<true>(J, hd, tl, lv_max, wide, false, C, my_pops, my_nnz, &nr, &S.sd[0]);
                 if (lane == 0) { S.head = hd; S.tail = tl; S.nbig = why; S.bl_tmp[0] = nr; }
             }
             __syncthreads();
@@ -934,6 +936,38 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         }
         if (lv_ok && burst > 1 && !lv_chain) { lv_wide = true; continue; }      // what would be a burst of the chain executor: level rounds instead
         lv_chain = false;
+        // ---- the master of a multi-workgroup job: its narrow levels (the adders of ecdsa_like between two wide frontiers, a chained
+        // circuit too large for one workgroup's LDS) as level rounds on device-memory state, in place of the fast wavefront rounds
+        if constexpr (TEAM) {
+            if (lvg_ok && lvg_hold) --lvg_hold;
+            else if (lvg_ok && !burst && !solo && !declined_wide && avail <= ECNE_LV_WIDE_AVAIL) {
+                const bool cut_exit = solo_ok && solo_cool == 0;
+                if (w == 0) {
+                    uint32_t hd = q.head, tl = q.tail, nr = 0;
+                    const uint32_t why = level_rounds<false>(J, hd, tl, 1u << 20, false, cut_exit, C, my_pops, my_nnz, &nr, &S.sd[0]);
+                    if (lane == 0) { S.head = hd; S.tail = tl; S.nbig = why; S.bl_tmp[0] = nr; }
+                }
+                __syncthreads();
+                const uint32_t why = S.nbig, nr = S.bl_tmp[0], done = S.head - q.head;
+#if defined(ECNE_FINE_TICKS) && !defined(ECNE_LVPROF)
+                if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: in the fast rounds' slots
+#endif
+#ifdef ECNE_ROUNDLOG
+                if (tid == 0) printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, wall_clock64() - qt_last);
+#endif
+                pops_total += done;
+                hits[13] += nr;
+                q.head = S.head; q.tail = S.tail;
+                declined_run = 0;                                     // (the streak -- evidence for a wide independent frontier -- is the wide rounds' own: left alone)
+                if (solo_cool) solo_cool = solo_cool > nr ? solo_cool - nr : 0u;
+                __syncthreads();
+                if (why == LV_DECLINED) lvg_hold = 1;                 // the row at the head: one iteration of the policy below (fast round, general executor)
+                else if (why == LV_CUT) solo = true;                   // chains side by side: solo drain rounds
+                else if (why == LV_WIDE) lvg_hold = 0;
+                QTICK(6);
+                continue;
+            }
+        }
         if (burst) {
             // The last chunk round committed only a handful of rows (a dependency chain): pop the next
             // `burst` rows strictly sequentially on wave 0 (cheaper per pop than a round), then look again.
