@@ -6,6 +6,85 @@
 
 namespace ecne {
 
+// P3, phase 1 of a pass (:1357-1386): every row from f on that is not dead is evaluated against the current state -- eligibility, the
+// number k of non-unique variables of C, the hash of that set -- and counted into its group. A function of its own: called once per
+// pass from the kernel body, whose 256 live registers made every call of the per-row evaluation a spill / reload of dozens of them.
+__device__ __noinline__ void p3_phase1(const Job& J, uint32_t f, uint32_t gtid, uint32_t gstride, uint32_t my_rank, uint32_t ht_cap, uint32_t* s_htn,
+                           bool& my_any, bool& my_hot) {
+    const uint32_t nC = J.nC;
+    const int lane = lane_id(), w = wave_id();
+    for (uint32_t r4 = (f & ~3u) + 4u * gtid; r4 < nC; r4 += 4u * gstride) {
+        const uint32_t dead4 = *reinterpret_cast<const uint32_t*>(J.rdead + r4);   // padded to a multiple of 4
+        if (((dead4 | (dead4 >> 1)) & 0x01010101u) == 0x01010101u) continue;       // all four dead or long
+        uint32_t want = 0, k4[4];
+        uint64_t h4[4], g4[4];
+        for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r)
+            if (!((dead4 >> (8 * (r - r4))) & 3)) want |= 1u << (r - r4);      // dead: every variable unique already (p3k[r] stays 0); long: below
+        p3_eval4(J, r4, want, k4, h4, g4);       // the four rows' loads in flight together
+        for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r) {
+            if (!((want >> (r - r4)) & 1u)) continue;
+            uint32_t k = k4[r - r4]; uint64_t h = h4[r - r4], h2 = g4[r - r4];
+            if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
+            if (k == 0xFFFFFFFFu) k = 0;
+            J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+            if (k == 1) atomicMin(&J.ctr->p3_cand1, r);
+            else if (k >= 2) {
+                J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
+                bool created = false;
+                uint32_t s = ht_slot(J, h, h2, true, &created);
+                if (s != 0xFFFFFFFFu) {
+                    // p3_hot is raised only when this group could be complete with this member (k rows
+                    // counting the frozen ones): otherwise nobody has to look for trigger rows this pass
+                    const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
+                    if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
+                }
+                my_any = true;
+                if (created) {   // remembered, so that only the slots in use are wiped afterwards
+                    const uint32_t pos = atomicAdd(s_htn, 1u);
+                    if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                }
+            }
+        }
+    }
+    // long rows: one WAVEFRONT per row, lanes across its entries (one lane walking a 1 025-term row made
+    // its whole workgroup -- and with it every workgroup of the job -- wait ~70 us per sweep)
+    for (uint32_t li = my_rank * ECNE_NWAVES + (uint32_t)w; li < J.nLong; li += J.nwg * ECNE_NWAVES) {
+        const uint32_t r = J.long_list[li];
+        if (r < f || (J.rdead[r] & 1)) continue;               // (wave-uniform)
+        bool nuab = false;
+        for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nuab |= !(J.flags[J.colA[e]] & 1);
+        for (uint32_t e = J.rpB[r] + lane; e < J.rpB[r + 1]; e += 64) nuab |= !(J.flags[J.colB[e]] & 1);
+        uint32_t k = 0; uint64_t h = 0, h2 = 0;
+        for (uint32_t e = J.rpC[r] + lane; e < J.rpC[r + 1]; e += 64) {
+            const uint32_t v = J.colC[e];
+            if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
+        }
+        for (int d = 32; d >= 1; d >>= 1) { k += __shfl_xor(k, d, 64); h += __shfl_xor(h, d, 64); h2 += __shfl_xor(h2, d, 64); }
+        const bool inelig = __ballot(nuab) != 0;
+        h = mixA(h + k);
+        if (lane == 0) {
+            if (inelig) k = 0;
+            else if (k == 0) J.rdead[r] |= 1;
+            J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+            if (k == 1) atomicMin(&J.ctr->p3_cand1, r);
+            else if (k >= 2) {
+                J.p3h[r] = h; J.p3h2[r] = h2;
+                bool created = false;
+                uint32_t s = ht_slot(J, h, h2, true, &created);
+                if (s != 0xFFFFFFFFu) {
+                    const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
+                    if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
+                }
+                my_any = true;
+                if (created) {
+                    const uint32_t pos = atomicAdd(s_htn, 1u);
+                    if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- k_solve
 struct WgDesc { uint32_t job, rank; };
 
@@ -331,72 +410,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 // phase 1: evaluate rows >= f against the current state
                 // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
                 bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
-                for (uint32_t r4 = (f & ~3u) + 4u * gtid; r4 < nC; r4 += 4u * gstride) {
-                    const uint32_t dead4 = *reinterpret_cast<const uint32_t*>(J.rdead + r4);   // padded to a multiple of 4
-                    if (((dead4 | (dead4 >> 1)) & 0x01010101u) == 0x01010101u) continue;       // all four dead or long
-                    for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r) {
-                        if ((dead4 >> (8 * (r - r4))) & 3) continue;   // dead: every variable unique already (p3k[r] stays 0); long: below
-                        uint32_t k; uint64_t h, h2;
-                        p3_eval(J, r, k, h, h2);
-                        if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
-                        if (k == 0xFFFFFFFFu) k = 0;
-                        J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
-                        if (k == 1) atomicMin(&ctr->p3_cand1, r);
-                        else if (k >= 2) {
-                            J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
-                            bool created = false;
-                            uint32_t s = ht_slot(J, h, h2, true, &created);
-                            if (s != 0xFFFFFFFFu) {
-                                // p3_hot is raised only when this group could be complete with this member (k rows
-                                // counting the frozen ones): otherwise nobody has to look for trigger rows this pass
-                                const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
-                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
-                            }
-                            my_any = true;
-                            if (created) {   // remembered, so that only the slots in use are wiped afterwards
-                                const uint32_t pos = atomicAdd(&s_htn, 1u);
-                                if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
-                            }
-                        }
-                    }
-                }
-                // long rows: one WAVEFRONT per row, lanes across its entries (one lane walking a 1 025-term row made
-                // its whole workgroup -- and with it every workgroup of the job -- wait ~70 us per sweep)
-                for (uint32_t li = my_rank * ECNE_NWAVES + (uint32_t)w; li < J.nLong; li += J.nwg * ECNE_NWAVES) {
-                    const uint32_t r = J.long_list[li];
-                    if (r < f || (J.rdead[r] & 1)) continue;               // (wave-uniform)
-                    bool nuab = false;
-                    for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nuab |= !(J.flags[J.colA[e]] & 1);
-                    for (uint32_t e = J.rpB[r] + lane; e < J.rpB[r + 1]; e += 64) nuab |= !(J.flags[J.colB[e]] & 1);
-                    uint32_t k = 0; uint64_t h = 0, h2 = 0;
-                    for (uint32_t e = J.rpC[r] + lane; e < J.rpC[r + 1]; e += 64) {
-                        const uint32_t v = J.colC[e];
-                        if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
-                    }
-                    for (int d = 32; d >= 1; d >>= 1) { k += __shfl_xor(k, d, 64); h += __shfl_xor(h, d, 64); h2 += __shfl_xor(h2, d, 64); }
-                    const bool inelig = __ballot(nuab) != 0;
-                    h = mixA(h + k);
-                    if (lane == 0) {
-                        if (inelig) k = 0;
-                        else if (k == 0) J.rdead[r] |= 1;
-                        J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
-                        if (k == 1) atomicMin(&ctr->p3_cand1, r);
-                        else if (k >= 2) {
-                            J.p3h[r] = h; J.p3h2[r] = h2;
-                            bool created = false;
-                            uint32_t s = ht_slot(J, h, h2, true, &created);
-                            if (s != 0xFFFFFFFFu) {
-                                const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
-                                if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
-                            }
-                            my_any = true;
-                            if (created) {
-                                const uint32_t pos = atomicAdd(&s_htn, 1u);
-                                if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
-                            }
-                        }
-                    }
-                }
+                p3_phase1(J, f, gtid, gstride, my_rank, ht_cap, &s_htn, my_any, my_hot);
                 if (my_any) __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (my_hot) __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (job_barrier(J, &s_err)) { p3_err = true; break; }
