@@ -6,6 +6,185 @@
 
 namespace ecne {
 
+// P4 (:1425-1483) of one outer iteration, all workgroups of the job. A function of its own (like P3's phase 1): with the sweep's locals
+// in the kernel body the compiler kept them alive across the whole outer loop -- spilled at its top by every thread of the team.
+// Returns true when a job barrier saw an error (the caller leaves the outer loop).
+__device__ __noinline__ bool p4_phase(const Job& J, ChunkShared& s_chunk, QState& q, QState* s_q, uint32_t* s_scan, unsigned long long* hits,
+                                      unsigned long long& steps, unsigned long long outer, uint32_t my_rank, int* s_err) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const bool master = my_rank == 0;
+    const uint32_t gtid = my_rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;
+    Counters* const ctr = J.ctr;
+    // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups.
+    // p4_b[i] / p4_s[i]: B variable and slope variable (bit 31: no slope -> DivideError) of the i-th
+    // statically eligible row. A row tags b iff b is not unique, still untagged, and the row is the
+    // FIRST such row of b in index order (varmin[b]).
+    {
+        bool my_live = false;      // a candidate whose b is neither unique nor tagged: some row will tag in this pass
+        for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+            const uint32_t b = J.p4_b[i];
+            if (J.flags[b] & 1) continue;
+            if (J.p4_s[i] & 0x80000000u) { raise(J, K_EDIVZERO); continue; }
+            if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
+            if (J.abz[b] == -1) my_live = true;
+        }
+        if (my_live) __hip_atomic_store(&ctr->p4_live, (unsigned)outer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (stamped with the outer iteration: never reset)
+        if (job_barrier(J, s_err)) return true;
+        // No live candidate anywhere: no row can tag, nothing to re-queue -- the pass ends at this barrier (every workgroup reads the
+        // same word). The minima stay: as long as b is not unique its first candidate row is the same row.
+        if (ld_agent(&ctr->p4_live) == (unsigned)outer) {
+        uint32_t my_fired = 0;
+        for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+            const uint32_t b = J.p4_b[i];
+            if ((J.flags[b] & 1) || ld_agent(&J.varmin[b]) != i || J.abz[b] != -1) continue;
+            J.abz[b] = (int32_t)(J.p4_s[i] & 0x7FFFFFFFu);
+            J.flags[b] |= 2 | 16;    // is_known; bit 4: carries a group tag (abz != -1)
+            J.fired[i] = 1;          // by list position; cleared again when the events are collected
+            ++my_fired;
+        }
+        {   // one device atomic per workgroup (the first sweep of a large circuit tags tens of thousands of rows)
+            uint32_t wg_fired;
+            wg_exclusive_scan(my_fired, s_scan, &wg_fired);
+            if (tid == 0 && wg_fired) atomicAdd(&ctr->p4_nfired, wg_fired);
+        }
+        if (master && tid == 0) ctr->q_cmd[2] = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
+        if (job_barrier(J, s_err)) return true;
+        const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // stable until the master clears it at the end of P4
+        // forget the per-variable minima (all workgroups; the next use is a whole queue phase away)
+        for (uint32_t i = gtid; i < J.nP4; i += gstride) {
+            const uint32_t b = J.p4_b[i];
+            if (!(J.flags[b] & 1)) J.varmin[b] = 0xFFFFFFFFu;
+        }
+        bool p4_done = false, p4_err = false;
+        if (J.nwg > 1 && p4_fired >= 2048) {
+            // Many rows tagged (the first sweep of a large circuit tags every decoder output): the ordered
+            // REQUEUE of their B variables runs on ALL workgroups -- same steps as resolve_pushes, with
+            // contiguous blocks per thread and job-wide scans (nothing is being popped: a candidate may
+            // push iff its row is not queued; the lowest candidate index per row wins).
+            const uint32_t tail0 = ld_agent(&ctr->q_cmd[2]);
+            const uint32_t T = gstride;
+            int err = 0;
+            // 1. the event list: B variables of the fired rows, ascending
+            const uint32_t iper = (J.nP4 + T - 1) / T;
+            const uint32_t i0 = gtid * iper < J.nP4 ? gtid * iper : J.nP4, i1 = (gtid + 1) * iper < J.nP4 ? (gtid + 1) * iper : J.nP4;
+            uint32_t cnt = 0;
+            for (uint32_t i = i0; i < i1; ++i) cnt += J.fired[i];
+            uint32_t nev = 0;
+            uint32_t o = team_exclusive_scan(J, s_chunk, my_rank, cnt, 0, &nev, s_err, &err);
+            if (!err) {
+                for (uint32_t i = i0; i < i1; ++i)
+                    if (J.fired[i]) { J.events[o++] = J.p4_b[i]; J.fired[i] = 0; }
+                err = job_barrier(J, s_err);
+            }
+            // 2. candidates
+            uint32_t M = 0, e0 = 0, e1 = 0, cbase = 0;
+            if (!err) {
+                const uint32_t eper = (nev + T - 1) / T;
+                e0 = gtid * eper < nev ? gtid * eper : nev;
+                e1 = (gtid + 1) * eper < nev ? (gtid + 1) * eper : nev;
+                uint32_t deg = 0;
+                for (uint32_t e = e0; e < e1; ++e) { const uint32_t v = J.events[e]; deg += J.fo_ptr[v + 1] - J.fo_ptr[v]; }
+                cbase = team_exclusive_scan(J, s_chunk, my_rank, deg, 1, &M, s_err, &err);
+            }
+            if (!err && M <= J.candcap) {
+                if (tid == 0) s_chunk.nbigev = 0;
+                __syncthreads();
+                uint32_t j = cbase;
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const uint32_t v = J.events[e];
+                    expand_event(J, s_chunk, v, 0, j, false);
+                    j += J.fo_ptr[v + 1] - J.fo_ptr[v];
+                }
+                expand_big_events(J, s_chunk, false);
+                err = job_barrier(J, s_err);
+                // 3. winners, in candidate order
+                uint32_t W = 0;
+                if (!err) {
+                    const uint32_t cper = (M + T - 1) / T;
+                    const uint32_t j0 = gtid * cper < M ? gtid * cper : M, j1 = (gtid + 1) * cper < M ? (gtid + 1) * cper : M;
+                    uint32_t nwin = 0;
+                    for (uint32_t jj = j0; jj < j1; ++jj) {
+                        const uint32_t cw = J.cand[jj];
+                        const uint32_t t = cw & 0x7FFFFFFFu;
+                        const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == jj;
+                        J.cand[jj] = t | (win ? 0x80000000u : 0u);
+                        nwin += win;
+                    }
+                    const uint32_t wbase = team_exclusive_scan(J, s_chunk, my_rank, nwin, 0, &W, s_err, &err);
+                    if (!err) {
+                        uint32_t oq = tail0 + wbase;
+                        for (uint32_t jj = j0; jj < j1; ++jj) {
+                            const uint32_t cw = J.cand[jj];
+                            const uint32_t t = cw & 0x7FFFFFFFu;
+                            if (cw & 0x80000000u) { J.queue[oq & J.qmask] = t; J.inq[t] = 1; ++oq; }
+                            J.best[t] = 0xFFFFFFFFu;
+                        }
+                        err = job_barrier(J, s_err);
+                    }
+                }
+                if (!err) {
+                    p4_done = true;
+                    if (master) {
+                        if (w == 0 && lane == 0) { q.tail = tail0 + W; *s_q = q; ctr->p4_nfired = 0; }
+                        __syncthreads();
+                        q = *s_q;
+                        steps += nev;
+                        if (w == 0) hits[11] += nev;
+                    }
+                }
+            } else if (!err) {
+                // (a B variable with a huge fan-out) the master replays the events one by one
+                if (master) {
+                    if (w == 0) {
+                        for (uint32_t e = 0; e < nev; ++e) requeue(J, q, J.events[e]);
+                        if (lane == 0) { *s_q = q; ctr->p4_nfired = 0; }
+                    }
+                    __syncthreads();
+                    q = *s_q;
+                    steps += nev;
+                    if (w == 0) { hits[11] += nev; hits[15]++; }
+                }
+                err = job_barrier(J, s_err);
+                if (!err) p4_done = true;
+            }
+            if (err) p4_err = true;
+        }
+        if (p4_err) return true;
+        if (master && p4_fired != 0 && !p4_done) {
+            __syncthreads();
+            if (tid == 0) ctr->p4_nfired = 0;
+            // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
+            if (w == 0 && lane == 0) *s_q = q;
+            __syncthreads();
+            q = *s_q;
+            // ordered event list = fired rows ascending -> their b variable
+            uint32_t nev = 0;
+            for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
+                uint32_t i = base + tid;
+                uint32_t fl = (i < J.nP4) ? J.fired[i] : 0;
+                uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
+                if (fl) { J.events[nev + off] = J.p4_b[i]; J.fired[i] = 0; }
+                nev += total;
+            }
+            __syncthreads();
+            // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
+            {
+                uint32_t tl = q.tail;
+                unsigned long long p4_fb = 0;
+                for (uint32_t eb = 0; eb < nev; eb += 4096) {
+                    const uint32_t cnt = (nev - eb) < 4096u ? (nev - eb) : 4096u;
+                    tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &p4_fb);      // (every thread counts a fallback in a copy of its own)
+                }
+                q.tail = tl;
+                steps += nev;
+                if (w == 0) { hits[11] += nev; hits[15] += p4_fb; }
+            }
+        }
+        }      // (a live candidate)
+    }
+    return false;
+}
+
 // P3, phase 1 of a pass (:1357-1386): every row from f on that is not dead is evaluated against the current state -- eligibility, the
 // number k of non-unique variables of C, the hash of that set -- and counted into its group. A function of its own: called once per
 // pass from the kernel body, whose 256 live registers made every call of the per-row evaluation a spill / reload of dozens of them.
@@ -82,6 +261,372 @@ __device__ __noinline__ void p3_phase1(const Job& J, uint32_t f, uint32_t gtid, 
                 }
             }
         }
+    }
+}
+
+// P3 (:1357-1417) of one outer iteration, all workgroups of the job: evaluation passes (p3_phase1), the master's search for the
+// earliest firing row, the freeze / restart behind a firing, the wipe of the group table. A function of its own (register budget,
+// see p4_phase). Returns true when a job barrier saw an error.
+__device__ __noinline__ bool p3_phase(const Job& J, QState& q, unsigned long long* hits, unsigned long long& steps, uint32_t my_rank, uint32_t ht_cap,
+                                      uint32_t* s_htn, unsigned long long* s_steps, uint32_t* m_rows, uint32_t* m_vars, unsigned long long* tk, int* s_err) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const bool master = my_rank == 0;
+    const uint32_t nC = J.nC;
+    const uint32_t gtid = my_rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;
+    Counters* const ctr = J.ctr;
+    uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
+    bool p3_err = false;
+    for (;;) {
+        if (master && tid == 0) tk[6]++;
+        // (ids above num_variables) the lowest row from f on whose visit reads such a state enters as a row that "fires": the
+        // pass then examines what comes before it, and the master raises instead of firing it (phase 3)
+        if (J.oob && master && tid == 0) { const uint32_t ro = oob_p3_first(J, f); if (ro != 0xFFFFFFFFu) atomicMin(&ctr->p3_cand1, ro); }
+        // phase 1: evaluate rows >= f against the current state
+        // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
+        bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
+        p3_phase1(J, f, gtid, gstride, my_rank, ht_cap, s_htn, my_any, my_hot);
+        if (my_any) __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (my_hot) __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (job_barrier(J, s_err)) { p3_err = true; break; }
+        const bool any = ld_agent(&ctr->p3_any) != 0;
+        const bool hot = ld_agent(&ctr->p3_hot) != 0;
+        // Nobody reported a one-variable group or a group that could be complete: nothing can fire in this pass, and every
+        // workgroup sees that from the same two words (the master does not touch them on this path) -- the pass ends here,
+        // without the master's search and the second barrier (most passes of most circuits: 28 of 28 on ecdsa_like(26)).
+        if (!hot && ld_agent(&ctr->p3_cand1) == 0xFFFFFFFFu) {
+            if (master && tid == 0 && any) ctr->p3_any = 0;      // (read again a whole outer iteration from now)
+            break;
+        }
+        // phase 2: rows whose group could reach its size in this pass
+        if (hot) {
+            for (uint32_t r = f + gtid; r < nC; r += gstride) {
+                uint32_t k = J.p3k[r];
+                if (k < 2) continue;
+                uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                if (s == 0xFFFFFFFFu) continue;
+                uint32_t fr = ld_agent(&J.ht_frozen[s]);
+                if (fr < k && fr + ld_agent(&J.ht_new[s]) >= k) {
+                    uint32_t pos = atomicAdd(&ctr->p3_nhot, 1u);
+                    if (pos < J.hotcap) J.hot[pos] = r;
+                }
+            }
+            if (job_barrier(J, s_err)) { p3_err = true; break; }
+        }
+        // phase 3 (master, wave 0): find the earliest trigger row that passes the test
+        if (master) {
+            if (w == 0) {
+                uint32_t nhot = hot ? ld_agent(&ctr->p3_nhot) : 0;
+                if (nhot > J.hotcap) { raise(J, K_ECAPACITY); nhot = 0; }
+                uint32_t best = ld_agent(&ctr->p3_cand1);   // k == 1: first arrival of a one-variable group always fires
+                for (uint32_t a = 0; a < nhot; ++a) {
+                    if ((a & 63u) == 0) job_heartbeat(J);      // (up to hotcap candidates, examined by the master alone)
+                    uint32_t t = J.hot[a];
+                    if (t >= best) continue;
+                    uint32_t k = J.p3k[t];
+                    uint64_t h = J.p3h[t], h2 = J.p3h2[t];
+                    uint32_t s = ht_slot(J, h, h2, false);
+                    uint32_t fr = (s == 0xFFFFFFFFu) ? 0 : ld_agent(&J.ht_frozen[s]);
+                    // arrival number of t = frozen + fresh members with index <= t
+                    uint32_t part = 0;
+                    for (uint32_t b = lane; b < nhot; b += 64) {
+                        uint32_t o = J.hot[b];
+                        if (o <= t && J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k) part++;
+                    }
+                    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                    if (fr + part != k) continue;
+                    if (k > 10) { raise(J, K_EDETSIZE); break; }
+                    // collect the k member rows in arrival (index) order and the k variables ascending
+                    if (lane == 0) {
+                        uint32_t n = 0;
+                        if (fr) {   // frozen members: rows < f with the same key at their time
+                            for (uint32_t r = 0; r < f && n < k; ++r)
+                                if (J.p3k[r] == k && J.p3h[r] == h && J.p3h2[r] == h2) m_rows[n++] = r;
+                        }
+                        uint32_t last = 0; bool have = false;
+                        while (n < k) {
+                            uint32_t mn = 0xFFFFFFFFu;
+                            for (uint32_t b = 0; b < nhot; ++b) {
+                                uint32_t o = J.hot[b];
+                                if (J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k && (!have || o > last) && o < mn) mn = o;
+                            }
+                            if (mn == 0xFFFFFFFFu) break;
+                            m_rows[n++] = mn; last = mn; have = true;
+                        }
+                        uint32_t nv = 0;
+                        for (uint32_t e = J.rpC[t]; e < J.rpC[t + 1]; ++e) {
+                            uint32_t v = J.colC[e];
+                            if (!(J.flags[v] & 1)) {
+                                uint32_t pos = nv++;
+                                while (pos > 0 && m_vars[pos - 1] > v) { m_vars[pos] = m_vars[pos - 1]; --pos; }
+                                m_vars[pos] = v;
+                            }
+                        }
+                    }
+                    wg_fence();
+                    if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
+                }
+                if (J.oob && best != 0xFFFFFFFFu && best == oob_p3_first(J, f)) raise(J, K_EBOUNDS);      // BoundsError at that row's visit (:1365)
+                if (lane == 0) ctr->p3_fire = best;
+            }
+        }
+        if (job_barrier(J, s_err)) { p3_err = true; break; }
+        // ready for the next pass -- only now: the other workgroups decide from p3_hot / p3_cand1 whether this pass goes on
+        // (above) at their own pace after the first barrier; all of them have done so once they are here
+        if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; }
+        const uint32_t fire = ld_agent(&ctr->p3_fire);
+        if (fire == 0xFFFFFFFFu) break;
+        const uint32_t upto = fire + 1;
+        // phase 4: freeze rows [f, upto): their arrivals are now history; forget fresh counts
+        if (any) {
+            for (uint32_t r = f + gtid; r < nC; r += gstride) {
+                uint32_t k = J.p3k[r];
+                if (k < 2) continue;
+                uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+                if (s == 0xFFFFFFFFu) continue;
+                if (r < upto) atomicAdd(&J.ht_frozen[s], 1u);
+                J.ht_new[s] = 0;
+            }
+        }
+        // apply the firing (master): the group's variables, ascending, become unique (:1403-1414)
+        if (master) {
+            if (w == 0) {
+                uint32_t k = J.p3k[fire];
+                steps += k; hits[10]++;
+                uint32_t lastv = 0;
+                for (uint32_t n = 0; n < k; ++n) {
+                    uint32_t mn = 0xFFFFFFFFu;
+                    for (uint32_t e = J.rpC[fire] + lane; e < J.rpC[fire + 1]; e += 64) {
+                        uint32_t v = J.colC[e];
+                        if (!(J.flags[v] & 1) && v > lastv && v < mn) mn = v;
+                    }
+                    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
+                    if (mn == 0xFFFFFFFFu) break;
+                    lastv = mn;
+                    J.events[n] = mn;
+                }
+                wg_fence();
+                for (uint32_t n = 0; n < k; ++n) {
+                    uint32_t v = J.events[n];
+                    mark_unique(J, v);
+                    requeue(J, q, v);
+                }
+                if (lane == 0) *s_steps = steps;
+            }
+            __syncthreads();
+            steps = *s_steps;
+        }
+        if (job_barrier(J, s_err)) { p3_err = true; break; }   // the firing's writes reach the helpers
+        f = fire + 1;
+    }
+    if (p3_err) return true;
+    // leave the table clean for the next outer iteration: every workgroup wipes the slots it created
+    __syncthreads();
+    {
+        const uint32_t nmine = *s_htn < ht_cap ? *s_htn : ht_cap;
+        for (uint32_t i = tid; i < nmine; i += ECNE_WG) {
+            const uint32_t s = J.ht_list[(size_t)my_rank * ht_cap + i];
+            J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) *s_htn = 0;
+    }
+    return false;
+}
+
+// Setup (:593-704), all workgroups of the job: initial per-variable state, the known variables, the initial queue (rows with at most
+// one variable outside known_variables, ascending), the L2 warm-up of a single-workgroup job. A function of its own (register budget).
+__device__ __noinline__ void setup_phase(const Job& J, ChunkShared& s_chunk, QState& q, uint32_t my_rank, uint32_t* s_scan, uint32_t* s_u32, int* s_err) {
+    const int tid = threadIdx.x;
+    const bool master = my_rank == 0;
+    const uint32_t nC = J.nC, nV = J.nV;
+    const uint32_t gtid = my_rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;
+    Counters* const ctr = J.ctr;
+    for (uint32_t i = tid; i < ECNE_BIGTAB; i += ECNE_WG) s_chunk.bt[i] = 0xFFFFFFFFu;
+    for (uint32_t v = gtid; v <= nV; v += gstride) {
+        J.flags[v] = 0;
+        J.abz[v] = -1;
+        J.nvalues[v] = 0;
+        st256(J.lb + 4ull * v, fp::make(0));
+        st256(J.ub + 4ull * v, fp::pminus1());
+        J.varmin[v] = 0xFFFFFFFFu;
+        J.wmarkU[v] = 0xFFFFFFFFu;
+        J.wmarkB[v] = 0xFFFFFFFFu;
+    }
+    if (J.nwg > 1 && J.drain)      // epoch 0 = never marked (drain.hip.hpp)
+        for (int p = 0; p < 6; ++p)
+            for (uint32_t v = gtid; v <= nV; v += gstride) J.dmk[p][v] = 0;
+    if (tid == 0) s_chunk.depoch = 0;
+    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
+    // the watched pairs of the long rows (a cache in words 1, 2 of their otherwise unused record lines, fastrow.hip.hpp) start empty
+    if (J.rec != nullptr)
+        for (uint32_t r = gtid; r < nC; r += gstride)
+            if ((J.rec[16ull * r] >> 24) == 0) const_cast<uint32_t*>(J.rec)[16ull * r + 1] = 0xFFFFFFFFu;
+    for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
+    for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
+    if (master && tid == 0) { ctr->err_key = ~0ull; ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; ctr->d_cut[0] = ctr->d_cut[1] = 0xFFFFFFFFu; ctr->d_pend2[0] = ctr->d_pend2[1] = 0; ctr->d_flag[0] = ctr->d_flag[1] = 0; }
+    job_barrier(J, s_err);
+    for (uint32_t i = gtid; i < J.nLong; i += gstride) J.rdead[J.long_list[i]] = 2;   // bit 1: a long row (P3 evaluates it on a wavefront)
+    for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
+        uint32_t v = J.knowns[i];
+        J.flags[v] = 3;
+        if (v == 1) { J.nvalues[1] = 1; st256(J.values + 8ull, fp::make(1)); }
+    }
+    job_barrier(J, s_err);
+    // initial queue: rows with at most one variable outside known_variables, ascending (:621-627).
+    // Every workgroup owns a contiguous block of rows: count, job-wide scan of the block totals, write.
+    q.head = 0; q.tail = 0; q.evout = nullptr; q.nev = 0; q.emit = 0;
+    {
+        const uint32_t per = (nC + J.nwg - 1) / J.nwg;
+        const uint32_t blk0 = my_rank * per < nC ? my_rank * per : nC;
+        const uint32_t blk1 = (my_rank + 1) * per < nC ? (my_rank + 1) * per : nC;
+        auto wants = [&](uint32_t r) -> uint32_t {
+            uint32_t first = 0, cnt = 0;
+            const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
+            const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
+            for (int p = 0; p < 3 && cnt < 2; ++p)
+                for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
+                    uint32_t v = cl[p][e];
+                    if (!(J.flags[v] & 1)) {
+                        if (cnt == 0) { first = v; cnt = 1; }
+                        else if (v != first) { cnt = 2; break; }
+                    }
+                }
+            return cnt <= 1;
+        };
+        uint32_t mine = 0;
+        for (uint32_t r = blk0 + tid; r < blk1; r += ECNE_WG) mine += wants(r);
+        uint32_t total_pushes = 0;
+        int scan_err = 0;
+        uint32_t base = team_exclusive_scan_any(J, s_chunk, my_rank, mine, &total_pushes, s_err, &scan_err);
+        // base = pushes of all lower workgroups + of lower threads of mine; but rows are interleaved
+        // across my threads, so redo my block in row order with workgroup scans from my block's base
+        uint32_t wg_base = base;
+        {   // subtract my own lower threads' share: block base = value at thread 0
+            if (tid == 0) s_u32[0] = base;
+            __syncthreads();
+            wg_base = s_u32[0];
+            __syncthreads();
+        }
+        uint32_t off_run = wg_base;
+        for (uint32_t b = blk0; b < blk1; b += ECNE_WG) {
+            const uint32_t r = b + tid;
+            const uint32_t push = (r < blk1) ? wants(r) : 0u;
+            uint32_t tot;
+            const uint32_t off = wg_exclusive_scan(push, s_scan, &tot);
+            if (push) { J.queue[(off_run + off) & J.qmask] = r; J.inq[r] = 1; }
+            off_run += tot;
+        }
+        q.tail = total_pushes;
+        (void)scan_err;
+    }
+    // ---------------- L2 warm-up. A workgroup meets most rows of a small system exactly once per visit and, after
+    // a fresh upload or on another XCD than last time, every first touch of a row's descriptor, entries and
+    // fan-out lists would be a round trip beyond this XCD's L2 in the middle of a dependency chain. One
+    // streaming pass over the static arrays (a few MB at most, all 512 lanes) makes them L2 hits.
+    if (J.nwg == 1 && J.warm_bytes) {
+        const uint4* const w0 = (const uint4*)J.rpA;          // the static arrays are one contiguous carve, rpA first
+        const uint32_t nq = J.warm_bytes / 16;
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < nq; i += ECNE_WG) { const uint4 x = w0[i]; acc ^= x.x ^ x.y ^ x.z ^ x.w; }
+        if (acc == 0x9E3779B9u && nq == 0xFFFFFFFFu) s_u32[1] = acc;   // (keeps the loads alive)
+    }
+}
+
+// P1 (:718-747) and P2 (:750-800): wavefront 0 of the master workgroup, in the reference's order (a function of its own: register budget)
+__device__ __noinline__ void p12_phase(const Job& J, QState& q, unsigned long long* hits, unsigned long long& steps) {
+    const int lane = lane_id();
+    const uint32_t nC = J.nC;
+    // P1 (:718-747). 64 specials are tested at a time, one per lane; the ones whose inputs are all
+    // unique fire in index order, and after every firing the later lanes look again (its outputs
+    // may complete their inputs), which is what the one-by-one sweep would have seen.
+    if (J.oob) oob_p1(J, q, hits, steps);      // (ids above num_variables: one special at a time, oob.hip.hpp)
+    else
+    for (uint32_t base = 0; base < J.nSp; base += 64) {
+        const uint32_t i = base + lane;
+        int from = 0;
+        job_heartbeat(J);
+        for (;;) {
+            bool can = i < J.nSp && lane >= from && !J.fired[nC + i];   // [nC..) = special_solved
+            if (can) {
+                // (four inputs per trip, ids first, then their flag bytes: two round trips per four inputs instead of per input)
+                const uint32_t e1 = J.sp_in_ptr[i + 1];
+                for (uint32_t e = J.sp_in_ptr[i]; e < e1 && can; e += 4) {
+                    uint32_t vv[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) vv[k] = e + k < e1 ? J.sp_in[e + k] : 1u;       // (padding: the constant wire, always unique)
+                    uint32_t all = 1;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) all &= J.flags[vv[k]];
+                    can = (all & 1) != 0;
+                }
+            }
+            const uint64_t m = __ballot(can);
+            if (!m) break;
+            const int src = __ffsll((long long)m) - 1;
+            const uint32_t is = base + (uint32_t)src;
+            if (lane == 0) J.fired[nC + is] = 1;
+            steps++; hits[8]++;
+            p1_fire_outputs(J, q, is);
+            from = src + 1;
+        }
+    }
+    // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair, from the two index lists
+    if (J.oob) { if (!J.ctr->error) oob_p2(J, q, hits); }
+    else
+    for (uint32_t a = 0; a < J.nK1; ++a) {
+        const uint32_t i = J.k1_list[a];
+        for (uint32_t bj = 0; bj < J.nK2; ++bj) {
+            const uint32_t j = J.k2_list[bj];
+            if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
+            uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
+            if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
+            hits[9]++;
+            for (uint32_t t = 0; t < 3; ++t) {                                   // constraint_j[2][1:3]
+                uint32_t v = J.sp_in[J.sp_in_ptr[j] + t];
+                if (J.flags[v] & 1) continue;
+                mark_unique(J, v);
+                requeue(J, q, v);
+            }
+        }
+        if (J.ctr->error) break;
+    }
+}
+
+// P5 isZero pairs (:1492-1550), ascending over the static candidates: the master workgroup (a function of its own: register budget)
+__device__ __noinline__ void p5_phase(const Job& J, QState& q, unsigned long long* hits, unsigned long long& steps, unsigned long long* s_steps, uint32_t my_rank) {
+    const int lane = lane_id(), w = wave_id();
+    const bool master = my_rank == 0;
+    if (master) {
+        if (w == 0) {
+            // 64 candidates are tested at a time, one per lane; the ones that pass fire in index order,
+            // and after every firing the later lanes look again (its newly unique y may complete their A)
+            if (J.oob) oob_p5(J, q, hits, steps);
+            else
+            for (uint32_t base = 0; base < J.nP5; base += 64) {
+                const uint32_t i = base + lane;
+                const uint32_t r = i < J.nP5 ? J.p5_rows[i] : 0, y = i < J.nP5 ? J.p5_y[i] : 0;
+                int from = 0;            // lanes below `from` are done
+                if ((base & 4095u) == 0) job_heartbeat(J);
+                for (;;) {
+                    bool can = i < J.nP5 && lane >= from && !(J.flags[y] & 1);
+                    if (can)
+                        for (uint32_t e = J.rpA[r]; e < J.rpA[r + 1] && can; ++e) can = (J.flags[J.colA[e]] & 1) != 0;
+                    const uint64_t m = __ballot(can);
+                    if (!m) break;
+                    const int src = __ffsll((long long)m) - 1;
+                    const uint32_t rs = __shfl(r, src, 64), ys = __shfl(y, src, 64);
+                    mark_unique(J, ys);
+                    if (lane == 0) { J.solved[rs] = 1; J.solved[rs + 1] = 1; }
+                    wg_fence();
+                    steps++; hits[12]++;
+                    requeue(J, q, ys);
+                    from = src + 1;
+                }
+            }
+            if (lane == 0) *s_steps = steps;
+        }
+        __syncthreads();
+        steps = *s_steps;
     }
 }
 
@@ -164,97 +709,9 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     if (tid == 0) { for (int i = 0; i < 8; ++i) tk[i] = 0; t_last = wall_clock64(); }
 #define ECNE_TICK(slot) do { if (master && tid == 0) { const unsigned long long t_now = wall_clock64(); tk[slot] += t_now - t_last; t_last = t_now; } } while (0)
 
-    // ---------------- setup (:593-704), all workgroups
-    for (uint32_t i = tid; i < ECNE_BIGTAB; i += ECNE_WG) s_chunk.bt[i] = 0xFFFFFFFFu;
-    for (uint32_t v = gtid; v <= nV; v += gstride) {
-        J.flags[v] = 0;
-        J.abz[v] = -1;
-        J.nvalues[v] = 0;
-        st256(J.lb + 4ull * v, fp::make(0));
-        st256(J.ub + 4ull * v, fp::pminus1());
-        J.varmin[v] = 0xFFFFFFFFu;
-        J.wmarkU[v] = 0xFFFFFFFFu;
-        J.wmarkB[v] = 0xFFFFFFFFu;
-    }
-    if (J.nwg > 1 && J.drain)      // epoch 0 = never marked (drain.hip.hpp)
-        for (int p = 0; p < 6; ++p)
-            for (uint32_t v = gtid; v <= nV; v += gstride) J.dmk[p][v] = 0;
-    if (tid == 0) s_chunk.depoch = 0;
-    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
-    // the watched pairs of the long rows (a cache in words 1, 2 of their otherwise unused record lines, fastrow.hip.hpp) start empty
-    if (J.rec != nullptr)
-        for (uint32_t r = gtid; r < nC; r += gstride)
-            if ((J.rec[16ull * r] >> 24) == 0) const_cast<uint32_t*>(J.rec)[16ull * r + 1] = 0xFFFFFFFFu;
-    for (uint32_t r = gtid; r < nC + J.nSp; r += gstride) J.fired[r] = 0;   // [nC..) = special_solved
-    for (uint32_t s = gtid; s <= J.htmask; s += gstride) { J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0; }
-    if (master && tid == 0) { ctr->err_key = ~0ull; ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; ctr->p3_fire = 0xFFFFFFFFu; ctr->q_cut = 0xFFFFFFFFu; ctr->d_cut[0] = ctr->d_cut[1] = 0xFFFFFFFFu; ctr->d_pend2[0] = ctr->d_pend2[1] = 0; ctr->d_flag[0] = ctr->d_flag[1] = 0; }
-    job_barrier(J, &s_err);
-    for (uint32_t i = gtid; i < J.nLong; i += gstride) J.rdead[J.long_list[i]] = 2;   // bit 1: a long row (P3 evaluates it on a wavefront)
-    for (uint32_t i = gtid; i < J.nKnown; i += gstride) {
-        uint32_t v = J.knowns[i];
-        J.flags[v] = 3;
-        if (v == 1) { J.nvalues[1] = 1; st256(J.values + 8ull, fp::make(1)); }
-    }
-    job_barrier(J, &s_err);
-    // initial queue: rows with at most one variable outside known_variables, ascending (:621-627).
-    // Every workgroup owns a contiguous block of rows: count, job-wide scan of the block totals, write.
+    // ---------------- setup (:593-704), all workgroups (setup_phase)
     QState q;
-    q.head = 0; q.tail = 0; q.evout = nullptr; q.nev = 0; q.emit = 0;
-    {
-        const uint32_t per = (nC + J.nwg - 1) / J.nwg;
-        const uint32_t blk0 = my_rank * per < nC ? my_rank * per : nC;
-        const uint32_t blk1 = (my_rank + 1) * per < nC ? (my_rank + 1) * per : nC;
-        auto wants = [&](uint32_t r) -> uint32_t {
-            uint32_t first = 0, cnt = 0;
-            const uint32_t* rp[3] = {J.rpA, J.rpB, J.rpC};
-            const uint32_t* cl[3] = {J.colA, J.colB, J.colC};
-            for (int p = 0; p < 3 && cnt < 2; ++p)
-                for (uint32_t e = rp[p][r]; e < rp[p][r + 1]; ++e) {
-                    uint32_t v = cl[p][e];
-                    if (!(J.flags[v] & 1)) {
-                        if (cnt == 0) { first = v; cnt = 1; }
-                        else if (v != first) { cnt = 2; break; }
-                    }
-                }
-            return cnt <= 1;
-        };
-        uint32_t mine = 0;
-        for (uint32_t r = blk0 + tid; r < blk1; r += ECNE_WG) mine += wants(r);
-        uint32_t total_pushes = 0;
-        int scan_err = 0;
-        uint32_t base = team_exclusive_scan_any(J, s_chunk, my_rank, mine, &total_pushes, &s_err, &scan_err);
-        // base = pushes of all lower workgroups + of lower threads of mine; but rows are interleaved
-        // across my threads, so redo my block in row order with workgroup scans from my block's base
-        uint32_t wg_base = base;
-        {   // subtract my own lower threads' share: block base = value at thread 0
-            if (tid == 0) s_u32[0] = base;
-            __syncthreads();
-            wg_base = s_u32[0];
-            __syncthreads();
-        }
-        uint32_t off_run = wg_base;
-        for (uint32_t b = blk0; b < blk1; b += ECNE_WG) {
-            const uint32_t r = b + tid;
-            const uint32_t push = (r < blk1) ? wants(r) : 0u;
-            uint32_t tot;
-            const uint32_t off = wg_exclusive_scan(push, s_scan, &tot);
-            if (push) { J.queue[(off_run + off) & J.qmask] = r; J.inq[r] = 1; }
-            off_run += tot;
-        }
-        q.tail = total_pushes;
-        (void)scan_err;
-    }
-    // ---------------- L2 warm-up. A workgroup meets most rows of a small system exactly once per visit and, after
-    // a fresh upload or on another XCD than last time, every first touch of a row's descriptor, entries and
-    // fan-out lists would be a round trip beyond this XCD's L2 in the middle of a dependency chain. One
-    // streaming pass over the static arrays (a few MB at most, all 512 lanes) makes them L2 hits.
-    if (J.nwg == 1 && J.warm_bytes) {
-        const uint4* const w0 = (const uint4*)J.rpA;          // the static arrays are one contiguous carve, rpA first
-        const uint32_t nq = J.warm_bytes / 16;
-        uint32_t acc = 0;
-        for (uint32_t i = tid; i < nq; i += ECNE_WG) { const uint4 x = w0[i]; acc ^= x.x ^ x.y ^ x.z ^ x.w; }
-        if (acc == 0x9E3779B9u && nq == 0xFFFFFFFFu) s_u32[1] = acc;   // (keeps the loads alive)
-    }
+    setup_phase(J, s_chunk, q, my_rank, s_scan, s_u32, &s_err);
     ECNE_TICK(0);
     unsigned long long steps = 0, prev_steps = ~0ull, outer = 0;
     // statistics only the master's wavefront 0 keeps (its lanes in lockstep: they read the same word and write the same sum): in LDS,
@@ -276,60 +733,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         // ================= P1, P2 and the queue: master only, in the reference's order
         if (master) {
             if (w == 0) {
-                // P1 (:718-747). 64 specials are tested at a time, one per lane; the ones whose inputs are all
-                // unique fire in index order, and after every firing the later lanes look again (its outputs
-                // may complete their inputs), which is what the one-by-one sweep would have seen.
-                if (J.oob) oob_p1(J, q, hits, steps);      // (ids above num_variables: one special at a time, oob.hip.hpp)
-                else
-                for (uint32_t base = 0; base < J.nSp; base += 64) {
-                    const uint32_t i = base + lane;
-                    int from = 0;
-                    job_heartbeat(J);
-                    for (;;) {
-                        bool can = i < J.nSp && lane >= from && !J.fired[nC + i];   // [nC..) = special_solved
-                        if (can) {
-                            // (four inputs per trip, ids first, then their flag bytes: two round trips per four inputs instead of per input)
-                            const uint32_t e1 = J.sp_in_ptr[i + 1];
-                            for (uint32_t e = J.sp_in_ptr[i]; e < e1 && can; e += 4) {
-                                uint32_t vv[4];
-#pragma unroll
-                                for (uint32_t k = 0; k < 4; ++k) vv[k] = e + k < e1 ? J.sp_in[e + k] : 1u;       // (padding: the constant wire, always unique)
-                                uint32_t all = 1;
-#pragma unroll
-                                for (uint32_t k = 0; k < 4; ++k) all &= J.flags[vv[k]];
-                                can = (all & 1) != 0;
-                            }
-                        }
-                        const uint64_t m = __ballot(can);
-                        if (!m) break;
-                        const int src = __ffsll((long long)m) - 1;
-                        const uint32_t is = base + (uint32_t)src;
-                        if (lane == 0) J.fired[nC + is] = 1;
-                        steps++; hits[8]++;
-                        p1_fire_outputs(J, q, is);
-                        from = src + 1;
-                    }
-                }
-                // P2 (:750-800): every (BigMultModP i, BigLessThan j) pair, from the two index lists
-                if (J.oob) { if (!J.ctr->error) oob_p2(J, q, hits); }
-                else
-                for (uint32_t a = 0; a < J.nK1; ++a) {
-                    const uint32_t i = J.k1_list[a];
-                    for (uint32_t bj = 0; bj < J.nK2; ++bj) {
-                        const uint32_t j = J.k2_list[bj];
-                        if (!J.secp_solve) { raise(J, K_EUNDEF_DSU); break; }                 // `dsu` undefined (:762)
-                        uint32_t ni = J.sp_in_ptr[i + 1] - J.sp_in_ptr[i], nj = J.sp_in_ptr[j + 1] - J.sp_in_ptr[j];
-                        if (ni < 9 || nj < 6) { raise(J, K_EBOUNDS); break; }                // [k+3], [k] for k = 1..6
-                        hits[9]++;
-                        for (uint32_t t = 0; t < 3; ++t) {                                   // constraint_j[2][1:3]
-                            uint32_t v = J.sp_in[J.sp_in_ptr[j] + t];
-                            if (J.flags[v] & 1) continue;
-                            mark_unique(J, v);
-                            requeue(J, q, v);
-                        }
-                    }
-                    if (J.ctr->error) break;
-                }
+                p12_phase(J, q, hits, steps);
                 if (J.queue_mode == 2 && chain_ok(J)) {
 #ifdef ECNE_POPPROF
                     if (tid == 0) { pop_prof().last = wall_clock64(); }
@@ -398,165 +802,8 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         else if (job_barrier(J, &s_err)) break;      // (sequential modes: the helpers have been waiting here for the master's queue phase)
         ECNE_TICK(1);
 
-        // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups
-        {
-            uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
-            bool p3_err = false;
-            for (;;) {
-                if (master && tid == 0) tk[6]++;
-                // (ids above num_variables) the lowest row from f on whose visit reads such a state enters as a row that "fires": the
-                // pass then examines what comes before it, and the master raises instead of firing it (phase 3)
-                if (J.oob && master && tid == 0) { const uint32_t ro = oob_p3_first(J, f); if (ro != 0xFFFFFFFFu) atomicMin(&ctr->p3_cand1, ro); }
-                // phase 1: evaluate rows >= f against the current state
-                // (the dead-row bytes are read four rows at a time: most of a large system is dead or idle)
-                bool my_any = false, my_hot = false;   // (one store per thread at the end, not one per row, to the two flag words)
-                p3_phase1(J, f, gtid, gstride, my_rank, ht_cap, &s_htn, my_any, my_hot);
-                if (my_any) __hip_atomic_store(&ctr->p3_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (my_hot) __hip_atomic_store(&ctr->p3_hot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (job_barrier(J, &s_err)) { p3_err = true; break; }
-                const bool any = ld_agent(&ctr->p3_any) != 0;
-                const bool hot = ld_agent(&ctr->p3_hot) != 0;
-                // Nobody reported a one-variable group or a group that could be complete: nothing can fire in this pass, and every
-                // workgroup sees that from the same two words (the master does not touch them on this path) -- the pass ends here,
-                // without the master's search and the second barrier (most passes of most circuits: 28 of 28 on ecdsa_like(26)).
-                if (!hot && ld_agent(&ctr->p3_cand1) == 0xFFFFFFFFu) {
-                    if (master && tid == 0 && any) ctr->p3_any = 0;      // (read again a whole outer iteration from now)
-                    break;
-                }
-                // phase 2: rows whose group could reach its size in this pass
-                if (hot) {
-                    for (uint32_t r = f + gtid; r < nC; r += gstride) {
-                        uint32_t k = J.p3k[r];
-                        if (k < 2) continue;
-                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
-                        if (s == 0xFFFFFFFFu) continue;
-                        uint32_t fr = ld_agent(&J.ht_frozen[s]);
-                        if (fr < k && fr + ld_agent(&J.ht_new[s]) >= k) {
-                            uint32_t pos = atomicAdd(&ctr->p3_nhot, 1u);
-                            if (pos < J.hotcap) J.hot[pos] = r;
-                        }
-                    }
-                    if (job_barrier(J, &s_err)) { p3_err = true; break; }
-                }
-                // phase 3 (master, wave 0): find the earliest trigger row that passes the test
-                if (master) {
-                    if (w == 0) {
-                        uint32_t nhot = hot ? ld_agent(&ctr->p3_nhot) : 0;
-                        if (nhot > J.hotcap) { raise(J, K_ECAPACITY); nhot = 0; }
-                        uint32_t best = ld_agent(&ctr->p3_cand1);   // k == 1: first arrival of a one-variable group always fires
-                        for (uint32_t a = 0; a < nhot; ++a) {
-                            if ((a & 63u) == 0) job_heartbeat(J);      // (up to hotcap candidates, examined by the master alone)
-                            uint32_t t = J.hot[a];
-                            if (t >= best) continue;
-                            uint32_t k = J.p3k[t];
-                            uint64_t h = J.p3h[t], h2 = J.p3h2[t];
-                            uint32_t s = ht_slot(J, h, h2, false);
-                            uint32_t fr = (s == 0xFFFFFFFFu) ? 0 : ld_agent(&J.ht_frozen[s]);
-                            // arrival number of t = frozen + fresh members with index <= t
-                            uint32_t part = 0;
-                            for (uint32_t b = lane; b < nhot; b += 64) {
-                                uint32_t o = J.hot[b];
-                                if (o <= t && J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k) part++;
-                            }
-                            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-                            if (fr + part != k) continue;
-                            if (k > 10) { raise(J, K_EDETSIZE); break; }
-                            // collect the k member rows in arrival (index) order and the k variables ascending
-                            if (lane == 0) {
-                                uint32_t n = 0;
-                                if (fr) {   // frozen members: rows < f with the same key at their time
-                                    for (uint32_t r = 0; r < f && n < k; ++r)
-                                        if (J.p3k[r] == k && J.p3h[r] == h && J.p3h2[r] == h2) m_rows[n++] = r;
-                                }
-                                uint32_t last = 0; bool have = false;
-                                while (n < k) {
-                                    uint32_t mn = 0xFFFFFFFFu;
-                                    for (uint32_t b = 0; b < nhot; ++b) {
-                                        uint32_t o = J.hot[b];
-                                        if (J.p3h[o] == h && J.p3h2[o] == h2 && J.p3k[o] == k && (!have || o > last) && o < mn) mn = o;
-                                    }
-                                    if (mn == 0xFFFFFFFFu) break;
-                                    m_rows[n++] = mn; last = mn; have = true;
-                                }
-                                uint32_t nv = 0;
-                                for (uint32_t e = J.rpC[t]; e < J.rpC[t + 1]; ++e) {
-                                    uint32_t v = J.colC[e];
-                                    if (!(J.flags[v] & 1)) {
-                                        uint32_t pos = nv++;
-                                        while (pos > 0 && m_vars[pos - 1] > v) { m_vars[pos] = m_vars[pos - 1]; --pos; }
-                                        m_vars[pos] = v;
-                                    }
-                                }
-                            }
-                            wg_fence();
-                            if (p3_odd_perm_sum_nonzero(J, m_rows, m_vars, k)) best = t;
-                        }
-                        if (J.oob && best != 0xFFFFFFFFu && best == oob_p3_first(J, f)) raise(J, K_EBOUNDS);      // BoundsError at that row's visit (:1365)
-                        if (lane == 0) ctr->p3_fire = best;
-                    }
-                }
-                if (job_barrier(J, &s_err)) { p3_err = true; break; }
-                // ready for the next pass -- only now: the other workgroups decide from p3_hot / p3_cand1 whether this pass goes on
-                // (above) at their own pace after the first barrier; all of them have done so once they are here
-                if (master && tid == 0) { ctr->p3_cand1 = 0xFFFFFFFFu; ctr->p3_nhot = 0; ctr->p3_any = 0; ctr->p3_hot = 0; }
-                const uint32_t fire = ld_agent(&ctr->p3_fire);
-                if (fire == 0xFFFFFFFFu) break;
-                const uint32_t upto = fire + 1;
-                // phase 4: freeze rows [f, upto): their arrivals are now history; forget fresh counts
-                if (any) {
-                    for (uint32_t r = f + gtid; r < nC; r += gstride) {
-                        uint32_t k = J.p3k[r];
-                        if (k < 2) continue;
-                        uint32_t s = ht_slot(J, J.p3h[r], J.p3h2[r], false);
-                        if (s == 0xFFFFFFFFu) continue;
-                        if (r < upto) atomicAdd(&J.ht_frozen[s], 1u);
-                        J.ht_new[s] = 0;
-                    }
-                }
-                // apply the firing (master): the group's variables, ascending, become unique (:1403-1414)
-                if (master) {
-                    if (w == 0) {
-                        uint32_t k = J.p3k[fire];
-                        steps += k; hits[10]++;
-                        uint32_t lastv = 0;
-                        for (uint32_t n = 0; n < k; ++n) {
-                            uint32_t mn = 0xFFFFFFFFu;
-                            for (uint32_t e = J.rpC[fire] + lane; e < J.rpC[fire + 1]; e += 64) {
-                                uint32_t v = J.colC[e];
-                                if (!(J.flags[v] & 1) && v > lastv && v < mn) mn = v;
-                            }
-                            for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
-                            if (mn == 0xFFFFFFFFu) break;
-                            lastv = mn;
-                            J.events[n] = mn;
-                        }
-                        wg_fence();
-                        for (uint32_t n = 0; n < k; ++n) {
-                            uint32_t v = J.events[n];
-                            mark_unique(J, v);
-                            requeue(J, q, v);
-                        }
-                        if (lane == 0) s_steps = steps;
-                    }
-                    __syncthreads();
-                    steps = s_steps;
-                }
-                if (job_barrier(J, &s_err)) { p3_err = true; break; }   // the firing's writes reach the helpers
-                f = fire + 1;
-            }
-            if (p3_err) break;
-            // leave the table clean for the next outer iteration: every workgroup wipes the slots it created
-            __syncthreads();
-            {
-                const uint32_t nmine = s_htn < ht_cap ? s_htn : ht_cap;
-                for (uint32_t i = tid; i < nmine; i += ECNE_WG) {
-                    const uint32_t s = J.ht_list[(size_t)my_rank * ht_cap + i];
-                    J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0;
-                }
-                __syncthreads();
-                if (tid == 0) s_htn = 0;
-            }
-        }
+        // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups (p3_phase)
+        if (p3_phase(J, q, hits, steps, my_rank, ht_cap, &s_htn, &s_steps, m_rows, m_vars, tk, &s_err)) break;
         if (team_phase && master) {
             // fold in what the helpers did during the rounds on teams: their atomics came before P3's first barrier (here, not inside
             // P3's loop: with the counters live across that loop the compiler spilled them, +0.27 GB of scratch writes per launch)
@@ -570,208 +817,12 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         }
         ECNE_TICK(2);
 
-        // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups.
-        // p4_b[i] / p4_s[i]: B variable and slope variable (bit 31: no slope -> DivideError) of the i-th
-        // statically eligible row. A row tags b iff b is not unique, still untagged, and the row is the
-        // FIRST such row of b in index order (varmin[b]).
-        {
-            bool my_live = false;      // a candidate whose b is neither unique nor tagged: some row will tag in this pass
-            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
-                const uint32_t b = J.p4_b[i];
-                if (J.flags[b] & 1) continue;
-                if (J.p4_s[i] & 0x80000000u) { raise(J, K_EDIVZERO); continue; }
-                if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
-                if (J.abz[b] == -1) my_live = true;
-            }
-            if (my_live) __hip_atomic_store(&ctr->p4_live, (unsigned)outer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (stamped with the outer iteration: never reset)
-            if (job_barrier(J, &s_err)) break;
-            // No live candidate anywhere: no row can tag, nothing to re-queue -- the pass ends at this barrier (every workgroup reads the
-            // same word). The minima stay: as long as b is not unique its first candidate row is the same row.
-            if (ld_agent(&ctr->p4_live) == (unsigned)outer) {
-            uint32_t my_fired = 0;
-            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
-                const uint32_t b = J.p4_b[i];
-                if ((J.flags[b] & 1) || ld_agent(&J.varmin[b]) != i || J.abz[b] != -1) continue;
-                J.abz[b] = (int32_t)(J.p4_s[i] & 0x7FFFFFFFu);
-                J.flags[b] |= 2 | 16;    // is_known; bit 4: carries a group tag (abz != -1)
-                J.fired[i] = 1;          // by list position; cleared again when the events are collected
-                ++my_fired;
-            }
-            {   // one device atomic per workgroup (the first sweep of a large circuit tags tens of thousands of rows)
-                uint32_t wg_fired;
-                wg_exclusive_scan(my_fired, s_scan, &wg_fired);
-                if (tid == 0 && wg_fired) atomicAdd(&ctr->p4_nfired, wg_fired);
-            }
-            if (master && tid == 0) ctr->q_cmd[2] = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
-            if (job_barrier(J, &s_err)) break;
-            const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // stable until the master clears it at the end of P4
-            // forget the per-variable minima (all workgroups; the next use is a whole queue phase away)
-            for (uint32_t i = gtid; i < J.nP4; i += gstride) {
-                const uint32_t b = J.p4_b[i];
-                if (!(J.flags[b] & 1)) J.varmin[b] = 0xFFFFFFFFu;
-            }
-            bool p4_done = false, p4_err = false;
-            if (J.nwg > 1 && p4_fired >= 2048) {
-                // Many rows tagged (the first sweep of a large circuit tags every decoder output): the ordered
-                // REQUEUE of their B variables runs on ALL workgroups -- same steps as resolve_pushes, with
-                // contiguous blocks per thread and job-wide scans (nothing is being popped: a candidate may
-                // push iff its row is not queued; the lowest candidate index per row wins).
-                const uint32_t tail0 = ld_agent(&ctr->q_cmd[2]);
-                const uint32_t T = gstride;
-                int err = 0;
-                // 1. the event list: B variables of the fired rows, ascending
-                const uint32_t iper = (J.nP4 + T - 1) / T;
-                const uint32_t i0 = gtid * iper < J.nP4 ? gtid * iper : J.nP4, i1 = (gtid + 1) * iper < J.nP4 ? (gtid + 1) * iper : J.nP4;
-                uint32_t cnt = 0;
-                for (uint32_t i = i0; i < i1; ++i) cnt += J.fired[i];
-                uint32_t nev = 0;
-                uint32_t o = team_exclusive_scan(J, s_chunk, my_rank, cnt, 0, &nev, &s_err, &err);
-                if (!err) {
-                    for (uint32_t i = i0; i < i1; ++i)
-                        if (J.fired[i]) { J.events[o++] = J.p4_b[i]; J.fired[i] = 0; }
-                    err = job_barrier(J, &s_err);
-                }
-                // 2. candidates
-                uint32_t M = 0, e0 = 0, e1 = 0, cbase = 0;
-                if (!err) {
-                    const uint32_t eper = (nev + T - 1) / T;
-                    e0 = gtid * eper < nev ? gtid * eper : nev;
-                    e1 = (gtid + 1) * eper < nev ? (gtid + 1) * eper : nev;
-                    uint32_t deg = 0;
-                    for (uint32_t e = e0; e < e1; ++e) { const uint32_t v = J.events[e]; deg += J.fo_ptr[v + 1] - J.fo_ptr[v]; }
-                    cbase = team_exclusive_scan(J, s_chunk, my_rank, deg, 1, &M, &s_err, &err);
-                }
-                if (!err && M <= J.candcap) {
-                    if (tid == 0) s_chunk.nbigev = 0;
-                    __syncthreads();
-                    uint32_t j = cbase;
-                    for (uint32_t e = e0; e < e1; ++e) {
-                        const uint32_t v = J.events[e];
-                        expand_event(J, s_chunk, v, 0, j, false);
-                        j += J.fo_ptr[v + 1] - J.fo_ptr[v];
-                    }
-                    expand_big_events(J, s_chunk, false);
-                    err = job_barrier(J, &s_err);
-                    // 3. winners, in candidate order
-                    uint32_t W = 0;
-                    if (!err) {
-                        const uint32_t cper = (M + T - 1) / T;
-                        const uint32_t j0 = gtid * cper < M ? gtid * cper : M, j1 = (gtid + 1) * cper < M ? (gtid + 1) * cper : M;
-                        uint32_t nwin = 0;
-                        for (uint32_t jj = j0; jj < j1; ++jj) {
-                            const uint32_t cw = J.cand[jj];
-                            const uint32_t t = cw & 0x7FFFFFFFu;
-                            const bool win = (cw & 0x80000000u) && ld_agent(&J.best[t]) == jj;
-                            J.cand[jj] = t | (win ? 0x80000000u : 0u);
-                            nwin += win;
-                        }
-                        const uint32_t wbase = team_exclusive_scan(J, s_chunk, my_rank, nwin, 0, &W, &s_err, &err);
-                        if (!err) {
-                            uint32_t oq = tail0 + wbase;
-                            for (uint32_t jj = j0; jj < j1; ++jj) {
-                                const uint32_t cw = J.cand[jj];
-                                const uint32_t t = cw & 0x7FFFFFFFu;
-                                if (cw & 0x80000000u) { J.queue[oq & J.qmask] = t; J.inq[t] = 1; ++oq; }
-                                J.best[t] = 0xFFFFFFFFu;
-                            }
-                            err = job_barrier(J, &s_err);
-                        }
-                    }
-                    if (!err) {
-                        p4_done = true;
-                        if (master) {
-                            if (w == 0 && lane == 0) { q.tail = tail0 + W; s_q = q; ctr->p4_nfired = 0; }
-                            __syncthreads();
-                            q = s_q;
-                            steps += nev;
-                            if (w == 0) hits[11] += nev;
-                        }
-                    }
-                } else if (!err) {
-                    // (a B variable with a huge fan-out) the master replays the events one by one
-                    if (master) {
-                        if (w == 0) {
-                            for (uint32_t e = 0; e < nev; ++e) requeue(J, q, J.events[e]);
-                            if (lane == 0) { s_q = q; ctr->p4_nfired = 0; }
-                        }
-                        __syncthreads();
-                        q = s_q;
-                        steps += nev;
-                        if (w == 0) { hits[11] += nev; hits[15]++; }
-                    }
-                    err = job_barrier(J, &s_err);
-                    if (!err) p4_done = true;
-                }
-                if (err) p4_err = true;
-            }
-            if (p4_err) break;
-            if (master && p4_fired != 0 && !p4_done) {
-                __syncthreads();
-                if (tid == 0) ctr->p4_nfired = 0;
-                // wave 0 owns the queue cursor during P1-P3; every master thread needs it now
-                if (w == 0 && lane == 0) s_q = q;
-                __syncthreads();
-                q = s_q;
-                // ordered event list = fired rows ascending -> their b variable
-                uint32_t nev = 0;
-                for (uint32_t base = 0; base < J.nP4; base += ECNE_WG) {
-                    uint32_t i = base + tid;
-                    uint32_t fl = (i < J.nP4) ? J.fired[i] : 0;
-                    uint32_t total, off = wg_exclusive_scan(fl, s_scan, &total);
-                    if (fl) { J.events[nev + off] = J.p4_b[i]; J.fired[i] = 0; }
-                    nev += total;
-                }
-                __syncthreads();
-                // REQUEUE(b) for every fired row, in row order, resolved by the whole workgroup
-                {
-                    uint32_t tl = q.tail;
-                    unsigned long long p4_fb = 0;
-                    for (uint32_t eb = 0; eb < nev; eb += 4096) {
-                        const uint32_t cnt = (nev - eb) < 4096u ? (nev - eb) : 4096u;
-                        tl = resolve_pushes(J, s_chunk, J.events + eb, false, cnt, -1, 0, tl, &p4_fb);      // (every thread counts a fallback in a copy of its own)
-                    }
-                    q.tail = tl;
-                    steps += nev;
-                    if (w == 0) { hits[11] += nev; hits[15] += p4_fb; }
-                }
-            }
-            }      // (a live candidate)
-        }
+        // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups (p4_phase)
+        if (p4_phase(J, s_chunk, q, &s_q, s_scan, hits, steps, outer, my_rank, &s_err)) break;
         ECNE_TICK(3);
 
         // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
-        if (master) {
-            if (w == 0) {
-                // 64 candidates are tested at a time, one per lane; the ones that pass fire in index order,
-                // and after every firing the later lanes look again (its newly unique y may complete their A)
-                if (J.oob) oob_p5(J, q, hits, steps);
-                else
-                for (uint32_t base = 0; base < J.nP5; base += 64) {
-                    const uint32_t i = base + lane;
-                    const uint32_t r = i < J.nP5 ? J.p5_rows[i] : 0, y = i < J.nP5 ? J.p5_y[i] : 0;
-                    int from = 0;            // lanes below `from` are done
-                    if ((base & 4095u) == 0) job_heartbeat(J);
-                    for (;;) {
-                        bool can = i < J.nP5 && lane >= from && !(J.flags[y] & 1);
-                        if (can)
-                            for (uint32_t e = J.rpA[r]; e < J.rpA[r + 1] && can; ++e) can = (J.flags[J.colA[e]] & 1) != 0;
-                        const uint64_t m = __ballot(can);
-                        if (!m) break;
-                        const int src = __ffsll((long long)m) - 1;
-                        const uint32_t rs = __shfl(r, src, 64), ys = __shfl(y, src, 64);
-                        mark_unique(J, ys);
-                        if (lane == 0) { J.solved[rs] = 1; J.solved[rs + 1] = 1; }
-                        wg_fence();
-                        steps++; hits[12]++;
-                        requeue(J, q, ys);
-                        from = src + 1;
-                    }
-                }
-                if (lane == 0) s_steps = steps;
-            }
-            __syncthreads();
-            steps = s_steps;
-        }
+        p5_phase(J, q, hits, steps, &s_steps, my_rank);
         ECNE_TICK(4);
     }
 

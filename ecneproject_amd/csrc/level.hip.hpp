@@ -36,6 +36,9 @@ static_assert(4u * (ECNE_LV_MARKS + ECNE_LV_QM + ECNE_LV_CAND) <= ECNE_W2_BYTES,
 #define ECNE_LV_WIDE_AVAIL 192u   // more rows than this queued: a wide frontier, the round schedule's business (unless it asks for level rounds: wide_ok)
 #endif
 
+#ifndef ECNE_LVG_WIDE_AVAIL
+#define ECNE_LVG_WIDE_AVAIL 128u  // ... on the master of a team: its solo drain rounds take 512 rows per level and win from about 250 queued rows on
+#endif                            //     (45 chains side by side, ~360 rows queued: 186 ms with level rounds up to 192 rows, 168 with solo drains)
 #ifndef ECNE_SOLO_RATIO
 #define ECNE_SOLO_RATIO 8       // (rounds.hip.hpp: solo drains when a narrow round committed less than 1 / ECNE_SOLO_RATIO of a well-filled window)
 #endif
@@ -124,7 +127,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
     };
     while (head != tail) {
         const uint32_t avail = tail - head;
-        if (!wide_ok && avail > ECNE_LV_WIDE_AVAIL) { why = LV_WIDE; break; }      // a wide frontier: the rounds on the whole workgroup first
+        if (!wide_ok && avail > (LDS ? ECNE_LV_WIDE_AVAIL : ECNE_LVG_WIDE_AVAIL)) { why = LV_WIDE; break; }      // a wide frontier: the rounds on the whole workgroup first
         if (rounds >= max_rounds) { why = LV_ROUNDS; break; }
         uint32_t n = avail < 64u ? avail : 64u;
         if (head + n > mtop) {                       // the window reaches beyond the mirror

@@ -940,7 +940,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // circuit too large for one workgroup's LDS) as level rounds on device-memory state, in place of the fast wavefront rounds
         if constexpr (TEAM) {
             if (lvg_ok && lvg_hold) --lvg_hold;
-            else if (lvg_ok && !burst && !solo && !declined_wide && avail <= ECNE_LV_WIDE_AVAIL) {
+            else if (lvg_ok && !burst && !solo && !declined_wide && avail <= ECNE_LVG_WIDE_AVAIL) {
                 const bool cut_exit = solo_ok && solo_cool == 0;
                 if (w == 0) {
                     uint32_t hd = q.head, tl = q.tail, nr = 0;

@@ -1,0 +1,20 @@
+#!/bin/bash
+# GPU box: the round-4 evidence in one go -> gpurun_out/final_r04/   (python tools/collect_final_r04.py files it under profiles/)
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/final_r04
+mkdir -p $O
+timeout 600 python bench.py > $O/ecdsa.json 2> $O/ecdsa.err
+for w in suite poseidon secp dag many; do timeout 900 python bench.py --workload $w --steps 5 --warmup 2 > $O/$w.json 2> $O/$w.err; done
+timeout 900 python bench.py --S 104 --steps 5 --warmup 2 --cpu-sample-S 26 > $O/ecdsa_S104.json 2> $O/ecdsa_S104.err
+bash tools/profile_r04.sh 26 > $O/profile_S26.log 2>&1
+cp gpurun_out/prof_r04_S26/*.txt gpurun_out/prof_r04_S26/*.json $O/ 2>/dev/null
+bash tools/profile_r04.sh 104 > $O/profile_S104.log 2>&1
+for f in trace fetch write sq; do cp gpurun_out/prof_r04_S104/$f.txt $O/S104_$f.txt 2>/dev/null; done
+cp gpurun_out/prof_r04_S104/bench_under_rocprof.json $O/S104_bench_under_rocprof.json 2>/dev/null
+timeout 2400 python tests/tools/scale_variants.py > $O/scale_variants.txt 2>&1
+timeout 900 python tests/tools/per_file_vs_oracle.py > $O/per_file_vs_oracle.txt 2>&1
+bash tools/gp_roundlog.sh > /dev/null 2>&1
+cp gpurun_out/roundlog_ecdsa_summary.txt $O/round_log_summary.txt 2>/dev/null
+bash tools/gp_lvprof.sh > $O/level_round_stages.txt 2>&1
+for f in ecdsa suite poseidon secp dag many ecdsa_S104; do tail -c 250 $O/$f.json; echo; done
+tail -4 $O/scale_variants.txt | cut -c1-200; tail -2 $O/per_file_vs_oracle.txt
