@@ -27,7 +27,7 @@ namespace ecne {
 #define ECNE_MAX_NWG 248     // workgroups one system can get (q_part[][256] and the scratch sizes follow it)
 #endif
 #ifndef ECNE_ROWS_PER_WG
-#define ECNE_ROWS_PER_WG 4096    // with drain rounds (round 3): ecdsa_like(26) 85 workgroups 11.2 ms, 128: 11.9, 170: 10.5, 248: 10.7 (prefix rounds, round 2: 85: 22.2, 57: 22.5, 43: 23.0, 22: 26.7)
+#define ECNE_ROWS_PER_WG 3072    // round 4 (level rounds on the master): 3072 -> 226 workgroups for ecdsa_like(26) 6.44 -> 6.40 ms, ecdsa_like(6) 3.65 -> 3.33; 2816: the same. With drain rounds (round 3, 4096): ecdsa_like(26) 85 workgroups 11.2 ms, 128: 11.9, 170: 10.5, 248: 10.7 (prefix rounds, round 2: 85: 22.2, 57: 22.5, 43: 23.0, 22: 26.7)
 #endif
 #ifndef ECNE_BIGK
 #define ECNE_BIGK 8         // long rows one workgroup takes along in one round
