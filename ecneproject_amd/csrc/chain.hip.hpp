@@ -84,9 +84,12 @@ __device__ __forceinline__ void chain_requeue(const ECNE_GLOBAL uint32_t* fo_row
 // Up to max_pops strictly sequential pops on wavefront 0 (all 64 lanes), stopping early when the queue runs empty,
 // an error is raised, or -- stop_avail != 0 -- more than stop_avail rows are waiting (a frontier that wide is the
 // round schedule's business). Requires flags and inq resident in LDS (J.lds_flags_off / J.lds_inq_off) and J.rec / J.foi.
-__device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_pops, uint32_t stop_avail, unsigned long long* hits,
-                                        unsigned long long& steps, unsigned long long& nuniq, unsigned long long& pops,
-                                        unsigned long long& pop_nnz) {
+// Returns 1 when it stopped in front of a live long row (stop_big): the caller pops that one with the whole workgroup -- its events
+// resolved in parallel -- where this loop would re-queue them one after the other (a binary decomposition of 89 terms whose R4 / R7
+// make every term unique: 67 us here, 12-16 us there).
+__device__ __noinline__ uint32_t chain_pops(const Job& J, QState& q, uint32_t max_pops, uint32_t stop_avail, unsigned long long* hits,
+                                            unsigned long long& steps, unsigned long long& nuniq, unsigned long long& pops,
+                                            unsigned long long& pop_nnz, bool stop_big = false) {
     const int lane = lane_id();
     uint8_t* const F = (uint8_t*)(ecne_dyn_lds + J.lds_flags_off);
     uint16_t* const Q = (uint16_t*)(ecne_dyn_lds + J.lds_inq_off);
@@ -118,7 +121,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
     cq.head = q.head; cq.tail = q.tail;
     wg_fence();
     chain_window_load(queue, qmask, cq);
-    uint32_t done = 0;
+    uint32_t done = 0, at_big = 0;
     bool stop = false;
     // The row of a pop -- record (lanes 0..15), descriptor (lanes 16..23), solved and orientation bytes -- is fetched
     // one pop AHEAD whenever the queue already holds the next entry: static data plus two bytes only the pop of that
@@ -148,6 +151,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
 #endif
         ECNE_PT(7);
         if (pf_pos != cq.head) fetch_row(cq.head);
+        if (stop_big && (rdlane(pf_w, 16) & SH_BIG) && !pf_solved) { at_big = 1; break; }
         const uint32_t row = pf_row;
         const uint32_t w = pf_w;
         const uint8_t is_solved = pf_solved, flip_in = pf_flip;
@@ -179,6 +183,9 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
             c_pops++;
             c_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
             if (is_solved) continue;
+#ifdef ECNE_ROUNDLOG
+            if (lane == 0) printf("RG row %u shape %x rec %u n %u xyslow %d\n", row, shape, w0 >> 24, (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]), (int)xy_slow);
+#endif
             QState qq;
             qq.head = cq.head; qq.tail = cq.tail; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
             flush();
@@ -336,6 +343,7 @@ __device__ __noinline__ void chain_pops(const Job& J, QState& q, uint32_t max_po
     wg_fence();
     q.head = cq.head;
     q.tail = cq.tail;
+    return at_big;
 }
 
 }  // namespace ecne

@@ -878,6 +878,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     const bool lv_ok = chain && v2 && level_rounds_on(J);      // level rounds: LDS-resident state, row records, the fast round's LDS block
     uint32_t lv_burst = 1;
     bool lv_wide = false, lv_chain = false;      // lv_chain: the burst that follows pops rows the level rounds declined (chain executor)
+    bool head_big = false;                       // the chain executor stopped in front of a live long row: popped alone, by the whole workgroup
     const bool v2wg = v2 && fast_wg_ok(J);
     uint32_t streak = 0;             // rows committed in a row without a dependency cutting a round short (evidence for a wide independent frontier)
     bool declined_wide = false;      // the fast wavefront round keeps declining the head row of a wide frontier
@@ -895,6 +896,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     while (q.head != q.tail) {
         // the error word is polled every 8th round (a raised error only has to stop the solve soon)
         job_heartbeat(J);   // "the master is alive"
+#ifdef ECNE_ROUNDLOG
+        unsigned long long rl_t0 = wall_clock64();      // (round log builds: every line's dt runs from here -- the prints themselves stay outside)
+#endif
         if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
         if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
         uint32_t avail = q.tail - q.head;
@@ -905,37 +909,77 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // ---- level rounds (level.hip.hpp): a single-workgroup job with LDS-resident state takes every frontier of up to 192 rows
         // level by level on wavefront 0, without coming back here between two levels. It returns in front of a row it does not
         // take (the chain executor pops that one; more of them in a row: longer bursts) or when the frontier has grown wide.
-        if (lv_ok && (lv_wide || (!burst && avail <= ECNE_LV_WIDE_AVAIL))) {
+        if (lv_ok && !head_big && (lv_wide || (!burst && avail <= ECNE_LV_WIDE_AVAIL))) {
             // (lv_wide: a round on the workgroup was cut short by a dependency with many rows queued -- chains side by side; the level
             //  rounds work the queue off 64 rows at a time for as many rounds as the burst would have had pops)
             const uint32_t lv_max = lv_wide ? burst : (1u << 20);
             const bool wide = lv_wide;
             lv_wide = false; if (wide) burst = 0;
             if (w == 0) {
-                uint32_t hd = q.head, tl = q.tail, nr = 0;
-                const uint32_t why = level_rounds<true>(J, hd, tl, lv_max, wide, false, C, my_pops, my_nnz, &nr, &S.sd[0]);
-                if (lane == 0) { S.head = hd; S.tail = tl; S.nbig = why; S.bl_tmp[0] = nr; }
+                // A row the level rounds do not take (a constant row, 1 = x + y, a short binary decomposition, a bound on the limbs) is
+                // popped right here by the general executor and the level rounds go on -- the way back through the policy and the chain
+                // executor's burst costs four times the pop. A live long row goes back: the whole workgroup pops it (head_big).
+                // (Tried: those shapes inside the level round through fast_decide, inline, out of line and as a second instantiation a
+                //  job switches to -- bit-exact, and slower every time: the loop is at its register limits, 248 VGPRs and scalar
+                //  registers already spilled to lanes; Poseidon 2.9 -> 3.4 us per level, secp256k1 7.2 -> 8.0 ms.)
+                uint32_t hd = q.head, tl = q.tail, nr = 0, why, left = lv_max, gdone = 0, gnnz = 0, big = 0;
+                unsigned long long st = 0, nu = 0, ht[16];
+                for (int i = 0; i < 16; ++i) ht[i] = 0;
+                for (;;) {
+                    uint32_t nr1 = 0;
+                    why = level_rounds<true>(J, hd, tl, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0]);
+                    nr += nr1;
+                    if (why != LV_DECLINED || gdone >= 256u) break;
+                    const uint32_t rr = J.queue[hd & J.qmask];
+                    const bool sv = J.solved[rr] != 0;
+                    // (tried: the empty pops of a live long decomposition row settled here from one wavefront walk -- secp256k1 7.19 -> 7.05 ms,
+                    //  EdDSAPoseidon 5.24 -> 5.37, EdDSAMiMCSponge 15.2 -> 15.5: the level rounds then go on where rounds on the workgroup do better)
+                    if ((J.rinfo[rr].shape & SH_BIG) && !sv) { big = 1; break; }
+                    hd++;
+                    if (lane == 0) J.inq[rr] = 0;
+                    wg_fence();
+                    ++gdone;
+                    gnnz += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
+                    if (!sv) {
+                        QState qq;
+                        qq.head = hd; qq.tail = tl; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                        exec_row(J, qq, rr, ht, st, nu);
+                        wg_fence();
+                        tl = qq.tail;
+                    }
+                    if (J.ctr->error) { why = LV_ROUNDS; break; }
+                    if (hd == tl) { why = LV_EMPTY; break; }
+                    left = left > nr1 + 1u ? left - nr1 - 1u : 1u;
+                }
+                if (lane == 0) {
+                    S.acc[0] += st; S.acc[1] += nu;
+                    for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
+                    S.acc[10] += gdone; S.acc[11] += gnnz;
+                    S.head = hd; S.tail = tl; S.nbig = why; S.bl_tmp[0] = nr; S.bl_tmp[1] = big;
+                }
             }
             __syncthreads();
             const uint32_t why = S.nbig, nr = S.bl_tmp[0], done = S.head - q.head;
+            if (S.bl_tmp[1]) head_big = true;
 #if defined(ECNE_FINE_TICKS) && !defined(ECNE_LVPROF)
             if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: level rounds in the fast rounds' slots
 #endif
 #ifdef ECNE_ROUNDLOG
-            if (tid == 0) printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, wall_clock64() - qt_last);
+            if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, d_); }
 #endif
             pops_total += done;
             hits[13] += nr;
             q.head = S.head; q.tail = S.tail;
             __syncthreads();
-            if (why == LV_DECLINED) { burst = lv_burst; lv_chain = true; if (nr < 2 && lv_burst < 64u) lv_burst *= 2; else if (nr >= 2) lv_burst = 1; }
+            if (why == LV_DECLINED && !head_big) { burst = lv_burst; lv_chain = true; if (nr < 2 && lv_burst < 64u) lv_burst *= 2; else if (nr >= 2) lv_burst = 1; }
             QTICK(6);
             if (why == LV_REFILL) lv_wide = true, burst = lv_max > nr ? lv_max - nr : 1u;      // (the mirrored part is used up: the same call again)
             if (why != LV_WIDE) continue;
             avail = q.tail - q.head;
         }
-        if (lv_ok && burst > 1 && !lv_chain) { lv_wide = true; continue; }      // what would be a burst of the chain executor: level rounds instead
+        if (lv_ok && burst > 1 && !lv_chain && !head_big) { lv_wide = true; continue; }      // what would be a burst of the chain executor: level rounds instead
         lv_chain = false;
+        if (head_big) burst = 0;
         // ---- the master of a multi-workgroup job: its narrow levels (the adders of ecdsa_like between two wide frontiers, a chained
         // circuit too large for one workgroup's LDS) as level rounds on device-memory state, in place of the fast wavefront rounds
         if constexpr (TEAM) {
@@ -953,7 +997,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: in the fast rounds' slots
 #endif
 #ifdef ECNE_ROUNDLOG
-                if (tid == 0) printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, wall_clock64() - qt_last);
+                if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, d_); }
 #endif
                 pops_total += done;
                 hits[13] += nr;
@@ -979,8 +1023,9 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 uint32_t done = 0;
                 if (chain_ok(J)) {      // flags / in_queue tags in LDS, rows in one line: the chain executor
                     unsigned long long pp = 0;
-                    chain_pops(J, qq, burst, burst_stop, ht, st, nu, pp, pn);
+                    const uint32_t at_big = chain_pops(J, qq, burst, burst_stop, ht, st, nu, pp, pn, true);
                     done = (uint32_t)pp;
+                    if (lane == 0) S.flag7 = at_big;
                 } else
                 while (done < burst && qq.head != qq.tail && !J.ctr->error) {
                     const uint32_t rr = J.queue[qq.head & J.qmask];
@@ -996,16 +1041,18 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                     for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
                     S.acc[10] += done; S.acc[11] += pn;
                     S.head = qq.head; S.tail = qq.tail; S.nbig = done;
+                    if (!chain_ok(J)) S.flag7 = 0;
                 }
             }
             __syncthreads();
             q.head = S.head; q.tail = S.tail;
             pops_total += S.nbig;
+            head_big = S.flag7 != 0;
 #ifdef ECNE_W2PROF
             if (tid == 0) { S.sd[3] += 1; S.sd[4] += S.nbig; S.sd[5] += wall_clock64() - qt_last; }     // (profiling builds: sequential bursts instead of general wavefront rounds)
 #endif
 #ifdef ECNE_ROUNDLOG
-            if (tid == 0) printf("RL burst avail %u n %u c %u dt %llu\n", avail, S.nbig, S.nbig, wall_clock64() - qt_last);
+            if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL burst avail %u n %u c %u dt %llu\n", avail, S.nbig, S.nbig, d_); }
 #endif
             burst = 0;
             __syncthreads();
@@ -1050,7 +1097,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         }
         if (v2wg && J.nwg == 1 && n > ECNE_WG) n = ECNE_WG;
         const bool eager = TEAM && drain_eager(J) && avail >= 2;
-        if (n <= 64 && !declined_wide && !eager) {
+        if (n <= 64 && !declined_wide && !eager && !head_big) {
             // a narrow level: the whole round on wavefront 0, no workgroup barrier inside (queue_round_wave)
             if (w == 0) {
                 uint32_t nt = q.tail, nx = n;
@@ -1074,7 +1121,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                         const bool to_solo = sc_ == 0 && solo_ok && av1 >= ECNE_SOLO_AVAIL && ECNE_SOLO_RATIO * cw <= (av1 < 64u ? av1 : 64u);
                         if (!to_solo && av2 >= 1u && av2 <= 64u) {
 #ifdef ECNE_ROUNDLOG
-                            if (lane == 0) { const unsigned long long t_ = wall_clock64(); printf("RL wave avail %u n %u c %u dt %llu\n", av1, nx & 0x7FFFFFFFu, cw, t_ - qt_last); qt_last = wall_clock64(); }      // (the print itself is not the round's time)
+                            if (lane == 0) { const unsigned long long t_ = wall_clock64(); printf("RL wave avail %u n %u c %u dt %llu\n", av1, nx & 0x7FFFFFFFu, cw, t_ - rl_t0); }
+                            rl_t0 = wall_clock64();      // (the print itself is not the round's time)
 #endif
                             if (sc_) --sc_;
                             pre_cw += cw; ++pre_k; hd += cw; tl = nt; nn = av2;
@@ -1127,7 +1175,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 }
 #endif
 #ifdef ECNE_ROUNDLOG
-                if (tid == 0) printf("RL wave avail %u n %u c %u dt %llu\n", avail, nx, cw, wall_clock64() - qt_last);
+                if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL wave avail %u n %u c %u dt %llu\n", avail, nx, cw, d_); }
 #endif
                 q.head += cw;
                 q.tail = ntw;
@@ -1149,7 +1197,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             }
             // (the window starts with a live long row: the general path below takes this round)
         }
-        if (v2wg && n > 64 && n <= ECNE_WG && !declined_wide) {
+        if (v2wg && n > 64 && n <= ECNE_WG && !declined_wide && !head_big) {
             // ---- a medium frontier: the fast round on the whole workgroup (one row per thread), see wave2.hip.hpp
             uint32_t nt = q.tail, nx = n;
             const uint32_t cw = chain ? queue_round_fast<true, true>(J, S, q.head, q.tail, n, C, my_pops, my_nnz, &nt, &nx, &S.sd[6])
@@ -1201,7 +1249,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         }
         // a live long row at the head is popped alone when it cannot ride along in a round (R2..R6 shapes) -- or when the
         // window is narrow anyway: a workgroup round for a handful of rows costs ten times the long row's own pop
-        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && (!big_plain(shape[0]) || n <= (v2wg ? (uint32_t)ECNE_WG : 64u))) ? 1u : 0u; }
+        if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && (head_big || !big_plain(shape[0]) || n <= (v2wg ? (uint32_t)ECNE_WG : 64u))) ? 1u : 0u; }
+        head_big = false;
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
             if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
@@ -1262,6 +1311,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 S.nbig = 0;
             }
             __syncthreads();
+            // (tried: wave 0 tests for an empty pop of a decomposition row with one walk first -- secp256k1 7.19 -> 7.43 ms: the walk and
+            //  its barrier cost what the general executor's own pass over an all-unique row does)
             const bool wgdone = J.solved[brow] || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig);
             if (wgdone) {
                 // done by the whole workgroup (or an already solved row: the pop is all that happens)
@@ -1288,7 +1339,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             pops_total++;
             hits[14]++;
 #ifdef ECNE_ROUNDLOG
-            if (tid == 0) printf("RL alone avail %u n %u c %u dt %llu\n", avail, S.nbig, 1u, wall_clock64() - qt_last);
+            if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL alone avail %u n %u c %u dt %llu\n", avail, S.nbig, 1u, d_); }
 #endif
             if (tid == 0) S.hasbig = 0;
             __syncthreads();
@@ -1489,7 +1540,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (tid == 0) big_reset(S);
         __syncthreads();
 #ifdef ECNE_ROUNDLOG
-        if (tid == 0) printf("RL wg avail %u n %u c %u dt %llu\n", avail, n, c, wall_clock64() - qt_last);
+        if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL wg avail %u n %u c %u dt %llu\n", avail, n, c, d_); }
 #endif
         q.head += c;
         q.tail = new_tail;
