@@ -25,7 +25,7 @@ from ._lib import Info, Opts, Summary, SystemInfo
 
 __all__ = ["readR1CS", "SolveConstraintsSymbolic", "solveWithTrustedFunctions", "solve_batch",
            "R1CS", "System", "SolveResult", "EcneError", "BoundsError", "DivideError", "UndefVarError",
-           "device_count", "classify", "set_host_threads", "set_frontend", "frontend_stats"]
+           "device_count", "classify", "set_host_threads", "set_frontend", "frontend_stats", "set_split"]
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -95,6 +95,12 @@ def set_frontend(mode=-1):
     """Which front-end turns files into the solver's arrays: FRONTEND_HOST, FRONTEND_DEVICE (parse, abstraction and layout as
     kernels on the current HIP device), FRONTEND_AUTO (device from 100 000 constraints on; the default). mode < 0 only reads."""
     return int(_lib.lib().ecne_set_frontend(int(mode)))
+
+
+def set_split(mode):
+    """One file, several independent parts (include/ecne.h: ecne_set_split): 0 never, 1 from the second solve of a system on when the
+    first took long enough (the default), 2 at the first solve."""
+    _check(_lib.lib().ecne_set_split(int(mode)))
 
 
 def frontend_stats():
@@ -179,6 +185,12 @@ class System:
         i = SystemInfo()
         _check(_lib.lib().ecne_system_info_get(self._h, C.byref(i)))
         return i
+
+    def split_info(self):
+        """(parts the next solve runs as -- 0: as one system --, groups of rows found, plan ms, a plan has been looked for): ecne_set_split"""
+        a = (C.c_double * 4)()
+        _check(_lib.lib().ecne_system_split_info(self._h, a))
+        return int(a[0]), int(a[1]), float(a[2]), bool(a[3])
 
     def io(self):
         """(known_variables, target_variables) the solve will be asked with"""

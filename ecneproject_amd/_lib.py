@@ -45,7 +45,7 @@ EXPORTS = [
     "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_states",
     "ecne_result_bad_rows", "ecne_result_free", "ecne_classify", "ecne_fp_selftest", "ecne_fp_sqrt",
     "ecne_device_count", "ecne_strerror", "ecne_version",
-    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve", "ecne_result_digest",
+    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve", "ecne_result_digest", "ecne_set_split", "ecne_system_split_info",
 ]
 
 _L = None
@@ -102,6 +102,8 @@ def lib():
     L.ecne_system_report_order.argtypes = [vp, C.c_int64, C.POINTER(i64p), C.POINTER(C.c_size_t)]
     L.ecne_abstract_stats.argtypes = [C.POINTER(C.c_double)]
     L.ecne_set_frontend.argtypes = [C.c_int]
+    L.ecne_set_split.argtypes = [C.c_int]
+    L.ecne_system_split_info.argtypes = [vp, C.POINTER(C.c_double)]
     L.ecne_system_set_secp_solve.argtypes = [vp, C.c_int]
     L.ecne_system_dict_rows.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
     L.ecne_debug_static_array.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]

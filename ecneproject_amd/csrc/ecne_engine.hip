@@ -22,6 +22,7 @@
 #include <array>
 #include <map>
 #include <set>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -164,6 +165,28 @@ struct DeviceImage {
     double classify_ms = 0;
 };
 
+// ---- One file, several independent parts. A file whose rows fall into groups that share no variable but the constant wire (N copies
+// of a circuit written into one file, sub-circuits that never meet) is N independent fixed points: the reference's one FIFO,
+// restricted to the rows of a group, IS that group's own FIFO (a pop only pushes rows of its own group), the batch phases P3 / P4 /
+// P5 act inside a group, and the outer loop runs while ANY group makes progress. The plan renumbers every group (or bin of groups)
+// into a system of its own -- variables and rows ascending, orders that depend on ids or on a row's neighbour taken from the file's
+// own ids (orig_var / orig_row) -- and the parts are solved as single-workgroup jobs of one launch, their outer loops in lockstep
+// (Family, engine_types.hpp), each with its state LDS-resident where the file as one system was a team on device-memory state
+// (45 x EdDSAMiMCSponge in one file: 178 ms as one system). Their states are scattered back into the file's own arrays on the device
+// (k_scatter_part), so results, digests and bad rows read as after any solve. Anything unusual -- an error in a part, a part that
+// changed the constant wire's state -- and the file is solved again as one system. ECNE_SPLIT: 0 never, 1 (default) from the second
+// solve of a system on, when the first took long enough to pay for the plan, 2 at the first solve.
+struct ecne_system;
+struct SplitPlan {
+    bool ok = false;
+    int device = -1;
+    std::vector<ecne_system*> kids;      // owned
+    std::vector<uint32_t*> d_map;        // per part: its variable -> the file's (device, n_vars + 1 words)
+    Family* d_family = nullptr;
+    double plan_ms = 0;
+    uint32_t n_groups = 0;
+    ~SplitPlan();
+};
 static uint64_t next_system_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1, std::memory_order_relaxed); }
 struct ecne_system {
     // dictionary order, current rows: the parsed file's own arrays until the first abstraction (no copy;
@@ -185,6 +208,13 @@ struct ecne_system {
     Layout L;
     DeviceImage dev;
     std::vector<int64_t> order_buf;   // ecne_system_report_order
+    // ---- one file as several independent parts (SplitPlan below). A part is a system of its own whose variables and rows are
+    // renumbered, both ascending: orig_var / orig_row give the file's ids back wherever the reference's order depends on them (the
+    // hash order of Set / Dict iteration, build_layout) or on a row's neighbour (P5's row pairs).
+    std::vector<uint32_t> orig_var, orig_row;
+    std::unique_ptr<SplitPlan> split;
+    bool split_tried = false;
+    double last_kernel_ms = 0;
     ~ecne_system() {
         if (dev.arena) {
             int prev = -1;
@@ -195,6 +225,15 @@ struct ecne_system {
         }
     }
 };
+SplitPlan::~SplitPlan() {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (device >= 0) (void)hipSetDevice(device);
+    for (uint32_t* m : d_map) if (m) (void)hipFree(m);
+    if (d_family) (void)hipFree(d_family);
+    for (ecne_system* k : kids) delete k;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
 // host copy of the system's current rows (lazily: a device-front-end system downloads them on first use)
 static int sys_host_rows(ecne_system& S) {
     if (S.cur) return K_OK;
@@ -258,6 +297,49 @@ __global__ __launch_bounds__(256) void k_gather_results(const Job* jobs, unsigne
     const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs[blockIdx.x].ctr);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)blockIdx.x * ECNE_RESULT_BYTES);
     if (threadIdx.x < ECNE_RESULT_BYTES / 4) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+// ---- a split file (SplitPlan): one part's state into the file's own arrays; the part's copy of the constant wire against what setup
+// left (any difference: the file is solved again as one system), part 0's copy is the one that is kept
+__global__ __launch_bounds__(256) void k_scatter_part(Job K, Job P, const uint32_t* map, uint32_t nv) {
+    for (uint32_t v = 1 + blockIdx.x * 256u + threadIdx.x; v <= nv; v += gridDim.x * 256u) {
+        if (v == 1) {
+            const Family* const F = K.family;
+            bool same = K.flags[1] == (uint8_t)F->snap_flags && K.nvalues[1] == (uint8_t)F->snap_nvalues && K.abz[1] == F->snap_abz;
+            for (int k = 0; k < 4; ++k) same = same && K.lb[4 + k] == F->snap_lb[k] && K.ub[4 + k] == F->snap_ub[k];
+            for (int k = 0; k < 8; ++k) same = same && K.values[8 + k] == F->snap_values[k];
+            if (!same) atomicOr(&K.family->var1_bad, 1u);
+            if (K.fam_rank != 0) continue;
+        }
+        const uint32_t pv = map[v];
+        P.flags[pv] = K.flags[v];
+        P.nvalues[pv] = K.nvalues[v];
+        const int32_t a = K.abz[v];
+        P.abz[pv] = a > 0 ? (int32_t)map[a] : a;          // (a group tag is a variable id, :960)
+        for (int k = 0; k < 4; ++k) { P.lb[4ull * pv + k] = K.lb[4ull * v + k]; P.ub[4ull * pv + k] = K.ub[4ull * v + k]; }
+        for (int k = 0; k < 8; ++k) P.values[8ull * pv + k] = K.values[8ull * v + k];
+    }
+}
+// ... and the verdict counts (:1558-1597) of the file from its own lists, as k_solve's epilogue takes them
+__global__ __launch_bounds__(256) void k_part_counts(Job P) {
+    __shared__ unsigned int acc[3];
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t un = 0, nn = 0, ut = 0;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x, st = gridDim.x * 256u;
+    for (uint32_t v = 1 + g; v <= P.nV; v += st)
+        if (P.nontrivial[v]) { nn++; if (P.flags[v] & 1) un++; }
+    for (uint32_t i = g; i < P.nTarget; i += st)
+        if (P.flags[P.targets[i]] & 1) ut++;
+    if (un) atomicAdd(&acc[0], un);
+    if (nn) atomicAdd(&acc[1], nn);
+    if (ut) atomicAdd(&acc[2], ut);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&P.ctr->unique_nontrivial, (unsigned long long)acc[0]);
+        atomicAdd(&P.ctr->n_nontrivial, (unsigned long long)acc[1]);
+        atomicAdd(&P.ctr->unique_targets, (unsigned long long)acc[2]);
+    }
 }
 
 // ecne_result_digest: per variable a splitmix64 chain over its state, summed over the variables (commutative: any thread order)
@@ -573,6 +655,9 @@ static void build_layout(ecne_system& S) {
 
     const fp::u256 ONE = fp::make(1), PM1 = fp::pminus1();
     struct E { uint32_t v; fp::u256 c; };
+    // (a part of a split file: hash orders from the file's own ids)
+    const uint32_t* const ov = S.orig_var.empty() ? nullptr : S.orig_var.data();
+    auto OV = [ov](uint32_t v) -> int64_t { return (int64_t)(ov ? ov[v] : v); };
     // per-row pass, one block of rows per task (every row writes its own slice of the flat arrays)
     for_chunks(nblk, [&](size_t blk, unsigned) {
     jl::SlotTable set;
@@ -599,7 +684,7 @@ static void build_layout(ecne_system& S) {
                 nz[p] = tmp;
             } else {
                 set.reset();
-                for (size_t t = 0; t < tmp.size(); ++t) { bool ins; set.upsert((int64_t)tmp[t].v, (int64_t)t, ins); }
+                for (size_t t = 0; t < tmp.size(); ++t) { bool ins; set.upsert(OV(tmp[t].v), (int64_t)t, ins); }
                 set.for_each([&](int64_t, int64_t pay) { nz[p].push_back(tmp[(size_t)pay]); });
             }
             for (auto& e : nz[p]) {
@@ -681,11 +766,11 @@ static void build_layout(ecne_system& S) {
             if (ri.shape & (SH_R5 | SH_R6)) {   // order of `for j in Set([k1, k2])`
                 set.reset();
                 bool ins;
-                set.upsert(ri.k1, 0, ins);
-                set.upsert(ri.k2, 1, ins);
+                set.upsert(OV(ri.k1), 0, ins);
+                set.upsert(OV(ri.k2), 1, ins);
                 int64_t first = -1;
                 set.for_each([&](int64_t key, int64_t) { if (first < 0) first = key; });
-                if ((uint32_t)first == ri.k2 && ri.k1 != ri.k2) ri.shape |= SH_R56_SWAP;
+                if (first == OV(ri.k2) && ri.k1 != ri.k2) ri.shape |= SH_R56_SWAP;
             }
         }
         if ((ri.shape & SH_R2) || (!(ri.shape & SH_HAS_AB) && nCc > 0)) {
@@ -733,6 +818,7 @@ static void build_layout(ecne_system& S) {
                 const uint32_t nb_next = L.rp[1][i + 2] - L.rp[1][i + 1];
                 const uint32_t nc_this = L.rp[2][i + 1] - L.rp[2][i];
                 if (nc_next != 0 || nb_next != 1 || nc_this != 2 || !a_equal_next[i]) continue;
+                if (!S.orig_row.empty() && S.orig_row[i + 1] != S.orig_row[i] + 1) continue;      // (a part: neighbours in the file only)
                 const uint32_t y = L.col[1][L.rp[1][i + 1]];
                 if (y == 1) continue;
                 bool bad = false;
@@ -1407,7 +1493,10 @@ int ecne_device_count(void) {
     return n;
 }
 
-static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out) {
+#define K_ESPLIT (-1000)      // internal: the split launch cannot be made (a part needs more than one workgroup, the parts do not fit the device)
+// sl: sys[0 .. n-2] are the parts of sys[n-1] (SplitPlan): the parts are solved, in lockstep, and scattered into the file's arrays;
+// the file itself gets no workgroup. fam_flags[0 / 1]: a part left early / the constant wire's state moved.
+static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out, SplitPlan* sl, uint32_t* fam_flags) {
     if (!sys || !out || n == 0) return ECNE_EINVAL;
     for (size_t i = 0; i < n; ++i) out[i] = nullptr;
     ecne_opts o;
@@ -1454,9 +1543,12 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 static const bool lv_off = []() { const char* e = getenv("ECNE_LEVEL"); return e && atoi(e) == 0; }();      // level rounds (level.hip.hpp) off: A/B runs
                 hj[i].lv_off = lv_off ? 1u : 0u;
             }
+            hj[i].family = nullptr; hj[i].fam_rank = 0; hj[i].fam_size = 0;
+            if (sl && i + 1 < n) { hj[i].family = sl->d_family; hj[i].fam_rank = (uint32_t)i; hj[i].fam_size = (uint32_t)(n - 1); }
             if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
         if (rc != ECNE_OK) break;
+        if (sl && hipMemsetAsync(sl->d_family, 0, sizeof(Family), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         // Workgroups per job: large systems get helpers for the row-parallel sweep passes. All
         // workgroups of one launch must be co-resident (they meet at a hand-rolled barrier), and
         // k_solve occupies a whole CU per workgroup (512 threads x 256 VGPRs), so a launch never
@@ -1489,12 +1581,16 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             if (hj[i].oob) want = 1;
             hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
             hj[i].lds_bytes = dyn_lds;
+            if (sl && i + 1 < n && hj[i].nwg != 1) rc = K_ESPLIT;      // (a part is a single-workgroup job)
+            if (sl && i + 1 == n) hj[i].nwg = 0;                       // the file itself: its arrays receive the parts' states
         }
+        if (sl && n - 1 > cap) rc = K_ESPLIT;
+        if (rc != ECNE_OK) break;
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         const hipEvent_t e0 = scratch.e0, e1 = scratch.e1;
         {
             // a launch that holds a multi-workgroup job must have the device to itself (its workgroups meet at a barrier)
-            bool any_multi = false;
+            bool any_multi = sl != nullptr;      // (parts meet at their family barrier: resident together, the device to themselves)
             for (size_t i = 0; i < n; ++i) any_multi |= hj[i].nwg > 1;
             std::unique_lock<std::shared_mutex> exclusive_lock(device_launch_mutex(o.device), std::defer_lock);
             std::shared_lock<std::shared_mutex> shared_lock(device_launch_mutex(o.device), std::defer_lock);
@@ -1542,6 +1638,15 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
                 }
                 if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
             }
+            if (sl && !fail && !refused) {
+                // the parts' states into the file's arrays, the file's verdict counts (inside the timed region: part of the solve)
+                const Job& PJ = hj[n - 1];
+                for (size_t k = 0; k + 1 < n; ++k) {
+                    const uint32_t nvk = (uint32_t)sys[k]->n_vars;
+                    hipLaunchKernelGGL(k_scatter_part, dim3(std::max(1u, std::min(1024u, (nvk + 255u) / 256u))), dim3(256), 0, stream, hj[k], PJ, (const uint32_t*)sl->d_map[k], nvk);
+                }
+                hipLaunchKernelGGL(k_part_counts, dim3(std::max(1u, std::min(1024u, (PJ.nV + 255u) / 256u))), dim3(256), 0, stream, PJ);
+            }
             (void)hipEventRecord(e1, stream);
             if (!fail && !refused) hipLaunchKernelGGL(k_gather_results, dim3((unsigned)n), dim3(256), 0, stream, (const Job*)d_jobs, scratch.d_res);
             if (refused) { rc = ECNE_ETIMEOUT; break; }      // the device cannot hold the job's workgroups together right now
@@ -1551,6 +1656,11 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
         (void)hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned char> h_res(ECNE_RESULT_BYTES * n);
         if (hipMemcpyAsync(h_res.data(), scratch.d_res, h_res.size(), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        if (sl && fam_flags) {
+            Family hf;
+            if (hipMemcpy(&hf, sl->d_family, sizeof(Family), hipMemcpyDeviceToHost) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+            fam_flags[0] = hf.abort; fam_flags[1] = hf.var1_bad;
+        }
         for (size_t i = 0; i < n; ++i) {
             ecne_system& S = *sys[i];
             const Layout& L = S.L;
@@ -1597,6 +1707,173 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
     } while (0);
     if (rc != ECNE_OK)
         for (size_t i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
+    return rc;
+}
+
+// ---- the plan of a split file (SplitPlan). Groups: union-find over variables and rows -- a row with every variable it names (zero
+// coefficients included) except the constant wire, and with the next row where the two could be one of P5's pairs (:1492-1536: a row
+// with two non-zero C terms followed by one with no C and a single B term). Bins: the groups, largest first, each into the bin with
+// the fewest rows so far, at most `cap` bins.
+static std::atomic<int>& split_setting() {
+    static std::atomic<int> m{[]() { const char* e = getenv("ECNE_SPLIT"); return e ? atoi(e) : 1; }()};
+    return m;
+}
+static int split_mode() { return split_setting().load(std::memory_order_relaxed); }
+static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
+    static const bool dbg = getenv("ECNE_SPLIT_DEBUG") != nullptr;
+#define SPLIT_NO(why) do { if (dbg) fprintf(stderr, "[ecne split] no plan: %s\n", why); return K_OK; } while (0)
+    const auto t0 = std::chrono::steady_clock::now();
+    P.split_tried = true;
+    if (!P.specials.empty() || !P.orig_var.empty() || !P.L.oob_blob.empty() || (int64_t)P.L.nV > P.n_vars) SPLIT_NO("trusted functions / ids above num_variables");
+    { const int rc = sys_host_rows(P); if (rc != K_OK) return rc; }
+    const Rows& R = P.rows();
+    const size_t nC = R.n();
+    const uint32_t nV = (uint32_t)P.n_vars;
+    if (nC < 2 || cap < 2) SPLIT_NO("too small");
+    for (int p = 0; p < 3; ++p)
+        for (uint32_t v : R.var[p]) if (v > nV || v == 0) SPLIT_NO("malformed ids");      // (one system)
+    // nodes: variables 0 .. nV, then rows
+    std::vector<uint32_t> uf((size_t)nV + 1 + nC);
+    for (size_t i = 0; i < uf.size(); ++i) uf[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+    auto unite = [&](uint32_t a, uint32_t b) { a = find(a); b = find(b); if (a != b) uf[a < b ? b : a] = a < b ? a : b; };
+    std::vector<uint32_t> nzc(nC, 0), nzb(nC, 0);
+    for (size_t i = 0; i < nC; ++i) {
+        const uint32_t rn = nV + 1 + (uint32_t)i;
+        for (int p = 0; p < 3; ++p)
+            for (uint64_t k = R.ptr[p][i]; k < R.ptr[p][i + 1]; ++k) {
+                const uint32_t v = R.var[p][k];
+                if (v != 1) unite(rn, v);
+                if (!fp::is_zero(R.coef[p][k])) { if (p == 2) nzc[i]++; else if (p == 1) nzb[i]++; }
+            }
+    }
+    for (size_t i = 0; i + 1 < nC; ++i)
+        if (nzc[i] == 2 && nzc[i + 1] == 0 && nzb[i + 1] == 1) unite(nV + 1 + (uint32_t)i, nV + 1 + (uint32_t)(i + 1));
+    // groups by rows
+    std::vector<uint32_t> grp_of_root(uf.size(), 0xFFFFFFFFu), grp_rows;
+    std::vector<uint32_t> row_grp(nC);
+    for (size_t i = 0; i < nC; ++i) {
+        const uint32_t r = find(nV + 1 + (uint32_t)i);
+        if (grp_of_root[r] == 0xFFFFFFFFu) { grp_of_root[r] = (uint32_t)grp_rows.size(); grp_rows.push_back(0); }
+        row_grp[i] = grp_of_root[r];
+        grp_rows[row_grp[i]]++;
+    }
+    const size_t nG = grp_rows.size();
+    if (nG < 2) SPLIT_NO("one group");
+    uint32_t big = 0;
+    for (uint32_t c : grp_rows) big = std::max(big, c);
+    if (!eager && (uint64_t)big * 5 > (uint64_t)nC * 3) SPLIT_NO("one group holds most of the file");      // nothing to gain
+    const uint32_t nB = (uint32_t)std::min<size_t>(nG, std::min<uint32_t>(cap, 240u));
+    std::vector<uint32_t> order(nG), grp_bin(nG);
+    for (size_t g = 0; g < nG; ++g) order[g] = (uint32_t)g;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return grp_rows[a] > grp_rows[b]; });
+    {
+        std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> pq;
+        for (uint32_t b = 0; b < nB; ++b) pq.push({0, b});
+        for (uint32_t g : order) { auto t = pq.top(); pq.pop(); grp_bin[g] = t.second; t.first += grp_rows[g]; pq.push(t); }
+    }
+    // variables: the bin of their group; variables no row names go with bin 0; the constant wire is in every bin
+    std::vector<uint32_t> var_bin((size_t)nV + 1, 0);
+    for (uint32_t v = 2; v <= nV; ++v) { const uint32_t g = grp_of_root[find(v)]; var_bin[v] = g == 0xFFFFFFFFu ? 0u : grp_bin[g]; }
+    std::unique_ptr<SplitPlan> plan(new SplitPlan());
+    plan->device = device;
+    plan->n_groups = (uint32_t)nG;
+    std::vector<uint32_t> child_id((size_t)nV + 1, 0);
+    std::vector<std::vector<uint32_t>> bin_vars(nB), bin_rows(nB);
+    for (uint32_t b = 0; b < nB; ++b) bin_vars[b] = {0u, 1u};          // ids 0 (unused) and 1 (the constant wire) keep their numbers
+    for (uint32_t v = 2; v <= nV; ++v) { child_id[v] = (uint32_t)bin_vars[var_bin[v]].size(); bin_vars[var_bin[v]].push_back(v); }
+    child_id[1] = 1;
+    for (size_t i = 0; i < nC; ++i) bin_rows[grp_bin[row_grp[i]]].push_back((uint32_t)i);
+    HIP_TRY(hipSetDevice(device));
+    for (uint32_t b = 0; b < nB; ++b) {
+        if (bin_rows[b].empty()) continue;
+        ecne_system* k = new ecne_system();
+        plan->kids.push_back(k);
+        plan->d_map.push_back(nullptr);
+        Rows& K = k->reduced;
+        K.start();
+        for (uint32_t i : bin_rows[b])
+            for (int p = 0; p < 3; ++p) {
+                for (uint64_t e = R.ptr[p][i]; e < R.ptr[p][i + 1]; ++e) { K.var[p].push_back(child_id[R.var[p][e]]); K.coef[p].push_back(R.coef[p][e]); }
+                K.ptr[p].push_back(K.var[p].size());
+            }
+        k->cur = &k->reduced;
+        k->n_vars = (int64_t)bin_vars[b].size() - 1;
+        k->n_rows_main = (int64_t)bin_rows[b].size();
+        k->orig_var = bin_vars[b];
+        k->orig_row = bin_rows[b];
+        for (int64_t v : P.knowns) if (v == 1 || (v >= 2 && v <= (int64_t)nV && var_bin[(size_t)v] == b)) k->knowns.push_back(child_id[(size_t)v]);
+        for (int64_t v : P.targets) if (v == 1 || (v >= 2 && v <= (int64_t)nV && var_bin[(size_t)v] == b)) k->targets.push_back(child_id[(size_t)v]);
+        { const int rc = upload_system(*k, device); if (rc != K_OK) { if (dbg) fprintf(stderr, "[ecne split] part %u: upload failed (%d)\n", b, rc); return rc; } }
+        uint32_t* dm = nullptr;
+        HIP_TRY(hipMalloc((void**)&dm, 4ull * bin_vars[b].size()));
+        plan->d_map.back() = dm;
+        HIP_TRY(hipMemcpy(dm, bin_vars[b].data(), 4ull * bin_vars[b].size(), hipMemcpyHostToDevice));
+    }
+    if (plan->kids.size() < 2) SPLIT_NO("fewer than two parts");
+    HIP_TRY(hipMalloc((void**)&plan->d_family, sizeof(Family)));
+    plan->ok = true;
+    plan->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (dbg) fprintf(stderr, "[ecne split] %zu groups -> %zu parts, plan %.1f ms\n", nG, plan->kids.size(), plan->plan_ms);
+    P.split = std::move(plan);
+    return K_OK;
+#undef SPLIT_NO
+}
+
+static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out) {
+    if (!sys || !out || n == 0) return ECNE_EINVAL;
+    const int mode = split_mode();
+    ecne_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    if (n == 1 && sys[0] && mode != 0 && o.queue_mode == 0 && o.debug == 0 && !o.secp_solve && sys[0]->secp_solve_override <= 0 && ecne_device_count() > o.device) {
+        ecne_system& P = *sys[0];
+        if (!P.split_tried && (mode >= 2 || (P.last_kernel_ms >= 3.0 && P.n_rows() > 2ull * ECNE_ROWS_PER_WG))) {
+            RestoreDevice restore;
+            int n_cu = 0;
+            if (hipSetDevice(o.device) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) == hipSuccess && n_cu > 16) {
+                // (the file itself is laid out and uploaded first: its arrays receive the parts' states)
+                int rc = upload_system(P, o.device);
+                if (rc == K_OK) rc = build_split(P, o.device, (uint32_t)(n_cu - 8), mode >= 2);
+                if (rc != K_OK) { if (getenv("ECNE_SPLIT_DEBUG")) fprintf(stderr, "[ecne split] plan failed (%d)\n", rc); P.split.reset(); (void)hipGetLastError(); }
+            }
+        }
+        if (P.split && P.split->ok && P.split->device == o.device) {
+            SplitPlan& sp = *P.split;
+            const size_t nk = sp.kids.size();
+            std::vector<ecne_system*> xs(sp.kids.begin(), sp.kids.end());
+            xs.push_back(&P);
+            std::vector<ecne_result*> xr(nk + 1, nullptr);
+            uint32_t ff[2] = {0, 0};
+            int rc = solve_batch_core(xs.data(), nk + 1, opts, xr.data(), &sp, ff);
+            bool good = rc == ECNE_OK && !ff[0] && !ff[1];
+            if (good) for (size_t k = 0; k < nk; ++k) good = good && xr[k]->sum.status == 0;
+            if (good) {
+                ecne_result* r = xr[nk];
+                ecne_summary& s = r->sum;
+                s.successful_steps = s.pops = s.num_unique = s.pop_nnz = 0;
+                for (int k = 0; k < 16; ++k) { s.rule_hits[k] = 0; s.sched[k] = 0; }
+                for (int k = 0; k < 8; ++k) { s.queue_ms[k] = s.multi_ms[k] = s.phase_ms[k] = 0; }
+                s.outer_iterations = xr[0]->sum.outer_iterations;
+                for (size_t k = 0; k < nk; ++k) {
+                    const ecne_summary& c = xr[k]->sum;
+                    s.successful_steps += c.successful_steps; s.pops += c.pops; s.num_unique += c.num_unique; s.pop_nnz += c.pop_nnz;
+                    for (int j = 0; j < 16; ++j) { s.rule_hits[j] += c.rule_hits[j]; s.sched[j] += c.sched[j]; }
+                    for (int j = 0; j < 8; ++j) { s.queue_ms[j] = std::max(s.queue_ms[j], c.queue_ms[j]); s.multi_ms[j] = std::max(s.multi_ms[j], c.multi_ms[j]); s.phase_ms[j] = std::max(s.phase_ms[j], c.phase_ms[j]); }
+                }
+                s.function_good = (s.status == 0 && s.unique_targets == s.n_targets) ? 1 : 0;
+                for (size_t k = 0; k < nk; ++k) delete xr[k];
+                out[0] = r;
+                return ECNE_OK;
+            }
+            if (getenv("ECNE_SPLIT_DEBUG")) fprintf(stderr, "[ecne split] split solve dropped: rc %d, part left early %u, constant wire written %u\n", rc, ff[0], ff[1]);
+            for (auto* x : xr) delete x;
+            if (rc != ECNE_OK && rc != K_ESPLIT) (void)hipGetLastError();
+            P.split.reset();        // (an error in a part, the constant wire written, parts that do not fit: the file as one system, from now on)
+        }
+    }
+    const int rc = solve_batch_core(sys, n, opts, out, nullptr, nullptr);
+    if (rc == ECNE_OK && n == 1 && out[0]) sys[0]->last_kernel_ms = out[0]->sum.device_ms;
     return rc;
 }
 
@@ -1708,6 +1985,8 @@ int ecne_fp_sqrt(const uint64_t* a, uint64_t* root) {
 static void system_changed_rows(ecne_system* sys) {
     sys->generation++;
     sys->laid_out = false;
+    sys->split.reset();
+    sys->split_tried = false;
     if (sys->dev.arena) {
         RestoreDevice restore;
         (void)hipSetDevice(sys->dev.device);
@@ -1808,6 +2087,20 @@ int ecne_debug_static_array(ecne_system* sys, int device, int which, const void*
         *bytes = n;
         return (int)ECNE_OK;
     });
+}
+int ecne_system_split_info(const ecne_system* sys, double out4[4]) {
+    if (!sys || !out4) return ECNE_EINVAL;
+    const SplitPlan* sp = sys->split.get();
+    out4[0] = sp && sp->ok ? (double)sp->kids.size() : 0.0;
+    out4[1] = sp ? (double)sp->n_groups : 0.0;
+    out4[2] = sp ? sp->plan_ms : 0.0;
+    out4[3] = sys->split_tried ? 1.0 : 0.0;
+    return ECNE_OK;
+}
+int ecne_set_split(int mode) {
+    if (mode < 0 || mode > 2) return ECNE_EINVAL;
+    split_setting().store(mode, std::memory_order_relaxed);
+    return ECNE_OK;
 }
 int ecne_set_frontend(int mode) {
     if (mode >= 0 && mode <= 2) frontend_setting().store(mode, std::memory_order_relaxed);

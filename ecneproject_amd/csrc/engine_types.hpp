@@ -115,6 +115,21 @@ struct Counters {   // one per job, device memory
     unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 
+// One file solved as several independent parts (ecne_engine.hip, SplitPlan): the parts -- single-workgroup jobs of one launch -- go
+// through the outer loop (:706-1556) in lockstep, as the one loop of the whole file does: an iteration takes place for all of
+// them when any of them made progress in the one before. One block per family, device memory, zeroed before every launch.
+struct Family {
+    alignas(128) unsigned int arrived;
+    alignas(128) unsigned int gen;
+    alignas(128) unsigned int progress[3];        // by outer iteration mod 3: somebody's successful_steps moved
+    unsigned int abort;                           // a part left with an error (or waited too long): the others leave as well
+    unsigned int var1_bad;                        // some part changed the state of the constant wire (the one variable the parts share)
+    // the constant wire's state after setup (part 0), what every part's copy is compared with afterwards
+    alignas(128) unsigned long long snap_lb[4], snap_ub[4], snap_values[8];
+    int snap_abz;
+    unsigned int snap_flags, snap_nvalues;
+};
+
 struct Job {
     // sizes
     uint32_t nC, nV, nSp, nKnown, nTarget, nP4, nP5, qmask, htmask, secp_solve, queue_mode, hotcap;
@@ -193,6 +208,9 @@ struct Job {
     // rows / specials that name a variable id above num_variables (malformed input): tables for the reference's lazy BoundsError
     // (oob.hip.hpp), or nullptr. Such a system is solved by one workgroup with strictly sequential pops.
     const uint32_t* oob;
+    // one of the independent parts of a file (see Family), or nullptr
+    Family* family;
+    uint32_t fam_rank, fam_size;
     Counters* ctr;
 };
 

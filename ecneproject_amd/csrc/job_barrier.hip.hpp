@@ -151,4 +151,36 @@ __device__ int job_barrier(const Job& J, int* s_err) {
     return *s_err;
 }
 
+// ---- the parts of one file (Family, engine_types.hpp): one thread of each part's workgroup, once per outer iteration. Returns 1 when
+// the loop goes on (some part made progress in the iteration before), 0 when it ends for everybody, 2 when a part left with an
+// error or the wait ran out (the host then solves the file as one system).
+__device__ __noinline__ uint32_t family_sync(const Job& J, bool progress, uint32_t outer) {
+    Family* const F = J.family;
+    const uint32_t slot = outer % 3u;
+    if (progress) atomicOr(&F->progress[slot], 1u);
+    if (outer == 0 && J.fam_rank == 0) {        // the constant wire as setup leaves it
+        for (int i = 0; i < 4; ++i) { F->snap_lb[i] = J.lb[4 + i]; F->snap_ub[i] = J.ub[4 + i]; }
+        for (int i = 0; i < 8; ++i) F->snap_values[i] = J.values[8 + i];
+        F->snap_abz = J.abz[1]; F->snap_flags = J.flags[1]; F->snap_nvalues = J.nvalues[1];
+    }
+    __threadfence();
+    if (ld_agent(&F->abort)) return 2u;
+    const uint32_t g = ld_agent(&F->gen);
+    if (atomicAdd(&F->arrived, 1u) == J.fam_size - 1u) {
+        __hip_atomic_store(&F->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&F->progress[(outer + 2u) % 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (next written two barriers from now)
+        __threadfence();
+        atomicAdd(&F->gen, 1u);
+    } else {
+        const unsigned long long t0 = wall_clock64(), bound = 100000ull * 20ull * (unsigned long long)(J.bar_timeout_ms ? J.bar_timeout_ms : 200u);
+        while (ld_agent(&F->gen) == g) {
+            if (ld_agent(&F->abort)) return 2u;
+            if (wall_clock64() - t0 > bound) { __hip_atomic_store(&F->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 2u; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __threadfence();
+    return ld_agent(&F->progress[slot]) ? 1u : 0u;
+}
+
 }  // namespace ecne

@@ -727,7 +727,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         if (master && tid == 0) ctr->sync_steps = steps;
         if (job_barrier(J, &s_err)) break;
         steps = __hip_atomic_load(&ctr->sync_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev_steps == steps) break;   // (:708-711)
+        if (J.family) {
+            // one of the independent parts of a file: the loop goes on while ANY part made progress (the file's one loop, :708-711)
+            if (tid == 0) s_u32[2] = family_sync(J, prev_steps != steps, (uint32_t)outer);
+            __syncthreads();
+            const uint32_t go = s_u32[2];
+            __syncthreads();
+            if (go != 1u) break;
+        } else if (prev_steps == steps) break;   // (:708-711)
         prev_steps = steps;
         outer++;
         // ================= P1, P2 and the queue: master only, in the reference's order
@@ -827,6 +834,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     }
 
     // ---------------- verdict counts (:1558-1597), all workgroups
+    if (J.family && tid == 0 && (s_err || ctr->error)) __hip_atomic_store(&J.family->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     job_barrier(J, &s_err);
     if (J.flags != g_flags) for (uint32_t v = tid; v <= nV; v += ECNE_WG) g_flags[v] = J.flags[v];   // (LDS-resident flags: the host reads them back)
     uint32_t un = 0, nn = 0, ut = 0;

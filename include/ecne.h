@@ -72,6 +72,18 @@ int ecne_set_host_threads(int n);
  * files, parts of 2^18 terms, a trusted function whose mapped inputs / outputs tie with other variables) go through the host
  * path on their own. mode < 0 only reads. Returns the mode in effect. */
 int ecne_set_frontend(int mode);
+/* One file, several independent parts. A file whose rows fall into groups that share no variable but the constant wire (N circuits
+ * written into one file; the reference pops them from ONE queue, /root/reference/src/R1CSConstraintSolver.jl:805-1349, but a pop
+ * only ever pushes rows of its own group) can be solved as a batch of single-workgroup jobs whose outer loops (:706-1556) run in
+ * lockstep, and their states scattered back into the file's own arrays on the device: results, digests and bad rows are those of
+ * the file as one system, bit for bit (tests/test_gpu_split.py). 0 = never, 1 = from the second ecne_solve of a system on, when
+ * the first took long enough to pay for the plan (the default; ECNE_SPLIT in the environment sets the initial value), 2 = at the
+ * first solve. Only ecne_solve / a batch of one, queue_mode 0, no trusted functions; anything unusual in a part (an error, the
+ * constant wire's state written) and the file is solved again as one system. Returns ECNE_OK, ECNE_EINVAL for another mode. */
+int ecne_set_split(int mode);
+/* out4 = {parts the system's next solve runs as (0: as one system), groups of rows found, host + upload time of the plan in ms,
+ * 1 if a plan has been looked for}. */
+int ecne_system_split_info(const ecne_system* sys, double out4[4]);
 /* Timing of the calling thread's last trip through the front-end: out16 = {parse on device (0/1), upload ms, part-offset kernels ms,
  * row-fill kernels ms, parse total ms, file bytes, abstraction on device (0/1), pattern prep ms, fingerprint ms, window scan ms,
  * verification ms, compaction ms, candidate windows, matched windows (+ 1e6 x windows re-verified on the host), layout on device

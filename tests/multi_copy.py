@@ -78,3 +78,48 @@ def cached(rel, copies, directory=None):
     if not os.path.exists(path):
         generate(path, rel, copies)
     return path
+
+
+def generate_mixed(path, rels, interleave=False, extra_rows=()):
+    """Several fixture circuits (a name may repeat) written into ONE file with disjoint variables (only the constant wire is
+    shared), their rows one circuit after the other or, interleave=True, dealt out round-robin; extra_rows are appended as they
+    are (rows over the constant wire only, say). Pure Python (r1cs_py): for small files. Variable layout as in generate()."""
+    import fixtures
+    pieces = []
+    for rel in rels:
+        hdr, rows = r1cs_py.parse_file(fixtures.path(rel))
+        pieces.append((hdr["nWires"], hdr["nPubOut"], hdr["nPubIn"], hdr["nPrvIn"], rows))
+    tot_out = sum(p[1] for p in pieces)
+    tot_in = sum(p[2] + p[3] for p in pieces)
+    ob = ib = tb = 0
+    mapped = []
+    for nw, nout, npub, nprv, rows in pieces:
+        nin = npub + nprv
+
+        def m(w, nout=nout, nin=nin, ob=ob, ib=ib, tb=tb):
+            if w == 1:
+                return 1
+            if w <= 1 + nout:
+                return w + ob
+            if w <= 1 + nout + nin:
+                return (w - nout) + tot_out + ib
+            return (w - nout - nin) + tot_out + tot_in + tb
+        mapped.append([[[(m(v), c) for v, c in part] for part in row] for row in rows])
+        ob += nout
+        ib += nin
+        tb += nw - nout - nin
+    out_rows = []
+    if interleave:
+        k = 0
+        while any(k < len(r) for r in mapped):
+            for r in mapped:
+                if k < len(r):
+                    out_rows.append(r[k])
+            k += 1
+    else:
+        for r in mapped:
+            out_rows.extend(r)
+    out_rows.extend(extra_rows)
+    n_wires = sum(p[0] for p in pieces)
+    r1cs_py.write(path, n_wires, tot_out, sum(p[2] for p in pieces), sum(p[3] for p in pieces), out_rows)
+    return dict(n_rows=len(out_rows), n_vars=n_wires + 1)

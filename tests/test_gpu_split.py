@@ -1,0 +1,91 @@
+"""One file, several independent parts (include/ecne.h: ecne_set_split; csrc/ecne_engine.hip: SplitPlan). A file whose rows fall into
+groups that share nothing but the constant wire is solved as a batch of single-workgroup jobs in lockstep and scattered back: state,
+counters, bad rows and digest must be those of the file as one system -- the oracle's, bit for bit -- for copies of one circuit,
+for different circuits in one file, with the rows of the circuits interleaved (the reference's hash orders and P5's row pairs come
+from the file's own ids), and when a part raises (the file is then solved as one system)."""
+import os
+
+import numpy as np
+import pytest
+
+import ecneproject_amd as E
+import fixtures
+import multi_copy
+import orc
+from gpu_common import assert_bit_exact, build_system
+
+pytestmark = pytest.mark.gpu
+POS = "ecne_circomlib_tests/Poseidon@poseidon.r1cs"
+BABY = "ecne_circomlib_tests/BabyPbk@babyjub.r1cs"
+MIMC = "ecne_circomlib_tests/MiMCSponge@mimcsponge.r1cs"
+SPONGE = "ecne_circomlib_tests/EdDSAMiMCSpongeVerifier@eddsamimcsponge.r1cs"
+
+
+@pytest.fixture(autouse=True)
+def split_at_first_solve():
+    E.set_split(2)
+    yield
+    E.set_split(1)
+
+
+def solve_both_ways(path):
+    s = build_system(None, path=path)
+    g = E.solve_batch([s], fetch_states="both")[0]
+    info = s.split_info()
+    E.set_split(0)
+    s1 = build_system(None, path=path)
+    g1 = E.solve_batch([s1], fetch_states="both")[0]
+    assert s1.split_info()[0] == 0
+    E.set_split(2)
+    return s, g, info, g1
+
+
+@pytest.mark.parametrize("rels,interleave", [([POS] * 3, False), ([POS] * 3, True), ([POS, BABY, MIMC], False), ([BABY, POS, MIMC, POS], True)])
+def test_parts_of_one_file_bit_exact(tmp_path, rels, interleave):
+    rels = [r for r in rels if r in fixtures.all_r1cs()]
+    assert len(rels) >= 3
+    p = str(tmp_path / "mixed.r1cs")
+    multi_copy.generate_mixed(p, rels, interleave=interleave)
+    s, g, info, g1 = solve_both_ways(p)
+    assert info[0] == len(rels) and info[1] >= len(rels), info          # solved as that many parts
+    o = orc.run(p)
+    assert_bit_exact("split %s" % (interleave,), g, o)
+    assert_bit_exact("one system", g1, o)
+    assert g.digest == g1.digest
+    g2 = E.solve_batch([s], fetch_states="both")[0]                      # the resident plan again
+    assert g2.digest == g.digest and g2.summary.pops == g.summary.pops
+
+
+def test_many_copies_fill_bins(tmp_path):
+    """more groups than bins would be fine too: 12 copies of Poseidon, parts = groups here; every variable's state comes back"""
+    p = multi_copy.cached(POS, 12)
+    s, g, info, g1 = solve_both_ways(p)
+    assert info[0] == 12
+    assert_bit_exact("12 x Poseidon", g, orc.run(p))
+    assert g.digest == g1.digest
+
+
+def test_a_raising_part_means_one_system(tmp_path):
+    """a row over the constant wire alone with an empty C raises BoundsError when it is popped (:875-942): the part that holds it
+    leaves, the others follow, the file is solved as one system and reports what the reference reports"""
+    p = str(tmp_path / "raise.r1cs")
+    multi_copy.generate_mixed(p, [POS, POS, POS], extra_rows=[[[(1, 1)], [(1, 1)], []]])
+    s = build_system(None, path=p)
+    o = orc.run(p)
+    assert o.status != 0
+    g = E.solve_batch([s])[0]
+    assert g.status == o.status
+    assert s.split_info()[0] == 0 and s.split_info()[3]              # the plan was made, used once and dropped
+
+
+def test_medium_chains_side_by_side():
+    """what the plan is for: N x EdDSAMiMCSponge in one file -- a team on device-memory state as one system, N LDS-resident
+    workgroups as parts"""
+    p = multi_copy.cached(SPONGE, 3)
+    s, g, info, g1 = solve_both_ways(p)
+    assert info[0] == 3
+    assert g.digest == g1.digest
+    assert tuple(g.counts()) == tuple(g1.counts())
+    assert g.summary.pops == g1.summary.pops == 3 * 28073 and g.summary.outer_iterations == g1.summary.outer_iterations
+    assert np.array_equal(g.bad_rows, g1.bad_rows)
+    assert g.summary.device_ms < g1.summary.device_ms

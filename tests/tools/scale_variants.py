@@ -32,17 +32,22 @@ for name, mk, trusted in cases:
     g = E.solve_batch([s])[0]
     t_first = time.perf_counter() - t0
     ms = []
-    for _ in range(3):
+    for _ in range(3):     # (from the second solve on a file of independent circuits runs as parts: ecne_set_split, include/ecne.h)
         r = E.solve_batch([s], fetch_states=False)[0]
         ms.append(r.summary.device_ms)
+    parts, groups, plan_ms, _tried = s.split_info()
+    g_parts = E.solve_batch([s])[0] if parts else None
     t0 = time.perf_counter()
     o = orc.run(p, [fixtures.path(t) for t in tr], nm)
     t_or = time.perf_counter() - t0
     assert_bit_exact(name, g, o)
+    if g_parts is not None:
+        assert_bit_exact(name + " as parts", g_parts, o)
     sm = g.summary
     sd = list(sm.sched)
     n_multi = int(sm.rule_hits[14]) >> 16
     print(json.dumps({"case": name, "rows_main": int(s.info.n_rows_main), "rows": len(s), "bit_exact": True, "verdict": bool(g.function_good),
+                      "kernel_ms_first_solve": round(float(sm.device_ms), 3), "parts": parts, "groups": groups, "plan_ms": round(plan_ms, 1),
                       "kernel_ms": round(min(ms), 3), "constraints_per_s": round(int(s.info.n_rows_main) / (min(ms) * 1e-3)),
                       "file_to_verdict_ms": round(t_first * 1e3, 1), "pops": int(sm.pops), "outer_iterations": int(sm.outer_iterations),
                       "rounds": int(sm.rule_hits[13]), "multi_workgroup_rounds": n_multi, "multi_ms": round(float(sm.queue_ms[7]), 2),
