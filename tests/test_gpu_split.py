@@ -89,3 +89,22 @@ def test_medium_chains_side_by_side():
     assert g.summary.pops == g1.summary.pops == 3 * 28073 and g.summary.outer_iterations == g1.summary.outer_iterations
     assert np.array_equal(g.bad_rows, g1.bad_rows)
     assert g.summary.device_ms < g1.summary.device_ms
+
+
+def test_fuzz_systems_as_parts(tmp_path):
+    """random small systems (tests/fuzz_r1cs.py: every rule, zero coefficients, rows over the constant wire alone, systems that
+    raise) fall into several groups more often than not: each solved as parts where a plan exists, against the oracle"""
+    import fuzz_r1cs
+    n_split = 0
+    for seed in range(360):
+        p = str(tmp_path / ("%d.r1cs" % seed))
+        fuzz_r1cs.write(p, fuzz_r1cs.make(seed) if seed < 300 else fuzz_r1cs.make_wide(seed - 300))
+        s = E.System(E.R1CS(p))
+        g = E.solve_batch([s])[0]
+        o = orc.run(p)
+        assert_bit_exact("fuzz %d" % seed, g, o)
+        if s.split_info()[0]:
+            n_split += 1
+            g2 = E.solve_batch([s])[0]                 # the resident plan again
+            assert_bit_exact("fuzz %d again" % seed, g2, o)
+    assert n_split >= 40, n_split
