@@ -438,6 +438,9 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             if (tid == 0 && left) atomicAdd(&ctr->d_pend2[par], (unsigned int)left);
         }
         if ((err = job_barrier(J, s_err))) return err;
+#ifdef ECNE_ROUNDLOG
+        if (g == 0) printf("RD level %u n %u pending %u flag %u\n", level, n_eff, ld_agent(&ctr->d_pend2[par]), lflag);
+#endif
         if (ld_agent(&ctr->d_pend2[par]) == 0) {
             if (g == 0) { ctr->d_flag[par] = 0; ctr->d_cut[par] = 0xFFFFFFFFu; }     // (all read before this level's last barrier)
             break;

@@ -834,7 +834,9 @@ __device__ __noinline__ int multi_chain(const Job& J, uint32_t K, ChunkShared& S
         st.rows += cm;
         st.sd[cm < 64 ? 0 : cm < 4096 ? 1 : 2] += 1;
         st.streak = (cm == nm && (!drain || levels <= 2 || K > 1)) ? st.streak + cm : 0;
-        if (drain && cm == nm) drain_window_update(levels, nm, cap_n, st.mwindow);
+        // (a drain round is never cut by a dependency: cm < nm means a long row the round does not take sits at rank cm -- the
+        //  window stays as it is; shrinking it there cost ecdsa_like(26) a ramp of three extra rounds, 4 096 -> 16 384 -> 65 536)
+        if (drain) { if (cm == nm) drain_window_update(levels, nm, cap_n, st.mwindow); }
         else multi_window_update(cm, nm, cap_n, st.mwindow, st.window);
         if (K == 1 && (cm < 2 * levels || cm < nm)) break;      // a solo drain that runs fewer than two rows per level is a chain: back to the fast rounds
         if (sub && st.tail - st.head > 2 * cap_n) break;        // the frontier has outgrown the team: the master commands a larger one
@@ -1094,6 +1096,22 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         if (v2 && J.nwg > 1 && !declined_wide && (avail < multi_min(J) || streak < streak_min)) {
             const uint32_t cap_ = v2wg ? (uint32_t)ECNE_WG : 64u;        // below the multi-workgroup threshold the fast rounds take the frontier
             n = avail < cap_ ? avail : cap_;
+        }
+        else if (TEAM && v2 && J.nwg > 1 && !declined_wide && avail > 64 && !drain_eager(J)) {
+            // A wide frontier about to go to all workgroups: a long row the rounds do not take (a binary decomposition, say) among the
+            // next 64 entries would end that round in front of it after everybody has loaded and marked a whole window (ecdsa_like(26):
+            // 104 296 rows examined, 16 committed, 144 us) -- the fast round takes the rows in front of it instead.
+            if (w == 0) {
+                const uint32_t r_ = J.queue[(q.head + (uint32_t)lane) & J.qmask];
+                const uint32_t sh_ = J.rinfo[r_].shape;
+                const bool alone_ = (sh_ & SH_BIG) && !J.solved[r_] && !big_plain(sh_);
+                const uint64_t m_ = __ballot(alone_) & ~1ull;      // (the row at the head itself: head_alone below)
+                if (lane == 0) S.bl_tmp[0] = m_ ? (uint32_t)(__ffsll((long long)m_) - 1) : 0u;
+            }
+            __syncthreads();
+            const uint32_t p_ = S.bl_tmp[0];
+            __syncthreads();
+            if (p_) n = p_;
         }
         if (v2wg && J.nwg == 1 && n > ECNE_WG) n = ECNE_WG;
         const bool eager = TEAM && drain_eager(J) && avail >= 2;
