@@ -1541,7 +1541,8 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                 static const bool sub_off = []() { const char* e = getenv("ECNE_SUBTEAM"); return e && atoi(e) == 0; }();      // bit 3: rounds always on all workgroups
                 if (sub_off) hj[i].drain |= 8u;
                 static const bool lv_off = []() { const char* e = getenv("ECNE_LEVEL"); return e && atoi(e) == 0; }();      // level rounds (level.hip.hpp) off: A/B runs
-                hj[i].lv_off = lv_off ? 1u : 0u;
+                static const bool crew_off = []() { const char* e = getenv("ECNE_CREW"); return e && atoi(e) == 0; }();      // crew rounds (crew.hip.hpp) off: A/B runs
+                hj[i].lv_off = (lv_off ? 1u : 0u) | (crew_off ? 2u : 0u);
             }
             hj[i].family = nullptr; hj[i].fam_rank = 0; hj[i].fam_size = 0;
             if (sl && i + 1 < n) { hj[i].family = sl->d_family; hj[i].fam_rank = (uint32_t)i; hj[i].fam_size = (uint32_t)(n - 1); }

@@ -42,8 +42,12 @@ static_assert(4u * (ECNE_LV_MARKS + ECNE_LV_QM + ECNE_LV_CAND) <= ECNE_W2_BYTES,
 #ifndef ECNE_SOLO_RATIO
 #define ECNE_SOLO_RATIO 8       // (rounds.hip.hpp: solo drains when a narrow round committed less than 1 / ECNE_SOLO_RATIO of a well-filled window)
 #endif
-__device__ __forceinline__ bool level_rounds_on(const Job& J) { return J.lv_off == 0; }
-enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_REFILL = 4, LV_CUT = 5 };
+__device__ __forceinline__ bool level_rounds_on(const Job& J) { return (J.lv_off & 1u) == 0; }
+// LV_FAT: more rows queued than a crew round takes (crew.hip.hpp) -- level rounds until LV_NARROW: the frontier is narrow again
+enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_REFILL = 4, LV_CUT = 5, LV_FAT = 6, LV_NARROW = 7 };
+#ifndef ECNE_CREW_MAX
+#define ECNE_CREW_MAX 8u          // rows per crew round = wavefronts of the workgroup
+#endif
 
 // Wavefront 0 of a single-workgroup job whose flags / in_queue tags are LDS-resident (chain_ok). head / tail: the queue cursors, in
 // and out. Returns why it stopped (LV_*); *n_rounds = rounds run.
@@ -53,7 +57,7 @@ enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_
 // dependency cut to an eighth returns LV_CUT (chains side by side: the caller's solo drain rounds take those).
 template <bool LDS>
 __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, uint32_t& tail_io, uint32_t max_rounds, bool wide_ok, bool cut_exit, LaneCtr& C,
-                                              uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, unsigned long long* prof) {
+                                              uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, unsigned long long* prof, bool narrow_exit = false) {
     const uint32_t lane = (uint32_t)lane_id();
     auto uni = [](const void* p) -> uint64_t {
         const uint64_t x = (uint64_t)p;
@@ -129,6 +133,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         const uint32_t avail = tail - head;
         if (!wide_ok && avail > (LDS ? ECNE_LV_WIDE_AVAIL : ECNE_LVG_WIDE_AVAIL)) { why = LV_WIDE; break; }      // a wide frontier: the rounds on the whole workgroup first
         if (rounds >= max_rounds) { why = LV_ROUNDS; break; }
+        if (narrow_exit && rounds && avail <= ECNE_CREW_MAX) { why = LV_NARROW; break; }      // a narrow frontier again: crew rounds (crew.hip.hpp)
         uint32_t n = avail < 64u ? avail : 64u;
         if (head + n > mtop) {                       // the window reaches beyond the mirror
             if (mtop - head < 16u && mtop != tail) { why = LV_REFILL; break; }

@@ -4,6 +4,7 @@
 #include "job_barrier.hip.hpp"
 #include "chain.hip.hpp"
 #include "level.hip.hpp"
+#include "crew.hip.hpp"
 
 namespace ecne {
 
@@ -917,52 +918,71 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             const uint32_t lv_max = lv_wide ? burst : (1u << 20);
             const bool wide = lv_wide;
             lv_wide = false; if (wide) burst = 0;
-            if (w == 0) {
-                // A row the level rounds do not take (a constant row, 1 = x + y, a short binary decomposition, a bound on the limbs) is
-                // popped right here by the general executor and the level rounds go on -- the way back through the policy and the chain
-                // executor's burst costs four times the pop. A live long row goes back: the whole workgroup pops it (head_big).
-                // (Tried: those shapes inside the level round through fast_decide, inline, out of line and as a second instantiation a
-                //  job switches to -- bit-exact, and slower every time: the loop is at its register limits, 248 VGPRs and scalar
-                //  registers already spilled to lanes; Poseidon 2.9 -> 3.4 us per level, secp256k1 7.2 -> 8.0 ms.)
-                uint32_t hd = q.head, tl = q.tail, nr = 0, why, left = lv_max, gdone = 0, gnnz = 0, big = 0;
-                unsigned long long st = 0, nu = 0, ht[16];
-                for (int i = 0; i < 16; ++i) ht[i] = 0;
-                for (;;) {
-                    uint32_t nr1 = 0;
-                    why = level_rounds<true>(J, hd, tl, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0]);
-                    nr += nr1;
-                    if (why != LV_DECLINED || gdone >= 256u) break;
-                    const uint32_t rr = J.queue[hd & J.qmask];
-                    const bool sv = J.solved[rr] != 0;
-                    // (tried: the empty pops of a live long decomposition row settled here from one wavefront walk -- secp256k1 7.19 -> 7.05 ms,
-                    //  EdDSAPoseidon 5.24 -> 5.37, EdDSAMiMCSponge 15.2 -> 15.5: the level rounds then go on where rounds on the workgroup do better)
-                    if ((J.rinfo[rr].shape & SH_BIG) && !sv) { big = 1; break; }
-                    hd++;
-                    if (lane == 0) J.inq[rr] = 0;
-                    wg_fence();
-                    ++gdone;
-                    gnnz += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
-                    if (!sv) {
-                        QState qq;
-                        qq.head = hd; qq.tail = tl; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
-                        exec_row(J, qq, rr, ht, st, nu);
+            // Narrow frontiers (up to eight queued rows) go to crew rounds -- one wavefront per row, all eight wavefronts (crew.hip.hpp);
+            // wider ones to level rounds on wavefront 0 until they are narrow again.
+            const bool crew = crew_on(J);
+            uint32_t hd = q.head, tl = q.tail, nr = 0, why = LV_FAT, ngen = 0, bigf = 0;
+            for (;;) {
+                if (crew && tl != hd && tl - hd <= ECNE_CREW_MAX) {
+                    uint32_t nr1 = 0, ng1 = 0, bg1 = 0;
+                    const uint32_t left = lv_max > nr + ngen ? lv_max - nr - ngen : 1u;
+                    why = crew_rounds(J, S, hd, tl, left, wide, C, my_pops, my_nnz, &nr1, &ng1, &bg1);
+                    nr += nr1; ngen += ng1;
+                    if (bg1) bigf = 1;
+                    if (why != LV_FAT) break;
+                }
+                if (w == 0) {
+                    // A row the level rounds do not take (a constant row, 1 = x + y, a short binary decomposition, a bound on the limbs) is
+                    // popped right here by the general executor and the level rounds go on -- the way back through the policy and the chain
+                    // executor's burst costs four times the pop. A live long row goes back: the whole workgroup pops it (head_big).
+                    // (Tried: those shapes inside the level round through fast_decide, inline, out of line and as a second instantiation a
+                    //  job switches to -- bit-exact, and slower every time: the loop is at its register limits, 248 VGPRs and scalar
+                    //  registers already spilled to lanes; Poseidon 2.9 -> 3.4 us per level, secp256k1 7.2 -> 8.0 ms.)
+                    uint32_t hd1 = hd, tl1 = tl, nr0 = 0, why1, left = lv_max > nr + ngen ? lv_max - nr - ngen : 1u, gdone = 0, gnnz = 0, big = 0;
+                    unsigned long long st = 0, nu = 0, ht[16];
+                    for (int i = 0; i < 16; ++i) ht[i] = 0;
+                    for (;;) {
+                        uint32_t nr1 = 0;
+                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew);
+                        nr0 += nr1;
+                        if (why1 != LV_DECLINED || gdone >= 256u) break;
+                        const uint32_t rr = J.queue[hd1 & J.qmask];
+                        const bool sv = J.solved[rr] != 0;
+                        // (tried: the empty pops of a live long decomposition row settled here from one wavefront walk -- secp256k1 7.19 -> 7.05 ms,
+                        //  EdDSAPoseidon 5.24 -> 5.37, EdDSAMiMCSponge 15.2 -> 15.5: the level rounds then go on where rounds on the workgroup do better)
+                        if ((J.rinfo[rr].shape & SH_BIG) && !sv) { big = 1; break; }
+                        hd1++;
+                        if (lane == 0) J.inq[rr] = 0;
                         wg_fence();
-                        tl = qq.tail;
+                        ++gdone;
+                        gnnz += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
+                        if (!sv) {
+                            QState qq;
+                            qq.head = hd1; qq.tail = tl1; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
+                            exec_row(J, qq, rr, ht, st, nu);
+                            wg_fence();
+                            tl1 = qq.tail;
+                        }
+                        if (J.ctr->error) { why1 = LV_ROUNDS; break; }
+                        if (hd1 == tl1) { why1 = LV_EMPTY; break; }
+                        if (crew && tl1 - hd1 <= ECNE_CREW_MAX) { why1 = LV_NARROW; break; }
+                        left = left > nr1 + 1u ? left - nr1 - 1u : 1u;
                     }
-                    if (J.ctr->error) { why = LV_ROUNDS; break; }
-                    if (hd == tl) { why = LV_EMPTY; break; }
-                    left = left > nr1 + 1u ? left - nr1 - 1u : 1u;
+                    if (lane == 0) {
+                        S.acc[0] += st; S.acc[1] += nu;
+                        for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
+                        S.acc[10] += gdone; S.acc[11] += gnnz;
+                        S.head = hd1; S.tail = tl1; S.nbig = why1; S.bl_tmp[0] = nr0; S.bl_tmp[1] = big; S.bl_tmp[2] = gdone;
+                    }
                 }
-                if (lane == 0) {
-                    S.acc[0] += st; S.acc[1] += nu;
-                    for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
-                    S.acc[10] += gdone; S.acc[11] += gnnz;
-                    S.head = hd; S.tail = tl; S.nbig = why; S.bl_tmp[0] = nr; S.bl_tmp[1] = big;
-                }
+                __syncthreads();
+                why = S.nbig; nr += S.bl_tmp[0]; ngen += S.bl_tmp[2]; hd = S.head; tl = S.tail;
+                if (S.bl_tmp[1]) bigf = 1;
+                __syncthreads();
+                if (why != LV_NARROW) break;
             }
-            __syncthreads();
-            const uint32_t why = S.nbig, nr = S.bl_tmp[0], done = S.head - q.head;
-            if (S.bl_tmp[1]) head_big = true;
+            const uint32_t done = hd - q.head;
+            if (bigf) head_big = true;
 #if defined(ECNE_FINE_TICKS) && !defined(ECNE_LVPROF)
             if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: level rounds in the fast rounds' slots
 #endif
@@ -971,8 +991,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #endif
             pops_total += done;
             hits[13] += nr;
-            q.head = S.head; q.tail = S.tail;
-            __syncthreads();
+            q.head = hd; q.tail = tl;
             if (why == LV_DECLINED && !head_big) { burst = lv_burst; lv_chain = true; if (nr < 2 && lv_burst < 64u) lv_burst *= 2; else if (nr >= 2) lv_burst = 1; }
             QTICK(6);
             if (why == LV_REFILL) lv_wide = true, burst = lv_max > nr ? lv_max - nr : 1u;      // (the mirrored part is used up: the same call again)
