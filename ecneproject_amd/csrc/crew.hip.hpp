@@ -32,7 +32,7 @@ namespace ecne {
 
 static_assert(ECNE_CREW_MAX <= ECNE_NWAVES, "one wavefront per row");
 #define ECNE_CREW_X (ECNE_LV_MARKS + ECNE_LV_QM + ECNE_LV_CAND)      // exchange words behind the level rounds' tables
-static_assert(4u * (ECNE_CREW_X + 32u) <= ECNE_W2_BYTES, "the crew's exchange words live in the fast wavefront round's LDS block");
+static_assert(4u * (ECNE_CREW_X + 32u + 128u) <= ECNE_W2_BYTES, "the crew's exchange words live in the fast wavefront round's LDS block");
 static_assert(ECNE_CREW_MAX * 64u <= ECNE_LV_CAND, "every row of a crew round can have 64 candidates");
 __device__ __forceinline__ bool crew_on(const Job& J) { return (J.lv_off & 3u) == 0; }
 
@@ -40,9 +40,10 @@ __device__ __forceinline__ bool crew_on(const Job& J) { return (J.lv_off & 3u) =
 // head / tail: the queue cursors, in and out (the same values on every thread). Returns why it stopped (LV_*); *n_rounds = rounds
 // run, *n_general = rows popped by the general executor in between, *big_out = 1: the row at the head is a live long row.
 __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint32_t& head_io, uint32_t& tail_io, uint32_t max_rounds, bool wide_ok,
-                                             LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, uint32_t* n_general, uint32_t* big_out) {
+                                             LaneCtr& C, uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, uint32_t* n_general, uint32_t* big_out, bool warm, uint32_t& mtop_io) {
     // (the wavefront's number as a scalar: everything that depends on it -- is there a row for me? am I in the prefix? -- is a scalar branch then)
     const uint32_t lane = (uint32_t)lane_id(), rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tid = threadIdx.x;
+    const uint32_t NONE = 0xFFFFFFFFu;
     auto uni = [](const void* p) -> uint64_t {
         const uint64_t x = (uint64_t)p;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
@@ -64,18 +65,28 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
     uint32_t* const qm = tb + ECNE_LV_MARKS;                   // queue mirror
     uint32_t* const cl = tb + ECNE_LV_MARKS + ECNE_LV_QM;      // candidate list
     uint32_t* const X_ROW = tb + ECNE_CREW_X;                  // the window's rows
-    uint32_t* const X_SLOW = X_ROW + 8;                        // per rank: 0 taken, 1 the general executor's, 2 a live long row, 3 more than 64 candidates
-    uint32_t* const X_BLK = X_ROW + 16;                        // per rank: bit 0 blocked, candidates << 8
+    uint32_t* const X_ST = X_ROW + 8;                          // per rank: 0 taken, 1 the general executor's, 2 a live long row, 3 more than 64 candidates; candidates << 8
     uint32_t* const X_CTL = X_ROW + 24;                        // wavefront 0's results: tail, mirror top, error
-    auto wslot = [](uint32_t v) -> uint32_t { return (v * 2654435761u) >> 24; };
-    const uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t* const X_RV = X_ROW + 32;                         // per rank 16 words: the variables whose flag bytes the pop has read (lane = word), 0xFFFFFFFF = none
+    // write marks: two tables of 128 slots, by round parity -- a round's marks are taken back while the next round already sets its own
+    auto wslot = [](uint32_t v, uint32_t par) -> uint32_t { return ((v * 2654435761u) >> 25) | (par << 7); };
 
     auto sc_ = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };      // a value every lane holds, as a scalar
     uint32_t head = sc_(head_io), tail = sc_(tail_io), rounds = 0, gdone = 0, why = LV_EMPTY, big = 0;
     max_rounds = sc_(max_rounds);
     const bool wide = sc_(wide_ok ? 1u : 0u) != 0;
     // (counters are wave-uniform here: lane 0 of every wavefront folds its own into the caller's per-thread counters at the exit)
+    // steps, nuniq, hits[0], hits[1], hits[3], hits[4] travel as six 10-bit fields of one 64-bit word (dd per pop, acc per 128 rounds)
     uint32_t c_steps = 0, c_nuniq = 0, c_h0 = 0, c_h1 = 0, c_h3 = 0, c_h4 = 0, c_pops = 0, c_nnz = 0;
+    unsigned long long acc = 0;
+    const unsigned long long D_ST = 1ull, D_NU = 1ull << 10, D_H0 = 1ull << 20, D_H1 = 1ull << 30, D_H3 = 1ull << 40, D_H4 = 1ull << 50;
+    auto fold = [&]() {
+        c_steps += (uint32_t)(acc & 1023u); c_nuniq += (uint32_t)((acc >> 10) & 1023u); c_h0 += (uint32_t)((acc >> 20) & 1023u);
+        c_h1 += (uint32_t)((acc >> 30) & 1023u); c_h3 += (uint32_t)((acc >> 40) & 1023u); c_h4 += (uint32_t)((acc >> 50) & 1023u);
+        acc = 0;
+    };
+    uint32_t lvl = 0;
+    uint32_t pm0 = NONE, pm1 = NONE;             // my write marks of the last round (slots), taken back at the top of the next one
     // the general executor's counters (wavefront 0)
     unsigned long long g_st = 0, g_nu = 0, g_ht[16];
     for (int i = 0; i < 16; ++i) g_ht[i] = 0;
@@ -88,12 +99,19 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
 #define CWT(k) do { } while (0)
 #endif
     // ---- entry: the tables of the fast wavefront round become ours (clean on entry, restored on exit); the mirror is filled from the ring
-    if (tid < ECNE_LV_MARKS) wm[tid] = NONE;
-    uint32_t mtop = head + ((tail - head) < ECNE_LV_QM ? (tail - head) : ECNE_LV_QM);
-    if (tid < mtop - head) qm[(head + tid) & (ECNE_LV_QM - 1)] = queue[(head + tid) & qmask];
-    __syncthreads();
+    // (warm: the level rounds left marks and mirror as this loop keeps them)
+    uint32_t mtop;
+    if (sc_(warm ? 1u : 0u)) mtop = sc_(mtop_io);
+    else {
+        if (tid < ECNE_LV_MARKS) wm[tid] = NONE;
+        mtop = head + ((tail - head) < ECNE_LV_QM ? (tail - head) : ECNE_LV_QM);
+        if (tid < mtop - head) qm[(head + tid) & (ECNE_LV_QM - 1)] = queue[(head + tid) & qmask];
+        __syncthreads();
+    }
     CWT(0);        // entry
     for (;;) {
+        // (my marks of the last round: everybody has looked at them -- a barrier lies behind us -- and this round's go to the other table)
+        if (lane == 0) { if (pm0 != NONE) { wm[pm0] = NONE; pm0 = NONE; } if (pm1 != NONE) { wm[pm1] = NONE; pm1 = NONE; } }
         if (head == tail) { why = LV_EMPTY; break; }
         const uint32_t avail = tail - head;
         if (!wide && avail > ECNE_LV_WIDE_AVAIL) { why = LV_WIDE; break; }
@@ -112,7 +130,8 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
         const bool mine = rank < n;
         // ---- 1-3: my row, decided. Outputs (wave-uniform): ob -- bit 0 the pop does something, 1 / 2 flag byte of wv0 / wv1 written, 3 / 4 their
         // bounds become [0,1], 5 bit check solved (values = the two roots), 6 orientation byte written, 7 its new value; dd -- counters, 4 bits each
-        uint32_t row = 0, slowk = 0, nnz_d = 0, ob = 0, dd = 0;
+        uint32_t row = 0, slowk = 0, nnz_d = 0, ob = 0;
+        unsigned long long dd = 0;
         uint32_t rv = NONE;                          // per lane: a variable whose flag byte this pop has read
         uint32_t cv = 0, ncand = 0;                  // lane i: target row of candidate i
         uint32_t wv0 = 0, wv1 = 0, wf = 0, validx = 0;
@@ -185,7 +204,7 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                 if (!m_nuab && __popcll(m_nuc) == 1) {
                     r1_src = (uint32_t)(__ffsll((long long)m_nuc) - 1);
                     wv0 = rdlane(v, r1_src); wf = rdlane(f, r1_src) | 3u; ob |= 2u;
-                    dd += 0x111u;          // steps, nuniq, h0
+                    dd += D_ST + D_NU + D_H0;
                     emit(r1_src);
                     r1_fired = true;
                 }
@@ -206,7 +225,7 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                                 if (shape & SH_R2_IS01) { nf = (nf & ~12u) | 4u; ob |= 8u; }      // make_bounds (:923-927)
                                 wv0 = x; wf = nf;
                                 emit(src);
-                                dd += 0x1001u;     // steps, h1
+                                dd += D_ST + D_H1;
                             }
                         }
                     }
@@ -235,12 +254,12 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                                 if (!(fn & 4u)) {                           // pivot still [0,p-1]: ub > 1 -> [0,1]  (:1035-1046)
                                     ob |= n_is_a ? 8u : 16u;
                                     fn = (fn & ~12u) | 4u | 2u;
-                                    dd += 0x10001u;    // steps, h3
+                                    dd += D_ST + D_H3;
                                     emit(n_is_a ? l1 : l2);
                                 }
                                 if ((fn & 1u) && !(fo_ & 1u)) {             // pivot unique: the other one becomes unique (:1049-1067)
                                     fo_ |= 3u;
-                                    dd += 0x10011u;    // steps, nuniq, h3
+                                    dd += D_ST + D_NU + D_H3;
                                     emit(n_is_a ? l2 : l1);
                                 }
                             }
@@ -249,14 +268,14 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                         // R5 (:1078-1146): bounds are [0,1] or [0,p-1] here, equal iff the class bits agree
                         if (((fa ^ fb) & 4u) || ((fa ^ fb) & 1u)) {
                             bool cha = false, chb = false;
-                            if ((fa ^ fb) & 1u) { fa |= 3u; dd += 0x20u; cha = chb = true; }        // key_1 written twice (sic, :1107-1108)
+                            if ((fa ^ fb) & 1u) { fa |= 3u; dd += 2 * D_NU; cha = chb = true; }        // key_1 written twice (sic, :1107-1108)
                             const bool wa = ((fa ^ fb) & 4u) && !(fa & 4u), wb = ((fa ^ fb) & 4u) && !(fb & 4u);
                             if (wa) { fa = (fa & ~12u) | 4u | 2u; ob |= 8u; }
                             if (wb) { fb = (fb & ~12u) | 4u | 2u; ob |= 16u; }
                             cha |= wa; chb |= wb;
                             const uint32_t nset = (cha ? 1u : 0u) + (chb ? 1u : 0u);
-                            dd += nset;
-                            if (nset) dd += 0x100000u;     // h4
+                            dd += nset * D_ST;
+                            if (nset) dd += D_H4;
                             if (sw) { if (chb) emit(l2); if (cha) emit(l1); }
                             else { if (cha) emit(l1); if (chb) emit(l2); }
                         }
@@ -278,44 +297,41 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
             if (slowk) { ob = 0; ncand = 0; rv = NONE; }
         }
         CWT(3);        // decisions
-        // ---- 4: write marks | barrier | blocked iff an earlier rank writes what I read
-        const bool marks = (ob & 1u) && n > 1u;
+        // ---- 4: write marks, read sets and what else the others have to know | barrier | every wavefront works out the whole prefix: lane 8 r + j
+        // looks up entries j and j + 8 of rank r's read set -- blocked iff an EARLIER rank writes what the row reads
+        const uint32_t par = (lvl++) & 1u;           // (every pass of the loop, also the ones that end in the general executor: the marks taken back at the top are the other table's)
+        if (lane < 16u) X_RV[16u * rank + lane] = rv;
         if (lane == 0) {
             X_ROW[rank] = row;
-            X_SLOW[rank] = slowk;
-            if (marks && (ob & 2u)) atomicMin(&wm[wslot(wv0)], rank);
-            if (marks && (ob & 4u)) atomicMin(&wm[wslot(wv1)], rank);
+            X_ST[rank] = slowk | (ncand << 8);
+            if ((ob & 3u) == 3u && n > 1u) { pm0 = wslot(wv0, par); atomicMin(&wm[pm0], rank); }
+            if ((ob & 5u) == 5u && n > 1u) { pm1 = wslot(wv1, par); atomicMin(&wm[pm1], rank); }
         }
         __syncthreads();
-        uint32_t blocked = 0;
-        if (mine && rank > 0u && !slowk) {
-            const uint32_t m = rv != NONE ? wm[wslot(rv)] : NONE;
-            blocked = __ballot(m < rank) != 0 ? 1u : 0u;
-        }
-        if (lane == 0) X_BLK[rank] = blocked | (ncand << 8);
-        __syncthreads();
-        CWT(4);        // marks + check (two barriers)
-        // ---- the prefix: ends in front of the first row that is blocked or not taken
         uint32_t c, base, M;
         {
-            const uint32_t xs = lane < 8u ? X_SLOW[lane] : 0u, xb = lane < 8u ? X_BLK[lane] : 0u;
-            const uint64_t stop = __ballot(lane < n && (xs != 0u || (xb & 1u)));
-            c = stop ? (uint32_t)(__ffsll((long long)stop) - 1) : n;
+            const uint32_t r_ = lane >> 3, j_ = lane & 7u;
+            const uint32_t v0 = X_RV[16u * r_ + j_], v1 = X_RV[16u * r_ + j_ + 8u];
+            const uint32_t xs = lane < 8u ? X_ST[lane] : 0u;
+            const uint32_t m0 = v0 != NONE ? wm[wslot(v0, par)] : NONE, m1 = v1 != NONE ? wm[wslot(v1, par)] : NONE;
+            const uint64_t bm = __ballot(r_ < n && (m0 < r_ || m1 < r_));                 // byte r: rank r is blocked
+            const uint64_t sm = __ballot(lane < n && (xs & 0xFFu) != 0u);                  // bit r: rank r is not taken by this loop
+            const uint64_t nz = (((bm & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | bm) & 0x8080808080808080ull;
+            const uint32_t cb = nz ? (uint32_t)(__ffsll((long long)nz) - 1) >> 3 : n, cs = sm ? (uint32_t)(__ffsll((long long)sm) - 1) : n;
+            c = cb < cs ? cb : cs;
             // candidates of the ranks below mine / of the whole prefix: an inclusive scan over lanes 0..7 (DPP row shifts, zero fill)
-            int sc = lane < c ? (int)(xb >> 8) : 0;
+            int sc = lane < c ? (int)(xs >> 8) : 0;
             sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xF, 0xF, true);
             sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xF, 0xF, true);
             sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xF, 0xF, true);
             M = rdlane((uint32_t)sc, 7);
             base = rank ? rdlane((uint32_t)sc, rank - 1u) : 0u;
         }
-        if (lane == 0) {          // (marks are the round's: the writers take them back)
-            if (marks && (ob & 2u)) wm[wslot(wv0)] = NONE;
-            if (marks && (ob & 4u)) wm[wslot(wv1)] = NONE;
-        }
+        CWT(4);        // marks + check (one barrier)
         if (c == 0u) {
             // ---- the row at the head is not ours
-            const uint32_t k0 = sc_(X_SLOW[0]);
+            const uint32_t k0 = sc_(X_ST[0]) & 0xFFu;
+            if (k0 == 3u) { why = LV_FAT; break; }      // more candidates than a wavefront has lanes: a level round resolves up to 960
             if (k0 != 1u || gdone >= 256u) { why = LV_DECLINED; big = k0 == 2u ? 1u : 0u; break; }
             // the general executor pops it right here (wavefront 0; the ring has to hold the whole queue for it)
             __syncthreads();
@@ -369,7 +385,7 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                     if ((ob & 8u) && lane < 8u) { uint64_t* const p = (lane < 4u ? J.lb : J.ub) + 4ull * wv0; p[lane & 3u] = lane == 4u ? 1ull : 0ull; }
                     if ((ob & 16u) && lane >= 8u && lane < 16u) { uint64_t* const p = (lane < 12u ? J.lb : J.ub) + 4ull * wv1; p[lane & 3u] = lane == 12u ? 1ull : 0ull; }
                 }
-                c_steps += dd & 15u; c_nuniq += (dd >> 4) & 15u; c_h0 += (dd >> 8) & 15u; c_h1 += (dd >> 12) & 15u; c_h3 += (dd >> 16) & 15u; c_h4 += (dd >> 20) & 15u;
+                acc += dd;
                 if (lane < ncand) cl[base + lane] = (rank << 24) | cv;
             }
         }
@@ -404,26 +420,30 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                     if (mt == new_tail) { const uint32_t room = ECNE_LV_QM - (new_tail - (head + c)); mt += nw < room ? nw : room; }
                     new_tail += nw;
                 }
-                // rows of the prefix that nobody re-queued are out of the queue now
-                if (lane < c) { const uint32_t r_ = X_ROW[lane]; if (Q[r_] >= 2u) Q[r_] = 0; }
                 if (lane == 0) { X_CTL[0] = new_tail; X_CTL[1] = mt; }
             }
             __syncthreads();
-            tail = sc_(X_CTL[0]); mtop = sc_(X_CTL[1]);
+            const uint32_t t_ = X_CTL[0], m_ = X_CTL[1];
+            // rows of the prefix that nobody re-queued are out of the queue now (every wavefront its own; the tags are next looked at behind two barriers)
+            if (rank < c && lane == 0 && Q[row] >= 2u) Q[row] = 0;
+            tail = sc_(t_); mtop = sc_(m_);
         }
         head += c;
-        ++rounds;
+        if ((++rounds & 127u) == 0u) fold();
         CWT(7);        // push resolution (one barrier)
     }
-    // ---- exit: what is queued goes to the ring; the tables are left as the fast wavefront round expects them
+    // ---- exit: what is queued goes to the ring; the tables are left as the fast wavefront round expects them (LV_FAT: the level rounds go on with them)
     __syncthreads();
-    if (tid < mtop - head) queue[(head + tid) & qmask] = qm[(head + tid) & (ECNE_LV_QM - 1)];
-    __syncthreads();
-    {
+    if (lane == 0) { if (pm0 != NONE) wm[pm0] = NONE; if (pm1 != NONE) wm[pm1] = NONE; }
+    if (why != LV_FAT) {
+        if (tid < mtop - head) queue[(head + tid) & qmask] = qm[(head + tid) & (ECNE_LV_QM - 1)];
+        __syncthreads();
         const uint32_t NS = ECNE_W2_SLOTS(0);
         for (uint32_t i = tid; i < NS; i += ECNE_WG) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
     }
+    mtop_io = mtop;
     if (lane == 0) {
+        fold();
         C.steps += c_steps; C.nuniq += c_nuniq; C.hits[0] += c_h0; C.hits[1] += c_h1; C.hits[3] += c_h3; C.hits[4] += c_h4;
         my_pops += c_pops; my_nnz += c_nnz;
     }

@@ -44,9 +44,14 @@ static_assert(4u * (ECNE_LV_MARKS + ECNE_LV_QM + ECNE_LV_CAND) <= ECNE_W2_BYTES,
 #endif
 __device__ __forceinline__ bool level_rounds_on(const Job& J) { return (J.lv_off & 1u) == 0; }
 // LV_FAT: more rows queued than a crew round takes (crew.hip.hpp) -- level rounds until LV_NARROW: the frontier is narrow again
-enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_REFILL = 4, LV_CUT = 5, LV_FAT = 6, LV_NARROW = 7 };
+// (LV_FAT / LV_NARROW leave the LDS tables and the queue mirror in place for the other loop -- `warm`, mtop_io; LV_NARROW_COLD: narrow again
+//  behind a pop of the general executor, tables restored)
+enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_REFILL = 4, LV_CUT = 5, LV_FAT = 6, LV_NARROW = 7, LV_NARROW_COLD = 8 };
 #ifndef ECNE_CREW_MAX
 #define ECNE_CREW_MAX 8u          // rows per crew round = wavefronts of the workgroup
+#endif
+#ifndef ECNE_CREW_ENTER
+#define ECNE_CREW_ENTER 4u        // level rounds hand over to crew rounds when at most this many rows are queued (a frontier that hovers around eight rows would change loops every round)
 #endif
 
 // Wavefront 0 of a single-workgroup job whose flags / in_queue tags are LDS-resident (chain_ok). head / tail: the queue cursors, in
@@ -57,7 +62,8 @@ enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_
 // dependency cut to an eighth returns LV_CUT (chains side by side: the caller's solo drain rounds take those).
 template <bool LDS>
 __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, uint32_t& tail_io, uint32_t max_rounds, bool wide_ok, bool cut_exit, LaneCtr& C,
-                                              uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, unsigned long long* prof, bool narrow_exit = false) {
+                                              uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, unsigned long long* prof, bool narrow_exit = false,
+                                              bool warm = false, uint32_t* mtop_io = nullptr) {
     const uint32_t lane = (uint32_t)lane_id();
     auto uni = [](const void* p) -> uint64_t {
         const uint64_t x = (uint64_t)p;
@@ -98,14 +104,19 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
 #define LVCOUNT(k) do { } while (0)
 #endif
     // ---- entry: the tables of the fast wavefront round become ours (clean on entry, restored on exit); the mirror is filled from the ring
-    for (uint32_t i = lane; i < ECNE_LV_MARKS; i += 64) wm[i] = 0xFFFFFFFFu;
-    wg_fence();
+    // (warm: the crew rounds left marks and mirror as this loop keeps them)
     // positions head .. mtop - 1 of the queue are mirrored in LDS (at most 256); what is queued behind them lives in the ring only. A
     // push lands in the mirror while the mirror holds everything that is queued, else in the ring (wide_ok: a long queue is worked
     // off 256 positions at a time -- the loop returns LV_REFILL when the mirrored part is used up and is entered again).
-    uint32_t mtop = head + ((tail - head) < ECNE_LV_QM ? (tail - head) : ECNE_LV_QM);
-    for (uint32_t i = lane; i < mtop - head; i += 64) qm[(head + i) & (ECNE_LV_QM - 1)] = queue[(head + i) & qmask];
-    lds_fence();
+    uint32_t mtop;
+    if (warm) mtop = *mtop_io;
+    else {
+        for (uint32_t i = lane; i < ECNE_LV_MARKS; i += 64) wm[i] = 0xFFFFFFFFu;
+        wg_fence();
+        mtop = head + ((tail - head) < ECNE_LV_QM ? (tail - head) : ECNE_LV_QM);
+        for (uint32_t i = lane; i < mtop - head; i += 64) qm[(head + i) & (ECNE_LV_QM - 1)] = queue[(head + i) & qmask];
+        lds_fence();
+    }
     LVT(0);        // entry
     const ECNE_GLOBAL uint32_t* const fo_rows = (const ECNE_GLOBAL uint32_t*)uni(J.fo_rows);
     // exclusive prefix sum of a small per-lane count (< 2^B) over the wavefront by bit planes: ballots and v_mbcnt, no cross-lane moves
@@ -133,7 +144,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         const uint32_t avail = tail - head;
         if (!wide_ok && avail > (LDS ? ECNE_LV_WIDE_AVAIL : ECNE_LVG_WIDE_AVAIL)) { why = LV_WIDE; break; }      // a wide frontier: the rounds on the whole workgroup first
         if (rounds >= max_rounds) { why = LV_ROUNDS; break; }
-        if (narrow_exit && rounds && avail <= ECNE_CREW_MAX) { why = LV_NARROW; break; }      // a narrow frontier again: crew rounds (crew.hip.hpp)
+        if (narrow_exit && rounds && avail <= ECNE_CREW_ENTER) { why = LV_NARROW; break; }      // a narrow frontier again: crew rounds (crew.hip.hpp)
         uint32_t n = avail < 64u ? avail : 64u;
         if (head + n > mtop) {                       // the window reaches beyond the mirror
             if (mtop - head < 16u && mtop != tail) { why = LV_REFILL; break; }
@@ -448,15 +459,18 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         ++rounds;
         LVT(7);        // push resolution
     }
-    // ---- exit: what is queued goes to the ring; the tables are left as the fast wavefront round expects them
+    // ---- exit: what is queued goes to the ring; the tables are left as the fast wavefront round expects them (LV_NARROW: the crew rounds go on with them)
     lds_fence();
-    for (uint32_t i = lane; i < mtop - head; i += 64) queue[(head + i) & qmask] = qm[(head + i) & (ECNE_LV_QM - 1)];
-    lds_fence();
-    {
-        const uint32_t NS = ECNE_W2_SLOTS(0);
-        for (uint32_t i = lane; i < NS; i += 64) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
+    if (why == LV_NARROW) { *mtop_io = mtop; wg_fence(); }
+    else {
+        for (uint32_t i = lane; i < mtop - head; i += 64) queue[(head + i) & qmask] = qm[(head + i) & (ECNE_LV_QM - 1)];
+        lds_fence();
+        {
+            const uint32_t NS = ECNE_W2_SLOTS(0);
+            for (uint32_t i = lane; i < NS; i += 64) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
+        }
+        wg_fence();
     }
-    wg_fence();
     LVT(15);       // exit
     C.steps += c_steps; C.nuniq += c_nuniq; C.hits[0] += c_h0; C.hits[1] += c_h1; C.hits[3] += c_h3; C.hits[4] += c_h4;
     my_pops += c_pops; my_nnz += c_nnz;

@@ -921,16 +921,27 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             // Narrow frontiers (up to eight queued rows) go to crew rounds -- one wavefront per row, all eight wavefronts (crew.hip.hpp);
             // wider ones to level rounds on wavefront 0 until they are narrow again.
             const bool crew = crew_on(J);
-            uint32_t hd = q.head, tl = q.tail, nr = 0, why = LV_FAT, ngen = 0, bigf = 0;
+            uint32_t hd = q.head, tl = q.tail, nr = 0, why = LV_FAT, ngen = 0, bigf = 0, mtop = 0;
+            bool warm = false;          // the other loop left the LDS tables and the queue mirror in place
             for (;;) {
                 if (crew && tl != hd && tl - hd <= ECNE_CREW_MAX) {
                     uint32_t nr1 = 0, ng1 = 0, bg1 = 0;
                     const uint32_t left = lv_max > nr + ngen ? lv_max - nr - ngen : 1u;
-                    why = crew_rounds(J, S, hd, tl, left, wide, C, my_pops, my_nnz, &nr1, &ng1, &bg1);
+#ifdef ECNE_ROUNDLOG
+                    const unsigned long long cl_t0 = wall_clock64(); const uint32_t cl_h0 = hd, cl_a0 = tl - hd;
+#endif
+                    why = crew_rounds(J, S, hd, tl, left, wide, C, my_pops, my_nnz, &nr1, &ng1, &bg1, warm, mtop);
+#ifdef ECNE_ROUNDLOG
+                    if (tid == 0) printf("RL crew avail %u n %u c %u dt %llu why %u gen %u\n", cl_a0, nr1, hd - cl_h0, wall_clock64() - cl_t0, why, ng1);
+#endif
                     nr += nr1; ngen += ng1;
                     if (bg1) bigf = 1;
                     if (why != LV_FAT) break;
+                    warm = true;
                 }
+#ifdef ECNE_ROUNDLOG
+                const unsigned long long ll_t0 = wall_clock64();
+#endif
                 if (w == 0) {
                     // A row the level rounds do not take (a constant row, 1 = x + y, a short binary decomposition, a bound on the limbs) is
                     // popped right here by the general executor and the level rounds go on -- the way back through the policy and the chain
@@ -938,12 +949,14 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                     // (Tried: those shapes inside the level round through fast_decide, inline, out of line and as a second instantiation a
                     //  job switches to -- bit-exact, and slower every time: the loop is at its register limits, 248 VGPRs and scalar
                     //  registers already spilled to lanes; Poseidon 2.9 -> 3.4 us per level, secp256k1 7.2 -> 8.0 ms.)
-                    uint32_t hd1 = hd, tl1 = tl, nr0 = 0, why1, left = lv_max > nr + ngen ? lv_max - nr - ngen : 1u, gdone = 0, gnnz = 0, big = 0;
+                    uint32_t hd1 = hd, tl1 = tl, nr0 = 0, why1, left = lv_max > nr + ngen ? lv_max - nr - ngen : 1u, gdone = 0, gnnz = 0, big = 0, mt1 = mtop;
+                    bool warm1 = warm;
                     unsigned long long st = 0, nu = 0, ht[16];
                     for (int i = 0; i < 16; ++i) ht[i] = 0;
                     for (;;) {
                         uint32_t nr1 = 0;
-                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew);
+                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew, warm1, &mt1);
+                        warm1 = false;
                         nr0 += nr1;
                         if (why1 != LV_DECLINED || gdone >= 256u) break;
                         const uint32_t rr = J.queue[hd1 & J.qmask];
@@ -965,21 +978,25 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                         }
                         if (J.ctr->error) { why1 = LV_ROUNDS; break; }
                         if (hd1 == tl1) { why1 = LV_EMPTY; break; }
-                        if (crew && tl1 - hd1 <= ECNE_CREW_MAX) { why1 = LV_NARROW; break; }
+                        if (crew && tl1 - hd1 <= ECNE_CREW_ENTER) { why1 = LV_NARROW_COLD; break; }
                         left = left > nr1 + 1u ? left - nr1 - 1u : 1u;
                     }
                     if (lane == 0) {
                         S.acc[0] += st; S.acc[1] += nu;
                         for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
                         S.acc[10] += gdone; S.acc[11] += gnnz;
-                        S.head = hd1; S.tail = tl1; S.nbig = why1; S.bl_tmp[0] = nr0; S.bl_tmp[1] = big; S.bl_tmp[2] = gdone;
+                        S.head = hd1; S.tail = tl1; S.nbig = why1; S.bl_tmp[0] = nr0; S.bl_tmp[1] = big; S.bl_tmp[2] = gdone; S.bl_tmp[3] = mt1;
                     }
                 }
                 __syncthreads();
-                why = S.nbig; nr += S.bl_tmp[0]; ngen += S.bl_tmp[2]; hd = S.head; tl = S.tail;
+#ifdef ECNE_ROUNDLOG
+                if (tid == 0) printf("RL lvl avail %u n %u c %u dt %llu why %u gen %u\n", tl - hd, S.bl_tmp[0], S.head - hd, wall_clock64() - ll_t0, S.nbig, S.bl_tmp[2]);
+#endif
+                why = S.nbig; nr += S.bl_tmp[0]; ngen += S.bl_tmp[2]; hd = S.head; tl = S.tail; mtop = S.bl_tmp[3];
                 if (S.bl_tmp[1]) bigf = 1;
                 __syncthreads();
-                if (why != LV_NARROW) break;
+                warm = why == LV_NARROW;
+                if (why != LV_NARROW && why != LV_NARROW_COLD) break;
             }
             const uint32_t done = hd - q.head;
             if (bigf) head_big = true;
@@ -987,7 +1004,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (tid == 0) { S.sd[0] += nr; S.sd[1] += done; S.sd[2] += wall_clock64() - qt_last; }      // schedule diagnostics: level rounds in the fast rounds' slots
 #endif
 #ifdef ECNE_ROUNDLOG
-            if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL level avail %u n %u c %u dt %llu\n", avail, nr, done, d_); }
+            if (tid == 0) { const unsigned long long d_ = wall_clock64() - rl_t0; printf("RL levelsum avail %u n %u c %u dt %llu\n", avail, nr, done, d_); }
 #endif
             pops_total += done;
             hits[13] += nr;
