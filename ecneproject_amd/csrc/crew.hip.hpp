@@ -173,6 +173,12 @@ __device__ __noinline__ uint32_t crew_rounds(const Job& J, ChunkShared& S, uint3
                     const uint32_t g0 = rdlane(g0_, 0), g1 = rdlane(g1_, 0);
                     bl_nop = (h0 == 0xFFFFFFFEu && f4) || (watched && long_watch_holds((uint8_t)g0, (uint8_t)g1, lr4));
                     if (bl_nop && watched) rv = lane == 1u ? h0 : lane == 2u ? h1 : NONE;
+                    if (!bl_nop && lr4 && h0 == 0xFFFFFFFEu) {
+                        // a decomposition all of whose terms are unique: nothing happens unless R4 still has the pivot's bounds to cut (long_r4_done)
+                        const uint32_t kpos = rdlane(w, 18), kneg = rdlane(w, 19);
+                        bl_nop = long_r4_done(J, shape, kpos, kneg, lenC, h0);
+                        if (bl_nop) rv = lane == 1u ? long_r4_pivot(shape, kpos, kneg) : NONE;
+                    }
                 }
                 if (bl_nop) nnz_d = lenC;
                 else slowk = ((shape & SH_BIG) && live) ? 2u : 1u;

@@ -1542,7 +1542,8 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                 if (sub_off) hj[i].drain |= 8u;
                 static const bool lv_off = []() { const char* e = getenv("ECNE_LEVEL"); return e && atoi(e) == 0; }();      // level rounds (level.hip.hpp) off: A/B runs
                 static const bool crew_off = []() { const char* e = getenv("ECNE_CREW"); return e && atoi(e) == 0; }();      // crew rounds (crew.hip.hpp) off: A/B runs
-                hj[i].lv_off = (lv_off ? 1u : 0u) | (crew_off ? 2u : 0u);
+                static const bool r4d_off = []() { const char* e = getenv("ECNE_R4DONE"); return e && atoi(e) == 0; }();      // long_r4_done (fastrow.hip.hpp) off: A/B runs
+                hj[i].lv_off = (lv_off ? 1u : 0u) | (crew_off ? 2u : 0u) | (r4d_off ? 4u : 0u);
             }
             hj[i].family = nullptr; hj[i].fam_rank = 0; hj[i].fam_size = 0;
             if (sl && i + 1 < n) { hj[i].family = sl->d_family; hj[i].fam_rank = (uint32_t)i; hj[i].fam_size = (uint32_t)(n - 1); }

@@ -192,7 +192,7 @@ struct Job {
     // monotone, final once both are set) and its B-class state (lb, ub, values, abz)
     uint32_t *wmarkU, *wmarkB;
     uint32_t* dmk[6];          // drain rounds (drain.hip.hpp): epoch-keyed mark planes X / A / C, U and B class each; multi-workgroup jobs only
-    uint32_t lv_off;           // bit 0: no level rounds (level.hip.hpp) on this job: ECNE_LEVEL=0; bit 1: no crew rounds (crew.hip.hpp): ECNE_CREW=0 -- A/B runs
+    uint32_t lv_off;           // bit 0: no level rounds (level.hip.hpp) on this job: ECNE_LEVEL=0; bit 1: no crew rounds (crew.hip.hpp): ECNE_CREW=0; bit 2: long_r4_done off: ECNE_R4DONE=0 -- A/B runs
     uint32_t subteam;          // device-side copies only: 1 = this Job stands for the first `nwg` workgroups of the job, which meet at the sub-team barrier
     uint32_t drain;            // bit 0: rounds on all workgroups are drain rounds (0: prefix rounds, queue_round_multi); bit 1: test hook, every frontier is drained; bit 2: no solo drains
     uint32_t* best;            // per row: lowest candidate index that wants to push it

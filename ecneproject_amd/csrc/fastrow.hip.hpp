@@ -409,6 +409,7 @@ __device__ __noinline__ void long_row_walk(const Job& J, uint32_t row0, uint32_t
         if (cnt >= 2 && v_w != 0xFFFFFFFFu) { hw[1] = v_w; hw[2] = v_w == u ? v_nu2 : u; }
         else hw[1] = 0xFFFFFFFFu;
         if (watch == 1 && (cnt == 0 || (cnt == 1 && !nuab))) hw[1] = 0xFFFFFFFEu;      // (after the R1 the caller performs:) every term unique, for good
+        if (watch == 2 && cnt == 0) hw[1] = 0xFFFFFFFEu;                                // a decomposition all of whose terms are unique (long_r4_done)
     }
     R.nnz = (a1 - a0) + (b1 - b0) + (c1 - c0);
     R.cnt = cnt; R.u = u; R.uf = uf; R.nuab = nuab; R.notknown = notknown;
@@ -417,6 +418,23 @@ __device__ __noinline__ void long_row_walk(const Job& J, uint32_t row0, uint32_t
 // a long row the wavefront walk covers: a plain sum or product, or a binary decomposition (R4 shape, l > 2)
 __device__ __forceinline__ bool long_r4(uint32_t shape) {
     return !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R5 | SH_R6)) && (((shape & SH_R4_T) != 0) != ((shape & SH_R4_T2) != 0));
+}
+// A long binary decomposition (long_r4) all of whose terms are unique -- word 1 of its record line (h0) says so, for good: exec_row() and
+// long_row_walk() leave 0xFFFFFFFE there -- is popped without effect: R1, R7 and R8 (:827-873, :1235-1348) find no non-unique variable and
+// R4 (:991-1076) only has the pivot's bounds left to cut, which it does iff ub(pivot) > 2^(l-1) - 1 (:1035), whatever the other bounds are
+// (its second half, :1049-1067, makes variables unique that already are). The pop has then read ub(pivot): the caller treats the
+// pivot as read. Secp256k1's 39 decompositions of 87-89 bits are popped ~140 times in that state, 11 us each through the general executor.
+__device__ __forceinline__ uint32_t long_r4_pivot(uint32_t shape, uint32_t kpos, uint32_t kneg) { return (shape & SH_R4_T) ? kpos : kneg; }
+// (out of line: its callers -- the policy, the crew rounds -- are at their register limits, and this is the rare path)
+__device__ __noinline__ bool long_r4_done(const Job& J, uint32_t shape, uint32_t kpos, uint32_t kneg, uint32_t lenC, uint32_t h0) {
+    if (h0 != 0xFFFFFFFEu || !long_r4(shape) || (J.lv_off & 4u)) return false;      // (lv_off bit 2: ECNE_R4DONE=0, A/B runs)
+    const uint32_t l = lenC;
+    if (l == 0 || l - 1 >= 254) return l != 0;
+    const fp::u256 nub = ld256(J.ub + 4ull * long_r4_pivot(shape, kpos, kneg));
+    fp::u256 ip = fp::make(0), im1;
+    ip.w[(l - 1) >> 6] = 1ull << ((l - 1) & 63);
+    fp::sub_raw(im1, ip, fp::make(1));
+    return fp::cmp(nub, im1) <= 0;
 }
 
 }  // namespace ecne

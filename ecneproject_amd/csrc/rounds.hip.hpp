@@ -963,13 +963,20 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                         const bool sv = J.solved[rr] != 0;
                         // (tried: the empty pops of a live long decomposition row settled here from one wavefront walk -- secp256k1 7.19 -> 7.05 ms,
                         //  EdDSAPoseidon 5.24 -> 5.37, EdDSAMiMCSponge 15.2 -> 15.5: the level rounds then go on where rounds on the workgroup do better)
-                        if ((J.rinfo[rr].shape & SH_BIG) && !sv) { big = 1; break; }
+                        bool nop_ = false;          // a long decomposition all of whose terms are unique: the pop is all that happens (long_r4_done)
+                        if ((J.rinfo[rr].shape & SH_BIG) && !sv) {
+                            const RowInfo ri_ = J.rinfo[rr];
+                            // (not while a wide frontier is worked off 256 positions at a time: the pop by the workgroup hands that frontier to the rounds on
+                            //  the workgroup, which do better on it -- EdDSAMiMCSponge 10.5 -> 11.1 ms with the row settled here)
+                            nop_ = !wide && long_r4_done(J, ri_.shape, ri_.kpos, ri_.kneg, ri_.lenC, J.rec[16ull * rr + 1]);
+                            if (!nop_) { big = 1; break; }
+                        }
                         hd1++;
                         if (lane == 0) J.inq[rr] = 0;
                         wg_fence();
                         ++gdone;
                         gnnz += (J.rpA[rr + 1] - J.rpA[rr]) + (J.rpB[rr + 1] - J.rpB[rr]) + (J.rpC[rr + 1] - J.rpC[rr]);
-                        if (!sv) {
+                        if (!sv && !nop_) {
                             QState qq;
                             qq.head = hd1; qq.tail = tl1; qq.evout = nullptr; qq.nev = 0; qq.emit = 0;
                             exec_row(J, qq, rr, ht, st, nu);
@@ -1367,7 +1374,10 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             __syncthreads();
             // (tried: wave 0 tests for an empty pop of a decomposition row with one walk first -- secp256k1 7.19 -> 7.43 ms: the walk and
             //  its barrier cost what the general executor's own pass over an all-unique row does)
-            const bool wgdone = J.solved[brow] || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig);
+            // (a long decomposition all of whose terms are unique: nothing happens -- long_r4_done, fastrow.hip.hpp)
+            const RowInfo bri_ = J.rinfo[brow];
+            const bool wgdone = J.solved[brow] || (J.rec != nullptr && long_r4_done(J, bri_.shape, bri_.kpos, bri_.kneg, bri_.lenC, J.rec[16ull * brow + 1]))
+                                || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig);
             if (wgdone) {
                 // done by the whole workgroup (or an already solved row: the pop is all that happens)
             } else if (w == 0) {

@@ -411,6 +411,11 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
             nunk += (uint32_t)__popcll(m);
             if (act && !(f & 1) && !(f & 2)) notknown = true;
         }
+        // a long binary decomposition all of whose terms are unique stays that way: its later pops are recognised from word 1 of its
+        // (otherwise unused) record line (long_r4_done, fastrow.hip.hpp)
+        const bool long_dec = l > 15 && J.rec != nullptr && !(shape & (SH_HAS_AB | SH_C_EMPTY | SH_R3 | SH_R5 | SH_R6))
+                              && (((shape & SH_R4_T) != 0) != ((shape & SH_R4_T2) != 0));
+        if (nunk == 0 && long_dec && lane == 0) const_cast<uint32_t*>(J.rec)[16ull * row + 1] = 0xFFFFFFFEu;
         if (nunk > 0 && !__ballot(notknown)) {
             const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
             bool fail = false;
@@ -439,6 +444,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
                     steps += nunk; hits[6]++;
                     uint32_t n = uniq_range_and_requeue(J, q, c0, c1, 0xFFFFFFFFu);
                     nuniq += n;
+                    if (long_dec && lane == 0) const_cast<uint32_t*>(J.rec)[16ull * row + 1] = 0xFFFFFFFEu;      // (every term is unique now)
                 }
             }
         }
