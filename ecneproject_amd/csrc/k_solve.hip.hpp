@@ -713,7 +713,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     QState q;
     setup_phase(J, s_chunk, q, my_rank, s_scan, s_u32, &s_err);
     ECNE_TICK(0);
-    unsigned long long steps = 0, prev_steps = ~0ull, outer = 0;
+    unsigned long long steps = 0, prev_steps = ~0ull, outer = 0, p3_steps = ~0ull, p3_nuniq = ~0ull, p4_acc = 0;      // p3_*: the counters when the last P3 pass began; p4_acc: steps P4 has counted so far
     // statistics only the master's wavefront 0 keeps (its lanes in lockstep: they read the same word and write the same sum): in LDS,
     // not in the registers / scratch frame of every thread across the outer loop
     __shared__ unsigned long long s_stat[3], hits[16];
@@ -810,7 +810,18 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         ECNE_TICK(1);
 
         // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups (p3_phase)
-        if (p3_phase(J, q, hits, steps, my_rank, ht_cap, &s_htn, &s_steps, m_rows, m_vars, tk, &s_err)) break;
+        // What a pass finds is a function of the unique bits alone (:1360-1386: A and B unique? which variables of C are not?). A pass that
+        // ended without a firing therefore ends the same way while no variable has become unique since -- and every rule that makes one
+        // unique counts a step or a unique variable (R1..R8, P1, P3, P4, P5). A single-workgroup job holds both counters complete at this
+        // point: when neither has moved since the last pass began (so that pass fired nothing either) -- P4's own steps aside: it tags variables and makes them known
+        // (:1455-1465), never unique -- the pass is skipped: the last outer iteration of every solve, the idle iterations of a converged
+        // part of a split file (EdDSAPoseidon: 0.36 of 0.72 ms of P3; still counted as a pass).
+        const bool p3_skip = J.nwg == 1 && !J.oob && outer > 1 && steps - p4_acc == p3_steps && nuniq == p3_nuniq;
+        // (the counters as the pass FINDS them: a pass that fires sweeps on behind the firing row only (:1388-1417) -- what its firing did to
+        //  the rows in front is the next pass's business, and its own steps make the next comparison fail)
+        p3_steps = steps - p4_acc; p3_nuniq = nuniq;
+        if (p3_skip) { if (tid == 0) tk[6]++; }
+        else if (p3_phase(J, q, hits, steps, my_rank, ht_cap, &s_htn, &s_steps, m_rows, m_vars, tk, &s_err)) break;
         if (team_phase && master) {
             // fold in what the helpers did during the rounds on teams: their atomics came before P3's first barrier (here, not inside
             // P3's loop: with the counters live across that loop the compiler spilled them, +0.27 GB of scratch writes per launch)
@@ -825,7 +836,9 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         ECNE_TICK(2);
 
         // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups (p4_phase)
+        const unsigned long long steps_p4 = steps;
         if (p4_phase(J, s_chunk, q, &s_q, s_scan, hits, steps, outer, my_rank, &s_err)) break;
+        p4_acc += steps - steps_p4;
         ECNE_TICK(3);
 
         // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
