@@ -19,7 +19,8 @@ for src, dst in (("bench_under_rocprof.json", "r04_bench_under_rocprof.json"), (
 for src, dst in (("trace", "r04_kernel_trace_stats"), ("fetch", "r04_pmc_FETCH_SIZE"), ("write", "r04_pmc_WRITE_SIZE"), ("sq", "r04_pmc_SQ_waves_busy_wait"), ("insts", "r04_pmc_SQ_insts"),
                  ("tcc", "r04_pmc_TCC_hit_miss"), ("suite", "r04_suite_kernel_trace_stats"), ("S104_trace", "r04_S104_kernel_trace_stats"), ("S104_fetch", "r04_S104_pmc_FETCH_SIZE"),
                  ("S104_write", "r04_S104_pmc_WRITE_SIZE"), ("S104_sq", "r04_S104_pmc_SQ_waves_busy_wait"), ("per_file_vs_oracle", "r04_per_file_vs_oracle"),
-                 ("round_log_summary", "r04_round_log_summary"), ("scale_variants", "r04_scale_variants"), ("level_round_stages", "r04_level_round_stages")):
+                 ("round_log_summary", "r04_round_log_summary"), ("scale_variants", "r04_scale_variants"), ("level_round_stages", "r04_level_round_stages"),
+                 ("crew_ab", "r04_crew_rounds_on_off"), ("soak_crew", "r04_soak_crew"), ("suite_per_file", "r04_suite_per_file")):
     try: shutil.copy(os.path.join(F, src + ".txt"), os.path.join(P, dst + ".txt"))
     except Exception as e: print("missing", src, e)      # noqa: E701,BLE001
 

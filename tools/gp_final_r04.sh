@@ -16,5 +16,8 @@ timeout 900 python tests/tools/per_file_vs_oracle.py > $O/per_file_vs_oracle.txt
 bash tools/gp_roundlog.sh > /dev/null 2>&1
 cp gpurun_out/roundlog_ecdsa_summary.txt $O/round_log_summary.txt 2>/dev/null
 bash tools/gp_lvprof.sh > $O/level_round_stages.txt 2>&1
+bash tools/gp_crew_ab.sh > $O/crew_ab.txt 2>&1
+timeout 600 python tests/tools/soak_crew.py 100 > $O/soak_crew.txt 2>&1
+timeout 600 python tools/suite_stats.py 3 > $O/suite_per_file.txt 2>&1
 for f in ecdsa suite poseidon secp dag many ecdsa_S104; do tail -c 250 $O/$f.json; echo; done
 tail -4 $O/scale_variants.txt | cut -c1-200; tail -2 $O/per_file_vs_oracle.txt

@@ -1,4 +1,6 @@
-"""Developer aid (GPU box, library built with ECNE_BUILD_FLAGS=-DECNE_LVPROF): stage clocks of the level rounds (level.hip.hpp).
+"""Developer aid (GPU box, library built with ECNE_BUILD_FLAGS=-DECNE_LVPROF): stage clocks of the level rounds (level.hip.hpp) and of the crew
+rounds (crew.hip.hpp), which share the slots -- a crew round: record + descriptor | flag bytes + inline fan-out lists | decisions | marks, read sets,
+barrier, prefix ("marks + check") | commit + barrier | push resolution by wavefront 0 + barrier; "fan-out lists" is the level rounds' own stage.
 python tools/lv_stages.py <fixture relpath> ..."""
 import os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
