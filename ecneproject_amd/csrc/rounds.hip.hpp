@@ -880,6 +880,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     uint32_t lvg_hold = 0;
     const bool lv_ok = chain && v2 && level_rounds_on(J);      // level rounds: LDS-resident state, row records, the fast round's LDS block
     uint32_t lv_burst = 1;
+    uint32_t crew_pen = 0, crew_hold = 0;        // hand-overs to crew rounds that came back after a few rounds (a frontier that keeps widening): level rounds keep it for a while
     bool lv_wide = false, lv_chain = false;      // lv_chain: the burst that follows pops rows the level rounds declined (chain executor)
     bool head_big = false;                       // the chain executor stopped in front of a live long row: popped alone, by the whole workgroup
     const bool v2wg = v2 && fast_wg_ok(J);
@@ -930,7 +931,12 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #ifdef ECNE_ROUNDLOG
                     const unsigned long long cl_t0 = wall_clock64(); const uint32_t cl_h0 = hd, cl_a0 = tl - hd;
 #endif
+                    const bool handed = warm;
                     why = crew_rounds(J, S, hd, tl, left, wide, C, my_pops, my_nnz, &nr1, &ng1, &bg1, warm, mtop);
+                    // (EdDSAPoseidon's frontier goes 2, 3, 4, 4, 12, 14 rows and round again: four crew rounds per hand-over gain what the two
+                    //  hand-overs cost -- after two such visits in a row the level rounds keep the frontier for their next 64 rounds)
+                    if (handed && why == LV_FAT && nr1 < 8u) { if (++crew_pen >= 2u) { crew_pen = 0; crew_hold = 64; } }
+                    else if (nr1 >= 8u) crew_pen = 0;
 #ifdef ECNE_ROUNDLOG
                     if (tid == 0) printf("RL crew avail %u n %u c %u dt %llu why %u gen %u\n", cl_a0, nr1, hd - cl_h0, wall_clock64() - cl_t0, why, ng1);
 #endif
@@ -955,7 +961,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                     for (int i = 0; i < 16; ++i) ht[i] = 0;
                     for (;;) {
                         uint32_t nr1 = 0;
-                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew, warm1, &mt1);
+                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew && crew_hold == 0, warm1, &mt1);
                         warm1 = false;
                         nr0 += nr1;
                         if (why1 != LV_DECLINED || gdone >= 256u) break;
@@ -985,7 +991,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                         }
                         if (J.ctr->error) { why1 = LV_ROUNDS; break; }
                         if (hd1 == tl1) { why1 = LV_EMPTY; break; }
-                        if (crew && tl1 - hd1 <= ECNE_CREW_ENTER) { why1 = LV_NARROW_COLD; break; }
+                        if (crew && crew_hold == 0 && tl1 - hd1 <= ECNE_CREW_ENTER) { why1 = LV_NARROW_COLD; break; }
                         left = left > nr1 + 1u ? left - nr1 - 1u : 1u;
                     }
                     if (lane == 0) {
@@ -1000,6 +1006,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 if (tid == 0) printf("RL lvl avail %u n %u c %u dt %llu why %u gen %u\n", tl - hd, S.bl_tmp[0], S.head - hd, wall_clock64() - ll_t0, S.nbig, S.bl_tmp[2]);
 #endif
                 why = S.nbig; nr += S.bl_tmp[0]; ngen += S.bl_tmp[2]; hd = S.head; tl = S.tail; mtop = S.bl_tmp[3];
+                crew_hold = crew_hold > S.bl_tmp[0] ? crew_hold - S.bl_tmp[0] : 0u;
                 if (S.bl_tmp[1]) bigf = 1;
                 __syncthreads();
                 warm = why == LV_NARROW;
