@@ -713,10 +713,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     QState q;
     setup_phase(J, s_chunk, q, my_rank, s_scan, s_u32, &s_err);
     ECNE_TICK(0);
-    unsigned long long steps = 0, prev_steps = ~0ull, outer = 0, p3_steps = ~0ull, p3_nuniq = ~0ull, p4_acc = 0;      // p3_*: the counters when the last P3 pass began; p4_acc: steps P4 has counted so far
+    unsigned long long steps = 0, prev_steps = ~0ull, outer = 0;
     // statistics only the master's wavefront 0 keeps (its lanes in lockstep: they read the same word and write the same sum): in LDS,
     // not in the registers / scratch frame of every thread across the outer loop
     __shared__ unsigned long long s_stat[3], hits[16];
+    // (P3's skip test below: steps -- P4's aside -- and num_unique when the last P3 pass began, steps P4 has counted so far, steps in front of the
+    //  running P4. In LDS: three 64-bit values alive across the outer loop in the registers of every thread are three more pairs spilled at its top)
+    __shared__ unsigned long long s_p3[4];
+    if (tid == 0) { s_p3[0] = ~0ull; s_p3[1] = ~0ull; s_p3[2] = 0; s_p3[3] = 0; }
     unsigned long long &nuniq = s_stat[0], &pops = s_stat[1], &pop_nnz = s_stat[2];
     if (tid < 16) hits[tid] = 0;
     if (tid < 3) s_stat[tid] = 0;
@@ -816,10 +820,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         // point: when neither has moved since the last pass began (so that pass fired nothing either) -- P4's own steps aside: it tags variables and makes them known
         // (:1455-1465), never unique -- the pass is skipped: the last outer iteration of every solve, the idle iterations of a converged
         // part of a split file (EdDSAPoseidon: 0.36 of 0.72 ms of P3; still counted as a pass).
-        const bool p3_skip = J.nwg == 1 && !J.oob && outer > 1 && steps - p4_acc == p3_steps && nuniq == p3_nuniq;
+        const bool p3_skip = J.nwg == 1 && !J.oob && outer > 1 && steps - s_p3[2] == s_p3[0] && nuniq == s_p3[1];
         // (the counters as the pass FINDS them: a pass that fires sweeps on behind the firing row only (:1388-1417) -- what its firing did to
         //  the rows in front is the next pass's business, and its own steps make the next comparison fail)
-        p3_steps = steps - p4_acc; p3_nuniq = nuniq;
+        if (J.nwg == 1) {
+            __syncthreads();
+            if (tid == 0) { s_p3[0] = steps - s_p3[2]; s_p3[1] = nuniq; }
+            __syncthreads();
+        }
         if (p3_skip) { if (tid == 0) tk[6]++; }
         else if (p3_phase(J, q, hits, steps, my_rank, ht_cap, &s_htn, &s_steps, m_rows, m_vars, tk, &s_err)) break;
         if (team_phase && master) {
@@ -836,9 +844,9 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         ECNE_TICK(2);
 
         // ================= P4 ABZ tagging (:1425-1483): marking and tagging on all workgroups (p4_phase)
-        const unsigned long long steps_p4 = steps;
+        if (tid == 0) s_p3[3] = steps;
         if (p4_phase(J, s_chunk, q, &s_q, s_scan, hits, steps, outer, my_rank, &s_err)) break;
-        p4_acc += steps - steps_p4;
+        if (tid == 0) s_p3[2] += steps - s_p3[3];
         ECNE_TICK(3);
 
         // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
