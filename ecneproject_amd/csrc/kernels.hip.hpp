@@ -17,7 +17,8 @@
 //                     DESIGN.md "Schedule"). Files, bottom up: rules_wave / rules_lane (one pop by a wavefront / a lane),
 //                     schedule (access sets, long rows, ordered REQUEUE), job_barrier, fastrow (the pop of the common row
 //                     shapes decided in registers, the walk of a long row), chain (sequential pops of a single-workgroup
-//                     job out of LDS), wave2 (the fast wavefront round), rounds (multi-workgroup round, the queue
+//                     job out of LDS), wave2 (the fast wavefront round), level / crew (the narrow dependency levels of a deep circuit: one lane / one
+//                     wavefront per queued row), drain (a window of the queue in dataflow order on a team of workgroups), rounds (multi-workgroup round, the queue
 //                     phase's policy), k_solve (setup, outer loop, P1-P5, verdict).
 //   (k_abs_*, k_fe_*, k_lay_*: the device front-end -- parse, abstraction, layout -- lives in the second translation unit,
 //                     ecne_frontend.hip / frontend.hip.hpp / abstract.hip.hpp)
