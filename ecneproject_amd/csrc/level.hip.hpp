@@ -60,10 +60,17 @@ enum : uint32_t { LV_EMPTY = 0, LV_DECLINED = 1, LV_WIDE = 2, LV_ROUNDS = 3, LV_
 // tags are read before anything is stored in a round (a prefix row's rank comes from the window in registers, not from its tag), a
 // round resolves at most 64 candidates, stores are fenced at the end of every round; cut_exit: a well-filled window whose prefix a
 // dependency cut to an eighth returns LV_CUT (chains side by side: the caller's solo drain rounds take those).
+// the fast wavefront round's LDS block as that round expects it (wavefront 0; after a level_rounds call that ended LV_DECLINED under `semi`)
+__device__ __forceinline__ void lv_tables_restore(const Job& J) {
+    uint32_t* const tb = (uint32_t*)(ecne_dyn_lds + J.lds_w2_off);
+    const uint32_t NS = ECNE_W2_SLOTS(0);
+    for (uint32_t i = (uint32_t)lane_id(); i < NS; i += 64) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
+    wg_fence();
+}
 template <bool LDS>
 __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, uint32_t& tail_io, uint32_t max_rounds, bool wide_ok, bool cut_exit, LaneCtr& C,
                                               uint32_t& my_pops, uint32_t& my_nnz, uint32_t* n_rounds, unsigned long long* prof, bool narrow_exit = false,
-                                              bool warm = false, uint32_t* mtop_io = nullptr) {
+                                              bool warm = false, uint32_t* mtop_io = nullptr, bool semi = false, bool semi_in = false) {
     const uint32_t lane = (uint32_t)lane_id();
     auto uni = [](const void* p) -> uint64_t {
         const uint64_t x = (uint64_t)p;
@@ -109,9 +116,11 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
     // push lands in the mirror while the mirror holds everything that is queued, else in the ring (wide_ok: a long queue is worked
     // off 256 positions at a time -- the loop returns LV_REFILL when the mirrored part is used up and is entered again).
     uint32_t mtop;
+    // (semi_in: the call before this one ended in front of a row it does not take and left the tables as they were -- lv_tables_restore -- the
+    //  marks are all taken back, only the mirror has to be filled again)
     if (warm) mtop = *mtop_io;
     else {
-        for (uint32_t i = lane; i < ECNE_LV_MARKS; i += 64) wm[i] = 0xFFFFFFFFu;
+        if (!semi_in) for (uint32_t i = lane; i < ECNE_LV_MARKS; i += 64) wm[i] = 0xFFFFFFFFu;
         wg_fence();
         mtop = head + ((tail - head) < ECNE_LV_QM ? (tail - head) : ECNE_LV_QM);
         for (uint32_t i = lane; i < mtop - head; i += 64) qm[(head + i) & (ECNE_LV_QM - 1)] = queue[(head + i) & qmask];
@@ -465,7 +474,9 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
     else {
         for (uint32_t i = lane; i < mtop - head; i += 64) queue[(head + i) & qmask] = qm[(head + i) & (ECNE_LV_QM - 1)];
         lds_fence();
-        {
+        // (LV_DECLINED with `semi`: the caller pops the one row and comes right back -- the 1 792 words of the tables are restored by
+        //  whoever leaves for good, lv_tables_restore)
+        if (!(semi && why == LV_DECLINED)) {
             const uint32_t NS = ECNE_W2_SLOTS(0);
             for (uint32_t i = lane; i < NS; i += 64) { tb[i] = 0u; tb[NS + i] = 0xFFFFFFFFu; }
         }

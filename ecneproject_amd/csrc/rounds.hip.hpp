@@ -956,13 +956,14 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                     //  job switches to -- bit-exact, and slower every time: the loop is at its register limits, 248 VGPRs and scalar
                     //  registers already spilled to lanes; Poseidon 2.9 -> 3.4 us per level, secp256k1 7.2 -> 8.0 ms.)
                     uint32_t hd1 = hd, tl1 = tl, nr0 = 0, why1, left = lv_max > nr + ngen ? lv_max - nr - ngen : 1u, gdone = 0, gnnz = 0, big = 0, mt1 = mtop;
-                    bool warm1 = warm;
+                    bool warm1 = warm, dirty = false;      // dirty: the last call left the LDS tables as they were (LV_DECLINED, semi)
                     unsigned long long st = 0, nu = 0, ht[16];
                     for (int i = 0; i < 16; ++i) ht[i] = 0;
                     for (;;) {
                         uint32_t nr1 = 0;
-                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew && crew_hold == 0, warm1, &mt1);
+                        why1 = level_rounds<true>(J, hd1, tl1, left, wide, false, C, my_pops, my_nnz, &nr1, &S.sd[0], crew && crew_hold == 0, warm1, &mt1, true, dirty);
                         warm1 = false;
+                        dirty = why1 == LV_DECLINED;
                         nr0 += nr1;
                         if (why1 != LV_DECLINED || gdone >= 256u) break;
                         const uint32_t rr = J.queue[hd1 & J.qmask];
@@ -994,6 +995,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                         if (crew && crew_hold == 0 && tl1 - hd1 <= ECNE_CREW_ENTER) { why1 = LV_NARROW_COLD; break; }
                         left = left > nr1 + 1u ? left - nr1 - 1u : 1u;
                     }
+                    if (dirty) lv_tables_restore(J);      // (left in front of a row for good: a live long row, an error, 256 pops, the crew's turn)
                     if (lane == 0) {
                         S.acc[0] += st; S.acc[1] += nu;
                         for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
