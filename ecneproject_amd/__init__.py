@@ -267,8 +267,11 @@ class SolveResult:
 
     flags = lb = ub = abz = nvalues = values = bad_rows = None
 
-    def __init__(self, handle, fetch_states=True):
+    def __init__(self, handle, fetch_states=True, summary=None):
         L = _lib.lib()
+        if summary is not None and not fetch_states:      # (solve_batch: the summaries of the whole batch came in one call, the handles are freed in one)
+            self.summary, self.status, self.function_good, self.digest = summary, int(summary.status), bool(summary.function_good), None
+            return
         s = Summary()
         _check(L.ecne_result_summary(handle, C.byref(s)))
         self.summary = s
@@ -340,6 +343,13 @@ def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None, 
     outs = (C.c_void_p * n)()
     o = _opts(device, secp_solve, queue_mode, stream, force_nwg)
     _check(L.ecne_solve_batch(hs, n, C.byref(o), outs), "ecne_solve_batch")
+    if not fetch_states and n > 1:
+        # only the summaries: one call for the whole batch, one to free the handles (504 small systems: two FFI calls per result were
+        # more time than the GPU spent on the batch)
+        sums = (Summary * n)()
+        _check(L.ecne_result_summaries(outs, n, sums), "ecne_result_summaries")
+        L.ecne_results_free(outs, n)
+        return [SolveResult(None, False, sums[i]) for i in range(n)]
     return [SolveResult(C.c_void_p(outs[i]), fetch_states) for i in range(n)]
 
 

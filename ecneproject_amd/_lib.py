@@ -42,7 +42,7 @@ class Summary(C.Structure):
 EXPORTS = [
     "ecne_r1cs_load", "ecne_r1cs_info", "ecne_r1cs_csr", "ecne_r1cs_io", "ecne_r1cs_free",
     "ecne_system_from_r1cs", "ecne_abstract", "ecne_system_info_get", "ecne_system_special",
-    "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_states",
+    "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_summaries", "ecne_results_free", "ecne_result_states",
     "ecne_result_bad_rows", "ecne_result_free", "ecne_classify", "ecne_fp_selftest", "ecne_fp_sqrt",
     "ecne_device_count", "ecne_strerror", "ecne_version",
     "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve", "ecne_result_digest", "ecne_set_split", "ecne_system_split_info",
@@ -87,6 +87,9 @@ def lib():
     L.ecne_result_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ecne_result_free.argtypes = [vp]
     L.ecne_result_free.restype = None
+    L.ecne_result_summaries.argtypes = [C.POINTER(vp), C.c_size_t, C.POINTER(Summary)]
+    L.ecne_results_free.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.ecne_results_free.restype = None
     L.ecne_classify.argtypes = [vp, C.POINTER(Opts), vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.ecne_fp_selftest.argtypes = [C.c_int, C.c_int, C.c_size_t, vp, vp, vp]
     L.ecne_fp_sqrt.argtypes = [vp, vp]

@@ -293,6 +293,13 @@ static std::shared_mutex& device_launch_mutex(int device) { static std::shared_m
 // circomlib suite, 4 % of it).
 #define ECNE_RESULT_BYTES (offsetof(Counters, sync_steps))
 static_assert(ECNE_RESULT_BYTES % 4 == 0 && ECNE_RESULT_BYTES <= 1024, "the result part of Counters is gathered 4 bytes per thread by 256 threads");
+// ... and before a launch every job's Counters are zeroed by one block each (504 hipMemsetAsync calls were 2 ms of host time per pass of
+// `bench.py --workload many`)
+__global__ __launch_bounds__(256) void k_zero_counters(const Job* jobs) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(jobs[blockIdx.x].ctr);
+    for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += 256) dst[i] = 0;
+}
+static_assert(sizeof(Counters) % 4 == 0, "Counters are zeroed four bytes per thread");
 __global__ __launch_bounds__(256) void k_gather_results(const Job* jobs, unsigned char* out) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs[blockIdx.x].ctr);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)blockIdx.x * ECNE_RESULT_BYTES);
@@ -1547,7 +1554,6 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             }
             hj[i].family = nullptr; hj[i].fam_rank = 0; hj[i].fam_size = 0;
             if (sl && i + 1 < n) { hj[i].family = sl->d_family; hj[i].fam_rank = (uint32_t)i; hj[i].fam_size = (uint32_t)(n - 1); }
-            if (hipMemsetAsync(hj[i].ctr, 0, sizeof(Counters), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
         }
         if (rc != ECNE_OK) break;
         if (sl && hipMemsetAsync(sl->d_family, 0, sizeof(Family), stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
@@ -1589,6 +1595,11 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
         if (sl && n - 1 > cap) rc = K_ESPLIT;
         if (rc != ECNE_OK) break;
         if (hipMemcpyAsync(d_jobs, hj.data(), sizeof(Job) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = ECNE_ENODEVICE; break; }
+        hipLaunchKernelGGL(k_zero_counters, dim3((unsigned)n), dim3(256), 0, stream, (const Job*)d_jobs);
+        // every launch's workgroup descriptors in one upload (a batch of more jobs than the device has CUs is several launches back to back)
+        size_t total_wg = 0;
+        for (size_t i = 0; i < n; ++i) total_wg += hj[i].nwg;
+        { const int st = scratch.prepare(o.device, n, std::max<size_t>(cap, total_wg)); if (st != K_OK) { rc = st; break; } }
         const hipEvent_t e0 = scratch.e0, e1 = scratch.e1;
         {
             // a launch that holds a multi-workgroup job must have the device to itself (its workgroups meet at a barrier)
@@ -1610,35 +1621,45 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             const size_t resident_cap = (size_t)std::max(wg_per_cu, 0) * (size_t)n_cu;
             bool refused = false;
             (void)hipEventRecord(e0, stream);
-            std::vector<WgDesc> descs;
-            WgDesc* const d_descs = scratch.d_descs;
-            size_t i = 0;
-            bool fail = false;
-            while (i < n && !fail) {
-                descs.clear();
-                while (i < n && descs.size() + hj[i].nwg <= cap) {
-                    for (uint32_t r = 0; r < hj[i].nwg; ++r) descs.push_back({(uint32_t)i, r});
-                    ++i;
+            std::vector<WgDesc> all_descs;
+            std::vector<size_t> launch_at;      // first descriptor of every launch, and the end
+            {
+                size_t i = 0;
+                while (i < n) {
+                    launch_at.push_back(all_descs.size());
+                    size_t in_launch = 0;
+                    while (i < n && in_launch + hj[i].nwg <= cap) {
+                        for (uint32_t r = 0; r < hj[i].nwg; ++r) all_descs.push_back({(uint32_t)i, r});
+                        in_launch += hj[i].nwg;
+                        ++i;
+                    }
+                    if (in_launch == 0 && i < n && hj[i].nwg != 0) break;      // (cannot happen: nwg <= cap)
                 }
-                if (hipMemcpyAsync(d_descs, descs.data(), sizeof(WgDesc) * descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) { fail = true; break; }
+                launch_at.push_back(all_descs.size());
+            }
+            bool fail = false;
+            if (!all_descs.empty() && hipMemcpyAsync(scratch.d_descs, all_descs.data(), sizeof(WgDesc) * all_descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) fail = true;
+            for (size_t li = 0; li + 1 < launch_at.size() && !fail; ++li) {
+                const size_t nd = launch_at[li + 1] - launch_at[li];
+                if (nd == 0) continue;
+                WgDesc* const d_descs = scratch.d_descs + launch_at[li];
                 // the workgroups of a multi-workgroup job meet at a barrier of their own: launched cooperatively, the runtime either
                 // makes the whole grid resident together or refuses the launch (no 0.2 s wait for workgroups that never start)
                 bool launched = false;
-                if (any_multi && descs.size() > resident_cap) { refused = true; fail = true; break; }
+                if (any_multi && nd > resident_cap) { refused = true; fail = true; break; }
                 if (any_multi && coop_ok) {
                     const Job* a0 = d_jobs;
                     const WgDesc* a1 = d_descs;
                     void* kargs[2] = {(void*)&a0, (void*)&a1};
-                    const hipError_t ce = hipLaunchCooperativeKernel(kernel, dim3((unsigned)descs.size()), dim3(ECNE_WG), kargs, dyn_lds, stream);
+                    const hipError_t ce = hipLaunchCooperativeKernel(kernel, dim3((unsigned)nd), dim3(ECNE_WG), kargs, dyn_lds, stream);
                     if (ce == hipSuccess) launched = true;
                     else if (ce == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); refused = true; fail = true; break; }
                     else (void)hipGetLastError();      // (not available on this stack: the plain launch below, with the barrier's own time bound)
                 }
                 if (!launched) {
-                    if (any_multi) hipLaunchKernelGGL(k_solve_team, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
-                    else hipLaunchKernelGGL(k_solve, dim3((unsigned)descs.size()), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                    if (any_multi) hipLaunchKernelGGL(k_solve_team, dim3((unsigned)nd), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
+                    else hipLaunchKernelGGL(k_solve, dim3((unsigned)nd), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
                 }
-                if (i < n && hipStreamSynchronize(stream) != hipSuccess) { fail = true; break; }   // d_descs is reused
             }
             if (sl && !fail && !refused) {
                 // the parts' states into the file's arrays, the file's verdict counts (inside the timed region: part of the solve)
@@ -1888,6 +1909,11 @@ int ecne_result_summary(const ecne_result* r, ecne_summary* out) {
     *out = r->sum;
     return ECNE_OK;
 }
+int ecne_result_summaries(ecne_result* const* r, size_t n, ecne_summary* out) {
+    if ((!r || !out) && n) return ECNE_EINVAL;
+    for (size_t i = 0; i < n; ++i) { if (!r[i]) return ECNE_EINVAL; out[i] = r[i]->sum; }
+    return ECNE_OK;
+}
 static int ecne_result_states_impl(const ecne_result* r, const uint8_t** flags, const uint64_t** lb, const uint64_t** ub,
                        const int32_t** abz, const uint8_t** nvalues, const uint64_t** values) {
     if (!r) return ECNE_EINVAL;
@@ -1929,6 +1955,7 @@ static int ecne_result_digest_impl(const ecne_result* r, uint64_t* out) {
 }
 int ecne_result_digest(const ecne_result* r, uint64_t out[2]) { return guarded([&] { return ecne_result_digest_impl(r, out); }); }
 void ecne_result_free(ecne_result* r) { delete r; }
+void ecne_results_free(ecne_result* const* r, size_t n) { if (r) for (size_t i = 0; i < n; ++i) delete r[i]; }
 
 static int ecne_classify_impl(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out, double* kernel_ms, uint64_t* bytes) {
     if (!sys) return ECNE_EINVAL;

@@ -201,11 +201,14 @@ typedef struct ecne_summary {
  * WITHOUT PROGRESS is bounded (0.2 s + 2 us per row, ECNE_BARRIER_TIMEOUT_MS overrides; the master workgroup's heartbeat
  * restarts the clock) and ends in ECNE_ETIMEOUT instead of a hang. The caller's current HIP device is left as it was.
  * Out-of-range ids (malformed input): a known id above n_vars raises ECNE_EBOUNDS as the reference's setup does
- * (:682), a target id above n_vars at the verdict (:1580); a ROW that mentions an id above n_vars is solved with the
- * state arrays widened (the reference raises BoundsError at the first rule that reads that state). */
+ * (:682), a target id above n_vars at the verdict (:1580); a ROW or a special that mentions an id above n_vars raises
+ * ECNE_EBOUNDS where the reference raises BoundsError: lazily, at the first rule that reads that state -- or never. */
 int ecne_solve(ecne_system* sys, const ecne_opts* opts, ecne_result** out);
 int ecne_solve_batch(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out);
 int ecne_result_summary(const ecne_result* r, ecne_summary* out);
+/* the summaries of a whole batch in one call (out[n]; a job runner that solves hundreds of small systems per pass -- the bulk runners of
+ * /root/reference/src/Ecne.jl:9-37 -- spends more time crossing the FFI per result than the GPU spends on the batch) */
+int ecne_result_summaries(ecne_result* const* r, size_t n, ecne_summary* out);
 /* per-variable VariableState (:135-160), variable v at index v-1; borrowed, valid until ecne_result_free. The state
  * is downloaded on the first call: it must come before the system is solved again, abstracted, edited
  * (ecne_system_set_io / _add_special) or freed -- afterwards ECNE_EINVAL.
@@ -221,6 +224,7 @@ int ecne_result_bad_rows(const ecne_result* r, const int64_t** rows, size_t* n);
  * ecne_result_states. tests/test_gpu_soak.py restates the digest in numpy and checks it against fetched states. */
 int ecne_result_digest(const ecne_result* r, uint64_t out[2]);
 void ecne_result_free(ecne_result* r);
+void ecne_results_free(ecne_result* const* r, size_t n);      /* ecne_result_free for every result of a batch */
 
 /* k_classify_rows output for tests/profiling: per-row shape word (see ecne_engine.hip SH_*) */
 int ecne_classify(ecne_system* sys, const ecne_opts* opts, uint32_t* shape_out /* n_rows */, double* kernel_ms,
