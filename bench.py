@@ -19,6 +19,7 @@ SURVEY.md §8d taken from the sequential oracle's pop/iteration counters) and `c
 (the sequential CPU oracle timed on the same workload: ~17 s of CPU work on one core).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -172,6 +173,9 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # (the cyclic collector is held off while the steps are timed: with torch loaded a full collection walks millions of objects -- 40 ms, once
+    #  per ~15 steps of a workload that keeps hundreds of result objects per step -- and is no part of the solve)
+    gc.collect(); gc.disable()
     t0 = time.perf_counter()
     inv = []
     for _ in range(args.steps):
@@ -179,6 +183,7 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         inv.append(res)
     torch.cuda.synchronize()
     t_rank = time.perf_counter() - t0
+    gc.enable()
     inv = [[step_invariants(r) for r in step] for step in inv]           # (after the timed region)
     if any(step != inv[0] for step in inv):
         raise SystemExit("bench.py: the timed steps did not reproduce the same result (verdicts / counts / counters differ between steps)")
@@ -239,6 +244,7 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
                                        "model": "cache-resident and dependency-depth bound: t ~ pops of the longest chain x us per sequential pop (+ rounds where the frontier is wide)"},
                      "note": "the working set of these circuits (<= 12 MB) lives in L2 / Infinity Cache; the HBM fraction is reported for completeness, the latency model is the bound"},
     }
+    out["config"]["python_gc"] = "cyclic collector held off during the timed steps (a full collection with torch loaded: ~40 ms)"
     out["config"]["invariants"] = {"steps_identical": True, "checked": "status, verdict, pops, successful_steps, num_unique, outer_iterations, the four printed counts, rule hits -- every job, every timed step"}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_jobs(jl, args.workload)
@@ -325,6 +331,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.collect(); gc.disable()          # (see run_jobs_workload)
     t0 = time.perf_counter()
     dev_ms, timed = [], []
     for _ in range(args.steps):
@@ -335,6 +342,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     inv = [step_invariants(r) for r in timed]                             # (after the timed region)
     if any(x != inv[0] for x in inv):
         raise SystemExit("bench.py: the timed steps did not reproduce the same result: %r" % (sorted(set(inv))[:2],))
@@ -402,6 +410,7 @@ def main():
                        "parallelism": "replicas x%d, RCCL all-reduce of the verdict word" % world if world > 1 else "1 GPU",
                        "verdict": bool(res.function_good), "status": int(res.status),
                        "outer_iterations": int(s.outer_iterations), "pops": int(s.pops),
+                       "python_gc": "cyclic collector held off during the timed steps (a full collection with torch loaded: ~40 ms)",
                        "invariants": {"steps_identical": True, "checked": "status, verdict, pops, successful_steps, num_unique, outer_iterations, the four printed counts, rule hits -- every timed step"},
                        "host_prep_s": {"generate": round(t_gen, 3), "parse": round(t_parse, 3), "abstract": round(t_abstract, 3)},
                        "runtime_warmup": {"ms": round(runtime_warmup_ms, 1), "what": "one 64 MB torch host-to-device copy before the front-end: the process's first copy initialises the HIP runtime's copy path; without it that time shows up as the first file's upload_ms"},
