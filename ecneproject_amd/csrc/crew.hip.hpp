@@ -7,18 +7,22 @@
 // longest row's walk whatever the width of the level -- ~1 000 instructions at ~7 cycles each on the one busy wavefront, 2.9-3.7 us
 // per level with 2-8 of 64 lanes at work (profiles/r04_level_round_stages.txt). The chain executor (chain.hip.hpp) pops ONE row in
 // ~300 instructions with its lanes across the row's entries. A crew round runs that short stream on up to eight rows at once, one
-// wavefront each, and pays for it with workgroup barriers (LDS traffic + s_barrier, ~0.1 us each):
+// wavefront each, and pays for it with workgroup barriers (~0.05 us each) and the LDS round trips of what the wavefronts tell each other:
 //   1. wavefront r takes the row at queue position head + r from the LDS mirror of the ring (level.hip.hpp's mirror);
 //   2. record + descriptor + solved / orientation bytes in one trip to the L2 (lanes 0..15 / 16..23), then lane 1 + e the flag
 //      byte of entry e (LDS) and, speculatively, the variable's inline fan-out foi[v] -- chain_pops() statement for statement;
 //   3. the pop is DECIDED with ballots, nothing is written: up to two flag bytes (+ bounds [0,1], the two roots of a bit check, the
 //      orientation byte), the REQUEUE candidates of its events in emission order (lane i holds candidate i), counters;
-//   4. hashed write marks in LDS (minimum rank per slot; a collision ends the prefix early, never wrongly late) | barrier | every
-//      lane looks its own variable up: blocked iff an EARLIER rank writes what the row reads | barrier | the prefix ends in front
-//      of the first blocked row (or the first row this loop does not take);
+//   4. published before the one barrier of the dependency test: write marks in one of two hashed LDS tables (minimum rank per slot; a
+//      collision ends the prefix early, never wrongly late; the tables alternate with every pass of the loop, so that a wavefront takes its
+//      marks back while the others already set theirs in the other table), the read set (the variables whose flag bytes the pop has
+//      read), the row, status and candidate count | barrier | EVERY wavefront works out the whole prefix by itself: lane 8 r + j looks
+//      entries j and j + 8 of rank r's read set up in the marks -- blocked iff an EARLIER rank writes what the row reads --, the prefix
+//      ends in front of the first blocked row (or the first row this loop does not take);
 //   5. the wavefronts of the prefix commit their pops and write their candidates (rank << 24 | target, in (rank, emission, position)
 //      order) to the LDS list | barrier | wavefront 0 resolves the pushes exactly as a level round does (the rows of the prefix carry
-//      2 + rank in their in_queue tag meanwhile, the lowest eligible candidate per target wins, winners go to the mirror) | barrier.
+//      2 + rank in their in_queue tag meanwhile, the lowest eligible candidate per target wins, winners go to the mirror) | barrier. A
+//      round without candidates ends at the commit barrier: two to three barriers per round, 2.0-2.2 us against 2.9-3.7 for a level round.
 // What the loop does not take -- a row without a record that its watched pair does not settle, another shape, a bound of the third
 // kind, R7 / R8 in reach, errors -- ends the window in front of it; at rank 0 wavefront 0 pops that one row with the general
 // executor right here (the others wait at the barrier), a live long row goes back to the caller (popped by the whole workgroup).
