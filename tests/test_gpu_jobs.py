@@ -87,3 +87,30 @@ def test_jobs_cli_one_process(tmp_path):
         assert by[s["name"]]["sound"] == o.verdict
         assert (by[s["name"]]["unique"], by[s["name"]]["of"]) == (o.summary.unique_nontrivial, o.summary.n_nontrivial)
     assert [l for l in lines if "jobs" in l][0] == {"jobs": 3, "n_gpus": 1, "all_ran": True, "wall_s": [l for l in lines if "jobs" in l][0]["wall_s"]}
+
+
+@pytest.mark.gpu
+def test_runner_many_jobs_several_launches_summaries_in_one_call():
+    """more jobs than one launch holds (3 copies of the 67 files = 201 jobs ... and 5 copies = 335 > 248): the Runner hands them to the engine
+    longest first and re-orders them by their own clocks after the first passes, the engine launches back to back, the summaries of the whole
+    batch come back through ecne_result_summaries -- job k's result is job k's whatever the order (verdict, counts, pops, steps, rule hits =
+    the oracle's), pass after pass"""
+    from ecneproject_amd import jobs as J
+    rels = fixtures.circomlib_suite()
+    jl = [J.Job(fixtures.path(r), "%s#%d" % (r, c)) for c in range(5) for r in rels]
+    runner = J.Runner(jl, rank=0, world=1, device=0, dist=None)
+    oracles = {r: orc.run(fixtures.path(r), want_states=False) for r in rels}
+    orders = []
+    for rep in range(4):
+        res, ok = runner.run(fetch_states=False)
+        orders.append(list(runner.order))
+        assert len(res) == len(jl)
+        for j, g in zip(jl, res):
+            o = oracles[j.name.split("#")[0]]
+            s = g.summary
+            assert (g.status, g.function_good) == (o.status, o.verdict), (j.name, rep)
+            if o.status == 0:
+                assert tuple(g.counts()) == tuple(o.counts()), (j.name, rep)
+                assert (s.pops, s.successful_steps, s.num_unique, s.outer_iterations) == (o.summary.pops, o.summary.successful_steps, o.summary.num_unique, o.summary.outer_iterations), (j.name, rep)
+                assert list(s.rule_hits[:13]) == list(o.summary.rule_hits[:13]), (j.name, rep)
+    assert sorted(orders[0]) == list(range(len(jl))) and orders[2] == orders[3]      # (settled after the first two passes)
