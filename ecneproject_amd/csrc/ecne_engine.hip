@@ -1665,15 +1665,7 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             }
             bool fail = false;
             if (!all_descs.empty() && hipMemcpyAsync(scratch.d_descs, all_descs.data(), sizeof(WgDesc) * all_descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) fail = true;
-            if (side_launch && !fail) {
-                // (the side stream starts behind the uploads and the zeroed counters; the caller's stream goes on behind the side stream's kernel)
-                const size_t first = launch_at[1];
-                if (hipEventRecord(scratch.e_up, stream) != hipSuccess || hipStreamWaitEvent(scratch.side, scratch.e_up, 0) != hipSuccess) fail = true;
-                else {
-                    hipLaunchKernelGGL(k_solve, dim3((unsigned)(all_descs.size() - first)), dim3(ECNE_WG), dyn_lds, scratch.side, (const Job*)d_jobs, (const WgDesc*)(scratch.d_descs + first));
-                    if (hipEventRecord(scratch.e_side, scratch.side) != hipSuccess) fail = true;
-                }
-            }
+            if (side_launch && !fail && (hipEventRecord(scratch.e_up, stream) != hipSuccess || hipStreamWaitEvent(scratch.side, scratch.e_up, 0) != hipSuccess)) fail = true;
             for (size_t li = 0; li + 1 < launch_at.size() && !fail; ++li) {
                 const size_t nd = launch_at[li + 1] - launch_at[li];
                 if (nd == 0) continue;
@@ -1695,6 +1687,13 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                     if (any_multi) hipLaunchKernelGGL(k_solve_team, dim3((unsigned)nd), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
                     else hipLaunchKernelGGL(k_solve, dim3((unsigned)nd), dim3(ECNE_WG), dyn_lds, stream, (const Job*)d_jobs, (const WgDesc*)d_descs);
                 }
+            }
+            if (side_launch && !fail) {
+                // (the side stream started behind the uploads and the zeroed counters, its kernel is submitted behind the team's; the caller's stream
+                //  goes on behind the side stream's kernel)
+                const size_t first = launch_at[1];
+                hipLaunchKernelGGL(k_solve, dim3((unsigned)(all_descs.size() - first)), dim3(ECNE_WG), dyn_lds, scratch.side, (const Job*)d_jobs, (const WgDesc*)(scratch.d_descs + first));
+                if (hipEventRecord(scratch.e_side, scratch.side) != hipSuccess) fail = true;
             }
             if (side_launch && !fail && hipStreamWaitEvent(stream, scratch.e_side, 0) != hipSuccess) fail = true;
             if (sl && !fail && !refused) {
