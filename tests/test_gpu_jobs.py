@@ -114,3 +114,27 @@ def test_runner_many_jobs_several_launches_summaries_in_one_call():
                 assert (s.pops, s.successful_steps, s.num_unique, s.outer_iterations) == (o.summary.pops, o.summary.successful_steps, o.summary.num_unique, o.summary.outer_iterations), (j.name, rep)
                 assert list(s.rule_hits[:13]) == list(o.summary.rule_hits[:13]), (j.name, rep)
     assert sorted(orders[0]) == list(range(len(jl))) and orders[2] == orders[3]      # (settled after the first two passes)
+
+
+@pytest.mark.gpu
+def test_team_job_next_to_single_workgroup_jobs_in_one_batch():
+    """a batch that holds a multi-workgroup job next to single-workgroup ones goes out as two kernels at once -- the team's and, on a stream of the
+    library's own, k_solve for the others (ecne_engine.hip, side launch): every result bit for bit the oracle's, with the team job first and
+    last in the batch, pass after pass (tests/tools/soak_side.py is the long version)"""
+    import ecneproject_amd as E
+    import ecdsa_like
+    from gpu_common import assert_bit_exact, build_system
+    cases = [(None, ["secp256k1.r1cs"], ["Secp256k1AddUnequal"], ecdsa_like.cached(6, 10)),
+             ("secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"], None),
+             ("ecne_circomlib_tests/Poseidon@poseidon.r1cs", [], [], None), ("target/division.r1cs", [], [], None),
+             ("ecne_circomlib_tests/BabyPbk@babyjub.r1cs", [], [], None)]
+    systems = [build_system(rel, tr, nm, path=path) for rel, tr, nm, path in cases]
+    oracles = [orc.run(path or fixtures.path(rel), [fixtures.path(t) for t in tr], nm, True) for rel, tr, nm, path in cases]
+    for it in range(4):
+        order = list(range(len(systems)))
+        if it % 2:
+            order = order[1:] + order[:1]
+        res = E.solve_batch([systems[k] for k in order], secp_solve=True)
+        assert res[order.index(0)].summary.pops == oracles[0].summary.pops
+        for k, g in zip(order, res):
+            assert_bit_exact("mixed batch %s pass %d" % (cases[k][0] or "ecdsa_like(6)", it), g, oracles[k])
