@@ -468,7 +468,7 @@ struct HostDsu {
 // Tables for the reference's lazy BoundsError (oob.hip.hpp; format: the OOB_* words there). Host-laid systems only (the device
 // layout hands a system with such ids back to the host): per row that names one with a non-zero coefficient, the variables in
 // front of the first such id in the order each rule walks the row -- R1: B, A (nonzeroKeys order, :828-846), then C; R2 and P3:
-// getVariables order (:36-56); P5: A of row i (:1503) -- and, for secp_solve, the dsu of the setup (:634-678) with ids as they are.
+// getVariables order (:36-56); P4: A in nonzeroKeys order (:1431), then B's key (:1443); P5: A of row i (:1503) -- and, for secp_solve, the dsu of the setup (:634-678) with ids as they are.
 static void build_oob_tables(ecne_system& S, const std::vector<uint8_t>& a_equal_next) {
     Layout& L = S.L;
     const Rows& R = S.rows();
@@ -486,9 +486,20 @@ static void build_oob_tables(ecne_system& S, const std::vector<uint8_t>& a_equal
         if (!any) continue;
         const uint32_t nA = L.rp[0][i + 1] - L.rp[0][i], nB = L.rp[1][i + 1] - L.rp[1][i], nCc = L.rp[2][i + 1] - L.rp[2][i];
         uint32_t flags = 0;
-        std::vector<uint32_t> strict, cpart, r2, p3;
+        std::vector<uint32_t> strict, cpart, r2, p3, p4;
         if (nA == 0 && nB == 0) flags |= 1u;                 // OOBF_LINEAR
         if (nCc == 0) flags |= 4u;                           // OOBF_C_EMPTY
+        if (nCc == 0) {
+            // P4's visit (:1427-1448): `unique_a` walks A in nonzeroKeys order while unique (:1431-1436), then -- at most one key in B --
+            // B's key is read (:1442-1448)
+            bool a_hit = false;
+            for (uint32_t e = L.rp[0][i]; e < L.rp[0][i + 1]; ++e) {
+                if (is_oob(L.col[0][e])) { a_hit = true; break; }
+                p4.push_back(L.col[0][e]);
+            }
+            if (a_hit) flags |= 8u;                          // OOBF_P4_A_HAS
+            if (nB == 1 && is_oob(L.col[1][L.rp[1][i]])) flags |= 16u;      // OOBF_P4_B
+        }
         bool hit = false;
         for (int p = 1; p >= 0 && !hit; --p)                 // B first, then A
             for (uint32_t e = L.rp[p][i]; e < L.rp[p][i + 1]; ++e) {
@@ -515,10 +526,12 @@ static void build_oob_tables(ecne_system& S, const std::vector<uint8_t>& a_equal
         rowrec_off.push_back((uint32_t)recs.size());
         recs.push_back(flags);
         recs.push_back((uint32_t)strict.size()); recs.push_back((uint32_t)cpart.size()); recs.push_back((uint32_t)r2.size()); recs.push_back((uint32_t)p3.size());
+        recs.push_back((uint32_t)p4.size());
         recs.insert(recs.end(), strict.begin(), strict.end());
         recs.insert(recs.end(), cpart.begin(), cpart.end());
         recs.insert(recs.end(), r2.begin(), r2.end());
         recs.insert(recs.end(), p3.begin(), p3.end());
+        recs.insert(recs.end(), p4.begin(), p4.end());
     }
     // P5 (:1492-1550) at row i: the three counts, then A of row i while unique, then (maps equal, y, C's keys) variable_states[y]
     for (uint32_t i = 0; i + 1 < nC; ++i) {
@@ -1539,6 +1552,7 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
     std::vector<Job> hj(n);
     int rc = ECNE_OK;
     do {
+        std::vector<uint8_t> seq_only(n, 0);
         for (size_t i = 0; i < n; ++i) {
             int st = classify_system(*sys[i], stream, d_jobs);
             if (st != K_OK) { rc = st; break; }
@@ -1550,7 +1564,12 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                 if (const char* e = getenv("ECNE_BARRIER_TIMEOUT_MS")) tmo = (uint64_t)std::max(1L, atol(e));
                 hj[i].bar_timeout_ms = (uint32_t)std::min<uint64_t>(tmo, 3600000);
             }
-            hj[i].queue_mode = hj[i].oob ? 1u : (uint32_t)o.queue_mode;      // (ids above num_variables: strictly sequential pops, oob.hip.hpp)
+            // (ids above num_variables: strictly sequential pops, oob.hip.hpp. The same for a caller's known_variables WITHOUT the constant
+            //  wire (:682-693 then leave variable 1 like any other unknown): every parallel schedule relies on its `unique` / `is_known` never
+            //  changing and pads short rows with it)
+            const bool wire_free = std::find(sys[i]->knowns.begin(), sys[i]->knowns.end(), (int64_t)1) == sys[i]->knowns.end();
+            seq_only[i] = hj[i].oob != nullptr || wire_free;
+            hj[i].queue_mode = seq_only[i] ? 1u : (uint32_t)o.queue_mode;
             {   // rounds on all workgroups: drain rounds (drain.hip.hpp) unless queue_mode 3 / ECNE_DRAIN=0 ask for the prefix rounds
                 static const int drain_env = []() { const char* e = getenv("ECNE_DRAIN"); return e ? atoi(e) : 1; }();      // 2: test hook (every frontier is drained)
                 static const bool solo_off = []() { const char* e = getenv("ECNE_SOLO"); return e && atoi(e) == 0; }();
@@ -1561,7 +1580,7 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                 static const bool lv_off = []() { const char* e = getenv("ECNE_LEVEL"); return e && atoi(e) == 0; }();      // level rounds (level.hip.hpp) off: A/B runs
                 static const bool crew_off = []() { const char* e = getenv("ECNE_CREW"); return e && atoi(e) == 0; }();      // crew rounds (crew.hip.hpp) off: A/B runs
                 static const bool r4d_off = []() { const char* e = getenv("ECNE_R4DONE"); return e && atoi(e) == 0; }();      // long_r4_done (fastrow.hip.hpp) off: A/B runs
-                hj[i].lv_off = (lv_off ? 1u : 0u) | (crew_off ? 2u : 0u) | (r4d_off ? 4u : 0u);
+                hj[i].lv_off = (lv_off ? 1u : 0u) | (crew_off ? 2u : 0u) | (r4d_off ? 4u : 0u) | (wire_free ? 8u : 0u);      // bit 3: known_variables without the constant wire (R2 as the reference states it, rules_wave.hip.hpp)
             }
             hj[i].family = nullptr; hj[i].fam_rank = 0; hj[i].fam_size = 0;
             if (sl && i + 1 < n) { hj[i].family = sl->d_family; hj[i].fam_rank = (uint32_t)i; hj[i].fam_size = (uint32_t)(n - 1); }
@@ -1597,7 +1616,7 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             const bool lds_fits = hj[i].rec && hj[i].nC <= ECNE_CHAIN_ROWS && ((size_t)hj[i].nV + 1 + 16) + (2ull * hj[i].nC + 16) + 8192 <= dyn_lds;
             if (hj[i].nC <= single_wg_rows || (lds_fits && !getenv("ECNE_SINGLE_WG_ROWS"))) want = 1;
             if (o.debug > 0) want = (uint32_t)o.debug;          // test hook: force the helper count
-            if (hj[i].oob) want = 1;
+            if (seq_only[i]) want = 1;
             hj[i].nwg = std::max<uint32_t>(1u, std::min<uint32_t>(want, std::min<uint32_t>(cap, (uint32_t)ECNE_MAX_NWG)));
             hj[i].lds_bytes = dyn_lds;
             if (sl && i + 1 < n && hj[i].nwg != 1) rc = K_ESPLIT;      // (a part is a single-workgroup job)
@@ -1783,6 +1802,7 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
     const auto t0 = std::chrono::steady_clock::now();
     P.split_tried = true;
     if (!P.specials.empty() || !P.orig_var.empty() || !P.L.oob_blob.empty() || (int64_t)P.L.nV > P.n_vars) SPLIT_NO("trusted functions / ids above num_variables");
+    if (std::find(P.knowns.begin(), P.knowns.end(), (int64_t)1) == P.knowns.end()) SPLIT_NO("known_variables without the constant wire");
     { const int rc = sys_host_rows(P); if (rc != K_OK) return rc; }
     const Rows& R = P.rows();
     const size_t nC = R.n();

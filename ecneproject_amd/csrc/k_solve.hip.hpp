@@ -20,15 +20,20 @@ __device__ __noinline__ bool p4_phase(const Job& J, ChunkShared& s_chunk, QState
     // statically eligible row. A row tags b iff b is not unique, still untagged, and the row is the
     // FIRST such row of b in index order (varmin[b]).
     {
+        // (ids above num_variables, one workgroup: the lowest row whose visit reads such a state (:1432, :1443) -- BoundsError there unless a
+        //  lower row divides by zero (:1467); every thread evaluates the same few records, oob.hip.hpp)
+        const uint32_t r_oob = J.oob ? oob_p4_first(J) : 0xFFFFFFFFu;
         bool my_live = false;      // a candidate whose b is neither unique nor tagged: some row will tag in this pass
         for (uint32_t i = gtid; i < J.nP4; i += gstride) {
             const uint32_t b = J.p4_b[i];
             if (J.flags[b] & 1) continue;
+            if (r_oob != 0xFFFFFFFFu && J.p4_list[i] >= r_oob) continue;
             if (J.p4_s[i] & 0x80000000u) { raise(J, K_EDIVZERO); continue; }
             if (ld_agent(&J.varmin[b]) > i) atomicMin(&J.varmin[b], i);
             if (J.abz[b] == -1) my_live = true;
         }
         if (my_live) __hip_atomic_store(&ctr->p4_live, (unsigned)outer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (stamped with the outer iteration: never reset)
+        if (r_oob != 0xFFFFFFFFu) { __syncthreads(); if (tid == 0) raise(J, K_EBOUNDS); }      // (after every DivideError of a lower row: raise keeps the first code)
         if (job_barrier(J, s_err)) return true;
         // No live candidate anywhere: no row can tag, nothing to re-queue -- the pass ends at this barrier (every workgroup reads the
         // same word). The minima stay: as long as b is not unique its first candidate row is the same row.
@@ -553,10 +558,10 @@ __device__ __noinline__ void p12_phase(const Job& J, QState& q, unsigned long lo
                 for (uint32_t e = J.sp_in_ptr[i]; e < e1 && can; e += 4) {
                     uint32_t vv[4];
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) vv[k] = e + k < e1 ? J.sp_in[e + k] : 1u;       // (padding: the constant wire, always unique)
+                    for (uint32_t k = 0; k < 4; ++k) vv[k] = e + k < e1 ? J.sp_in[e + k] : 1u;
                     uint32_t all = 1;
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) all &= J.flags[vv[k]];
+                    for (uint32_t k = 0; k < 4; ++k) all &= e + k < e1 ? (uint32_t)J.flags[vv[k]] : 1u;      // (padding counts as unique whatever the constant wire's state is: a caller's known_variables need not hold it)
                     can = (all & 1) != 0;
                 }
             }

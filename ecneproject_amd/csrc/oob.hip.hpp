@@ -14,6 +14,7 @@
 //   R1 (:827-873), any other row:               B then A are walked while unique (strict part), C until the second non-unique
 //   R2 (:875-942), C empty:                     getVariables order until the second variable that is not is_known
 //   P3 (:1357-1417) visit of the row:           getVariables order; only a non-unique variable of A n B in front ends the walk (:1366)
+//   P4 (:1425-1483) visit of a row, C empty:   A in nonzeroKeys order while unique (:1431-1436); B's only key (:1443)
 //   P5 (:1492-1550) at row i:                   A of row i while unique (:1503); then `variable_states[var_key]` (:1533)
 //   P1 (:718-747), P2 (:750-800):               the specials' id lists, directly (the k-loop's dsu roots and `same_set` are static: per-pair codes)
 // A system with such ids is solved by ONE workgroup with strictly sequential pops (queue_mode 1), so the first raise is the
@@ -25,8 +26,8 @@ namespace ecne {
 
 // blob header words (host: OobBlob in ecne_engine.hip)
 enum : uint32_t { OOB_NROWS = 0, OOB_NP5 = 1, OOB_NVREF = 2, OOB_DSU_SIZE = 3, OOB_OFF_ROWIDS = 4, OOB_OFF_ROWREC = 5, OOB_OFF_P5 = 6, OOB_OFF_P2 = 7, OOB_HDR = 8 };
-// row record: [flags, nS, nCn, nR2, nP3, vars ...]
-enum : uint32_t { OOBF_LINEAR = 1u, OOBF_STRICT_HAS = 2u, OOBF_C_EMPTY = 4u };
+// row record: [flags, nS, nCn, nR2, nP3, nP4, vars ...]
+enum : uint32_t { OOBF_LINEAR = 1u, OOBF_STRICT_HAS = 2u, OOBF_C_EMPTY = 4u, OOBF_P4_A_HAS = 8u, OOBF_P4_B = 16u, OOB_REC_HDR = 6u };
 
 __device__ __forceinline__ bool oob_all_unique(const Job& J, const uint32_t* v, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) if (!(J.flags[v[i]] & 1)) return false;
@@ -56,7 +57,7 @@ __device__ __noinline__ int oob_pop(const Job& J, uint32_t row) {
     if (!r) return 0;
     const uint32_t fl = r[0], nS = r[1], nCn = r[2], nR2 = r[3];
     if (fl & OOBF_LINEAR) return 2;
-    const uint32_t* v = r + 5;
+    const uint32_t* v = r + OOB_REC_HDR;
     // R1: strict part (B, then A) while unique; C until the second non-unique
     if (oob_all_unique(J, v, nS)) {
         if (fl & OOBF_STRICT_HAS) return 2;
@@ -74,7 +75,21 @@ __device__ __noinline__ uint32_t oob_p3_first(const Job& J, uint32_t f) {
     for (uint32_t k = 0; k < b[OOB_NROWS]; ++k) {
         if (ids[k] < f) continue;
         const uint32_t* r = b + rec[k];
-        if (oob_all_unique(J, r + 5 + r[1] + r[2] + r[3], r[4])) return ids[k];
+        if (oob_all_unique(J, r + OOB_REC_HDR + r[1] + r[2] + r[3], r[4])) return ids[k];
+    }
+    return 0xFFFFFFFFu;
+}
+// P4 (:1425-1483): the lowest row whose visit raises, or 0xFFFFFFFF. A row with C empty: `unique_a` reads the states of A's keys in
+// Set order up to the first one that is not unique (:1431-1436 -- the flag is never used, the reads happen); then, B holding at most
+// one key, that key's state (:1443). P4 makes nothing unique, so one evaluation in front of the sweep holds for all of it.
+__device__ __noinline__ uint32_t oob_p4_first(const Job& J) {
+    const uint32_t* b = J.oob;
+    const uint32_t* ids = b + b[OOB_OFF_ROWIDS];
+    const uint32_t* rec = b + b[OOB_OFF_ROWREC];
+    for (uint32_t k = 0; k < b[OOB_NROWS]; ++k) {
+        const uint32_t* r = b + rec[k];
+        if (!(r[0] & (OOBF_P4_A_HAS | OOBF_P4_B))) continue;
+        if ((r[0] & OOBF_P4_B) || oob_all_unique(J, r + OOB_REC_HDR + r[1] + r[2] + r[3] + r[4], r[5])) return ids[k];
     }
     return 0xFFFFFFFFu;
 }

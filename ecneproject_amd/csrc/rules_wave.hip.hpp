@@ -199,6 +199,48 @@ __device__ __forceinline__ PopProf& pop_prof() { __shared__ PopProf p; return p;
 #define ECNE_PT(k) do { } while (0)
 #endif
 
+// R2 check_quadratic (:875-942) as the reference states it, for the one situation the static shapes do not cover: a caller's
+// known_variables WITHOUT the constant wire (Job.lv_off bit 3) while variable 1 is not is_known yet. The shapes (SH_R2 / SH_R2_BOUNDSERR /
+// SH_R2_DIV0, RowInfo.x, the two precomputed roots) are laid down for "variable 1 is known from the setup on"; here the variable that
+// is not known may be the wire itself. Strictly sequential pops only (such a system runs in queue_mode 1), every lane the same walk.
+// Returns true when the pop raised.
+__device__ __noinline__ bool r2_constant_wire_free(const Job& J, QState& q, uint32_t row, unsigned long long* hits, unsigned long long& steps) {
+    const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1], b0 = J.rpB[row], b1 = J.rpB[row + 1];
+    uint32_t u = 0, cnt = 0;                                  // `unknown_var` (:880-889): the one variable that is not is_known
+    for (uint32_t e = a0; e < a1; ++e) { const uint32_t v = J.colA[e]; if (!(J.flags[v] & 2)) { if (cnt == 0) { u = v; cnt = 1; } else if (v != u) cnt = 2; } }
+    for (uint32_t e = b0; e < b1; ++e) { const uint32_t v = J.colB[e]; if (!(J.flags[v] & 2)) { if (cnt == 0) { u = v; cnt = 1; } else if (v != u) cnt = 2; } }
+    if (cnt >= 2) return false;
+    fp::u256 sa = fp::make(0), ia = fp::make(0), sb = fp::make(0), ib = fp::make(0);
+    for (uint32_t e = a0; e < a1; ++e) {                      // :892-899 (`i == unknown_var` is tested first)
+        const uint32_t v = J.colA[e];
+        if (cnt == 1 && v == u) sa = ld256(J.coefA + 4ull * e);
+        else if (v == 1) ia = ld256(J.coefA + 4ull * e);
+        else return false;
+    }
+    for (uint32_t e = b0; e < b1; ++e) {                      // :902-909
+        const uint32_t v = J.colB[e];
+        if (cnt == 1 && v == u) sb = ld256(J.coefB + 4ull * e);
+        else if (v == 1) ib = ld256(J.coefB + 4ull * e);
+        else return false;
+    }
+    if (cnt == 0) { raise_ranked(J, q.head - 1, K_EBOUNDS); return true; }                       // variable_states[-1] (:916, read before the divisions)
+    if (fp::is_zero(sa) || fp::is_zero(sb)) { raise_ranked(J, q.head - 1, K_EDIVZERO); return true; }   // :919-920
+    const fp::u256 ra = fp::mul(fp::neg(ia), fp::inv(sa)), rb = fp::mul(fp::neg(ib), fp::inv(sb));
+    if (lane_id() == 0) {
+        st256(J.values + 8ull * u, ra);
+        st256(J.values + 8ull * u + 4, rb);
+        J.nvalues[u] = 2;
+        J.flags[u] = (uint8_t)((J.flags[u] | 2) & ~16u);      // make_values: is_known, abz reset by the constructor (:158)
+        J.abz[u] = -1;
+        if ((fp::is_zero(ra) && fp::is_one(rb)) || (fp::is_one(ra) && fp::is_zero(rb))) set_bounds(J, u, fp::make(0), fp::make(1));   // :923-927
+        J.solved[row] = 1;
+    }
+    wg_fence();
+    requeue(J, q, u);
+    steps++; hits[1]++;
+    return false;
+}
+
 // ---- one queue pop: rules R1..R8 on row `row`, in the reference's order (:824-1348)
 __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, unsigned long long* hits,
                          unsigned long long& steps, unsigned long long& nuniq) {
@@ -255,7 +297,9 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
     }
     const unsigned long long steps_at_r1 = steps, nuniq_at_r1 = nuniq;
     // R2 check_quadratic (:875-942)
-    if (shape & SH_C_EMPTY) {
+    if ((shape & SH_C_EMPTY) && (J.lv_off & 8u) && !(J.flags[1] & 2)) {
+        if (r2_constant_wire_free(J, q, row, hits, steps)) return;
+    } else if (shape & SH_C_EMPTY) {
         if (shape & SH_R2_BOUNDSERR) { raise_ranked(J, q.head - 1, K_EBOUNDS); return; }   // (the row was popped just before)
         if (shape & SH_R2) {
             const uint32_t x = ri.x;

@@ -940,6 +940,10 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
         // P4 ABZ tagging :1425-1483
         for (int64_t i = 1; i <= nC; ++i) {
             if (nzk_c[i - 1].count != 0) continue;
+            // unique_a :1430-1436 -- its value is never used, but the walk READS variable_states[j] for every key of A in Set
+            // order up to the first one that is not unique: an id above num_variables in front of it raises BoundsError here
+            for (int64_t j : nzk_a[i - 1].ordered_keys(ctx))
+                if (!st(j).unique) break;
             if (nzk_b[i - 1].count > 1) continue;
             int64_t b_val = 0;
             bool unique_b = true;
@@ -1015,7 +1019,8 @@ static void solve(std::vector<Eq>& constraints, const std::vector<Special>& spec
 
 // solveWithTrustedFunctions :502-581 (without the text output)
 static Result* run(const char* main_path, int ntrusted, const char** tpaths, const char** tnames,
-                   int secp_solve, int policy, uint64_t seed, int shuffle_queue) {
+                   int secp_solve, int policy, uint64_t seed, int shuffle_queue,
+                   const int64_t* known_override = nullptr, int64_t n_known = 0, const int64_t* target_override = nullptr, int64_t n_target = 0) {
     Result* R = new Result();
     OrderCtx ctx;
     ctx.policy = policy;
@@ -1044,6 +1049,9 @@ static Result* run(const char* main_path, int ntrusted, const char** tpaths, con
         R->n_specials = (int64_t)specials.size();
         R->n_vars = main.nvars;
         R->specials = specials;
+        // SolveConstraintsSymbolic called directly (:583-592): the caller's known_variables / target_variables instead of readR1CS's
+        if (known_override) main.knowns.assign(known_override, known_override + n_known);
+        if (target_override) main.outputs.assign(target_override, target_override + n_target);
         R->knowns = main.knowns;
         R->targets = main.outputs;
         solve(main.eqs, specials, main.knowns, main.outputs, main.nvars, secp_solve != 0, &ctx,
@@ -1075,6 +1083,11 @@ struct orc_summary {
 void* orc_run(const char* main_path, int ntrusted, const char** tpaths, const char** tnames,
               int secp_solve, int policy, uint64_t seed, int shuffle_queue) {
     return run(main_path, ntrusted, tpaths, tnames, secp_solve, policy, seed, shuffle_queue);
+}
+// the same with the caller's known_variables / target_variables (a null list keeps the file's)
+void* orc_run_io(const char* main_path, int ntrusted, const char** tpaths, const char** tnames, int secp_solve,
+                 const int64_t* knowns, int64_t n_known, const int64_t* targets, int64_t n_target) {
+    return run(main_path, ntrusted, tpaths, tnames, secp_solve, 0, 0, 0, knowns, n_known, targets, n_target);
 }
 void orc_get_summary(void* h, orc_summary* s) {
     Result* R = (Result*)h;

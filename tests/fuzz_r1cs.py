@@ -257,6 +257,98 @@ def make_oob(seed):
     return dict(n_wires=base["n_wires"], n_out=base["n_out"], n_pub=base["n_pub"], n_prv=base["n_prv"], rows=rows, witness=w)
 
 
+def make_oob_p4(seed):
+    """Systems around P4's two state reads on rows that name an id above num_variables (src/R1CSConstraintSolver.jl:1430-1436 `unique_a`
+    walks nzk_a in ITS Set order while unique -- before the `length(nzk_b[i]) > 1` test --, :1443 reads B's only key). P3's walk
+    (:1364-1372, `getVariables` order over A u B u C) comes first and raises unless a non-unique variable of A n B stands in front of the
+    id in THAT order; the two orders differ when the tables differ in size, so B carries 0..20 further entries (inputs, mostly). Around
+    them: rows that make the A n B variable unique at once / in a later outer iteration / never, rows that divide by zero in P4 (:1467)
+    below and above, bit checks on the same variables (R2 walks getVariables too), isZero pairs sharing the A. Returns raw rows."""
+    import ref2
+    rng = random.Random(9176 * seed + 11)
+    npub = rng.randint(8, 26)
+    nprv = rng.randint(0, 3)
+    nout = rng.randint(1, 2)
+    nint = rng.randint(4, 14)
+    nw = nout + npub + nprv + nint             # wires 0..nw-1, nVars = nw + 1 (variable ids 1..nw+1; the last id is internal too)
+    nv = nw + 1
+    outs = list(range(2, 2 + nout))
+    ins = list(range(2 + nout, 2 + nout + npub + nprv))
+    internal = list(range(2 + nout + npub + nprv, nv + 1))
+    Wid = lambda: nv + rng.randint(1, 90)                                    # noqa: E731
+    coef = lambda: rng.choice([1, 1, 1, 2, 5, P - 1, 7])                     # noqa: E731
+    rows = []
+    # filler: products of inputs into internal variables (R1 at the first pop), chains, a constant row
+    for x in rng.sample(internal, rng.randint(0, min(4, len(internal)))):
+        a, b = rng.choice(ins), rng.choice(ins)
+        rows.append(([(a, 1)], [(b, 1)], [(x, 1)]))
+    if rng.random() < 0.4:
+        x, y = rng.choice(internal), rng.choice(internal)
+        rows.append(([], [], [(x, 1), (y, P - 1)]))
+    for _ in range(rng.choice([1, 1, 1, 2, 3])):
+        v = rng.choice(internal + outs)        # the variable of A n B (unique or not, depending on the filler)
+        w = Wid()
+        kind = rng.random()
+        a = [(v, coef()), (w, coef())]
+        if kind < 0.15:
+            a.append((rng.choice(ins), 1))
+        elif kind < 0.25:
+            a.append((1, coef()))
+        elif kind < 0.32:
+            a.append((rng.choice(internal), 1))
+        elif kind < 0.36:
+            a = [(w, coef())]                  # the id alone in A
+        rng.shuffle(a)
+        nb = rng.choice([0, 1, 2, 5, 8, 9] + list(range(10, 21)) * 2)
+        b = [(x, 1) for x in rng.sample(ins, min(nb, len(ins)))]
+        r = rng.random()
+        if r < 0.8:
+            b.insert(rng.randint(0, len(b)), (v, coef()))
+        elif r < 0.88:
+            b = [(Wid(), 1)] if rng.random() < 0.5 else [(w, 1)]            # B's only key is such an id (:1443)
+        elif r < 0.94:
+            b.insert(rng.randint(0, len(b)), (rng.choice(internal), 1))
+        if rng.random() < 0.1:
+            b.append((w, 0))                   # explicit zero: not a key
+        c = [] if rng.random() < 0.9 else [(rng.choice(ins), 1)]
+        if rng.random() < 0.85 and any(x == w for x, _c in a) and any(x == v for x, _c in a) and any(x == v for x, _c in b):
+            # steer towards the case only P4 decides: v in front of the id in getVariables order (P3 ends at v), the id in front of v
+            # in nzk_a's own order. The orders are Julia's (second reading's Set model); try other ids until they come out that way.
+            for _try in range(60):
+                fa, fb = ref2.FDict(), ref2.FDict()
+                for x, cf in a:
+                    fa[x] = cf % P
+                for x, cf in b:
+                    fb[x] = cf % P
+                gv = list(ref2.get_variables(ref2.Equation(fa, fb, ref2.FDict())))
+                na = list(ref2.nonzero_keys(fa))
+                if w in gv and v in gv and gv.index(v) < gv.index(w) and na.index(w) < na.index(v):
+                    break
+                w2 = Wid()
+                a = [(w2 if x == w else x, cf) for x, cf in a]
+                w = w2
+        new = [(a, b, c)]
+        if rng.random() < 0.12:                # an isZero-shaped pair on the same A (P5 :1503 walks it as well)
+            y = rng.choice(internal)
+            new = [(a, [(rng.choice(ins), 1)], [(1, 1), (y, P - 1)]), (a, [(y, 1)], [])]
+        pos = rng.randint(0, len(rows))
+        rows[pos:pos] = new
+    for _ in range(rng.choice([0] * 10 + [1, 2])):         # P4 rows that divide by zero (no slope variable in A), somewhere
+        x = rng.choice(internal + outs)
+        a = [] if rng.random() < 0.3 else [(1, coef())]
+        rows.insert(rng.randint(0, len(rows)), (a, [(x, 1)], []))
+    for _ in range(rng.randint(0, 2)):         # ordinary P4 rows / bit checks
+        x = rng.choice(internal)
+        if rng.random() < 0.5:
+            rows.insert(rng.randint(0, len(rows)), ([(x, 1), (1, P - 1)], [(x, 1)], []))
+        else:
+            rows.insert(rng.randint(0, len(rows)), ([(rng.choice(internal), 1), (1, 3)], [(x, 1)], []))
+    if rng.random() < 0.3:                     # makes a variable unique only in the second outer iteration (P3 single-row group -> R1)
+        x, y = rng.choice(internal), rng.choice(internal)
+        rows.append(([(rng.choice(ins), 1)], [(x, 1)], [(y, 1)]))
+    return dict(n_wires=nw, n_out=nout, n_pub=npub, n_prv=nprv, rows=rows)
+
+
 def write(path, spec):
     rows = []
     for A, B, C in spec["rows"]:

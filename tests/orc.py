@@ -49,6 +49,9 @@ def lib():
         L.orc_run.restype = C.c_void_p
         L.orc_run.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                               C.c_int, C.c_int, C.c_uint64, C.c_int]
+        L.orc_run_io.restype = C.c_void_p
+        L.orc_run_io.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int,
+                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.orc_get_summary.argtypes = [C.c_void_p, C.POINTER(Summary)]
         L.orc_get_states.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.orc_get_bad_rows.argtypes = [C.c_void_p, C.c_void_p]
@@ -113,13 +116,22 @@ class OracleResult:
 
 
 def run(main_path, trusted=(), names=(), secp_solve=False, policy=ORDER_JULIA, seed=0,
-        shuffle_queue=False, want_states=True):
+        shuffle_queue=False, want_states=True, known_variables=None, target_variables=None):
+    """known_variables / target_variables: SolveConstraintsSymbolic's own arguments (:583-592) instead of what readR1CS returns"""
     L = lib()
     n = len(trusted)
     tp = (C.c_char_p * max(n, 1))(*[os.fsencode(t) for t in trusted])
     tn = (C.c_char_p * max(n, 1))(*[s.encode() for s in names])
-    h = L.orc_run(os.fsencode(main_path), n, tp, tn, int(secp_solve), int(policy), int(seed),
-                  int(shuffle_queue))
+    if known_variables is not None or target_variables is not None:
+        assert policy == ORDER_JULIA and not shuffle_queue
+        kn = None if known_variables is None else np.asarray(list(known_variables), np.int64)
+        tg = None if target_variables is None else np.asarray(list(target_variables), np.int64)
+        h = L.orc_run_io(os.fsencode(main_path), n, tp, tn, int(secp_solve),
+                         None if kn is None else max(kn.ctypes.data, 8), 0 if kn is None else len(kn),
+                         None if tg is None else max(tg.ctypes.data, 8), 0 if tg is None else len(tg))
+    else:
+        h = L.orc_run(os.fsencode(main_path), n, tp, tn, int(secp_solve), int(policy), int(seed),
+                      int(shuffle_queue))
     try:
         s = Summary()
         L.orc_get_summary(h, C.byref(s))
