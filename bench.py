@@ -63,7 +63,47 @@ def csrc_sha16():
                 h.update(f.read())
     with open(os.path.join(HERE, "include", "ecne.h"), "rb") as f:
         h.update(f.read())
+    # (round 5) what the sources are compiled WITH belongs to the build: the recipe (compiler flags live in ecneproject_amd/build.py) and
+    # the developer's extra flags (ECNE_BUILD_FLAGS, e.g. -DECNE_ROUNDLOG)
+    with open(os.path.join(HERE, "ecneproject_amd", "build.py"), "rb") as f:
+        h.update(f.read())
+    h.update(os.environ.get("ECNE_BUILD_FLAGS", "").encode())
     return h.hexdigest()[:16]
+
+
+def schedule_env():
+    """the ECNE_* environment switches of this process: most of them change the schedule the engine runs (ECNE_CREW, ECNE_LEVEL, ECNE_DRAIN,
+    ECNE_SIDE_LAUNCH, ECNE_ROWS_PER_WG, ECNE_SPLIT, ECNE_LDS_BYTES, ...), so counter traffic measured under one set is not another set's"""
+    skip = ("ECNE_FULL_ORACLE", "ECNE_FE_DEBUG", "ECNE_SPLIT_DEBUG", "ECNE_BUILD_FLAGS")
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("ECNE_") and k not in skip}
+
+
+# DESIGN.md section 6, the table of predicted ms per step at N = 1, 2, 4, 8 GPUs (LPT packing of the measured single-job times of one MI355X;
+# a batch takes as long as its longest job). `bench.py --gpus N` prints measured next to predicted so that the first run on an 8-GPU node
+# grades the model by itself. "ecdsa": one circuit does not shard -- replicas, the time per step stays, the rate grows N-fold.
+DESIGN_PREDICTED_MS = {
+    "ecdsa": {1: 6.2, 2: 6.2, 4: 6.2, 8: 6.2},
+    "suite": {1: 10.6, 2: 10.2, 4: 10.2, 8: 10.2},
+    "dag": {1: 8.7, 2: 7.3, 4: 7.3, 8: 7.3},
+    "many": {1: 3.0, 2: 1.6, 4: 1.2, 8: 1.2},
+    "secp": {1: 7.3, 2: 7.3, 4: 7.3, 8: 7.3},
+    "poseidon": {1: 1.13, 2: 1.13, 4: 1.13, 8: 1.13},
+}
+
+
+def scaling_check(workload, world, ms_per_step, rank_ms, extra=None):
+    """measured against DESIGN.md section 6's prediction for this workload and N (no efficiency is reported: the driver computes it from
+    its own per-N runs; this is the model's self-check)"""
+    pred = DESIGN_PREDICTED_MS.get(workload, {})
+    out = {"n_gpus": world, "measured_ms_per_step": round(ms_per_step, 3), "predicted_ms_per_step": pred.get(world),
+           "measured_over_predicted": round(ms_per_step / pred[world], 3) if pred.get(world) else None,
+           "rank_ms_per_step": [round(x, 3) for x in rank_ms],
+           "slowest_over_mean_rank": round(max(rank_ms) / max(sum(rank_ms) / len(rank_ms), 1e-9), 3) if rank_ms else None,
+           "predicted_table_ms": {str(k): v for k, v in sorted(pred.items())},
+           "source": "DESIGN.md section 6 (single-GPU measurements of round 5 + LPT packing; no multi-GPU run behind it until a SCALE file exists)"}
+    if extra:
+        out.update(extra)
+    return out
 
 
 def step_invariants(r):
@@ -225,6 +265,7 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         "dtype": "u64x4 (BN254 Fp limbs) + u8/u32 flags", "data": data,
         "config": {"workload": label, "jobs": len(jl), "rows": rows, "verdicts_true": sum(int(j["verdict"]) for j in alljobs),
                    "all_ran": bool(ok),
+                   "scaling_check": scaling_check(args.workload, world, ms_per_step, [pr["ms_per_step"] for pr in per_rank]),
                    "per_rank": [{"rank": pr["rank"], "ms_per_step": round(pr["ms_per_step"], 3), "jobs": [j["job"] for j in pr["jobs"]],
                                  "longest_job_ms": round(max((j["device_ms"] for j in pr["jobs"]), default=0.0), 3)} for pr in per_rank],
                    "lpt": {"weights": "non-zeros of the main file", "rank_loads": loads, "imbalance": (max(loads) / max(sum(loads) / len(loads), 1e-9)) if loads else None,
@@ -310,51 +351,62 @@ def main():
     info = system.info
     stream = torch.cuda.current_stream().cuda_stream
 
+    from ecneproject_amd import sharding
+
     def step():
         r = E.solve_batch([system], device=local_rank, stream=stream, fetch_states=False,
                           queue_mode=args.queue_mode)[0]
-        if world > 1:
-            word = torch.tensor([1 if (r.status == 0 and r.function_good) else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(word, op=dist.ReduceOp.MIN)      # the done/verdict flag, RCCL over xGMI
-        return r
+        # the done / verdict flag: MIN all-reduce of one int32, RCCL over xGMI (a single circuit does not shard: replicas)
+        word = sharding.allreduce_verdict(r.status == 0 and r.function_good, dist, device="cuda") if world > 1 else (r.status == 0 and bool(r.function_good))
+        return r, word
 
     _shape, classify_ms_cold, classify_bytes = E.classify(system, device=local_rank)     # first launch: code object load, cold caches
     t_first = time.perf_counter()
-    res = step()                       # first solve: layout upload + classification happen here (untimed)
+    res, _w = step()                   # first solve: layout upload + classification happen here (untimed)
     torch.cuda.synchronize()
     first_call = {"wall_ms": round((time.perf_counter() - t_first) * 1e3, 3), "kernel_ms": round(float(res.summary.device_ms), 3)}
     frontend_stats = E.frontend_stats()                 # (abstraction and layout of this system; the parse figures are the main file's)
     for k in ("parse_device", "upload_ms", "offsets_ms", "fill_ms", "parse_ms", "file_bytes"):
         frontend_stats[k] = parse_stats[k]
-    for _ in range(max(args.warmup - 1, 0)):
-        res = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     gc.collect(); gc.disable()          # (see run_jobs_workload)
-    t0 = time.perf_counter()
-    dev_ms, timed = [], []
-    for _ in range(args.steps):
-        res = step()
-        dev_ms.append(res.summary.device_ms)
-        timed.append(res)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # W - 1 more untimed steps, barrier + synchronize, exactly K timed steps, synchronize + barrier, MAX over ranks (sharding.timed_replica_steps;
+    # the same function runs under gloo in tests/test_multirank_gloo.py)
+    elapsed, elapsed_rank, timed, words = sharding.timed_replica_steps(step, args.steps, max(args.warmup - 1, 0), dist, world, sync=torch.cuda.synchronize, device="cuda")
     gc.enable()
+    res = timed[-1]
+    dev_ms = [r.summary.device_ms for r in timed]
     inv = [step_invariants(r) for r in timed]                             # (after the timed region)
     if any(x != inv[0] for x in inv):
         raise SystemExit("bench.py: the timed steps did not reproduce the same result: %r" % (sorted(set(inv))[:2],))
+    # whole-state parity of THIS build on THIS workload, every run: the device-side digest of the per-variable state (ecne_result_digest)
+    # of one more solve (untimed) against the oracle's, committed as tests/golden/scale_goldens.json by tests/golden/make_scale_goldens.py
+    # (vectors, not the oracle: S = 104 costs the oracle minutes)
+    state_check = None
+    gold_path = os.path.join(HERE, "tests", "golden", "scale_goldens.json")
+    if os.path.exists(gold_path) and args.stride == 10 and args.queue_mode == 0:
+        with open(gold_path) as f:
+            gold = json.load(f).get("ecdsa_like(%d,10)+Secp256k1AddUnequal" % args.S)
+        if gold is not None:
+            rd = E.solve_batch([system], device=local_rank, stream=stream, fetch_states="digest")[0]
+            got = ["%016x" % rd.digest[0], "%016x" % rd.digest[1]]
+            gs = rd.summary
+            tup = (int(rd.status), bool(rd.function_good), int(gs.pops), int(gs.successful_steps), int(gs.num_unique), int(gs.outer_iterations),
+                   [int(x) for x in rd.counts()], [int(x) for x in list(gs.rule_hits)[:13]])
+            want = (gold["status"], gold["verdict"], gold["pops"], gold["steps"], gold["num_unique"], gold["outer"], gold["counts"], gold["rule_hits"])
+            if got != gold["digest"] or tup != want:
+                raise SystemExit("bench.py: the state of this build differs from the oracle's golden digest: %r %r vs %r %r" % (got, tup, gold["digest"], want))
+            state_check = {"digest": got, "what": "ecne_result_digest of the whole per-variable state (flags, bounds, tags, values) and the counters of one more "
+                                                  "solve equal the sequential oracle's, committed in tests/golden/scale_goldens.json"}
     # k_classify_rows, warm (after the timed steps: clocks up, the same resident rows; the kernel is idempotent)
     warm = sorted(E.classify(system, device=local_rank)[1] for _ in range(7))
     classify_ms, classify_ms_best = warm[len(warm) // 2], warm[0]                             # the figure reported: their median
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = n_main * world * args.steps / elapsed
+    rank_ms = [elapsed_rank * 1e3 / max(args.steps, 1)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_ms[0])
+        rank_ms = gathered
 
     if rank == 0:
         s = res.summary
@@ -377,8 +429,10 @@ def main():
             ts = t.get("by_S", {}).get(str(args.S))          # one entry per workload size the PMC passes were taken on (26: the headline, 104: beyond the Infinity Cache)
             if ts is None:
                 traffic_src = "no PMC passes on file for S = %d (tools/profile_r04.sh %d)" % (args.S, args.S)
-            elif t.get("csrc_sha16") == csrc_sha16():
+            elif t.get("csrc_sha16") == csrc_sha16() and t.get("schedule_env", {}) == schedule_env():
                 traffic, traffic_src = ts.get("k_solve_bytes_per_launch"), ts.get("source")
+            elif t.get("csrc_sha16") == csrc_sha16():
+                traffic_src = "not comparable: the PMC passes ran under ECNE_* switches %r, this process under %r" % (t.get("schedule_env", {}), schedule_env())
             else:      # the PMC passes were taken on another build of the library: not this line's traffic
                 traffic_src = "stale: profiles/traffic_latest.json was measured on csrc %s, this build is %s (re-run tools/profile_r04.sh)" % (t.get("csrc_sha16"), csrc_sha16())
         achieved = b_alg / (k_ms * 1e-3) / 1e9
@@ -408,6 +462,9 @@ def main():
                        "rows_main": n_main, "rows_reduced": int(info.n_rows), "nnz_reduced": nnz,
                        "specials": int(info.n_specials), "n_vars": int(info.n_vars),
                        "parallelism": "replicas x%d, RCCL all-reduce of the verdict word" % world if world > 1 else "1 GPU",
+                       "scaling_check": scaling_check("ecdsa" if args.S == 26 else "ecdsa_S%d" % args.S, world, ms_per_step, rank_ms,
+                                                      {"model": "replicas: value(N) = N x rows / t_step(slowest rank); the all-reduce of one word and the two barriers are the only coupling",
+                                                       "all_ranks_agreed_on_the_verdict_word": bool(all(words)) == bool(res.status == 0 and res.function_good)}),
                        "verdict": bool(res.function_good), "status": int(res.status),
                        "outer_iterations": int(s.outer_iterations), "pops": int(s.pops),
                        "python_gc": "cyclic collector held off during the timed steps (a full collection with torch loaded: ~40 ms)",
@@ -433,6 +490,10 @@ def main():
                          "multi_ms": {k: round(v, 3) for k, v in zip(["mark", "check_and_cut", "exec_and_scan", "expand", "count_and_scan", "write"], list(s.multi_ms)[:6])},
                          "note": "fixed point is dependency-depth bound; see DESIGN.md"},
         }
+        if state_check is not None:
+            out["config"]["invariants"]["state_matches_oracle_digest"] = state_check
+            if args.cpu_sample_S != args.S or args.no_cpu_baseline or world > 1:      # (else the live oracle leg below says it)
+                out["config"]["invariants"]["matches_oracle"] = "counters and the digest of the whole state equal the oracle's golden vectors for this workload (tests/golden/scale_goldens.json)"
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             import orc
             sp = ecdsa_like.cached(args.cpu_sample_S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid())

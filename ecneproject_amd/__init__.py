@@ -272,6 +272,12 @@ class SolveResult:
         if summary is not None and not fetch_states:      # (solve_batch: the summaries of the whole batch came in one call, the handles are freed in one)
             self.summary, self.status, self.function_good, self.digest = summary, int(summary.status), bool(summary.function_good), None
             return
+        try:
+            self._read(L, handle, fetch_states)
+        finally:
+            L.ecne_result_free(handle)      # whatever happened above: the handle keeps its result object alive
+
+    def _read(self, L, handle, fetch_states):
         s = Summary()
         _check(L.ecne_result_summary(handle, C.byref(s)))
         self.summary = s
@@ -283,10 +289,8 @@ class SolveResult:
             _check(L.ecne_result_digest(handle, d))
             self.digest = (int(d[0]), int(d[1]))
             if fetch_states == "digest":
-                L.ecne_result_free(handle)
                 return
         if not fetch_states:
-            L.ecne_result_free(handle)
             return
         nv = int(s.n_vars)
         fl, lb, ub = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
@@ -307,7 +311,6 @@ class SolveResult:
         rows, n = C.POINTER(C.c_int64)(), C.c_size_t()
         _check(L.ecne_result_bad_rows(handle, C.byref(rows), C.byref(n)))
         self.bad_rows = np.array([rows[i] for i in range(n.value)], dtype=np.int64)
-        L.ecne_result_free(handle)
 
     @property
     def unique(self):
@@ -347,10 +350,20 @@ def solve_batch(systems, secp_solve=False, device=0, queue_mode=0, stream=None, 
         # only the summaries: one call for the whole batch, one to free the handles (504 small systems: two FFI calls per result were
         # more time than the GPU spent on the batch)
         sums = (Summary * n)()
-        _check(L.ecne_result_summaries(outs, n, sums), "ecne_result_summaries")
-        L.ecne_results_free(outs, n)
+        try:
+            _check(L.ecne_result_summaries(outs, n, sums), "ecne_result_summaries")
+        finally:
+            L.ecne_results_free(outs, n)
         return [SolveResult(None, False, sums[i]) for i in range(n)]
-    return [SolveResult(C.c_void_p(outs[i]), fetch_states) for i in range(n)]
+    results, err = [], None
+    for i in range(n):      # (every handle is read or at least freed: an exception on one result must not leak the others)
+        try:
+            results.append(SolveResult(C.c_void_p(outs[i]), fetch_states))
+        except Exception as e:      # noqa: BLE001
+            err = err or e
+    if err is not None:
+        raise err
+    return results
 
 
 def classify(system, device=0):

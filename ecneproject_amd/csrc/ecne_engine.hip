@@ -107,17 +107,8 @@ static int ensure_host_rows(const ecne_r1cs* h) {
     R1CSFile& f = const_cast<ecne_r1cs*>(h)->f;
     std::lock_guard<std::mutex> g(g_lazy_rows_mu);
     if (f.host_rows) return K_OK;
-    if (!f.path.empty() && !(h->drows && f.n_cons >= 4096)) {      // small files: from the file again where it still is (cheaper than a download); a file that changed on disk since is caught by the counts only, so anything larger comes from the resident rows
-        FileView fv(f.path.c_str());
-        R1CSFile again;
-        size_t cons_off = 0;
-        if (read_r1cs_header(fv, again, cons_off) == K_OK && again.n_cons == f.n_cons && again.n_wires == f.n_wires &&
-            read_r1cs_rows(fv, cons_off, f.path.c_str(), again) == K_OK && again.nnz[0] == f.nnz[0] && again.nnz[1] == f.nnz[1] && again.nnz[2] == f.nnz[2]) {
-            f.rows = std::move(again.rows);
-            f.host_rows = true;
-            return K_OK;
-        }
-    }
+    // always from the rows the solve runs on (the device-resident ones): a file replaced on disk since the load must not give the host
+    // side -- abstraction patterns, the tables of ids above num_variables, split plans -- other rows than the device has
     if (h->drows) {
         const int rc = fe::download_rows(*h->drows, f.rows);
         if (rc != K_OK) return rc;
@@ -1527,7 +1518,11 @@ int ecne_device_count(void) {
 #define K_ESPLIT (-1000)      // internal: the split launch cannot be made (a part needs more than one workgroup, the parts do not fit the device)
 // sl: sys[0 .. n-2] are the parts of sys[n-1] (SplitPlan): the parts are solved, in lockstep, and scattered into the file's arrays;
 // the file itself gets no workgroup. fam_flags[0 / 1]: a part left early / the constant wire's state moved.
+// the side launch of the calling thread's last solve_batch_core (a team's kernel and k_solve at the same time on two streams); a batch whose
+// team timed out at its barrier under it is solved once more without (ecne_solve_batch)
+static thread_local bool tl_side_used = false, tl_side_forbid = false;
 static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, ecne_result** out, SplitPlan* sl, uint32_t* fam_flags) {
+    tl_side_used = false;
     if (!sys || !out || n == 0) return ECNE_EINVAL;
     for (size_t i = 0; i < n; ++i) out[i] = nullptr;
     ecne_opts o;
@@ -1649,6 +1644,11 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             const void* const kernel = any_multi ? (const void*)k_solve_team : (const void*)k_solve;      // single-workgroup jobs: the kernel without team code
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kernel, ECNE_WG, dyn_lds) != hipSuccess) { wg_per_cu = 1; (void)hipGetLastError(); }
             const size_t resident_cap = (size_t)std::max(wg_per_cu, 0) * (size_t)n_cu;
+            // (the side launch runs k_solve_team and k_solve at the same time: both kernels' occupancy counts -- the same today, 512 threads x 256
+            //  VGPRs and the same dynamic LDS, one workgroup per CU)
+            int wg_per_cu_side = wg_per_cu;
+            if (any_multi && hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu_side, (const void*)k_solve, ECNE_WG, dyn_lds) != hipSuccess) { wg_per_cu_side = 1; (void)hipGetLastError(); }
+            const size_t resident_cap_both = (size_t)std::max(std::min(wg_per_cu, wg_per_cu_side), 0) * (size_t)n_cu;
             bool refused = false;
             (void)hipEventRecord(e0, stream);
             std::vector<WgDesc> all_descs;
@@ -1660,8 +1660,9 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             size_t n_side = 0, total_all = 0;
             for (size_t i = 0; i < n; ++i) { total_all += hj[i].nwg; if (hj[i].nwg == 1) ++n_side; }
             static const bool side_off = []() { const char* e = getenv("ECNE_SIDE_LAUNCH"); return e && atoi(e) == 0; }();
-            const bool side_launch = !sl && any_multi && n_side > 0 && n_side < n && total_all <= cap && total_all <= resident_cap && !coop_ok && !side_off &&
+            const bool side_launch = !sl && any_multi && n_side > 0 && n_side < n && total_all <= cap && total_all <= resident_cap_both && !coop_ok && !side_off && !tl_side_forbid &&
                                      scratch.side_stream() == K_OK;
+            tl_side_used = side_launch;
             if (side_launch) {
                 for (size_t i = 0; i < n; ++i) if (hj[i].nwg > 1) for (uint32_t r = 0; r < hj[i].nwg; ++r) all_descs.push_back({(uint32_t)i, r});
                 launch_at.push_back(0);
@@ -1950,7 +1951,19 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             P.split.reset();        // (an error in a part, the constant wire written, parts that do not fit: the file as one system, from now on)
         }
     }
-    const int rc = solve_batch_core(sys, n, opts, out, nullptr, nullptr);
+    int rc = solve_batch_core(sys, n, opts, out, nullptr, nullptr);
+    if (rc == ECNE_OK && tl_side_used) {
+        // a team that gave up at its barrier (ECNE_ETIMEOUT) while a second kernel shared the device: the co-residency the occupancy
+        // queries promised did not hold (another process, a dispatch order nobody controls) -- once more, one launch after the other
+        bool timed_out = false;
+        for (size_t i = 0; i < n; ++i) timed_out |= out[i] && out[i]->sum.status == ECNE_ETIMEOUT;
+        if (timed_out) {
+            for (size_t i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
+            tl_side_forbid = true;
+            rc = solve_batch_core(sys, n, opts, out, nullptr, nullptr);
+            tl_side_forbid = false;
+        }
+    }
     if (rc == ECNE_OK && n == 1 && out[0]) sys[0]->last_kernel_ms = out[0]->sum.device_ms;
     return rc;
 }

@@ -62,6 +62,11 @@ def test_full_size_properties():
     if os.environ.get("ECNE_FULL_ORACLE", "1") != "0":      # the whole state against the oracle, ~20 s of CPU (ECNE_FULL_ORACLE=0 skips it)
         o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
         assert_bit_exact("ecdsa_like(26,10)", g, o)
+        # (pins tests/golden/scale_goldens.json -- what bench.py checks its own state against -- to the oracle on every run of the suite)
+        from state_digest import numpy_digest
+        assert ["%016x" % x for x in numpy_digest(o)] == _golden("ecdsa_like(26,10)+Secp256k1AddUnequal")["digest"]
+        gd = E.solve_batch([s], fetch_states="digest")[0]
+        _assert_matches_golden("ecdsa_like(26,10)", gd, _golden("ecdsa_like(26,10)+Secp256k1AddUnequal"))
 
 
 @pytest.mark.parametrize("force_nwg", [0, 43])
@@ -75,18 +80,43 @@ def test_mid_size_bit_exact(force_nwg):
     assert_bit_exact("ecdsa_like(6,10) nwg=%d" % force_nwg, g, o)
 
 
-@pytest.mark.skipif(os.environ.get("ECNE_FULL_ORACLE", "1") != "2", reason="ECNE_FULL_ORACLE=2 switches the 4.4 M-row comparison on (oracle: 3-7 minutes on one core)")
+def _golden(key):
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scale_goldens.json")) as f:
+        return json.load(f)[key]
+
+
+def _assert_matches_golden(tag, g, gold):
+    """g: a SolveResult fetched with the device-side digest; gold: the oracle's entry of tests/golden/scale_goldens.json"""
+    s = g.summary
+    assert g.status == gold["status"] == 0 and g.function_good == gold["verdict"], tag
+    assert [int(x) for x in g.counts()] == gold["counts"], tag
+    assert (int(s.pops), int(s.successful_steps), int(s.num_unique), int(s.outer_iterations)) == (gold["pops"], gold["steps"], gold["num_unique"], gold["outer"]), tag
+    assert [int(x) for x in list(s.rule_hits)[:13]] == gold["rule_hits"], tag
+    assert ["%016x" % g.digest[0], "%016x" % g.digest[1]] == gold["digest"], tag      # flags, bounds, tags, values of every variable
+
+
 def test_scale_out_full_state_parity():
-    """ecdsa_like(104): 4.4 M rows -- the only case beyond the 256 MiB Infinity Cache -- through the device front-end, the whole
-    per-variable state against the oracle; plus one million-row input of a different shape (1 400 Poseidon copies side by side)."""
+    """ecdsa_like(104): 4.4 M rows -- the only case beyond the 256 MiB Infinity Cache -- through the device front-end, and one million-row
+    input of a different shape (1 400 Poseidon copies side by side): counters and the WHOLE per-variable state against the oracle's, through
+    the digest the engine computes on the device (ecne_result_digest; tests/test_gpu_soak.py checks the digest against its numpy
+    restatement) and the oracle's digest committed by tests/golden/make_scale_goldens.py. ECNE_FULL_ORACLE=2 also runs the oracle itself
+    (3-7 minutes) and compares array by array."""
     import multi_copy
+    from state_digest import numpy_digest
     path = ecdsa_like.cached(104, 10)
     s = build_system(None, *TRUSTED, path=path)
     assert E.frontend_stats()["layout_device"] in (0.0, 1.0)
-    g = E.solve_batch([s])[0]
-    o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
-    assert o.verdict is True
-    assert_bit_exact("ecdsa_like(104,10)", g, o)
+    full = os.environ.get("ECNE_FULL_ORACLE", "1") == "2"
+    g = E.solve_batch([s], fetch_states="both" if full else "digest")[0]
+    _assert_matches_golden("ecdsa_like(104,10)", g, _golden("ecdsa_like(104,10)+Secp256k1AddUnequal"))
     p2 = multi_copy.cached("ecne_circomlib_tests/Poseidon@poseidon.r1cs", 1400)
     s2 = build_system(None, path=p2)
-    assert_bit_exact("1400 x Poseidon", E.solve_batch([s2])[0], orc.run(p2))
+    g2 = E.solve_batch([s2], fetch_states="both" if full else "digest")[0]
+    _assert_matches_golden("1400 x Poseidon", g2, _golden("1400xPoseidon@poseidon"))
+    if full:
+        o = orc.run(path, [fixtures.path("secp256k1.r1cs")], TRUSTED[1])
+        assert o.verdict is True
+        assert_bit_exact("ecdsa_like(104,10)", g, o)
+        assert ["%016x" % x for x in numpy_digest(o)] == _golden("ecdsa_like(104,10)+Secp256k1AddUnequal")["digest"]
+        assert_bit_exact("1400 x Poseidon", g2, orc.run(p2))

@@ -253,3 +253,83 @@ def test_two_rank_many_workload(tmp_path):
     assert not any(k in n for n in res["names"] for k in bench.MANY_EXCLUDES)
     assert min(res["rows"]) > 0 and abs(res["loads"][0] - res["loads"][1]) <= max(res["loads"]) * 0.05      # balanced: no job dominates
     assert res["ok"] is True and 0 < res["verdicts_true"] < len(jl)
+
+
+REPLICA_WORKER = r'''
+import os, sys, json, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch, torch.distributed as dist
+import fixtures, orc, ecdsa_like
+import bench
+from ecneproject_amd import sharding
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+path = ecdsa_like.cached(2, 10)
+calls = {"n": 0}
+bad_rank = int(os.environ.get("ECNE_TEST_BAD_RANK", "-1"))
+
+
+def step():
+    """bench.py's replica step with the oracle standing in for the GPU solve (no GPU here); rank 1 is made the slow one"""
+    calls["n"] += 1
+    o = orc.run(path, [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"], want_states=False)
+    good = o.status == 0 and bool(o.verdict) and rank != bad_rank
+    return o, sharding.allreduce_verdict(good, dist, device="cpu")
+
+
+# (the all-reduce inside every step keeps the ranks in step; what can differ is what the device still has in flight when the loop ends --
+#  the synchronisation at the end of the timed region, here a sleep on rank 1)
+syncs = {"n": 0}
+
+
+def sync():
+    syncs["n"] += 1
+    if syncs["n"] == 2 and rank == 1:      # the one behind the timed steps
+        time.sleep(0.25)
+
+
+elapsed, mine, results, words = sharding.timed_replica_steps(step, 3, 1, dist, world, sync=sync, device="cpu")
+n_main = int(results[-1].summary.n_rows_main)
+gathered = [None] * world
+dist.all_gather_object(gathered, {"elapsed": elapsed, "mine": mine, "words": words, "calls": calls["n"], "rows": n_main})
+if rank == 0:
+    chk = bench.scaling_check("ecdsa", world, elapsed * 1e3 / 3, [g["mine"] * 1e3 / 3 for g in gathered])
+    print("RESULT " + json.dumps({"ranks": gathered, "value": n_main * world * 3 / elapsed, "check": chk}))
+dist.destroy_process_group()
+'''
+
+
+def _run_replicas(tmp_path, port, bad_rank=None):
+    import json
+    script = tmp_path / "replica_worker.py"
+    script.write_text(REPLICA_WORKER % {"root": ROOT, "tests": HERE})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if bad_rank is not None:
+        env["ECNE_TEST_BAD_RANK"] = str(bad_rank)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+
+
+def test_two_rank_replicas_of_one_circuit(tmp_path):
+    """`bench.py --workload ecdsa --gpus 2`: one circuit does not shard -- every rank solves its replica (sharding.timed_replica_steps, the
+    function bench.py times its steps with): W untimed + exactly K timed steps per rank, the reported time is the MAX over ranks (rank 1's
+    device synchronisation takes longer: both ranks must report ITS time), the verdict word is the MIN over ranks, value = rows x N x K / time."""
+    res = _run_replicas(tmp_path, 29537)
+    r0, r1 = res["ranks"]
+    assert r0["calls"] == r1["calls"] == 4                              # 1 warm-up + 3 timed
+    assert r0["elapsed"] == r1["elapsed"] >= r1["mine"] > r0["mine"]    # MAX over ranks, identical on both
+    assert r1["mine"] - r0["mine"] > 0.15                               # (rank 1's synchronisation takes 0.25 s longer)
+    assert r0["words"] == r1["words"] == [True, True, True]
+    assert abs(res["value"] - r0["rows"] * 2 * 3 / r0["elapsed"]) < 1e-6 * res["value"]
+    assert res["check"]["n_gpus"] == 2 and len(res["check"]["rank_ms_per_step"]) == 2 and res["check"]["slowest_over_mean_rank"] > 1.0
+    assert res["check"]["predicted_ms_per_step"] is not None
+
+
+def test_two_rank_replicas_one_rank_disagrees(tmp_path):
+    """the MIN all-reduce: one rank whose replica does not reach the verdict turns the word to False on every rank"""
+    res = _run_replicas(tmp_path, 29538, bad_rank=1)
+    assert res["ranks"][0]["words"] == res["ranks"][1]["words"] == [False, False, False]
