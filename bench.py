@@ -447,6 +447,10 @@ def main():
                    "multi_workgroup_rounds": n_multi, "us_per_multi_round": 1e3 * multi_ms / max(n_multi, 1),
                    "fast_wavefront_rounds": sd[0], "rows_in_fast_rounds": sd[1], "us_per_fast_round": sd[2] * 1e-2 / max(sd[0], 1),
                    "outer_iterations": int(s.outer_iterations),
+                   # (round 5) outer iterations the master workgroup of the team finished alone: P3 / P4 from the rows popped since the last pass
+                   # (no job barrier, no sweep over the system); the others ran the full sweeps with every workgroup
+                   "iterations_on_the_master_alone": int(s.team[0]), "rows_their_passes_looked_at": int(s.team[1]), "iterations_with_full_sweeps": int(s.team[2]),
+                   "ms_in_iterations_on_the_master_alone": round(int(s.team[3]) * 1e-5, 3), "P1_P2_ms": round(float(s.phase_ms[7]), 3),
                    # drain rounds (csrc/drain.hip.hpp): a window executed in dataflow order, level by level, pushes resolved once per window;
                    # a level costs 2 job barriers (nobody contested anything) to 4, the resolution 4
                    "drain_rounds": int(round(float(s.multi_ms[7]) * 1e5)), "drain_levels": int(round(float(s.multi_ms[6]) * 1e5)),

@@ -35,7 +35,7 @@ class Summary(C.Structure):
                 ("pops", C.c_int64), ("num_unique", C.c_int64),
                 ("rule_hits", C.c_int64 * 16), ("n_rows", C.c_int64), ("n_vars", C.c_int64), ("pop_nnz", C.c_int64),
                 ("device_ms", C.c_double), ("classify_ms", C.c_double), ("queue_ms", C.c_double * 8), ("multi_ms", C.c_double * 8), ("phase_ms", C.c_double * 8),
-                ("sched", C.c_int64 * 16)]
+                ("sched", C.c_int64 * 16), ("team", C.c_int64 * 4)]
 
 
 # every symbol include/ecne.h declares

@@ -1076,6 +1076,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_queue = c.take(4ull * qcap);
     size_t o_varmin = c.take(4ull * (nV + 1));
     size_t o_rdead = c.take(std::max<size_t>(nC, 1) + 4);   // read four rows at a time
+    size_t o_p3stamp = c.take(4ull * std::max<size_t>(nC, 1));
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_htlist = c.take(4ull * ((size_t)nC + (size_t)ECNE_MAX_NWG * 2049 + 64));
@@ -1196,6 +1197,7 @@ static int upload_system(ecne_system& S, int device) {
     J.rdead = (uint8_t*)(base + o_rdead);
     J.nLong = (uint32_t)n_long;
     J.nBigRows = (uint32_t)n_bigrows;
+    J.p3stamp = (uint32_t*)(base + o_p3stamp);
     J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
@@ -1779,6 +1781,7 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
             for (int k = 0; k < 8; ++k) s.queue_ms[k] = (double)c.qticks[k] * 1e-5;
             for (int k = 0; k < 8; ++k) s.multi_ms[k] = (double)c.mticks[k] * 1e-5;
             for (int k = 0; k < 16; ++k) s.sched[k] = (int64_t)c.sched[k];
+            for (int k = 0; k < 4; ++k) s.team[k] = (int64_t)c.team_stat[k];
             for (int k = 0; k < 8; ++k) s.phase_ms[k] = (k == 6) ? (double)c.phase_ticks[k] : (double)c.phase_ticks[k] * 1e-5;
             out[i] = r;
         }

@@ -88,6 +88,7 @@ struct Counters {   // one per job, device memory
     unsigned long long qticks[8];        // queue phase (master): head, mark, check+unmark, exec, flatten, resolve, alone+bursts, multi rounds
     unsigned long long mticks[8];        // multi-workgroup rounds: mark, check+cut, exec+scan, expand, count+scan, write
     unsigned long long sched[16];        // schedule diagnostics of the master (ecne_summary.sched)
+    unsigned long long team_stat[4];     // ecne_summary.team
     // job-wide synchronisation words (zeroed before every launch)
     unsigned long long sync_steps;
     int error_snap;
@@ -112,6 +113,11 @@ struct Counters {   // one per job, device memory
     unsigned int d_cut[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows left after the level, bit 0 "somebody is unstable" / bit 1 "somebody marked A"
     unsigned int q_part[2][256];
     unsigned int q_blk[2][ECNE_MAX_NWG * 8];   // per-wavefront totals of the block-order scan (team_block_scan)
+    // (round 5) outer iterations the master of a team runs alone (k_solve.hip.hpp): whether the loop goes on (read by the helpers behind the
+    // barrier at the loop top), what the helpers do when the master lets them out of the queue phase, and the state of P3's group table
+    unsigned int sync_go;
+    unsigned int team_cmd, team_outer;   // team_cmd: TEAM_FULL = P3 and P4 of iteration team_outer with everybody, TEAM_EXIT = the loop has ended
+    unsigned int p3_tbl;                 // 0 = P3's group table is empty; 1 = it holds the counts of the last pass (kept for the incremental passes); 2 = the same, and slots were created that no list records (wiped as a whole)
     unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 
@@ -182,6 +188,7 @@ struct Job {
     const uint32_t* long_list; // every row with more than ECNE_SMALL_ROW entries, ascending
     uint32_t nLong;
     uint8_t* p3k;
+    uint32_t* p3stamp;         // per row: the outer iteration whose incremental P3 / P4 pass has looked at the row (a row popped twice is looked at once)
     uint64_t *p3h, *p3h2;
     uint64_t *ht_key, *ht_key2;
     uint32_t *ht_new, *ht_frozen;

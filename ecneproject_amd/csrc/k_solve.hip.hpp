@@ -190,6 +190,56 @@ __device__ __noinline__ bool p4_phase(const Job& J, ChunkShared& s_chunk, QState
     return false;
 }
 
+// One evaluated row into the caches (p3k / p3h / p3h2) and the group table: k = its non-unique variables of C (0: not eligible, or none
+// left), h / h2 the key of that set. A FULL pass (INC = false) starts from an empty table. An INCREMENTAL pass (INC = true: the table and the
+// caches still hold the last pass, p3p4_incremental below) first takes the row's old status out of its group. Returns bit 0: a one-variable
+// group (fires at its first row, :1402), bit 1: the row's group could be complete with it, bit 2: a group of two and more.
+template <bool INC>
+__device__ __forceinline__ uint32_t p3_apply(const Job& J, uint32_t r, uint32_t k, uint64_t h, uint64_t h2, uint32_t my_rank, uint32_t ht_cap, uint32_t* s_htn) {
+    uint32_t st = 0;
+    if constexpr (INC) {
+        if (J.p3k[r] >= 2) {
+            const uint32_t so = ht_slot(J, J.p3h[r], J.p3h2[r], false);
+            if (so != 0xFFFFFFFFu) atomicSub(&J.ht_new[so], 1u);
+        }
+    }
+    J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
+    if (k == 1) st |= 1u;
+    else if (k >= 2) {
+        J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
+        bool created = false;
+        const uint32_t s = ht_slot(J, h, h2, true, &created);
+        if (s != 0xFFFFFFFFu) {
+            // "hot" only when this group could be complete with this member (k rows counting the frozen ones): otherwise nobody has
+            // to look for trigger rows this pass
+            const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
+            if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) st |= 2u;
+        }
+        st |= 4u;
+        if (created) {   // remembered, so that only the slots in use are wiped afterwards
+            const uint32_t pos = atomicAdd(s_htn, 1u);
+            if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);      // (an incremental pass is only started with room for every row it looks at)
+        }
+    }
+    return st;
+}
+
+// P3 status of a LONG row, one wavefront: lanes across its entries. Returns "a variable of A or B is not unique" (not eligible, :1366-1382).
+__device__ __forceinline__ bool p3_eval_long(const Job& J, uint32_t r, uint32_t& k, uint64_t& h, uint64_t& h2) {
+    const int lane = lane_id();
+    bool nuab = false;
+    for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nuab |= !(J.flags[J.colA[e]] & 1);
+    for (uint32_t e = J.rpB[r] + lane; e < J.rpB[r + 1]; e += 64) nuab |= !(J.flags[J.colB[e]] & 1);
+    k = 0; h = 0; h2 = 0;
+    for (uint32_t e = J.rpC[r] + lane; e < J.rpC[r + 1]; e += 64) {
+        const uint32_t v = J.colC[e];
+        if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { k += __shfl_xor(k, d, 64); h += __shfl_xor(h, d, 64); h2 += __shfl_xor(h2, d, 64); }
+    h = mixA(h + k);
+    return __ballot(nuab) != 0;
+}
+
 // P3, phase 1 of a pass (:1357-1386): every row from f on that is not dead is evaluated against the current state -- eligibility, the
 // number k of non-unique variables of C, the hash of that set -- and counted into its group. A function of its own: called once per
 // pass from the kernel body, whose 256 live registers made every call of the per-row evaluation a spill / reload of dozens of them.
@@ -207,27 +257,13 @@ __device__ __noinline__ void p3_phase1(const Job& J, uint32_t f, uint32_t gtid, 
         p3_eval4(J, r4, want, k4, h4, g4);       // the four rows' loads in flight together
         for (uint32_t r = r4 < f ? f : r4; r < r4 + 4 && r < nC; ++r) {
             if (!((want >> (r - r4)) & 1u)) continue;
-            uint32_t k = k4[r - r4]; uint64_t h = h4[r - r4], h2 = g4[r - r4];
+            uint32_t k = k4[r - r4];
             if (k == 0) J.rdead[r] = 1;        // eligible with no unknown left: nothing can change for this row
             if (k == 0xFFFFFFFFu) k = 0;
-            J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
-            if (k == 1) atomicMin(&J.ctr->p3_cand1, r);
-            else if (k >= 2) {
-                J.p3h[r] = h; J.p3h2[r] = h2;   // only read for k >= 2
-                bool created = false;
-                uint32_t s = ht_slot(J, h, h2, true, &created);
-                if (s != 0xFFFFFFFFu) {
-                    // p3_hot is raised only when this group could be complete with this member (k rows
-                    // counting the frozen ones): otherwise nobody has to look for trigger rows this pass
-                    const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
-                    if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
-                }
-                my_any = true;
-                if (created) {   // remembered, so that only the slots in use are wiped afterwards
-                    const uint32_t pos = atomicAdd(s_htn, 1u);
-                    if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
-                }
-            }
+            const uint32_t st = p3_apply<false>(J, r, k, h4[r - r4], g4[r - r4], my_rank, ht_cap, s_htn);
+            if (st & 1u) atomicMin(&J.ctr->p3_cand1, r);
+            if (st & 2u) my_hot = true;
+            if (st & 4u) my_any = true;
         }
     }
     // long rows: one WAVEFRONT per row, lanes across its entries (one lane walking a 1 025-term row made
@@ -235,52 +271,101 @@ __device__ __noinline__ void p3_phase1(const Job& J, uint32_t f, uint32_t gtid, 
     for (uint32_t li = my_rank * ECNE_NWAVES + (uint32_t)w; li < J.nLong; li += J.nwg * ECNE_NWAVES) {
         const uint32_t r = J.long_list[li];
         if (r < f || (J.rdead[r] & 1)) continue;               // (wave-uniform)
-        bool nuab = false;
-        for (uint32_t e = J.rpA[r] + lane; e < J.rpA[r + 1]; e += 64) nuab |= !(J.flags[J.colA[e]] & 1);
-        for (uint32_t e = J.rpB[r] + lane; e < J.rpB[r + 1]; e += 64) nuab |= !(J.flags[J.colB[e]] & 1);
-        uint32_t k = 0; uint64_t h = 0, h2 = 0;
-        for (uint32_t e = J.rpC[r] + lane; e < J.rpC[r + 1]; e += 64) {
-            const uint32_t v = J.colC[e];
-            if (!(J.flags[v] & 1)) { ++k; h += mixA(v); h2 += mixB(v); }
-        }
-        for (int d = 32; d >= 1; d >>= 1) { k += __shfl_xor(k, d, 64); h += __shfl_xor(h, d, 64); h2 += __shfl_xor(h2, d, 64); }
-        const bool inelig = __ballot(nuab) != 0;
-        h = mixA(h + k);
+        uint32_t k; uint64_t h, h2;
+        const bool inelig = p3_eval_long(J, r, k, h, h2);
         if (lane == 0) {
             if (inelig) k = 0;
             else if (k == 0) J.rdead[r] |= 1;
-            J.p3k[r] = (uint8_t)(k > 255 ? 255 : k);
-            if (k == 1) atomicMin(&J.ctr->p3_cand1, r);
-            else if (k >= 2) {
-                J.p3h[r] = h; J.p3h2[r] = h2;
-                bool created = false;
-                uint32_t s = ht_slot(J, h, h2, true, &created);
-                if (s != 0xFFFFFFFFu) {
-                    const uint32_t before = atomicAdd(&J.ht_new[s], 1u);
-                    if (before + 1 + ld_agent(&J.ht_frozen[s]) >= k) my_hot = true;
-                }
-                my_any = true;
-                if (created) {
-                    const uint32_t pos = atomicAdd(s_htn, 1u);
-                    if (pos < ht_cap) J.ht_list[(size_t)my_rank * ht_cap + pos] = s; else raise(J, K_ECAPACITY);
-                }
-            }
+            const uint32_t st = p3_apply<false>(J, r, k, h, h2, my_rank, ht_cap, s_htn);
+            if (st & 1u) atomicMin(&J.ctr->p3_cand1, r);
+            if (st & 2u) my_hot = true;
+            if (st & 4u) my_any = true;
         }
     }
+}
+
+// P3 (:1357-1417) and P4 (:1425-1483) of an outer iteration in which only a few rows were popped: the MASTER workgroup alone, no job barrier.
+// What either sweep finds is a function of the unique bits (P3: which rows have A and B unique and which variables of C are not; P4: a
+// statically eligible row whose B variable is neither unique nor tagged) and of the group tags R2 resets (:916, :925) -- and every rule that
+// changes either re-queues the rows of the variable it changed (:861-866, :928-933, ...), so the rows whose status can differ from what the
+// last pass saw are rows POPPED since then: queue positions [h0, h1) of the ring (every executor on a team leaves the popped rows there).
+// The last P3 pass ended without a firing and left its group table and the per-row caches standing (p3_tbl = 1); this pass moves the popped
+// rows from their old groups to their new ones. If one of them now is a one-variable group or completes a group -- or a P4 candidate has
+// come alive -- nothing is decided here: the full passes run (with everybody, in row order, from a clean table). Otherwise both sweeps would
+// have found nothing to do, exactly as the full passes would: no firing needs k rows of one group, and the counts are the full pass's counts.
+// Returns non-zero when the full passes are needed.
+__device__ __noinline__ int p3p4_incremental(const Job& J, uint32_t h0, uint32_t h1, uint32_t stamp, uint32_t ht_cap, uint32_t* s_htn, uint32_t* s_flag, uint32_t* s_long) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if (tid == 0) { s_flag[0] = 0; s_long[64] = 0; }
+    __syncthreads();
+    uint32_t bad = 0;
+    for (uint32_t n = (uint32_t)tid; n < h1 - h0; n += ECNE_WG) {
+        const uint32_t r = J.queue[(h0 + n) & J.qmask];
+        if (atomicExch(&J.p3stamp[r], stamp) == stamp) continue;      // popped more than once since the last pass
+        const RowInfo ri = J.rinfo[r];
+        if (ri.shape & SH_P4) {      // (:1437-1469) some row would tag in this pass: a candidate whose B variable is neither unique nor tagged
+            const uint32_t b = ri.kpos;
+            if (!(J.flags[b] & 1) && J.abz[b] == -1) bad = 1;
+        }
+        const uint8_t dead = J.rdead[r];
+        if (dead & 1) continue;                                       // every variable unique, for good
+        if (dead & 2) {                                               // a long row: one wavefront each, below
+            const uint32_t pos = atomicAdd(&s_long[64], 1u);
+            if (pos < 64) s_long[pos] = r; else bad = 1;
+            continue;
+        }
+        uint32_t k; uint64_t h, h2;
+        p3_eval(J, r, k, h, h2);
+        if (k == 0) J.rdead[r] = 1;
+        if (k == 0xFFFFFFFFu) k = 0;
+        if (p3_apply<true>(J, r, k, h, h2, 0, ht_cap, s_htn) & 3u) bad = 1;      // a one-variable group, or a group that could be complete
+    }
+    __syncthreads();
+    const uint32_t nl = s_long[64] < 64u ? s_long[64] : 64u;
+    for (uint32_t li = (uint32_t)w; li < nl; li += ECNE_NWAVES) {
+        const uint32_t r = s_long[li];
+        uint32_t k; uint64_t h, h2;
+        const bool inelig = p3_eval_long(J, r, k, h, h2);
+        if (lane == 0) {
+            if (inelig) k = 0;
+            else if (k == 0) J.rdead[r] |= 1;
+            if (p3_apply<true>(J, r, k, h, h2, 0, ht_cap, s_htn) & 3u) bad = 1;
+        }
+    }
+    if (bad) atomicOr(&s_flag[0], 1u);
+    __syncthreads();
+    const int need_full = (int)s_flag[0];
+    __syncthreads();
+    return need_full;
 }
 
 // P3 (:1357-1417) of one outer iteration, all workgroups of the job: evaluation passes (p3_phase1), the master's search for the
 // earliest firing row, the freeze / restart behind a firing, the wipe of the group table. A function of its own (register budget,
 // see p4_phase). Returns true when a job barrier saw an error.
+// keep_ok (a team, round 5): a pass that ends without a firing leaves the group table and the per-row caches standing (ctr->p3_tbl = 1) for
+// the incremental passes of the iterations the master runs alone (p3p4_incremental); a pass that finds such a table wipes it first.
 __device__ __noinline__ bool p3_phase(const Job& J, QState& q, unsigned long long* hits, unsigned long long& steps, uint32_t my_rank, uint32_t ht_cap,
-                                      uint32_t* s_htn, unsigned long long* s_steps, uint32_t* m_rows, uint32_t* m_vars, unsigned long long* tk, int* s_err) {
+                                      uint32_t* s_htn, unsigned long long* s_steps, uint32_t* m_rows, uint32_t* m_vars, unsigned long long* tk, int* s_err, bool keep_ok) {
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const bool master = my_rank == 0;
     const uint32_t nC = J.nC;
     const uint32_t gtid = my_rank * ECNE_WG + tid, gstride = J.nwg * ECNE_WG;
     Counters* const ctr = J.ctr;
     uint32_t f = 0;   // rows < f are frozen (already swept in this pass)
-    bool p3_err = false;
+    bool p3_err = false, keep = false;
+    if (keep_ok && ld_agent(&ctr->p3_tbl) != 0) {
+        // (every workgroup reads the word the master wrote before the barrier that let them out of the queue phase; the master writes it
+        //  again at the end of this function, at least one barrier from here)
+        __syncthreads();
+        const uint32_t nmine = *s_htn < ht_cap ? *s_htn : ht_cap;
+        for (uint32_t i = tid; i < nmine; i += ECNE_WG) {
+            const uint32_t s = J.ht_list[(size_t)my_rank * ht_cap + i];
+            J.ht_key[s] = 0; J.ht_key2[s] = 0; J.ht_new[s] = 0; J.ht_frozen[s] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) *s_htn = 0;
+        if (job_barrier(J, s_err)) return true;
+    }
     for (;;) {
         if (master && tid == 0) tk[6]++;
         // (ids above num_variables) the lowest row from f on whose visit reads such a state enters as a row that "fires": the
@@ -300,6 +385,7 @@ __device__ __noinline__ bool p3_phase(const Job& J, QState& q, unsigned long lon
         // without the master's search and the second barrier (most passes of most circuits: 28 of 28 on ecdsa_like(26)).
         if (!hot && ld_agent(&ctr->p3_cand1) == 0xFFFFFFFFu) {
             if (master && tid == 0 && any) ctr->p3_any = 0;      // (read again a whole outer iteration from now)
+            keep = keep_ok && f == 0;                              // nothing fired in this pass: table and caches describe the state as it is
             break;
         }
         // phase 2: rows whose group could reach its size in this pass
@@ -424,6 +510,8 @@ __device__ __noinline__ bool p3_phase(const Job& J, QState& q, unsigned long lon
         f = fire + 1;
     }
     if (p3_err) return true;
+    if (keep_ok && master && tid == 0) ctr->p3_tbl = keep ? 1u : 0u;
+    if (keep) return false;
     // leave the table clean for the next outer iteration: every workgroup wipes the slots it created
     __syncthreads();
     {
@@ -461,7 +549,7 @@ __device__ __noinline__ void setup_phase(const Job& J, ChunkShared& s_chunk, QSt
         for (int p = 0; p < 6; ++p)
             for (uint32_t v = gtid; v <= nV; v += gstride) J.dmk[p][v] = 0;
     if (tid == 0) s_chunk.depoch = 0;
-    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; }
+    for (uint32_t r = gtid; r < nC; r += gstride) { J.inq[r] = 0; J.solved[r] = 0; J.flip3[r] = 0; J.best[r] = 0xFFFFFFFFu; J.rdead[r] = 0; J.p3k[r] = 0; J.p3stamp[r] = 0; }
     // the watched pairs of the long rows (a cache in words 1, 2 of their otherwise unused record lines, fastrow.hip.hpp) start empty
     if (J.rec != nullptr)
         for (uint32_t r = gtid; r < nC; r += gstride)
@@ -635,8 +723,56 @@ __device__ __noinline__ void p5_phase(const Job& J, QState& q, unsigned long lon
     }
 }
 
+// The queue phase (:805-1349) as strictly sequential pops on wavefront 0 of the master: queue_mode 1 (exec_row(): the reference's schedule
+// verbatim -- debugging, parity runs, systems that name ids above num_variables, known_variables without the constant wire) and
+// queue_mode 2 (the chain executor where it applies). A function of its own: inside the kernel body its calls cost the outer loop registers.
+__device__ __noinline__ void seq_queue_phase(const Job& J, QState& q, unsigned long long* hits, unsigned long long& steps, unsigned long long& nuniq,
+                                             unsigned long long& pops, unsigned long long& pop_nnz) {
+    const int tid = threadIdx.x, lane = lane_id();
+    const uint32_t nC = J.nC;
+    (void)tid;
+    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
+#ifdef ECNE_POPPROF
+    if (tid == 0) { pop_prof().last = wall_clock64(); }
+#endif
+    if (J.queue_mode == 2 && chain_ok(J)) {
+        // QUEUE, strictly sequential pops on the chain executor (chain.hip.hpp)
+        while (q.head != q.tail && !J.ctr->error) {
+            if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+            chain_pops(J, q, 1u << 16, 0, hits, steps, nuniq, pops, pop_nnz);
+        }
+        return;
+    }
+    // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
+    while (q.head != q.tail && !J.ctr->error) {
+        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+        ECNE_PT(7);
+        uint32_t row = J.queue[q.head & J.qmask];
+        q.head++;
+        if (lane == 0) J.inq[row] = 0;
+        wg_fence();
+        ECNE_PT(0);
+        pops++;
+        pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
+        if (J.solved[row]) continue;
+        ECNE_PT(1);
+        if (J.oob) {      // a row that names an id above num_variables: BoundsError at the first read of that state, else nothing
+            const int k = oob_pop(J, row);
+            if (k == 2) { raise_ranked(J, q.head - 1, K_EBOUNDS); break; }
+            if (k == 1) continue;
+        }
+        // (a caller's known_variables without the constant wire, variable 1 not known yet: R2 as the reference states it)
+        if ((J.lv_off & 8u) && !(J.flags[1] & 2) && (J.rinfo[row].shape & SH_C_EMPTY)) { if (r2_constant_wire_free(J, q, row, hits, steps)) break; }
+        else exec_row(J, q, row, hits, steps, nuniq);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- k_solve
 struct WgDesc { uint32_t job, rank; };
+enum : uint32_t { TEAM_FULL = 1u, TEAM_EXIT = 2u };      // Counters.team_cmd
+#ifndef ECNE_INC_MAX
+#define ECNE_INC_MAX 4096u      // an outer iteration with at most this many pops is finished by the master alone (p3p4_incremental)
+#endif
 
 // TEAM = false: the kernel of single-workgroup jobs. It has no code for helper workgroups, rounds on all workgroups or drain
 // rounds: with that code in the same kernel (registers of the callee chain, 1.2 KB more scratch per lane) every phase of a
@@ -732,7 +868,39 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     __syncthreads();
     // `steps` is the loop-control value: the master publishes it in ctr->sync_steps before each barrier
 
+    // A TEAM (round 5). The helpers take part in an outer iteration only where there is work for them: the rounds on teams of the queue phase and
+    // the full P3 / P4 sweeps. An iteration in which the master popped a few rows by itself is finished by the master alone -- P3 and P4 over the
+    // popped rows only (p3p4_incremental), P5 -- and the next one begun, while the helpers go on waiting for the queue phase's next command
+    // (`parked`): no job barrier in such an iteration (four before: loop top, end of the queue phase, P3, P4), no sweep over the whole system for
+    // the three rows an adder's outputs wake up (ecdsa_like(26): 25 of 28 iterations). TEAM_FULL lets them out into the full sweeps of the
+    // iteration the master names, TEAM_EXIT out of the loop.
+    const bool team_phase = TEAM && J.nwg > 1 && !seq_mode;
+    const bool p3_keep_ok = team_phase && !J.oob;
+    bool parked = false;
+    __shared__ uint32_t s_inc[4], s_longrows[65];      // s_inc[0]: result of the incremental pass, [1]: queue position up to which P3 has seen the pops
+    __shared__ unsigned long long s_team[4], s_team_t0;           // ecne_summary.team
+    if (tid == 0) { s_inc[1] = 0; s_team[0] = s_team[1] = s_team[2] = s_team[3] = 0; }
+    auto team_leave = [&](uint32_t cmd) {      // master: the queue phase is over for the helpers (they wait at its command barrier)
+        if (tid == 0) {
+            ctr->team_cmd = cmd; ctr->team_outer = (unsigned)outer;
+            __hip_atomic_store(&ctr->q_cmd[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return job_barrier(J, &s_err);
+    };
     for (;;) {
+        if (team_phase) {
+            if (master) {
+                const bool go = prev_steps != steps;      // (:708-711)
+                if (!parked) {
+                    if (tid == 0) { ctr->sync_steps = steps; ctr->sync_go = go ? 1u : 0u; }
+                    if (job_barrier(J, &s_err)) break;
+                } else if (!go) { team_leave(TEAM_EXIT); parked = false; }
+                if (!go) break;
+            } else {
+                if (job_barrier(J, &s_err)) break;
+                if (ld_agent(&ctr->sync_go) == 0u) break;
+            }
+        } else {
         if (master && tid == 0) ctr->sync_steps = steps;
         if (job_barrier(J, &s_err)) break;
         steps = __hip_atomic_load(&ctr->sync_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -744,48 +912,16 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             __syncthreads();
             if (go != 1u) break;
         } else if (prev_steps == steps) break;   // (:708-711)
+        }
         prev_steps = steps;
         outer++;
+        if (team_phase && master && tid == 0) s_team_t0 = wall_clock64();
         // ================= P1, P2 and the queue: master only, in the reference's order
+        uint32_t team_io = 0;
         if (master) {
             if (w == 0) {
                 p12_phase(J, q, hits, steps);
-                if (J.queue_mode == 2 && chain_ok(J)) {
-#ifdef ECNE_POPPROF
-                    if (tid == 0) { pop_prof().last = wall_clock64(); }
-#endif
-                    // QUEUE, strictly sequential pops on the chain executor (chain.hip.hpp)
-                    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
-                    while (q.head != q.tail && !J.ctr->error) {
-                        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
-                        chain_pops(J, q, 1u << 16, 0, hits, steps, nuniq, pops, pop_nnz);
-                    }
-                } else if (seq_mode) {
-                    // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
-                    const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[nC] + J.rpB[nC] + J.rpC[nC]);
-#ifdef ECNE_POPPROF
-                    if (tid == 0) { pop_prof().last = wall_clock64(); }
-#endif
-                    while (q.head != q.tail && !J.ctr->error) {
-                        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
-                        ECNE_PT(7);
-                        uint32_t row = J.queue[q.head & J.qmask];
-                        q.head++;
-                        if (lane == 0) J.inq[row] = 0;
-                        wg_fence();
-                        ECNE_PT(0);
-                        pops++;
-                        pop_nnz += (J.rpA[row + 1] - J.rpA[row]) + (J.rpB[row + 1] - J.rpB[row]) + (J.rpC[row + 1] - J.rpC[row]);
-                        if (J.solved[row]) continue;
-                        ECNE_PT(1);
-                        if (J.oob) {      // a row that names an id above num_variables: BoundsError at the first read of that state, else nothing
-                            const int k = oob_pop(J, row);
-                            if (k == 2) { raise_ranked(J, q.head - 1, K_EBOUNDS); break; }
-                            if (k == 1) continue;
-                        }
-                        exec_row(J, q, row, hits, steps, nuniq);
-                    }
-                }
+                if (seq_mode) seq_queue_phase(J, q, hits, steps, nuniq, pops, pop_nnz);      // (queue_mode 1 / 2: strictly sequential pops)
                 if (lane == 0) { s_q = q; s_steps = steps; }
                 if (lane == 0) tk[7] += wall_clock64() - t_last;      // diagnostics: P1 + P2 alone (phase_ms[7]); the slot-1 clock keeps running
             }
@@ -796,28 +932,49 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 // P1/P2 raised: the queue phase is skipped, but the helpers are waiting at its command
                 // barrier — meet them there (they leave on the error snapshot)
                 if (J.nwg > 1) job_barrier(J, &s_err);
+                team_io = 2u;
             } else if (!seq_mode) {
                 // QUEUE (:805-1349), chunk-parallel schedule; counters other than `steps` live in wave 0
                 unsigned long long st2 = steps, nu2 = 0, pp2 = 0, pn2 = 0, ht2[16];
                 for (int i = 0; i < 16; ++i) ht2[i] = 0;
-                queue_phase_chunked<TEAM>(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err);
+                queue_phase_chunked<TEAM>(J, q, s_chunk, ht2, st2, nu2, pp2, pn2, &s_err, team_phase ? &team_io : nullptr);
                 steps = st2;
                 if (w == 0) { nuniq += nu2; pops += pp2; pop_nnz += pn2; for (int i = 0; i < 8; ++i) hits[i] += ht2[i]; for (int i = 13; i < 16; ++i) hits[i] += ht2[i]; }
             }
         }
         else if (!seq_mode) { if constexpr (TEAM) queue_phase_helper(J, s_chunk, my_rank, &s_err); }
-        // A team leaves the queue phase through a job barrier of its own (the master's last command): that barrier has published the
+        // A team leaves the queue phase through a job barrier of its own (the master's TEAM_FULL / TEAM_EXIT): that barrier has published the
         // phase's state changes and left every workgroup the same snapshot of the error word -- a second barrier here would only make
         // the helpers' counters visible, and those are folded in behind P3's first barrier instead (4.5 us per outer iteration).
-        const bool team_phase = TEAM && J.nwg > 1 && !seq_mode;
-#ifdef ECNE_POSTQ_BARRIER
-        if (team_phase) { if (job_barrier(J, &s_err)) break; }
-#else
-        if (team_phase) { if (s_err) break; }
-#endif
-        else if (job_barrier(J, &s_err)) break;      // (sequential modes: the helpers have been waiting here for the master's queue phase)
-        ECNE_TICK(1);
+        bool solo_done = false;      // (master) P3 and P4 of this iteration are done: nothing for them to do, found from the popped rows alone
+        if (team_phase) {
+            if (master) {
+                parked = true;       // the helpers sit at the command barrier of the queue phase
+                if (team_io & 2u) { parked = false; break; }                                      // (an error has sent them home already)
+                if (wg_error(J, &s_err)) { team_leave(TEAM_FULL); parked = false; break; }          // (they leave on the barrier's error snapshot)
+                ECNE_TICK(1);
+                // the iteration on the master alone? No rounds on the team in this phase (the helpers' counters of such rounds have to be
+                // folded in before the loop test, :708), P3's table kept from a pass without a firing, few pops since, room in this workgroup's
+                // slot list for a new group per popped row
+                const uint32_t h0 = s_inc[1], h1 = q.head;
+                if (!(team_io & 1u) && p3_keep_ok && ld_agent(&ctr->p3_tbl) == 1u && h1 - h0 <= ECNE_INC_MAX && h1 - h0 <= J.qmask && s_htn + (h1 - h0) <= ht_cap) {
+                    if (tid == 0) { tk[6]++; s_team[1] += h1 - h0; }
+                    solo_done = p3p4_incremental(J, h0, h1, (uint32_t)outer, ht_cap, &s_htn, &s_inc[0], s_longrows) == 0;
+                    if (tid == 0 && solo_done) s_team[0]++;
+                }
+                __syncthreads();
+                if (tid == 0) s_inc[1] = h1;
+                if (!solo_done) { if (tid == 0) s_team[2]++; if (team_leave(TEAM_FULL)) { parked = false; break; } parked = false; }
+            } else {
+                if (s_err) break;
+                if (ld_agent(&ctr->team_cmd) == TEAM_EXIT) break;
+                outer = ld_agent(&ctr->team_outer);
+            }
+        }
+        else if (job_barrier(J, &s_err)) break;      // (sequential modes, single-workgroup jobs: the helpers have been waiting here for the master's queue phase)
+        if (!team_phase) ECNE_TICK(1);
 
+        if (!solo_done) {
         // ================= P3 linear systems (:1357-1417): evaluation passes on all workgroups (p3_phase)
         // What a pass finds is a function of the unique bits alone (:1360-1386: A and B unique? which variables of C are not?). A pass that
         // ended without a firing therefore ends the same way while no variable has become unique since -- and every rule that makes one
@@ -834,7 +991,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
             __syncthreads();
         }
         if (p3_skip) { if (tid == 0) tk[6]++; }
-        else if (p3_phase(J, q, hits, steps, my_rank, ht_cap, &s_htn, &s_steps, m_rows, m_vars, tk, &s_err)) break;
+        else if (p3_phase(J, q, hits, steps, my_rank, ht_cap, &s_htn, &s_steps, m_rows, m_vars, tk, &s_err, p3_keep_ok)) break;
         if (team_phase && master) {
             // fold in what the helpers did during the rounds on teams: their atomics came before P3's first barrier (here, not inside
             // P3's loop: with the counters live across that loop the compiler spilled them, +0.27 GB of scratch writes per launch)
@@ -853,11 +1010,14 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
         if (p4_phase(J, s_chunk, q, &s_q, s_scan, hits, steps, outer, my_rank, &s_err)) break;
         if (tid == 0) s_p3[2] += steps - s_p3[3];
         ECNE_TICK(3);
+        } else ECNE_TICK(2);
 
         // ================= P5 isZero pairs (:1492-1550), ascending over the static candidates (master)
         p5_phase(J, q, hits, steps, &s_steps, my_rank);
         ECNE_TICK(4);
+        if (team_phase && master && tid == 0 && solo_done) s_team[3] += wall_clock64() - s_team_t0;      // 100 MHz ticks of the iterations finished alone
     }
+    if (team_phase && master && parked) team_leave(TEAM_EXIT);      // (left the loop with the helpers still waiting for a command: an error on the way)
 
     // ---------------- verdict counts (:1558-1597), all workgroups
     if (J.family && tid == 0 && (s_err || ctr->error)) __hip_atomic_store(&J.family->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -895,6 +1055,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
 #endif
                 for (int i = 0; i < 8; ++i) ctr->mticks[i] = s_chunk.mt[i];
                 for (int i = 0; i < 16; ++i) ctr->sched[i] = s_chunk.sd[i];
+                for (int i = 0; i < 4; ++i) ctr->team_stat[i] = team_phase ? s_team[i] : 0ull;
             }
         }
     }

@@ -443,7 +443,12 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
                 if (win) {
                     // into the mirror while it holds everything queued and has room (256 positions from the new head on), else to the ring
                     const uint32_t pos = new_tail + (uint32_t)__popcll(wmask & lanes_below());
-                    if (mtop == new_tail && pos - (head + c) < ECNE_LV_QM) qm[pos & (ECNE_LV_QM - 1)] = t; else queue[pos & qmask] = t;
+                    if (mtop == new_tail && pos - (head + c) < ECNE_LV_QM) {
+                        qm[pos & (ECNE_LV_QM - 1)] = t;
+                        // (the master of a team: the ring keeps every queue position that was ever pushed -- the positions popped since the last
+                        //  P3 pass are that pass's work list, p3p4_incremental in k_solve.hip.hpp; the round stores to device memory anyway)
+                        if constexpr (!LDS) queue[pos & qmask] = t;
+                    } else queue[pos & qmask] = t;
                     stQ(t, 1u);
                 }
                 if constexpr (!LDS) {                 // (one block) a row of the prefix that a winner re-queued keeps its tag

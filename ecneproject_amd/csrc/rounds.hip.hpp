@@ -851,10 +851,13 @@ __device__ __noinline__ int multi_chain(const Job& J, uint32_t K, ChunkShared& S
     }
     return rc;
 }
+// team_io (a team's master, else null): out bit 0 = a chain of rounds ran on the helpers in this phase, bit 1 = an error seen at a job barrier
+// has already sent the helpers home. The helpers are NOT told that the phase is over: the caller does that (team_leave, k_solve.hip.hpp) --
+// or goes on alone, with them waiting for the next command.
 template <bool TEAM>
 __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkShared& S, unsigned long long* hits,
                                     unsigned long long& steps, unsigned long long& nuniq,
-                                    unsigned long long& pops, unsigned long long& pop_nnz, int* s_err) {
+                                    unsigned long long& pops, unsigned long long& pop_nnz, int* s_err, uint32_t* team_io = nullptr) {
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long pop_cap = 4096ull + 64ull * (J.rpA[J.nC] + J.rpB[J.nC] + J.rpC[J.nC]);
     if (tid < 12) S.acc[tid] = 0;
@@ -896,6 +899,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
     bool solo = false;
     uint32_t solo_cool = 0;
     bool helpers_released = false;   // an error seen at a job barrier has already sent the helpers home
+    bool used_team = false;
     __syncthreads();
     while (q.head != q.tail) {
         // the error word is polled every 8th round (a raised error only has to stop the solve soon)
@@ -1350,6 +1354,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 J.ctr->q_cmd[7] = K; J.ctr->q_cmd[8] = sg;
                 __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            used_team = true;
             if (job_barrier(J, s_err)) { helpers_released = true; break; }
             ChainState st;
             st.head = q.head; st.tail = q.tail; st.window = window; st.mwindow = mwindow; st.streak = streak; st.rounds = 0; st.rows = 0;
@@ -1626,11 +1631,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         else if (c < n / 4) { uint32_t wn = 4 * c; window = wn < ECNE_WMIN ? ECNE_WMIN : wn; }
         else next_burst = 16;
     }
-    // ---- tell the helper workgroups (waiting at the command barrier) that the queue phase is over
-    if (J.nwg > 1 && !helpers_released) {
-        if (tid == 0) __hip_atomic_store(&J.ctr->q_cmd[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        job_barrier(J, s_err);
-    }
+    // ---- the helper workgroups wait at the command barrier: the caller tells them that the queue phase is over (team_leave) -- or does not
+    if (team_io) *team_io = (used_team ? 1u : 0u) | (helpers_released ? 2u : 0u);
     // ---- reduce the per-lane counters
     __syncthreads();
     if (C.steps) atomicAdd(&S.acc[0], (unsigned long long)C.steps);
@@ -1649,7 +1651,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 }
 
 // Queue phase as seen by a helper workgroup: wait for the master's commands, join multi rounds.
-__device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, uint32_t wgrank, int* s_err) {
+__device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, uint32_t wgrank, int* s_err) {      // (leaves on q_cmd[0] == 0: ctr->team_cmd / team_outer say what is next)
     LaneCtr C;
     C.steps = C.nuniq = 0;
     for (int i = 0; i < 8; ++i) C.hits[i] = 0;

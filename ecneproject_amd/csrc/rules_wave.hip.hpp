@@ -202,7 +202,9 @@ __device__ __forceinline__ PopProf& pop_prof() { __shared__ PopProf p; return p;
 // R2 check_quadratic (:875-942) as the reference states it, for the one situation the static shapes do not cover: a caller's
 // known_variables WITHOUT the constant wire (Job.lv_off bit 3) while variable 1 is not is_known yet. The shapes (SH_R2 / SH_R2_BOUNDSERR /
 // SH_R2_DIV0, RowInfo.x, the two precomputed roots) are laid down for "variable 1 is known from the setup on"; here the variable that
-// is not known may be the wire itself. Strictly sequential pops only (such a system runs in queue_mode 1), every lane the same walk.
+// is not known may be the wire itself. Strictly sequential pops only (such a system runs in queue_mode 1: the pop loop of k_solve calls this INSTEAD of
+// exec_row() for a row without C -- R1 needs a non-unique variable of C, and behind R2 such a row has nothing left to do, :944-946 or an empty C
+// in R3..R8 --; inside exec_row() the call cost every caller of exec_row() registers across it), every lane the same walk.
 // Returns true when the pop raised.
 __device__ __noinline__ bool r2_constant_wire_free(const Job& J, QState& q, uint32_t row, unsigned long long* hits, unsigned long long& steps) {
     const uint32_t a0 = J.rpA[row], a1 = J.rpA[row + 1], b0 = J.rpB[row], b1 = J.rpB[row + 1];
@@ -297,9 +299,7 @@ __device__ __noinline__ void exec_row(const Job& J, QState& q, uint32_t row, uns
     }
     const unsigned long long steps_at_r1 = steps, nuniq_at_r1 = nuniq;
     // R2 check_quadratic (:875-942)
-    if ((shape & SH_C_EMPTY) && (J.lv_off & 8u) && !(J.flags[1] & 2)) {
-        if (r2_constant_wire_free(J, q, row, hits, steps)) return;
-    } else if (shape & SH_C_EMPTY) {
+    if (shape & SH_C_EMPTY) {
         if (shape & SH_R2_BOUNDSERR) { raise_ranked(J, q.head - 1, K_EBOUNDS); return; }   // (the row was popped just before)
         if (shape & SH_R2) {
             const uint32_t x = ri.x;

@@ -188,6 +188,10 @@ typedef struct ecne_summary {
                                 (x == y), R7/R8 in reach (sum); 12 = rounds of ONE pop whose events had more than three target
                                 rows (committed by the fast round itself since round 2, not a decline); 13..15 multi-workgroup
                                 rounds that committed < 64, < 4096, more rows */
+    int64_t team[4];         /* (round 5, appended) a system on several workgroups: [0] outer iterations its master workgroup finished
+                                alone -- P3 and P4 from the rows popped since the last pass, no job barrier --, [1] rows those passes
+                                looked at, [2] full P3 / P4 sweeps with every workgroup, [3] 100 MHz ticks of the
+                                iterations of [0], everything included */
 } ecne_summary;
 
 /* SolveConstraintsSymbolic :583-1646 on the GPU. Fails with ECNE_ENODEVICE when no HIP device is

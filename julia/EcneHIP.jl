@@ -22,7 +22,7 @@ struct EcneSummary
     successful_steps::Int64; outer_iterations::Int64; pops::Int64; num_unique::Int64
     rule_hits::NTuple{16,Int64}; n_rows::Int64; n_vars::Int64; pop_nnz::Int64
     device_ms::Float64; classify_ms::Float64; queue_ms::NTuple{8,Float64}; multi_ms::NTuple{8,Float64}; phase_ms::NTuple{8,Float64}
-    sched::NTuple{16,Int64}
+    sched::NTuple{16,Int64}; team::NTuple{4,Int64}
 end
 struct EcneInfo
     field_size::UInt32; n_wires::UInt32; n_pub_out::UInt32; n_pub_in::UInt32; n_prv_in::UInt32
