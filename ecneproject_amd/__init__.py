@@ -82,6 +82,14 @@ def device_count():
     return _lib.lib().ecne_device_count()
 
 
+def warmup(device=0):
+    """Pays a cold process's one-off costs up front (the HIP runtime's copy path, the library's code objects, the device's scratch memory
+    for the solve kernels) instead of inside the first readR1CS / solve; returns the milliseconds it took. Optional."""
+    ms = C.c_double()
+    _check(_lib.lib().ecne_warmup(int(device), C.byref(ms)), "ecne_warmup")
+    return float(ms.value)
+
+
 def set_host_threads(n=0):
     """Opt in to host worker threads for parsing, abstraction and the flat-array layout (n <= 0: the cores present,
     at most 32). The library works on the calling thread unless asked. Returns the count now in effect."""

@@ -45,7 +45,7 @@ EXPORTS = [
     "ecne_system_rows", "ecne_system_free", "ecne_solve", "ecne_solve_batch", "ecne_result_summary", "ecne_result_summaries", "ecne_results_free", "ecne_result_states",
     "ecne_result_bad_rows", "ecne_result_free", "ecne_classify", "ecne_fp_selftest", "ecne_fp_sqrt",
     "ecne_device_count", "ecne_strerror", "ecne_version",
-    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve", "ecne_result_digest", "ecne_set_split", "ecne_system_split_info",
+    "ecne_set_host_threads", "ecne_system_set_io", "ecne_system_clear_specials", "ecne_system_add_special", "ecne_system_io", "ecne_system_report_order", "ecne_abstract_stats", "ecne_fp_solve_quadratic", "ecne_set_frontend", "ecne_frontend_stats", "ecne_system_dict_rows", "ecne_debug_static_array", "ecne_system_set_secp_solve", "ecne_result_digest", "ecne_set_split", "ecne_system_split_info", "ecne_warmup",
 ]
 
 _L = None

@@ -2202,6 +2202,52 @@ int ecne_set_split(int mode) {
     split_setting().store(mode, std::memory_order_relaxed);
     return ECNE_OK;
 }
+static int ecne_warmup_impl(int device, double* ms_out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (device < 0 || device >= ecne_device_count()) return ECNE_ENODEVICE;
+    RestoreDevice restore;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));
+    {   // the runtime's copy path: pageable memory to the device and back (what the front-end's upload of a file does)
+        const size_t bytes = 8u << 20;
+        std::vector<unsigned char> h(bytes, 1);
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes));
+        const hipError_t e1 = hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice), e2 = hipMemcpy(h.data(), d, 4096, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return ECNE_ENODEVICE; }
+    }
+    { const int rc = fe::warmup(device); if (rc != K_OK) return rc; }
+    // both solve kernels once: code object, kernel arguments, scratch memory. Three rows over six variables: c = a * b (R1), d = c (R5), e = 5 (R3)
+    ecne_system s;
+    Rows& K = s.reduced;
+    K.start();
+    auto term = [&](int p, uint32_t v, const fp::u256& c) { K.var[p].push_back(v); K.coef[p].push_back(c); };
+    auto end_row = [&]() { for (int p = 0; p < 3; ++p) K.ptr[p].push_back(K.var[p].size()); };
+    term(0, 3, fp::make(1)); term(1, 4, fp::make(1)); term(2, 2, fp::make(1)); end_row();
+    term(2, 5, fp::make(1)); term(2, 2, fp::pminus1()); end_row();
+    term(2, 6, fp::make(1)); term(2, 1, fp::neg(fp::make(5))); end_row();
+    s.cur = &s.reduced;
+    s.n_vars = 6; s.n_rows_main = 3;
+    s.knowns = {1, 3, 4};
+    s.targets = {2};
+    s.split_tried = true;
+    for (int nwg : {0, 2}) {
+        ecne_opts o;
+        std::memset(&o, 0, sizeof o);
+        o.device = device; o.debug = nwg;
+        ecne_system* ps = &s;
+        ecne_result* r = nullptr;
+        const int rc = solve_batch_core(&ps, 1, &o, &r, nullptr, nullptr);
+        const bool ok = rc == ECNE_OK && r && r->sum.status == 0 && r->sum.function_good == 1;
+        delete r;
+        if (!ok) return rc != ECNE_OK ? rc : ECNE_ENODEVICE;
+    }
+    if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return ECNE_OK;
+}
+int ecne_warmup(int device, double* ms_out) { return guarded([&] { return ecne_warmup_impl(device, ms_out); }); }
+
 int ecne_set_frontend(int mode) {
     if (mode >= 0 && mode <= 2) frontend_setting().store(mode, std::memory_order_relaxed);
     return frontend_setting().load(std::memory_order_relaxed);

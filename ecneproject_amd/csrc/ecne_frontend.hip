@@ -905,6 +905,15 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
     return K_OK;
 }
 
+// ecne_warmup: the front-end's code object is loaded by its first launch (this translation unit is a code object of its own)
+__global__ void k_fe_noop(uint32_t* p) { if (p != nullptr && threadIdx.x == 0xFFFFu) *p = 0; }
+int warmup(int device) {
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return K_ENODEVICE; }
+    hipLaunchKernelGGL(k_fe_noop, dim3(1), dim3(64), 0, 0, (uint32_t*)nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return K_ENODEVICE; }
+    return K_OK;
+}
+
 int mark_bytes(int device, uint8_t* dst, const std::vector<uint32_t>& ids) {
     if (ids.empty()) return K_OK;
     DeviceGuard guard(device);

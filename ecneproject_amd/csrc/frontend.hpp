@@ -48,6 +48,7 @@ struct ParseStats {
 // (input the device path does not take: 4 GiB and more, parts of 2^18 terms and more, a hash table that grows past its scratch).
 int parse_on_device(const uint8_t* file, size_t file_size, size_t cons_off, uint32_t n_cons, int device, std::shared_ptr<DevRows>& out, ParseStats& st);
 int download_rows(const DevRows& D, Rows& out);
+int warmup(int device);      // loads the front-end's code object (ecne_warmup)
 
 struct AbstractDevStats {
     double fp_ms = 0, scan_ms = 0, verify_ms = 0, compact_ms = 0, prep_ms = 0;

@@ -1313,7 +1313,8 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl) {
             row[sl] = 0; shape[sl] = 0; xv[sl] = 0;
-            if (sl < rpl && r0 + sl < n && (!want_multi || (tid == 0 && sl == 0))) {
+            // (head_big: the executor before this one stopped in front of a live long row -- only that row matters, it is popped alone below)
+            if (sl < rpl && r0 + sl < n && ((!want_multi && !head_big) || (tid == 0 && sl == 0))) {
                 row[sl] = J.queue[(q.head + r0 + sl) & J.qmask];
                 const RowInfo ri = J.rinfo[row[sl]];
                 shape[sl] = ri.shape;
@@ -1324,12 +1325,14 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         // a live long row at the head is popped alone when it cannot ride along in a round (R2..R6 shapes) -- or when the
         // window is narrow anyway: a workgroup round for a handful of rows costs ten times the long row's own pop
         if (tid == 0) { S.cut = n; S.fallback = ((shape[0] & SH_BIG) && (live & 1u) && (head_big || !big_plain(shape[0]) || n <= (v2wg ? (uint32_t)ECNE_WG : 64u))) ? 1u : 0u; }
+        const bool was_head_big = head_big;
         head_big = false;
 #pragma unroll
         for (uint32_t sl = 0; sl < ECNE_RPL; ++sl)   // a long row that can ride along sends the round down the general path
             if (sl < rpl && r0 + sl < n && (shape[sl] & SH_BIG) && (live & (1u << sl)) && big_plain(shape[sl])) S.hasbig = 1;
         __syncthreads();
         QTICK(0);
+        if (was_head_big && !S.fallback) { if (tid == 0) S.hasbig = 0; __syncthreads(); continue; }      // (not a live long row after all: the round again, with its window loaded)
         if (!S.fallback && want_multi) {
             declined_wide = false;
             // a wide frontier: a chain of rounds on a team of workgroups (multi_chain) -- all of them for a frontier that fills their

@@ -249,6 +249,14 @@ int ecne_fp_sqrt(const uint64_t* a, uint64_t* root);
  * literal == 0 gives the true roots (-b +- sqrt(disc))/(2a). */
 int ecne_fp_solve_quadratic(const uint64_t* a, const uint64_t* b, const uint64_t* c, int literal, uint64_t* roots, int* n_roots);
 
+/* Optional, once per process and device, before the first file: pays the one-off costs of a cold process up front instead of inside
+ * the first ecne_r1cs_load / ecne_solve -- the HIP runtime's copy path (its first host-to-device copy sets up staging buffers: 27-100 ms
+ * on ROCm 7.2, whoever copies first), the library's two code objects (loaded by their first launch) and the device's scratch memory for
+ * the solve kernels (grown by the runtime at their first launch: the first k_solve_team launch took 9.3 instead of 6.1 ms). It solves a
+ * three-row system once on one workgroup and once on a team of two. Replaces nothing of the reference (readR1CS on a CPU has no such
+ * phase, /root/reference/src/ParseR1CS.jl:50-124); without the call everything works, the first file just pays. ms_out (may be NULL):
+ * wall-clock of the call. Works on `device` and leaves the calling thread's current device as it found it. */
+int ecne_warmup(int device, double* ms_out);
 int ecne_device_count(void);
 const char* ecne_strerror(int status);
 const char* ecne_version(void);

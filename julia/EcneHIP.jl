@@ -9,7 +9,7 @@
 # this shim has not been executed there; it mirrors ecneproject_amd/_lib.py + __init__.py + report.py (ctypes) call for call.
 module EcneHIP
 
-export readR1CS, SolveConstraintsSymbolic, solveWithTrustedFunctions, EcneSystem, EcneR1CS
+export readR1CS, SolveConstraintsSymbolic, solveWithTrustedFunctions, EcneSystem, EcneR1CS, warmup
 
 const LIB = get(ENV, "ECNE_HIP_LIB", joinpath(@__DIR__, "..", "ecneproject_amd", "libecne_hip.so"))
 
@@ -146,6 +146,13 @@ function print_debug_states(sys::EcneSystem, res::Ptr{Cvoid})
         n > 0 && println("All possible values: ", sort!(BigInt[limbs(vals[], 2 * (v - 1) + k) for k in 0:n-1]))
         println()
     end
+end
+
+# optional: the one-off costs of a cold process (HIP copy path, code objects, scratch memory) before the first file; returns milliseconds
+function warmup(device::Integer=0)
+    ms = Ref{Cdouble}(0.0)
+    check(ccall((:ecne_warmup, LIB), Cint, (Cint, Ref{Cdouble}), device, ms))
+    ms[]
 end
 
 function readR1CS(filename::String)                  # -> (equations, known, outputs, nVars)
