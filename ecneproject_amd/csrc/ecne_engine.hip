@@ -297,6 +297,14 @@ __global__ __launch_bounds__(256) void k_gather_results(const Job* jobs, unsigne
     if (threadIdx.x < ECNE_RESULT_BYTES / 4) dst[threadIdx.x] = src[threadIdx.x];
 }
 
+// rows whose descriptor carries any bit of `mask` (build_split's screen: rows that can write the constant wire's state)
+__global__ __launch_bounds__(256) void k_count_shape(Job J, uint32_t mask, uint32_t* out) {
+    uint32_t n = 0;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < J.nC; r += gridDim.x * 256u) n += (J.rinfo[r].shape & mask) ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
+}
+
 // ---- a split file (SplitPlan): one part's state into the file's own arrays; the part's copy of the constant wire against what setup
 // left (any difference: the file is solved again as one system), part 0's copy is the one that is kept
 __global__ __launch_bounds__(256) void k_scatter_part(Job K, Job P, const uint32_t* map, uint32_t nv) {
@@ -1102,9 +1110,37 @@ static int upload_system(ecne_system& S, int device) {
     //  call starts over instead of launching on a half-filled image)
     struct ArenaGuard { char* p; ecne_system& S; bool done = false; ~ArenaGuard() { if (!done) { (void)hipFree(p); S.dev = DeviceImage(); } } } arena_guard{base, S};
     if (getenv("ECNE_POISON")) HIP_TRY(hipMemset(base, 0xA5, c.off));      // test hook: whatever the solve reads before writing it shows up
+    // The image of a SMALL system (a circomlib file, a part of a split file) is some forty arrays of a few kilobytes: one synchronous
+    // hipMemcpy each cost more than the bytes (~10 us a call: 240 parts = 100 ms of calls). Pieces are collected and neighbouring ones
+    // (the carve puts the static arrays side by side, 256-byte aligned) go up as ONE copy from a staging buffer; pieces of a megabyte
+    // and more are copied as they are.
+    struct Piece { size_t off; const void* src; size_t bytes; };
+    std::vector<Piece> pieces;
     auto up = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
-        return hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
+        if (bytes >= (1u << 20)) return hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
+        pieces.push_back({off, src, bytes});
+        return hipSuccess;
+    };
+    auto up_flush = [&]() -> hipError_t {
+        std::sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.off < b.off; });
+        std::vector<unsigned char> stage;
+        for (size_t i = 0; i < pieces.size();) {
+            size_t j = i + 1, end = pieces[i].off + pieces[i].bytes;
+            while (j < pieces.size() && pieces[j].off >= end && pieces[j].off - end <= 512 && pieces[j].off + pieces[j].bytes - pieces[i].off <= (8u << 20)) { end = pieces[j].off + pieces[j].bytes; ++j; }
+            if (j == i + 1) {
+                const hipError_t e = hipMemcpy(base + pieces[i].off, pieces[i].src, pieces[i].bytes, hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+            } else {
+                stage.assign(end - pieces[i].off, 0);      // (the alignment gaps between two arrays belong to nobody)
+                for (size_t k = i; k < j; ++k) std::memcpy(stage.data() + (pieces[k].off - pieces[i].off), pieces[k].src, pieces[k].bytes);
+                const hipError_t e = hipMemcpy(base + pieces[i].off, stage.data(), stage.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+            }
+            i = j;
+        }
+        pieces.clear();
+        return hipSuccess;
     };
     if (!dev_layout) {
         for (int p = 0; p < 3; ++p) {
@@ -1141,6 +1177,7 @@ static int upload_system(ecne_system& S, int device) {
     HIP_TRY(up(o_knowns, L.knowns.data(), 4ull * L.knowns.size()));
     HIP_TRY(up(o_targets, L.targets.data(), 4ull * L.targets.size()));
     if (!L.oob_blob.empty()) HIP_TRY(up(o_oob, L.oob_blob.data(), 4ull * L.oob_blob.size()));
+    HIP_TRY(up_flush());
     Job& J = S.dev.job;
     std::memset(&J, 0, sizeof J);
     J.oob = L.oob_blob.empty() ? nullptr : (const uint32_t*)(base + o_oob);
@@ -1807,7 +1844,24 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
     P.split_tried = true;
     if (!P.specials.empty() || !P.orig_var.empty() || !P.L.oob_blob.empty() || (int64_t)P.L.nV > P.n_vars) SPLIT_NO("trusted functions / ids above num_variables");
     if (std::find(P.knowns.begin(), P.knowns.end(), (int64_t)1) == P.knowns.end()) SPLIT_NO("known_variables without the constant wire");
+    // Screen before anything is downloaded or planned: the parts share ONE variable, the constant wire, and a part that writes its state
+    // (every `x <== 1` of a circuit is a row x - 1 = 0 whose R4 / R5 shapes can move the wire's bounds: SH_TOUCH1, set by k_classify_rows)
+    // makes the split solve void (Family.var1_bad) -- plan, part uploads and a whole solve for nothing. Such a file stays one system.
+    if (P.dev.classified && P.dev.device == device && P.dev.job.nC) {
+        uint32_t* d_n = nullptr;
+        uint32_t h_n = 0;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMalloc((void**)&d_n, 4));
+        hipError_t e = hipMemset(d_n, 0, 4);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_count_shape, dim3(std::min<uint32_t>(1024u, (P.dev.job.nC + 255u) / 256u)), dim3(256), 0, 0, P.dev.job, (uint32_t)SH_TOUCH1, d_n); e = hipMemcpy(&h_n, d_n, 4, hipMemcpyDeviceToHost); }
+        (void)hipFree(d_n);
+        if (e != hipSuccess) { (void)hipGetLastError(); return ECNE_ENODEVICE; }
+        if (h_n) SPLIT_NO("rows that can write the constant wire's bounds");
+    }
+    auto lap = [&](const char* what) { if (dbg) fprintf(stderr, "[ecne split] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
+    lap("screen");
     { const int rc = sys_host_rows(P); if (rc != K_OK) return rc; }
+    lap("host rows");
     const Rows& R = P.rows();
     const size_t nC = R.n();
     const uint32_t nV = (uint32_t)P.n_vars;
@@ -1831,6 +1885,7 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
     }
     for (size_t i = 0; i + 1 < nC; ++i)
         if (nzc[i] == 2 && nzc[i + 1] == 0 && nzb[i + 1] == 1) unite(nV + 1 + (uint32_t)i, nV + 1 + (uint32_t)(i + 1));
+    lap("union-find");
     // groups by rows
     std::vector<uint32_t> grp_of_root(uf.size(), 0xFFFFFFFFu), grp_rows;
     std::vector<uint32_t> row_grp(nC);
@@ -1867,8 +1922,11 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
     child_id[1] = 1;
     for (size_t i = 0; i < nC; ++i) bin_rows[grp_bin[row_grp[i]]].push_back((uint32_t)i);
     HIP_TRY(hipSetDevice(device));
+    lap("groups, bins, ids");
+    double t_rows = 0, t_up = 0;
     for (uint32_t b = 0; b < nB; ++b) {
         if (bin_rows[b].empty()) continue;
+        const auto tk0 = std::chrono::steady_clock::now();
         ecne_system* k = new ecne_system();
         plan->kids.push_back(k);
         plan->d_map.push_back(nullptr);
@@ -1886,12 +1944,15 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
         k->orig_row = bin_rows[b];
         for (int64_t v : P.knowns) if (v == 1 || (v >= 2 && v <= (int64_t)nV && var_bin[(size_t)v] == b)) k->knowns.push_back(child_id[(size_t)v]);
         for (int64_t v : P.targets) if (v == 1 || (v >= 2 && v <= (int64_t)nV && var_bin[(size_t)v] == b)) k->targets.push_back(child_id[(size_t)v]);
+        const auto tk1 = std::chrono::steady_clock::now();
         { const int rc = upload_system(*k, device); if (rc != K_OK) { if (dbg) fprintf(stderr, "[ecne split] part %u: upload failed (%d)\n", b, rc); return rc; } }
+        t_rows += std::chrono::duration<double, std::milli>(tk1 - tk0).count(); t_up += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk1).count();
         uint32_t* dm = nullptr;
         HIP_TRY(hipMalloc((void**)&dm, 4ull * bin_vars[b].size()));
         plan->d_map.back() = dm;
         HIP_TRY(hipMemcpy(dm, bin_vars[b].data(), 4ull * bin_vars[b].size(), hipMemcpyHostToDevice));
     }
+    if (dbg) fprintf(stderr, "[ecne split] parts: rows copied %.1f ms, layout + upload %.1f ms\n", t_rows, t_up);
     if (plan->kids.size() < 2) SPLIT_NO("fewer than two parts");
     HIP_TRY(hipMalloc((void**)&plan->d_family, sizeof(Family)));
     plan->ok = true;

@@ -148,3 +148,17 @@ def test_per_system_secp_solve_in_one_batch():
         s.set_secp_solve(None)
     ra2, rb2, rc2 = E.solve_batch([a, b, c], secp_solve=True)   # back to "what the launch says"
     assert ra2.status == 0 and ra2.function_good and rc2.status == 0 and rc2.function_good and rb2.status == 0
+
+
+@pytest.mark.gpu
+def test_warmup_is_optional_and_repeatable():
+    """ecne_warmup (include/ecne.h): pays the cold-process costs up front; callable any number of times, leaves the current device alone,
+    refuses a device that is not there"""
+    import ecneproject_amd as E
+    a = E.warmup(0)
+    b = E.warmup(0)
+    assert a > 0 and b > 0
+    with pytest.raises(E.NoDeviceError):
+        E.warmup(E.device_count() + 3)
+    g = E.solve_batch([E.System(E.R1CS(fixtures.path("target/division.r1cs")))])[0]
+    assert g.status == 0 and g.function_good is False
