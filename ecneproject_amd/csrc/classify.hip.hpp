@@ -263,25 +263,36 @@ __device__ void classify_row(const Job& J, uint32_t row, uint32_t* wave_scratch)
     }
 }
 
-// Rows with at most ECNE_CLS_LANE entries in C (almost all of them) are classified by ONE lane each:
-// 64 rows per wavefront, so the field inversions of bit-check / single-variable rows run on full
-// SIMDs instead of one lane of a wave. Same results as classify_row, written serially.
-#define ECNE_CLS_LANE 8
+// Rows with at most ECNE_CLS_LANE entries in C (99 % of an --O0 circuit: products, bit checks, x == y, constants, 1 = x + y) are
+// classified by ONE lane each: 64 rows per wavefront, coalesced row descriptors, the C entries of the workgroup's rows staged in LDS.
+// Round 5: the lane path is the STREAMING path and nothing else -- three entries at most, every array a fixed set of registers (the
+// eight-entry version kept its sort keys in scratch memory, 272 B per lane, and the field inversion's registers capped the kernel at three
+// wavefronts per SIMD), divisors +-1 only (bit checks b * (b - 1), constants x = v: every divisor a circuit presents in practice).
+// Rows with more entries are on the layout's list (cls_list) and get a wavefront each (k_classify_wave, classify_row: the general path);
+// a short row whose divisor needs the binary EGCD is DEFERRED to the same path: its id goes to a list, k_classify_wave runs once more
+// behind the streaming pass (same results either way, tests/test_gpu_classify.py).
 #ifndef ECNE_CLS_STAGE
-#define ECNE_CLS_STAGE 1024      // C entries of 256 consecutive rows staged in LDS per workgroup (36 KB); the average row has 1.6
+#define ECNE_CLS_STAGE 768       // C entries of 256 consecutive rows staged in LDS per workgroup (27 KB: five workgroups per CU); at most 3 x 256 can be staged rows' entries
 #endif
+// -num / den for den = +-1; false: the caller defers the row
+__device__ __forceinline__ bool neg_div_unit(const fp::u256& num, const fp::u256& den, fp::u256& out) {
+    if (fp::is_one(den)) { out = fp::neg(num); return true; }
+    if (fp::is_one(fp::neg(den))) { out = num; return true; }
+    return false;
+}
 // cfC / clC: where the row's C entries are read from -- the CSR arrays themselves (cbase = 0), or the workgroup's LDS copy of the
-// entries [cbase, ...) of its 256 rows (k_classify_rows stages them with coalesced 16-byte loads: one lane walking its own row
-// through device memory is a chain of dependent round trips per entry).
-__device__ __forceinline__ void classify_row_lane(const Job& J, uint32_t row, RowInfo ri, const uint64_t* __restrict__ cfC, const uint32_t* __restrict__ clC, uint32_t cbase) {
+// entries [cbase, ...) of its 256 rows. Returns false when the row has to be deferred (nothing it wrote matters: the general path writes
+// everything again).
+__device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, RowInfo ri, const uint64_t* __restrict__ cfC, const uint32_t* __restrict__ clC, uint32_t cbase) {
     const uint32_t shape_in = ri.shape, kpos_in = ri.kpos, kneg_in = ri.kneg;
     // a product a * b = c (or any row with C empty that is no bit check) needs nothing from this pass
-    if ((shape_in & SH_HAS_AB) && !(shape_in & SH_R2) && !((shape_in & SH_C_HAS1) && (shape_in & SH_R5))) return;
+    if ((shape_in & SH_HAS_AB) && !(shape_in & SH_R2) && !((shape_in & SH_C_HAS1) && (shape_in & SH_R5))) return true;
     const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
     const uint32_t l = c1 - c0;
     uint32_t shape = ri.shape;
     if ((shape & SH_R2) && !(shape & SH_R2_DIV0)) {
         fp::u256 val[2];
+#pragma unroll
         for (int part = 0; part < 2; ++part) {
             const uint32_t* rp = part == 0 ? J.rpA : J.rpB;
             const uint32_t* col = part == 0 ? J.colA : J.colB;
@@ -293,39 +304,51 @@ __device__ __forceinline__ void classify_row_lane(const Job& J, uint32_t row, Ro
                 if (v == ri.x) slope = c;
                 else if (v == 1) icpt = c;
             }
-            val[part] = neg_div(icpt, slope);
-            st256(J.vals + 4ull * (ri.validx + part), val[part]);
+            if (!neg_div_unit(icpt, slope, val[part])) return false;
         }
+        st256(J.vals + 4ull * ri.validx, val[0]);
+        st256(J.vals + 4ull * (ri.validx + 1), val[1]);
         if ((fp::is_zero(val[0]) && fp::is_one(val[1])) || (fp::is_one(val[0]) && fp::is_zero(val[1]))) shape |= SH_R2_IS01;
     }
     if (!(shape & SH_HAS_AB) && l > 0) {
-        if (shape & SH_R3) {
-            fp::u256 c1v = fp::make(0), cx = fp::make(0);
-            for (uint32_t k = c0; k < c1; ++k) {
-                uint32_t v = clC[k - cbase];
-                if (v == 1) c1v = ld256(cfC + 4ull * (k - cbase));
-                else if (v == ri.x) cx = ld256(cfC + 4ull * (k - cbase));
-            }
-            st256(J.vals + 4ull * ri.validx, neg_div(c1v, cx));
+        // the (at most three) entries, in registers
+        fp::u256 c[ECNE_CLS_LANE];
+        uint32_t v[ECNE_CLS_LANE];
+#pragma unroll
+        for (uint32_t e = 0; e < ECNE_CLS_LANE; ++e) {
+            const bool on = e < l;
+            c[e] = on ? ld256(cfC + 4ull * (c0 + e - cbase)) : fp::make(0);
+            v[e] = on ? clC[c0 + e - cbase] : 0u;
         }
-        fp::u256 key[ECNE_CLS_LANE];
+        if (shape & SH_R3) {
+            fp::u256 c1v = fp::make(0), cx = fp::make(0), tv;
+#pragma unroll
+            for (uint32_t e = 0; e < ECNE_CLS_LANE; ++e) {
+                if (e >= l) continue;
+                if (v[e] == 1) c1v = c[e];
+                else if (v[e] == ri.x) cx = c[e];
+            }
+            if (!neg_div_unit(c1v, cx, tv)) return false;
+            st256(J.vals + 4ull * ri.validx, tv);
+        }
         if (!(shape & SH_CZERO)) {
             uint32_t n_one = 0, n_mone = 0, kpos = 0, kneg = 0;
-            uint32_t maskT = 0, maskT2 = 0;     // exponents seen (l <= 8: exponents 0..6)
+            uint32_t maskT = 0, maskT2 = 0;     // exponents seen (l <= 3: exponents 0..1)
             bool okT = true, okT2 = true;
-            for (uint32_t k = c0; k < c1; ++k) {
-                const fp::u256 c = ld256(cfC + 4ull * (k - cbase));
-                const fp::u256 nc = fp::neg(c);
-                const bool one = fp::is_one(c), mone = fp::is_one(nc);
-                if (one) { ++n_one; if (n_one == 1) kpos = clC[k - cbase]; }
-                if (mone) { ++n_mone; if (n_mone == 1) kneg = clC[k - cbase]; }
+#pragma unroll
+            for (uint32_t e = 0; e < ECNE_CLS_LANE; ++e) {
+                if (e >= l) continue;
+                const fp::u256 nc = fp::neg(c[e]);
+                const bool one = fp::is_one(c[e]), mone = fp::is_one(nc);
+                if (one) { ++n_one; if (n_one == 1) kpos = v[e]; }
+                if (mone) { ++n_mone; if (n_mone == 1) kneg = v[e]; }
                 if (!one) {
-                    int e = (popc256(nc) == 1) ? ctz256(nc) : 999;
-                    if (e > (int)l - 2 || (maskT >> e & 1)) okT = false; else maskT |= 1u << e;
+                    int ex = (popc256(nc) == 1) ? ctz256(nc) : 999;
+                    if (ex > (int)l - 2 || (maskT >> ex & 1)) okT = false; else maskT |= 1u << ex;
                 }
                 if (!mone) {
-                    int e = (popc256(c) == 1) ? ctz256(c) : 999;
-                    if (e > (int)l - 2 || (maskT2 >> e & 1)) okT2 = false; else maskT2 |= 1u << e;
+                    int ex = (popc256(c[e]) == 1) ? ctz256(c[e]) : 999;
+                    if (ex > (int)l - 2 || (maskT2 >> ex & 1)) okT2 = false; else maskT2 |= 1u << ex;
                 }
             }
             const bool isT = okT && n_one == 1, isT2 = okT2 && n_mone == 1;
@@ -334,25 +357,23 @@ __device__ __forceinline__ void classify_row_lane(const Job& J, uint32_t row, Ro
             if (isT || isT2) {
                 ri.kpos = kpos;
                 ri.kneg = kneg;
-                fp::u256 pw = fp::make(1);
-                for (uint32_t s = 0; s + 1 < l; ++s) pw = fp::add(pw, pw);
-                st256(J.vals + 4ull * (ri.validx + 1), fp::sub(pw, fp::make(1)));
+                st256(J.vals + 4ull * (ri.validx + 1), fp::make(l == 1 ? 0ull : l == 2 ? 1ull : 3ull));      // 2^(l-1) - 1
             }
         }
-        // R7 order: stable insertion sort of the (at most 8) entries by |signed coefficient|
+        // R7 order: stable by |signed coefficient| -- the rank of each entry from three comparisons
         {
             const bool negated = (shape & SH_R4_T2) && !(shape & SH_R4_T);
-            uint32_t idx[ECNE_CLS_LANE];
-            for (uint32_t k = 0; k < l; ++k) {
-                fp::u256 c = ld256(cfC + 4ull * (c0 + k - cbase));
-                if (negated) c = fp::neg(c);
-                c = r7_abs(c);
-                uint32_t pos = k;
-                while (pos > 0 && fp::cmp(key[pos - 1], c) > 0) { key[pos] = key[pos - 1]; idx[pos] = idx[pos - 1]; --pos; }
-                key[pos] = c;
-                idx[pos] = k;
-            }
-            for (uint32_t k = 0; k < l; ++k) J.csort[c0 + k] = idx[k];
+            fp::u256 key[ECNE_CLS_LANE];
+#pragma unroll
+            for (uint32_t e = 0; e < ECNE_CLS_LANE; ++e) key[e] = r7_abs(negated ? fp::neg(c[e]) : c[e]);
+            // before(i, j), i < j: entry i sorts in front of entry j (ties keep the stored order)
+            const bool b01 = fp::cmp(key[0], key[1]) <= 0, b02 = fp::cmp(key[0], key[2]) <= 0, b12 = fp::cmp(key[1], key[2]) <= 0;
+            uint32_t rank0 = 0, rank1 = 0, rank2 = 0;
+            if (l >= 2) { if (b01) rank1++; else rank0++; }
+            if (l >= 3) { if (b02) rank2++; else rank0++; if (b12) rank2++; else rank1++; }
+            J.csort[c0 + rank0] = 0;
+            if (l >= 2) J.csort[c0 + rank1] = 1;
+            if (l >= 3) J.csort[c0 + rank2] = 2;
             shape |= SH_R7_SORTED;
         }
     }
@@ -361,24 +382,25 @@ __device__ __forceinline__ void classify_row_lane(const Job& J, uint32_t row, Ro
         ri.shape = shape;
         J.rinfo[row] = ri;
     }
+    return true;
 }
 
-// One launch, two kinds of workgroups: the first n_long_blocks take the long rows the host listed (cls_list: lenC >
-// ECNE_CLS_LANE), one wavefront per row; the others the short rows, one lane per row. The long rows are latency-bound (a few
-// hundred rows, each a chain of loads): dispatched first and in the same launch, they overlap with the streaming part.
+// The streaming pass: the short rows, one lane per row (round 5: nothing else in this kernel -- with the long rows' wavefront path in
+// the same kernel, its field inversion and rank sort set the register count for the streaming lanes too, 148 VGPRs = three wavefronts
+// per SIMD; the long rows and the deferred ones get k_classify_wave, launched behind it).
 __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index, uint32_t n_long_blocks) {
-    __shared__ uint32_t scratch[4][16];
     __shared__ Job sJ;
     if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
     __syncthreads();
-    if (blockIdx.x >= n_long_blocks) {
+    {
         // the C entries of the workgroup's 256 rows are one contiguous stretch of the CSR arrays: staged in LDS with coalesced 16-byte
         // loads (36 B per entry), then every lane classifies its row from there. A stretch that does not fit (a long row among the 256:
         // its own entries alone are more than the buffer) is read from device memory as before.
         __shared__ uint4 s_coef[2 * ECNE_CLS_STAGE];
         __shared__ uint32_t s_col[ECNE_CLS_STAGE];
-        const uint32_t nb0 = gridDim.x - n_long_blocks;
-        for (uint32_t rb = (blockIdx.x - n_long_blocks) * 256; rb < sJ.nC; rb += nb0 * 256) {      // (uniform trip count: barriers inside)
+        (void)n_long_blocks;
+        const uint32_t nb0 = gridDim.x;
+        for (uint32_t rb = blockIdx.x * 256; rb < sJ.nC; rb += nb0 * 256) {      // (uniform trip count: barriers inside)
             const uint32_t rend = rb + 256 < sJ.nC ? rb + 256 : sJ.nC;
             const uint32_t clo = sJ.rpC[rb], chi = sJ.rpC[rend];
             const uint32_t n_ent = chi - clo;
@@ -391,19 +413,38 @@ __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t
             }
             __syncthreads();
             const uint32_t row = rb + threadIdx.x;
+            bool defer = false;
             if (row < sJ.nC) {
                 const RowInfo ri = sJ.rinfo[row];
                 if (ri.lenC <= ECNE_CLS_LANE) {
-                    if (staged) classify_row_lane(sJ, row, ri, reinterpret_cast<const uint64_t*>(s_coef), s_col, clo);
-                    else classify_row_lane(sJ, row, ri, sJ.coefC, sJ.colC, 0u);
+                    if (staged) defer = !classify_row_lane(sJ, row, ri, reinterpret_cast<const uint64_t*>(s_coef), s_col, clo);
+                    else defer = !classify_row_lane(sJ, row, ri, sJ.coefC, sJ.colC, 0u);
+                }      // (longer rows are on the layout's list, cls_list: k_classify_wave)
+            }
+            {   // the deferred rows of a wavefront in one atomic (cls_defer[0] = count, zeroed by the host before the launch)
+                const uint64_t m = __ballot(defer);
+                if (m) {
+                    uint32_t base = 0;
+                    if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&sJ.cls_defer[0], (uint32_t)__popcll(m));
+                    base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+                    if (defer) sJ.cls_defer[1 + base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = row;
                 }
             }
             __syncthreads();
         }
-        return;
     }
+}
+
+// One wavefront per row, the general path (classify_row), behind the streaming pass: the rows the layout listed (cls_list: more than
+// ECNE_CLS_LANE entries in C -- latency-bound, each a chain of loads) and the rows k_classify_rows' lanes deferred.
+__global__ __launch_bounds__(256) void k_classify_wave(const Job* jobs, uint32_t job_index) {
+    __shared__ uint32_t scratch[4][16];
+    __shared__ Job sJ;
+    if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
+    __syncthreads();
+    const uint32_t n0 = sJ.nBigCls, n = n0 + sJ.cls_defer[0];
     const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t i = blockIdx.x * 4 + wave; i < sJ.nBigCls; i += n_long_blocks * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
+    for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) classify_row(sJ, i < n0 ? sJ.cls_list[i] : sJ.cls_defer[1 + (i - n0)], scratch[wave]);
 }
 
 }  // namespace ecne

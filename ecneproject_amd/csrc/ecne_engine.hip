@@ -808,7 +808,7 @@ static void build_layout(ecne_system& S) {
             ++vals_here;
         }
         L.rinfo[i] = ri;
-        if (nCc > 8) blk_cls[blk].push_back((uint32_t)i);
+        if (nCc > ECNE_CLS_LANE) blk_cls[blk].push_back((uint32_t)i);
         // A-map equality with the next row, zeros included (:1512)
         if (i + 1 < nC) {
             const uint64_t x0 = R.ptr[0][i], x1 = R.ptr[0][i + 1], y0 = R.ptr[0][i + 1], y1 = R.ptr[0][i + 2];
@@ -1085,6 +1085,7 @@ static int upload_system(ecne_system& S, int device) {
     size_t o_varmin = c.take(4ull * (nV + 1));
     size_t o_rdead = c.take(std::max<size_t>(nC, 1) + 4);   // read four rows at a time
     size_t o_p3stamp = c.take(4ull * std::max<size_t>(nC, 1));
+    size_t o_clsdefer = c.take(4ull * ((size_t)nC + 1));
     size_t o_p3k = c.take(std::max<size_t>(nC, 1)), o_p3h = c.take(8ull * std::max<size_t>(nC, 1)), o_p3h2 = c.take(8ull * std::max<size_t>(nC, 1));
     size_t o_htkey = c.take(8ull * htcap), o_htkey2 = c.take(8ull * htcap), o_htnew = c.take(4ull * htcap), o_htfrozen = c.take(4ull * htcap);
     size_t o_htlist = c.take(4ull * ((size_t)nC + (size_t)ECNE_MAX_NWG * 2049 + 64));
@@ -1235,6 +1236,7 @@ static int upload_system(ecne_system& S, int device) {
     J.nLong = (uint32_t)n_long;
     J.nBigRows = (uint32_t)n_bigrows;
     J.p3stamp = (uint32_t*)(base + o_p3stamp);
+    J.cls_defer = (uint32_t*)(base + o_clsdefer);
     J.p3k = (uint8_t*)(base + o_p3k); J.p3h = (uint64_t*)(base + o_p3h); J.p3h2 = (uint64_t*)(base + o_p3h2);
     J.ht_key = (uint64_t*)(base + o_htkey); J.ht_key2 = (uint64_t*)(base + o_htkey2);
     J.ht_new = (uint32_t*)(base + o_htnew); J.ht_frozen = (uint32_t*)(base + o_htfrozen);
@@ -1275,9 +1277,14 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     if (nblk0 == 0) nblk0 = 1;
     uint32_t nblk1 = (S.L.n_cls + 3) / 4;
     if (nblk1 > 256 * 16) nblk1 = 256 * 16;
+    HIP_TRY(hipMemsetAsync(S.dev.job.cls_defer, 0, 4, stream));
     HIP_TRY(hipEventRecord(e0, stream));
-    // one launch: the long-row workgroups first (latency-bound), the streaming ones behind them (see k_classify_rows)
-    hipLaunchKernelGGL(k_classify_rows, dim3(nblk1 + nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, nblk1);
+    // two launches: the streaming pass (one lane per row with at most three entries in C), then one wavefront per row for the rows the
+    // layout listed (cls_list: more entries) and the ones the streaming lanes deferred (a divisor that needs a real inversion: usually none).
+    // (Tried: the listed rows on a stream of their own next to the streaming pass -- 0.143 -> 0.140 ms at 2.8 M rows, 0.053 -> 0.054 at 0.7 M:
+    //  not worth a second stream, two events and a lock.)
+    hipLaunchKernelGGL(k_classify_rows, dim3(nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, 0u);
+    hipLaunchKernelGGL(k_classify_wave, dim3(std::max<uint32_t>(nblk1, 64u)), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());

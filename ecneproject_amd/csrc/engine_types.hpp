@@ -23,6 +23,9 @@ namespace ecne {
 #ifndef ECNE_SMALL_ROW
 #define ECNE_SMALL_ROW 64   // rows with more entries than this are "long": handled by a whole workgroup
 #endif
+// k_classify_rows: rows with at most this many entries in C are classified by one lane each (the streaming pass); longer ones are listed
+// by the layout (cls_list) and get a wavefront each (k_classify_wave)
+#define ECNE_CLS_LANE 3
 #ifndef ECNE_MAX_NWG
 #define ECNE_MAX_NWG 248     // workgroups one system can get (q_part[][256] and the scratch sizes follow it)
 #endif
@@ -168,6 +171,7 @@ struct Job {
     const uint32_t* p4_b;      // per P4 row: the B variable
     const uint32_t* p4_s;      // per P4 row: slope variable of A; bit 31 set = none (divexact by zero, :1467)
     const uint32_t* cls_list;   // rows with lenC > 8, ascending
+    uint32_t* cls_defer;        // k_classify_rows: [0] = how many rows its lanes deferred to a wavefront, then their ids (classify.hip.hpp)
     const uint32_t *p5_rows, *p5_y;
     // mutable state
     uint8_t* flags;

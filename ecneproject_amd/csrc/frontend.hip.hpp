@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void k_lay_rows(AbsRowsDev R, uint32_t nC, con
     ri.shape = shape;
     rinfo[r] = ri;
     f_p4[r] = p4 ? 1u : 0u;
-    f_cls[r] = n[2] > 8 ? 1u : 0u;
+    f_cls[r] = n[2] > ECNE_CLS_LANE ? 1u : 0u;
     f_big[r] = (shape & SH_BIG) ? 1u : 0u;
     f_val[r] = ((shape & SH_R2) || (!(shape & SH_HAS_AB) && n[2] > 0)) ? 1u : 0u;
     // A-map equality with the next row, zeros included (:1512): same keys, same values (position by position first)
