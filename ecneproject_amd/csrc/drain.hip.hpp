@@ -99,12 +99,58 @@ __device__ __noinline__ uint32_t dr_gen_p3(const Job& J, uint32_t row, uint32_t 
 // ---- the registered long rows of this workgroup (S.bl_*, S.dr_st[k]: bit 0 pending, 1 unstable, 2 demoted, 3 waiting, 4 ran
 // in this level). All threads of the workgroup, uniform control flow. Sets: reads U of every non-final variable and B of C's
 // non-unique ones, may write U of C's non-final ones (exact = conservative: R1 / R7 / R8 decide on the whole row).
+// (round 5) The walks over a long row's entries take FOUR strides per trip -- the ids of all four first, then their flag bytes, then the
+// mark words, then the atomics -- so that a 1 025-term row is three or four dependent trips to memory per phase instead of three per
+// stride (nine and more): with two or three such rows registered in one workgroup (the sums of a multiplexer sit next to each other
+// in the queue) every level of the round waited for them.
+#define ECNE_BW 4u
+template <class F>
+__device__ __forceinline__ void big_walk(const uint32_t* __restrict__ col, const uint8_t* flags, uint32_t e0, uint32_t e1, F f) {
+    for (uint32_t base = e0 + threadIdx.x; base < e1; base += ECNE_BW * ECNE_WG) {
+        uint32_t v[ECNE_BW];
+        uint8_t fl[ECNE_BW];
+#pragma unroll
+        for (uint32_t j = 0; j < ECNE_BW; ++j) v[j] = base + j * ECNE_WG < e1 ? col[base + j * ECNE_WG] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < ECNE_BW; ++j) fl[j] = base + j * ECNE_WG < e1 ? flags[v[j]] : (uint8_t)3;
+        f(v, fl, base, e1);
+    }
+}
+// marks of up to four variables on one plane: the words first, the atomics where they are needed (dr_mark)
+__device__ __forceinline__ void dr_mark4(uint32_t* plane, const uint32_t* v, const bool* want, uint32_t key) {
+    uint32_t m[ECNE_BW];
+#pragma unroll
+    for (uint32_t j = 0; j < ECNE_BW; ++j) m[j] = want[j] ? ld_agent(&plane[v[j]]) : 0xFFFFFFFFu;
+#pragma unroll
+    for (uint32_t j = 0; j < ECNE_BW; ++j) if (want[j] && m[j] < key) atomicMax(&plane[v[j]], key);
+}
 __device__ __noinline__ void dr_big_p1(const Job& J, ChunkShared& S, uint32_t epoch) {
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         if (!(S.dr_st[k] & 1u)) continue;
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
-        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) { const uint32_t v = J.colC[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DX_U], v, key); }
+        big_walk(J.colC, J.flags, J.rpC[row], J.rpC[row + 1], [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+            bool w[ECNE_BW];
+#pragma unroll
+            for (uint32_t j = 0; j < ECNE_BW; ++j) w[j] = base + j * ECNE_WG < e1 && (fl[j] & 3) != 3;
+            dr_mark4(J.dmk[DX_U], v, w, key);
+        });
     }
+}
+// what a reader finds on plane px for up to four variables (dr_see): 1 a lower rank marked (unstable), 2 a higher one (the access is contested:
+// marked on plane pa); `u` / `am` collect the two outcomes
+__device__ __forceinline__ void dr_look4(const Job& J, int px, int pa, const uint32_t* v, const bool* want, uint32_t key, bool& u, bool& am) {
+    uint32_t x[ECNE_BW];
+    bool contested[ECNE_BW];
+#pragma unroll
+    for (uint32_t j = 0; j < ECNE_BW; ++j) x[j] = want[j] ? ld_agent(&J.dmk[px][v[j]]) : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < ECNE_BW; ++j) {
+        const uint32_t s = !want[j] ? 0u : x[j] > key ? 1u : (x[j] < key && (x[j] >> 17) == (key >> 17)) ? 2u : 0u;
+        if (s == 1) u = true;
+        contested[j] = s == 2;
+        if (s == 2) am = true;
+    }
+    dr_mark4(J.dmk[pa], v, contested, key);
 }
 // returns (to every thread) bit 1 if some long row of this workgroup marked a contested access
 __device__ __noinline__ uint32_t dr_big_p2(const Job& J, ChunkShared& S, uint32_t epoch) {
@@ -113,31 +159,55 @@ __device__ __noinline__ uint32_t dr_big_p2(const Job& J, ChunkShared& S, uint32_
         if (!(S.dr_st[k] & 1u)) continue;
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
         bool u = false;
-        auto look = [&](int px, int pa, uint32_t v) { const uint32_t s = dr_see(J.dmk[px], v, key); if (s == 1) u = true; else if (s == 2) { dr_mark(J.dmk[pa], v, key); am = true; } };
-        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3) look(DX_U, DA_U, v); }
-        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3) look(DX_U, DA_U, v); }
-        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
-            const uint32_t v = J.colC[e];
-            const uint8_t f = J.flags[v];
-            if ((f & 3) != 3) look(DX_U, DA_U, v);
-            if (!(f & 1)) look(DX_B, DA_B, v);
-        }
+        auto ab = [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+            bool w[ECNE_BW];
+#pragma unroll
+            for (uint32_t j = 0; j < ECNE_BW; ++j) w[j] = base + j * ECNE_WG < e1 && (fl[j] & 3) != 3;
+            dr_look4(J, DX_U, DA_U, v, w, key, u, am);
+        };
+        big_walk(J.colA, J.flags, J.rpA[row], J.rpA[row + 1], ab);
+        big_walk(J.colB, J.flags, J.rpB[row], J.rpB[row + 1], ab);
+        big_walk(J.colC, J.flags, J.rpC[row], J.rpC[row + 1], [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+            bool wu[ECNE_BW], wb[ECNE_BW];
+#pragma unroll
+            for (uint32_t j = 0; j < ECNE_BW; ++j) { const bool on = base + j * ECNE_WG < e1; wu[j] = on && (fl[j] & 3) != 3; wb[j] = on && !(fl[j] & 1); }
+            dr_look4(J, DX_U, DA_U, v, wu, key, u, am);
+            dr_look4(J, DX_B, DA_B, v, wb, key, u, am);
+        });
         if (u) atomicOr(&S.dr_st[k], 2u);
     }
     const int any_am = __syncthreads_or(am ? 1 : 0);
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
         if ((S.dr_st[k] & 3u) != 3u) continue;       // unstable: C (what it could write) and A (what it can access)
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
-        for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DA_U], v, key); }
-        for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3) dr_mark(J.dmk[DA_U], v, key); }
-        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
-            const uint32_t v = J.colC[e];
-            const uint8_t f = J.flags[v];
-            if ((f & 3) != 3) { dr_mark(J.dmk[DC_U], v, key); dr_mark(J.dmk[DA_U], v, key); }
-            if (!(f & 1)) dr_mark(J.dmk[DA_B], v, key);
-        }
+        auto ab = [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+            bool w[ECNE_BW];
+#pragma unroll
+            for (uint32_t j = 0; j < ECNE_BW; ++j) w[j] = base + j * ECNE_WG < e1 && (fl[j] & 3) != 3;
+            dr_mark4(J.dmk[DA_U], v, w, key);
+        };
+        big_walk(J.colA, J.flags, J.rpA[row], J.rpA[row + 1], ab);
+        big_walk(J.colB, J.flags, J.rpB[row], J.rpB[row + 1], ab);
+        big_walk(J.colC, J.flags, J.rpC[row], J.rpC[row + 1], [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+            bool wu[ECNE_BW], wb[ECNE_BW];
+#pragma unroll
+            for (uint32_t j = 0; j < ECNE_BW; ++j) { const bool on = base + j * ECNE_WG < e1; wu[j] = on && (fl[j] & 3) != 3; wb[j] = on && !(fl[j] & 1); }
+            dr_mark4(J.dmk[DC_U], v, wu, key);
+            dr_mark4(J.dmk[DA_U], v, wu, key);
+            dr_mark4(J.dmk[DA_B], v, wb, key);
+        });
     }
     return any_am ? 2u : 0u;
+}
+// a mark of the current epoch with a lower rank on plane p for any of up to four variables (dr_lower)
+__device__ __forceinline__ bool dr_lower4(const Job& J, int p, const uint32_t* v, const bool* want, uint32_t key) {
+    uint32_t x[ECNE_BW];
+#pragma unroll
+    for (uint32_t j = 0; j < ECNE_BW; ++j) x[j] = want[j] ? ld_agent(&J.dmk[p][v[j]]) : 0u;
+    bool any = false;
+#pragma unroll
+    for (uint32_t j = 0; j < ECNE_BW; ++j) any |= want[j] && x[j] > key;
+    return any;
 }
 __device__ __noinline__ void dr_big_p3(const Job& J, ChunkShared& S, uint32_t epoch, bool look_c) {
     for (uint32_t k = 0; k < ECNE_BIGK; ++k) {
@@ -145,15 +215,24 @@ __device__ __noinline__ void dr_big_p3(const Job& J, ChunkShared& S, uint32_t ep
         const uint32_t row = S.bl_row[k], key = dr_key(epoch, S.bl_rank[k]);
         uint32_t r = 0;
         if (look_c) {
-            for (uint32_t e = J.rpA[row] + threadIdx.x; e < J.rpA[row + 1]; e += ECNE_WG) { const uint32_t v = J.colA[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
-            for (uint32_t e = J.rpB[row] + threadIdx.x; e < J.rpB[row + 1]; e += ECNE_WG) { const uint32_t v = J.colB[e]; if ((J.flags[v] & 3) != 3 && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; }
+            auto ab = [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+                bool w[ECNE_BW];
+#pragma unroll
+                for (uint32_t j = 0; j < ECNE_BW; ++j) w[j] = base + j * ECNE_WG < e1 && (fl[j] & 3) != 3;
+                if (dr_lower4(J, DC_U, v, w, key)) r |= 4u;
+            };
+            big_walk(J.colA, J.flags, J.rpA[row], J.rpA[row + 1], ab);
+            big_walk(J.colB, J.flags, J.rpB[row], J.rpB[row + 1], ab);
         }
-        for (uint32_t e = J.rpC[row] + threadIdx.x; e < J.rpC[row + 1]; e += ECNE_WG) {
-            const uint32_t v = J.colC[e];
-            const uint8_t f = J.flags[v];
-            if ((f & 3) != 3) { if (look_c && dr_lower(J.dmk[DC_U], v, key)) r |= 4u; if (dr_lower(J.dmk[DA_U], v, key)) r |= 8u; }
-            if (look_c && !(f & 1) && dr_lower(J.dmk[DC_B], v, key)) r |= 4u;
-        }
+        big_walk(J.colC, J.flags, J.rpC[row], J.rpC[row + 1], [&](const uint32_t* v, const uint8_t* fl, uint32_t base, uint32_t e1) {
+            bool wu[ECNE_BW], wb[ECNE_BW], none[ECNE_BW];
+#pragma unroll
+            for (uint32_t j = 0; j < ECNE_BW; ++j) { const bool on = base + j * ECNE_WG < e1; wu[j] = on && (fl[j] & 3) != 3; wb[j] = on && look_c && !(fl[j] & 1); none[j] = false; }
+            if (look_c && dr_lower4(J, DC_U, v, wu, key)) r |= 4u;
+            if (dr_lower4(J, DA_U, v, wu, key)) r |= 8u;
+            if (look_c && dr_lower4(J, DC_B, v, wb, key)) r |= 4u;
+            (void)none;
+        });
         if (r) atomicOr(&S.dr_st[k], r);
         if (r & 4u) atomicMin(&S.dcut, S.bl_rank[k]);
     }

@@ -331,16 +331,27 @@ __device__ __noinline__ bool exec_big_row_wg(const Job& J, ChunkShared& S, uint3
     const uint32_t k1 = c0 + (((uint32_t)tid + 1) * per < l ? ((uint32_t)tid + 1) * per : l);
     uint32_t cnt = 0, u = 0, amin = 0xFFFFFFFFu, amax = 0;
     bool notknown = false;
-    for (uint32_t k = k0; k < k1; ++k) {
-        const uint32_t v = J.colC[k];
-        const uint8_t f = J.flags[v];
-        if (f & 1) continue;
-        if (!cnt) u = v;
-        ++cnt;
-        if (!(f & 2)) notknown = true;
-        const uint32_t a = (uint32_t)J.abz[v];   // -1 (no group) is the largest value
-        amin = a < amin ? a : amin;
-        amax = a > amax ? a : amax;
+    // (four entries per trip: the ids, then the flag bytes, then the group tags of the non-unique ones -- three trips for a thread's share
+    //  of a 1 025-term row instead of three per entry)
+    for (uint32_t kb = k0; kb < k1; kb += 4) {
+        uint32_t v4[4];
+        uint8_t f4[4];
+        uint32_t a4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) v4[j] = kb + j < k1 ? J.colC[kb + j] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) f4[j] = kb + j < k1 ? J.flags[v4[j]] : (uint8_t)1;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) a4[j] = (kb + j < k1 && !(f4[j] & 1)) ? (uint32_t)J.abz[v4[j]] : 0u;   // -1 (no group) is the largest value
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (kb + j >= k1 || (f4[j] & 1)) continue;
+            if (!cnt) u = v4[j];
+            ++cnt;
+            if (!(f4[j] & 2)) notknown = true;
+            amin = a4[j] < amin ? a4[j] : amin;
+            amax = a4[j] > amax ? a4[j] : amax;
+        }
     }
     if (nuab) sh[0] = 1;
     if (cnt) {
