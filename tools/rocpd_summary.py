@@ -19,8 +19,10 @@ def summarise(path):
     cols = [r[1] for r in cur.execute("pragma table_info(%s)" % kd)]
     scols = [r[1] for r in cur.execute("pragma table_info(%s)" % ks)]
     name_col = "kernel_name" if "kernel_name" in scols else ("display_name" if "display_name" in scols else scols[-1])
+    # (one line per kernel AND grid size: ecne_warmup launches both solve kernels once on a three-row system -- 1 024 threads -- and those
+    #  launches must not be averaged into the solves of the workload)
     q = ("select s.%s, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), max(d.end - d.start), "
-         "max(d.grid_size_x), max(d.workgroup_size_x) from %s d join %s s on d.kernel_id = s.id group by s.%s order by 3 desc"
+         "d.grid_size_x, max(d.workgroup_size_x) from %s d join %s s on d.kernel_id = s.id group by s.%s, d.grid_size_x order by 3 desc"
          % (name_col, kd, ks, name_col))
     rows = list(cur.execute(q))
     tot = sum(r[2] for r in rows) or 1
@@ -35,14 +37,14 @@ def summarise(path):
         if "event_id" in pcols and "pmc_id" in pcols:
             # event_id -> kernel dispatch via rocpd_event? fall back to a plain per-counter, per-kernel sum
             try:
-                q = ("select s.%s, i.name, count(*), sum(p.value), avg(p.value) from %s p join %s i on p.pmc_id = i.id "
-                     "join %s d on p.event_id = d.event_id join %s s on d.kernel_id = s.id group by s.%s, i.name order by 4 desc"
+                q = ("select s.%s, i.name, count(*), sum(p.value), avg(p.value), d.grid_size_x from %s p join %s i on p.pmc_id = i.id "
+                     "join %s d on p.event_id = d.event_id join %s s on d.kernel_id = s.id group by s.%s, i.name, d.grid_size_x order by 4 desc"
                      % (name_col, pe, pi, kd, ks, name_col))
                 rows = list(cur.execute(q))
                 if rows:
-                    print("%-60s %-14s %6s %18s %18s" % ("kernel", "counter", "n", "sum", "avg_per_dispatch"))
-                    for n, cn, c, sm, av in rows:
-                        print("%-60s %-14s %6d %18.1f %18.1f" % (n[:60], cn, c, sm, av))
+                    print("%-60s %-14s %6s %18s %18s %9s" % ("kernel", "counter", "n", "sum", "avg_per_dispatch", "grid_x"))
+                    for n, cn, c, sm, av, gx in rows:
+                        print("%-60s %-14s %6d %18.1f %18.1f %9d" % (n[:60], cn, c, sm, av, gx))
             except sqlite3.Error as e:
                 print("pmc query failed:", e, pcols, icols)
     print()
