@@ -299,6 +299,9 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
     int myslot = -1;               // my row is a long row registered in this slot
     for (;;) {
         ++level;
+#ifdef ECNE_ROUNDLOG
+        unsigned long long rd_t[6]; rd_t[0] = wall_clock64(); rd_t[1] = rd_t[2] = rd_t[3] = rd_t[4] = rd_t[5] = rd_t[0];
+#endif
         if (wgrank == 0 && (level & 15u) == 0) job_heartbeat(J);      // (a window of dependent rows drains one row per level: thousands of levels in one round)
         if (epoch >= ECNE_DRAIN_EPOCH_MAX) {
             // the epoch field is used up (once per 32 766 levels): wipe the planes; the marks of this round start over
@@ -377,8 +380,14 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
             if (kind == 4) myslot = big_slot_of(S, r0);
         }
         if (S.bl_any) dr_big_p1(J, S, epoch);
+#ifdef ECNE_ROUNDLOG
+        rd_t[1] = wall_clock64();
+#endif
         if ((err = job_barrier(J, s_err))) return err;
         MTICK(0);
+#ifdef ECNE_ROUNDLOG
+        rd_t[2] = wall_clock64();
+#endif
         if (level == 1) {
             const uint32_t qc = ld_agent(&ctr->q_cut);
             if (qc < n_eff) n_eff = qc;           // the window ends in front of a long row the round does not take (nothing has run yet)
@@ -422,6 +431,9 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
         }
         if ((err = job_barrier(J, s_err))) return err;
         MTICK(1);
+#ifdef ECNE_ROUNDLOG
+        rd_t[3] = wall_clock64();
+#endif
         const uint32_t lflag = ld_agent(&ctr->d_flag[par]);
         const bool slow_level = (lflag & 1u) != 0;      // somebody is unstable: its conservative marks have to be looked at
         uint32_t dcut = 0xFFFFFFFFu;
@@ -455,6 +467,9 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
                 dcut = ld_agent(&ctr->d_cut[par]);
             }
         }
+#ifdef ECNE_ROUNDLOG
+        rd_t[4] = wall_clock64();
+#endif
         // ------------------------------------------------------------------ run what is ready
         if (pending && kind != 4 && !unstable && !waiting && !demoted && r0 < dcut) {
             pending = false;
@@ -511,6 +526,10 @@ __device__ __noinline__ int queue_round_drain(const Job& J, ChunkShared& S, uint
         }
         // nobody marked A or C: nobody was unstable, demoted or made to wait -- everything has run, the window has drained
         // (multi_finish's first barrier orders these stores before anybody reads them)
+#ifdef ECNE_ROUNDLOG
+        rd_t[5] = wall_clock64();
+        if (g == 0) printf("RDT level %u p1 %llu bar %llu p2+bar %llu p3 %llu run %llu bl_any %u\n", level, rd_t[1] - rd_t[0], rd_t[2] - rd_t[1], rd_t[3] - rd_t[2], rd_t[4] - rd_t[3], rd_t[5] - rd_t[4], (unsigned)S.bl_any);
+#endif
         if (!lflag) break;
         {
             const int left = __syncthreads_count(pending ? 1 : 0);
