@@ -83,12 +83,12 @@ def schedule_env():
 # a batch takes as long as its longest job). `bench.py --gpus N` prints measured next to predicted so that the first run on an 8-GPU node
 # grades the model by itself. "ecdsa": one circuit does not shard -- replicas, the time per step stays, the rate grows N-fold.
 DESIGN_PREDICTED_MS = {
-    "ecdsa": {1: 6.2, 2: 6.2, 4: 6.2, 8: 6.2},
-    "suite": {1: 10.6, 2: 10.2, 4: 10.2, 8: 10.2},
-    "dag": {1: 8.7, 2: 7.3, 4: 7.3, 8: 7.3},
+    "ecdsa": {1: 5.6, 2: 5.6, 4: 5.6, 8: 5.6},
+    "suite": {1: 10.5, 2: 10.2, 4: 10.2, 8: 10.2},
+    "dag": {1: 8.4, 2: 7.3, 4: 7.3, 8: 7.3},
     "many": {1: 3.0, 2: 1.6, 4: 1.2, 8: 1.2},
     "secp": {1: 7.3, 2: 7.3, 4: 7.3, 8: 7.3},
-    "poseidon": {1: 1.13, 2: 1.13, 4: 1.13, 8: 1.13},
+    "poseidon": {1: 1.12, 2: 1.12, 4: 1.12, 8: 1.12},
 }
 
 
