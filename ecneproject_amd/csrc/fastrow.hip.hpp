@@ -437,4 +437,32 @@ __device__ __noinline__ bool long_r4_done(const Job& J, uint32_t shape, uint32_t
     return fp::cmp(nub, im1) <= 0;
 }
 
+// A long binary decomposition whose pivot AND lowest bit (the two terms with coefficients 1 and -1: kpos / kneg) are both not unique is
+// popped without effect when (gp, gb: their flag bytes)
+//   R1 (:827-873)   two terms are not unique: nothing;
+//   R4 (:991-1076)  bit 0 lacks bounds [0,1]: the loop at :1020-1029 returns; else the pivot's bounds are cut iff ub(pivot) > 2^(l-1) - 1
+//                   (:1035) -- nothing when it is not; the second half (:1049-1067) wants the pivot unique;
+//   R7 (:1235-1298) a term that is not unique and not known: returns (:1252) -- else the two smallest |coefficients| are the pivot's and
+//                   bit 0's, both 1: quotient 1, remainder 0, and the rule returns iff 1 <= ub - lb of the first of them (:1262-1266):
+//                   bit 0's bounds are [0,1] (gb bit 2), the pivot's are looked at;
+//   R8 (:1304-1348) a term that is not unique and carries no group tag: returns.
+// secp256k1's 39 decompositions are popped ~60 times in that state (between the pop that cuts the pivot's bounds and the one that finds
+// the pivot unique), 11 us each through the general executor and each at the head of the queue, by the whole workgroup. The pop has
+// read the state of the pivot and of bit 0: the caller treats both as read. Exact for any state: false = "ask the general executor".
+__device__ __noinline__ bool long_r4_idle(const Job& J, uint32_t gp, uint32_t gb, uint32_t pivot, uint32_t lenC) {
+    if (((gp | gb) & 1u) || ((gp & gb) & 16u) || (J.lv_off & 4u)) return false;
+    const uint32_t l = lenC;
+    if (l < 3 || l - 1 >= 254) return false;
+    const bool r7_unknown = !((gp & gb) & 2u);
+    if (!(gb & 4u)) return r7_unknown;
+    const fp::u256 nub = ld256(J.ub + 4ull * pivot);
+    fp::u256 ip = fp::make(0), im1;
+    ip.w[(l - 1) >> 6] = 1ull << ((l - 1) & 63);
+    fp::sub_raw(im1, ip, fp::make(1));
+    if (fp::cmp(nub, im1) > 0) return false;
+    if (r7_unknown) return true;
+    const fp::u256 nlb = ld256(J.lb + 4ull * pivot);
+    return fp::cmp(nub, nlb) > 0;
+}
+
 }  // namespace ecne

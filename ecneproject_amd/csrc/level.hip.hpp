@@ -191,12 +191,18 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
         const bool lr4 = long_r4(shape);
         const bool biglin = live && norec && (f4 || lr4) && lenC > 15;
         bool bl_nop = false, watched = false;
+        uint32_t wv0 = w[1], wv1 = w[2];
         if (__ballot(biglin)) {
             const uint32_t h0 = w[1], h1 = w[2];
             watched = biglin && h0 < 0xFFFFFFFEu;
             const uint8_t g0 = ldF(watched ? h0 : 0u), g1 = ldF(watched ? h1 : 0u);
             bl_nop = (biglin && h0 == 0xFFFFFFFEu && f4) || (watched && long_watch_holds(g0, g1, lr4));
             watched = watched && bl_nop;
+            // (round 5) ... and a decomposition whose pivot and lowest bit are not unique, the pivot's bounds cut already (long_r4_idle):
+            // that pop has read those two
+            if (biglin && lr4 && !bl_nop && long_r4_idle(J, ldF(kpos), ldF(kneg), long_r4_pivot(shape, kpos, kneg), lenC)) {
+                bl_nop = watched = true; wv0 = kpos; wv1 = kneg;
+            }
         }
         bool slow = mine && !bl_nop && (norec || (shape & SH_BIG) || (!is_solved && !(xy || f1 || f2 || f4)));
         // ---- 3: products and plain sums walk their entries (R1, :827-873): flag bytes from LDS, counted on the fly. The loop is
@@ -316,7 +322,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
             if (blk & 1u) blocked = true;
             if (__ballot(cand && watched)) {       // the watched pair of a long row is what its empty pop has read
                 const bool on = cand && watched;
-                const uint32_t m0 = wm[wslot(on ? w[1] : 0u)], m1 = wm[wslot(on ? w[2] : 0u)];
+                const uint32_t m0 = wm[wslot(on ? wv0 : 0u)], m1 = wm[wslot(on ? wv1 : 0u)];
                 if (on && (m0 < rank || m1 < rank)) blocked = true;
             }
             const uint64_t m = __ballot(blocked);

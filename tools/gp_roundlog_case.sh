@@ -8,5 +8,5 @@ ECNE_BUILD_FLAGS="-DECNE_ROUNDLOG -DECNE_FINE_TICKS" python -m ecneproject_amd.b
 N=$(basename "$1" | tr "@." "__")
 timeout 600 python tools/solve_case.py "$1" 0 > gpurun_out/roundlog_$N.txt 2>&1 || true
 python tools/round_log.py gpurun_out/roundlog_$N.txt --seq > gpurun_out/roundlog_${N}_summary.txt 2>&1 || true
-head -12 gpurun_out/roundlog_${N}_summary.txt
+head -11 gpurun_out/roundlog_${N}_summary.txt
 cp /tmp/libecne_hip.so.keep ecneproject_amd/libecne_hip.so
