@@ -465,4 +465,59 @@ __device__ __noinline__ bool long_r4_idle(const Job& J, uint32_t gp, uint32_t gb
     return fp::cmp(nub, nlb) > 0;
 }
 
+// The two pops of a long binary decomposition that DO something -- both through R4 (:991-1076) alone -- on one wavefront, without the
+// general executor's R1 / R7 / R8 passes (exec_row(): 18 and 14 us on an 88-bit row, secp256k1 has 39 of each):
+//   (a) pivot and lowest bit not unique, every bit bounded [0,1]: R4 cuts the pivot's bounds to [0, 2^(l-1) - 1] iff ub(pivot) is above
+//       (:1031-1048; is_known, one step, REQUEUE(pivot)); R1 (two terms not unique), R7 and R8 do nothing for long_r4_idle()'s reasons --
+//       R7 sees the pivot known and bounded [0, 2^(l-1) - 1] after the cut;
+//   (b) pivot unique, at least two bits not unique (one: R1's, :827-873), every bit bounded: the cut as in (a), then every bit that is not
+//       unique becomes unique, in the row's order, one step and one REQUEUE each (:1049-1067); nothing is left for R7 / R8.
+// Anything else: false, nothing written -- the general executor's. All 64 lanes; q.emit as exec_row().
+__device__ __noinline__ bool exec_long_r4(const Job& J, QState& q, uint32_t row, const RowInfo& ri, unsigned long long* hits,
+                                          unsigned long long& steps, unsigned long long& nuniq) {
+    const int lane = lane_id();
+    const uint32_t shape = ri.shape, l = ri.lenC;
+    if (!long_r4(shape) || l < 3 || l - 1 >= 254 || ri.validx == 0xFFFFFFFFu) return false;
+    const bool t1 = (shape & SH_R4_T) != 0;
+    const uint32_t piv = t1 ? ri.kpos : ri.kneg, bit0 = t1 ? ri.kneg : ri.kpos;
+    const uint32_t gp = J.flags[piv], gb = J.flags[bit0];
+    const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+    bool bad = false, nk = false;
+    uint32_t cnt = 0;
+    for (uint32_t k = c0 + (uint32_t)lane; k < c1; k += 64) {
+        const uint32_t v = J.colC[k];
+        const uint32_t f = J.flags[v];
+        if (v != piv) { bad |= !(f & 4u); cnt += (f & 1u) ? 0u : 1u; nk |= !(f & 3u); }
+    }
+    if (__ballot(bad)) return false;
+    const bool notknown = __ballot(nk) != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    const fp::u256 fub = ld256(J.vals + 4ull * (ri.validx + 1));
+    const fp::u256 nlb = ld256(J.lb + 4ull * piv), nub = ld256(J.ub + 4ull * piv);
+    fp::u256 ip = fp::make(0), im1;
+    ip.w[(l - 1) >> 6] = 1ull << ((l - 1) & 63);
+    fp::sub_raw(im1, ip, fp::make(1));
+    const bool cut = !(fp::is_zero(nlb) && fp::eq(nub, fub)) && fp::cmp(nub, im1) > 0;
+    if (gp & 1u) {
+        if (cnt < 2) return false;
+    } else {
+        if ((gb & 1u) || ((gp & gb) & 16u)) return false;
+        const bool r7_unknown = notknown || (!(gp & 2u) && !cut);
+        if (!r7_unknown && !cut && fp::cmp(nub, nlb) <= 0) return false;
+    }
+    if (cut) {
+        if (lane == 0) { set_bounds(J, piv, fp::make(0), fub); J.flags[piv] |= 2; }
+        wg_fence();
+        steps++; hits[3]++;
+        requeue(J, q, piv);
+    }
+    if (gp & 1u) {
+        const uint32_t n = uniq_range_and_requeue(J, q, c0, c1, piv);
+        nuniq += n; steps += n; hits[3] += n;
+        if (lane == 0 && J.rec != nullptr && l > 15) const_cast<uint32_t*>(J.rec)[16ull * row + 1] = 0xFFFFFFFEu;      // (as exec_row(): long_r4_done)
+    }
+    return true;
+}
+
 }  // namespace ecne
