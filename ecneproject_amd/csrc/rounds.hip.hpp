@@ -1409,7 +1409,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                 qq.head = q.head + 1; qq.tail = q.tail; qq.evout = J.bigev; qq.nev = 0; qq.emit = 1;
                 unsigned long long st = 0, nu = 0, ht[16];
                 for (int i = 0; i < 16; ++i) ht[i] = 0;
-                if (!exec_long_r4(J, qq, rr, bri_, ht, st, nu)) exec_row(J, qq, rr, ht, st, nu);
+                if (TEAM || !exec_long_r4(J, qq, rr, bri_, ht, st, nu)) exec_row(J, qq, rr, ht, st, nu);
                 if (lane == 0) {
                     S.acc[0] += st; S.acc[1] += nu;
                     for (int i = 0; i < 8; ++i) S.acc[2 + i] += ht[i];
