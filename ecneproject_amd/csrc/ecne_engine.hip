@@ -192,6 +192,9 @@ struct ecne_system {
     std::vector<Special> specials;
     std::vector<int64_t> knowns, targets;
     int64_t n_vars = 0, n_rows_main = 0;
+    uint32_t screen[4] = {0, 0, 0, 0};      // build_split's device screen (split_screen)
+    bool screen_done = false;
+    double screen_ms = 0;
     int secp_solve_override = -1;      // ecne_system_set_secp_solve: this system's kwarg secp_solve inside a batch (-1: the launch's opts decide)
     bool laid_out = false;
     uint64_t generation = 0;   // bumped by every solve
@@ -303,6 +306,83 @@ __global__ __launch_bounds__(256) void k_count_shape(Job J, uint32_t mask, uint3
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < J.nC; r += gridDim.x * 256u) n += (J.rinfo[r].shape & mask) ? 1u : 0u;
     for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
+}
+
+// ---- build_split's screen on the device: the groups of rows that share a variable other than the constant wire, from the resident
+// fan-out lists (variable -> rows, :628-633: the only way a pop reaches another row) -- union-find over the ROWS by atomic hooking
+// (the larger root under the smaller, path halving), one thread per variable for lists of up to 16 rows, one workgroup per longer list
+// (a multiplexer's select wire is in 84 000 rows: consecutive pairs, lanes across them); P5's row pairs (:1492-1536) as build_split
+// unites them. Then every row's root, the rows per root, the number of roots and the largest group. The host plan that follows a
+// positive answer unites through zero coefficients too (a dictionary key the device arrays do not hold): its groups can only be coarser.
+__device__ __forceinline__ uint32_t cc_find(uint32_t* p, uint32_t x) {
+    for (;;) {
+        const uint32_t px = __hip_atomic_load(&p[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (px == x) return x;
+        const uint32_t ppx = __hip_atomic_load(&p[px], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ppx != px) __hip_atomic_store(&p[x], ppx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (halving: any ancestor is a valid parent)
+        x = px;
+    }
+}
+__device__ __forceinline__ void cc_unite(uint32_t* p, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = cc_find(p, a); b = cc_find(p, b);
+        if (a == b) return;
+        if (a > b) { const uint32_t t = a; a = b; b = t; }
+        uint32_t expect = b;
+        if (__hip_atomic_compare_exchange_strong(&p[b], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+}
+__global__ __launch_bounds__(256) void k_cc_init(uint32_t* parent, uint32_t* cnt, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { parent[i] = i; cnt[i] = 0; }
+}
+#define ECNE_CC_SHORT 16u
+#define ECNE_CC_LONGCAP 65536u
+// out: [0] roots, [1] largest group, [2] long lists, [3] long lists that did not fit the list (the answer is then void)
+__global__ __launch_bounds__(256) void k_cc_hook(Job J, uint32_t* parent, uint32_t* long_vars, uint32_t* out) {
+    const uint32_t nV = J.nV;
+    for (uint32_t v = 2 + blockIdx.x * 256u + threadIdx.x; v <= nV; v += gridDim.x * 256u) {
+        const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+        if (f1 - f0 < 2) continue;
+        if (f1 - f0 > ECNE_CC_SHORT) {
+            const uint32_t k = atomicAdd(&out[2], 1u);
+            if (k < ECNE_CC_LONGCAP) long_vars[k] = v; else atomicAdd(&out[3], 1u);
+            continue;
+        }
+        const uint32_t r0 = J.fo_rows[f0];
+        for (uint32_t e = f0 + 1; e < f1; ++e) cc_unite(parent, r0, J.fo_rows[e]);
+    }
+    // P5's pairs: rows i, i + 1 with two non-zero terms in C, then none in C and one in B (the static half of :1493-1506)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i + 1 < J.nC; i += gridDim.x * 256u)
+        if (J.rpC[i + 1] - J.rpC[i] == 2 && J.rpC[i + 2] - J.rpC[i + 1] == 0 && J.rpB[i + 2] - J.rpB[i + 1] == 1) cc_unite(parent, i, i + 1);
+}
+__global__ __launch_bounds__(256) void k_cc_hook_long(Job J, uint32_t* parent, const uint32_t* long_vars, const uint32_t* out) {
+    const uint32_t n = out[2] < ECNE_CC_LONGCAP ? out[2] : ECNE_CC_LONGCAP;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint32_t v = long_vars[k];
+        const uint32_t f0 = J.fo_ptr[v], f1 = J.fo_ptr[v + 1];
+        for (uint32_t e = f0 + 1 + threadIdx.x; e < f1; e += 256u) cc_unite(parent, J.fo_rows[e - 1], J.fo_rows[e]);
+    }
+}
+__global__ __launch_bounds__(256) void k_cc_count(uint32_t* parent, uint32_t* cnt, uint32_t n, uint32_t* out) {
+    // (one atomic per distinct root of a wavefront: a file that is ONE group would otherwise send a million additions to one word)
+    uint32_t roots = 0, best = 0;
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {      // (uniform trip count: ballots inside)
+        const uint32_t i = i0 + threadIdx.x;
+        bool todo = i < n;
+        const uint32_t r = todo ? cc_find(parent, i) : 0u;
+        if (todo && r == i) ++roots;
+        for (uint64_t m = __ballot(todo); m; m = __ballot(todo)) {
+            const uint32_t lr = (uint32_t)__shfl((int)r, __ffsll((long long)m) - 1, 64);
+            const uint64_t same = __ballot(todo && r == lr);
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1)) {
+                const uint32_t c = atomicAdd(&cnt[lr], (uint32_t)__popcll(same)) + (uint32_t)__popcll(same);
+                best = c > best ? c : best;
+            }
+            if (r == lr) todo = false;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { roots += __shfl_xor(roots, d, 64); const uint32_t o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+    if ((threadIdx.x & 63u) == 0) { if (roots) atomicAdd(&out[0], roots); if (best) atomicMax(&out[1], best); }
 }
 
 // ---- a split file (SplitPlan): one part's state into the file's own arrays; the part's copy of the constant wire against what setup
@@ -1844,7 +1924,42 @@ static std::atomic<int>& split_setting() {
     return m;
 }
 static int split_mode() { return split_setting().load(std::memory_order_relaxed); }
-static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
+// The device screen of build_split: classification (SH_TOUCH1 comes from there), rows that can write the constant wire's state, the
+// groups of rows (k_cc_*). P.screen = {groups, rows of the largest, SH_TOUCH1 rows, 1 = the long-variable list overflowed: no answer}.
+static int split_screen(ecne_system& P, int device) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t nC = P.dev.job.nC;
+    uint32_t* d = nullptr;      // parent[nC], cnt[nC], long_vars[LONGCAP], out[4], then a Job slot for the classification
+    const size_t words = 2ull * nC + ECNE_CC_LONGCAP + 4;
+    HIP_TRY(hipMalloc((void**)&d, 4 * words + sizeof(Job) + 256));
+    uint32_t* const parent = d, * const cnt = d + nC, * const longv = d + 2ull * nC, * const out = longv + ECNE_CC_LONGCAP;
+    Job* const slot = (Job*)(((uintptr_t)(out + 4) + 255) & ~(uintptr_t)255);
+    int rc = classify_system(P, 0, slot);
+    uint32_t h[4] = {0, 0, 0, 0}, touch = 0;
+    hipError_t e = hipSuccess;
+    if (rc == K_OK) {
+        const uint32_t nb = std::min<uint32_t>(4096u, (std::max(nC, P.dev.job.nV) + 255u) / 256u);
+        e = hipMemsetAsync(out, 0, 16, 0);
+        hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, 0, parent, cnt, nC);
+        hipLaunchKernelGGL(k_cc_hook, dim3(nb), dim3(256), 0, 0, P.dev.job, parent, longv, out);
+        hipLaunchKernelGGL(k_cc_hook_long, dim3(1024), dim3(256), 0, 0, P.dev.job, parent, (const uint32_t*)longv, (const uint32_t*)out);
+        hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, 0, parent, cnt, nC, out);
+        if (e == hipSuccess) e = hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemsetAsync(out, 0, 4, 0);
+        hipLaunchKernelGGL(k_count_shape, dim3(std::min<uint32_t>(1024u, (nC + 255u) / 256u)), dim3(256), 0, 0, P.dev.job, (uint32_t)SH_TOUCH1, out);
+        if (e == hipSuccess) e = hipMemcpy(&touch, out, 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (rc != K_OK) return rc;
+    if (e != hipSuccess) { (void)hipGetLastError(); return ECNE_ENODEVICE; }
+    P.screen[0] = h[0]; P.screen[1] = h[1]; P.screen[2] = touch; P.screen[3] = h[3] ? 1u : 0u;
+    P.screen_done = true;
+    P.screen_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return K_OK;
+}
+
+static int build_split(ecne_system& P, int device, uint32_t cap, bool eager, bool first_solve = false) {
     static const bool dbg = getenv("ECNE_SPLIT_DEBUG") != nullptr;
 #define SPLIT_NO(why) do { if (dbg) fprintf(stderr, "[ecne split] no plan: %s\n", why); return K_OK; } while (0)
     const auto t0 = std::chrono::steady_clock::now();
@@ -1854,18 +1969,20 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
     // Screen before anything is downloaded or planned: the parts share ONE variable, the constant wire, and a part that writes its state
     // (every `x <== 1` of a circuit is a row x - 1 = 0 whose R4 / R5 shapes can move the wire's bounds: SH_TOUCH1, set by k_classify_rows)
     // makes the split solve void (Family.var1_bad) -- plan, part uploads and a whole solve for nothing. Such a file stays one system.
-    if (P.dev.classified && P.dev.device == device && P.dev.job.nC) {
-        uint32_t* d_n = nullptr;
-        uint32_t h_n = 0;
-        HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipMalloc((void**)&d_n, 4));
-        hipError_t e = hipMemset(d_n, 0, 4);
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_count_shape, dim3(std::min<uint32_t>(1024u, (P.dev.job.nC + 255u) / 256u)), dim3(256), 0, 0, P.dev.job, (uint32_t)SH_TOUCH1, d_n); e = hipMemcpy(&h_n, d_n, 4, hipMemcpyDeviceToHost); }
-        (void)hipFree(d_n);
-        if (e != hipSuccess) { (void)hipGetLastError(); return ECNE_ENODEVICE; }
-        if (h_n) SPLIT_NO("rows that can write the constant wire's bounds");
-    }
     auto lap = [&](const char* what) { if (dbg) fprintf(stderr, "[ecne split] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
+    // (round 5) ... and the groups themselves are counted on the device first (split_screen: union-find over the resident fan-out lists,
+    // ~0.1-0.5 ms): a file that is one group -- nearly every file -- is known to be one before its rows are downloaded (18 ms per million)
+    // and united on the host (17 ms)
+    if (P.dev.arena && P.dev.device == device && P.dev.job.nC) {
+        if (!P.screen_done) { const int rc = split_screen(P, device); if (rc != K_OK) return rc; }
+        if (dbg) fprintf(stderr, "[ecne split] device screen: %u groups, largest %u of %u rows, %u rows can write the constant wire, %.2f ms\n", P.screen[0], P.screen[1], P.dev.job.nC, P.screen[2], P.screen_ms);
+        if (P.screen[2]) SPLIT_NO("rows that can write the constant wire's bounds");
+        if (!P.screen[3]) {
+            if (P.screen[0] < 2) SPLIT_NO("one group (device screen)");
+            if (!eager && (uint64_t)P.screen[1] * 5 > (uint64_t)P.dev.job.nC * 3) SPLIT_NO("one group holds most of the file (device screen)");
+            if (first_solve && (P.screen[0] < 8 || (uint64_t)P.screen[1] * 8 > (uint64_t)P.dev.job.nC)) { P.split_tried = false; SPLIT_NO("not before the first solve: fewer than eight groups or one with more than an eighth of the rows"); }
+        } else if (first_solve) { P.split_tried = false; SPLIT_NO("not before the first solve: the screen's list of long variables overflowed"); }
+    } else if (first_solve) { P.split_tried = false; SPLIT_NO("not before the first solve: not resident"); }
     lap("screen");
     { const int rc = sys_host_rows(P); if (rc != K_OK) return rc; }
     lap("host rows");
@@ -1930,13 +2047,20 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
     for (size_t i = 0; i < nC; ++i) bin_rows[grp_bin[row_grp[i]]].push_back((uint32_t)i);
     HIP_TRY(hipSetDevice(device));
     lap("groups, bins, ids");
-    double t_rows = 0, t_up = 0;
-    for (uint32_t b = 0; b < nB; ++b) {
-        if (bin_rows[b].empty()) continue;
+    // the parts: rows copied out under their new ids, laid out and uploaded -- independent of each other: side by side on the host's
+    // worker threads when the caller has asked for any (ecne_set_host_threads / ECNE_HOST_THREADS; every part's place in the plan is fixed
+    // beforehand, so the plan does not depend on the thread count)
+    std::vector<uint32_t> live_bins;
+    for (uint32_t b = 0; b < nB; ++b) if (!bin_rows[b].empty()) live_bins.push_back(b);
+    plan->kids.assign(live_bins.size(), nullptr);
+    plan->d_map.assign(live_bins.size(), nullptr);
+    std::vector<int> part_rc(live_bins.size(), K_OK);
+    std::vector<double> part_t(2 * live_bins.size(), 0.0);
+    for_chunks(live_bins.size(), [&](size_t slot, unsigned) {
+        const uint32_t b = live_bins[slot];
         const auto tk0 = std::chrono::steady_clock::now();
         ecne_system* k = new ecne_system();
-        plan->kids.push_back(k);
-        plan->d_map.push_back(nullptr);
+        plan->kids[slot] = k;
         Rows& K = k->reduced;
         K.start();
         for (uint32_t i : bin_rows[b])
@@ -1952,14 +2076,26 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager) {
         for (int64_t v : P.knowns) if (v == 1 || (v >= 2 && v <= (int64_t)nV && var_bin[(size_t)v] == b)) k->knowns.push_back(child_id[(size_t)v]);
         for (int64_t v : P.targets) if (v == 1 || (v >= 2 && v <= (int64_t)nV && var_bin[(size_t)v] == b)) k->targets.push_back(child_id[(size_t)v]);
         const auto tk1 = std::chrono::steady_clock::now();
-        { const int rc = upload_system(*k, device); if (rc != K_OK) { if (dbg) fprintf(stderr, "[ecne split] part %u: upload failed (%d)\n", b, rc); return rc; } }
-        t_rows += std::chrono::duration<double, std::milli>(tk1 - tk0).count(); t_up += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk1).count();
-        uint32_t* dm = nullptr;
-        HIP_TRY(hipMalloc((void**)&dm, 4ull * bin_vars[b].size()));
-        plan->d_map.back() = dm;
-        HIP_TRY(hipMemcpy(dm, bin_vars[b].data(), 4ull * bin_vars[b].size(), hipMemcpyHostToDevice));
+        int rc = upload_system(*k, device);
+        if (rc == K_OK) {
+            uint32_t* dm = nullptr;
+            if (hipMalloc((void**)&dm, 4ull * bin_vars[b].size()) != hipSuccess) rc = K_ENODEVICE;
+            else {
+                plan->d_map[slot] = dm;
+                if (hipMemcpy(dm, bin_vars[b].data(), 4ull * bin_vars[b].size(), hipMemcpyHostToDevice) != hipSuccess) rc = K_ENODEVICE;
+            }
+        }
+        part_rc[slot] = rc;
+        part_t[2 * slot] = std::chrono::duration<double, std::milli>(tk1 - tk0).count();
+        part_t[2 * slot + 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk1).count();
+    });
+    double t_rows = 0, t_up = 0;
+    for (size_t slot = 0; slot < live_bins.size(); ++slot) {
+        t_rows += part_t[2 * slot]; t_up += part_t[2 * slot + 1];
+        if (part_rc[slot] != K_OK) { if (dbg) fprintf(stderr, "[ecne split] part %u: upload failed (%d)\n", live_bins[slot], part_rc[slot]); return part_rc[slot]; }
     }
-    if (dbg) fprintf(stderr, "[ecne split] parts: rows copied %.1f ms, layout + upload %.1f ms\n", t_rows, t_up);
+    lap("parts");
+    if (dbg) fprintf(stderr, "[ecne split] parts: rows copied %.1f ms, layout + upload %.1f ms (summed over %u worker threads)\n", t_rows, t_up, for_chunks_workers(live_bins.size()));
     if (plan->kids.size() < 2) SPLIT_NO("fewer than two parts");
     HIP_TRY(hipMalloc((void**)&plan->d_family, sizeof(Family)));
     plan->ok = true;
@@ -1978,13 +2114,16 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
     if (opts) o = *opts;
     if (n == 1 && sys[0] && mode != 0 && o.queue_mode == 0 && o.debug == 0 && !o.secp_solve && sys[0]->secp_solve_override <= 0 && ecne_device_count() > o.device) {
         ecne_system& P = *sys[0];
-        if (!P.split_tried && (mode >= 2 || (P.last_kernel_ms >= 3.0 && P.n_rows() > 2ull * ECNE_ROWS_PER_WG))) {
+        // (round 5: also before the FIRST solve of a file of more than two workgroups' rows -- the device screen costs a few launches, and only
+        //  a file of eight or more groups none of which holds an eighth of the rows is planned then: the shape a team is worst at)
+        const bool never_solved = P.last_kernel_ms == 0.0;
+        if (!P.split_tried && (mode >= 2 || (P.n_rows() > 2ull * ECNE_ROWS_PER_WG && (P.last_kernel_ms >= 3.0 || never_solved)))) {
             RestoreDevice restore;
             int n_cu = 0;
             if (hipSetDevice(o.device) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) == hipSuccess && n_cu > 16) {
                 // (the file itself is laid out and uploaded first: its arrays receive the parts' states)
                 int rc = upload_system(P, o.device);
-                if (rc == K_OK) rc = build_split(P, o.device, (uint32_t)(n_cu - 8), mode >= 2);
+                if (rc == K_OK) rc = build_split(P, o.device, (uint32_t)(n_cu - 8), mode >= 2, mode < 2 && never_solved);
                 if (rc != K_OK) { if (getenv("ECNE_SPLIT_DEBUG")) fprintf(stderr, "[ecne split] plan failed (%d)\n", rc); P.split.reset(); (void)hipGetLastError(); }
             }
         }
@@ -2155,6 +2294,7 @@ static void system_changed_rows(ecne_system* sys) {
     sys->laid_out = false;
     sys->split.reset();
     sys->split_tried = false;
+    sys->screen_done = false;
     if (sys->dev.arena) {
         RestoreDevice restore;
         (void)hipSetDevice(sys->dev.device);

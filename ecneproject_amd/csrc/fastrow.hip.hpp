@@ -449,7 +449,11 @@ __device__ __noinline__ bool long_r4_done(const Job& J, uint32_t shape, uint32_t
 // secp256k1's 39 decompositions are popped ~60 times in that state (between the pop that cuts the pivot's bounds and the one that finds
 // the pivot unique), 11 us each through the general executor and each at the head of the queue, by the whole workgroup. The pop has
 // read the state of the pivot and of bit 0: the caller treats both as read. Exact for any state: false = "ask the general executor".
-__device__ __noinline__ bool long_r4_idle(const Job& J, uint32_t gp, uint32_t gb, uint32_t pivot, uint32_t lenC) {
+// (f_pos / f_neg: the flag bytes of kpos / kneg; which of the two is the pivot depends on the row's orientation: SH_R4_T -- the pivot is the
+//  term with coefficient 1 --, SH_R4_T2 -- the reference negates the row at its first visit, :1001-1011, and the -1 term is the pivot)
+__device__ __noinline__ bool long_r4_idle(const Job& J, uint32_t shape, uint32_t f_pos, uint32_t f_neg, uint32_t kpos, uint32_t kneg, uint32_t lenC) {
+    const bool t1 = (shape & SH_R4_T) != 0;
+    const uint32_t gp = t1 ? f_pos : f_neg, gb = t1 ? f_neg : f_pos, pivot = t1 ? kpos : kneg;
     if (((gp | gb) & 1u) || ((gp & gb) & 16u) || (J.lv_off & 4u)) return false;
     const uint32_t l = lenC;
     if (l < 3 || l - 1 >= 254) return false;

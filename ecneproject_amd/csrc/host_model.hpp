@@ -65,16 +65,22 @@ inline unsigned set_host_threads(int n) {
     return host_threads();
 }
 // f(chunk, worker) for every chunk in [0, n_chunks), chunks handed out dynamically
+// (a for_chunks inside a worker of another one runs on that worker: the parts of a split file are laid out side by side, each layout
+//  serially -- not 32 x 32 threads)
+inline bool& in_for_chunks_worker() { static thread_local bool b = false; return b; }
 template <class F>
 inline void for_chunks(size_t n_chunks, F&& f) {
-    const unsigned T = (unsigned)std::min<size_t>(host_threads(), n_chunks);
+    const unsigned T = in_for_chunks_worker() ? 1u : (unsigned)std::min<size_t>(host_threads(), n_chunks);
     if (T <= 1) {
         for (size_t c = 0; c < n_chunks; ++c) f(c, 0u);
         return;
     }
     std::atomic<size_t> next{0};
     auto work = [&](unsigned w) {
+        const bool was = in_for_chunks_worker();
+        in_for_chunks_worker() = true;
         for (size_t c; (c = next.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) f(c, w);
+        in_for_chunks_worker() = was;
     };
     std::vector<std::thread> pool;
     pool.reserve(T - 1);
@@ -82,7 +88,7 @@ inline void for_chunks(size_t n_chunks, F&& f) {
     work(0);
     for (auto& t : pool) t.join();
 }
-inline unsigned for_chunks_workers(size_t n_chunks) { return (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_chunks)); }
+inline unsigned for_chunks_workers(size_t n_chunks) { return in_for_chunks_worker() ? 1u : (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_chunks)); }
 
 // std::allocator whose resize() leaves trivially-constructible elements uninitialised: the big row arrays are
 // sized once and then written (first touched) by the worker threads

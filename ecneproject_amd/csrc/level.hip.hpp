@@ -200,7 +200,7 @@ __device__ __noinline__ uint32_t level_rounds(const Job& J, uint32_t& head_io, u
             watched = watched && bl_nop;
             // (round 5) ... and a decomposition whose pivot and lowest bit are not unique, the pivot's bounds cut already (long_r4_idle):
             // that pop has read those two
-            if (biglin && lr4 && !bl_nop && long_r4_idle(J, ldF(kpos), ldF(kneg), long_r4_pivot(shape, kpos, kneg), lenC)) {
+            if (biglin && lr4 && !bl_nop && long_r4_idle(J, shape, ldF(kpos), ldF(kneg), kpos, kneg, lenC)) {
                 bl_nop = watched = true; wv0 = kpos; wv1 = kneg;
             }
         }

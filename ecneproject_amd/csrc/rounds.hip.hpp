@@ -980,7 +980,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
                             // (not while a wide frontier is worked off 256 positions at a time: the pop by the workgroup hands that frontier to the rounds on
                             //  the workgroup, which do better on it -- EdDSAMiMCSponge 10.5 -> 11.1 ms with the row settled here)
                             nop_ = !wide && (long_r4_done(J, ri_.shape, ri_.kpos, ri_.kneg, ri_.lenC, J.rec[16ull * rr + 1])
-                                             || (long_r4(ri_.shape) && long_r4_idle(J, J.flags[ri_.kpos], J.flags[ri_.kneg], long_r4_pivot(ri_.shape, ri_.kpos, ri_.kneg), ri_.lenC)));
+                                             || (long_r4(ri_.shape) && long_r4_idle(J, ri_.shape, J.flags[ri_.kpos], J.flags[ri_.kneg], ri_.kpos, ri_.kneg, ri_.lenC)));
                             if (!nop_) { big = 1; break; }
                         }
                         hd1++;
@@ -1397,7 +1397,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             // (round 5: ... or whose pivot and lowest bit are not unique and whose pivot's bounds are cut already -- long_r4_idle)
             bool idle = false;
             if (long_r4(bri_.shape) && !J.solved[brow]) {
-                idle = long_r4_idle(J, J.flags[bri_.kpos], J.flags[bri_.kneg], long_r4_pivot(bri_.shape, bri_.kpos, bri_.kneg), bri_.lenC);
+                idle = long_r4_idle(J, bri_.shape, J.flags[bri_.kpos], J.flags[bri_.kneg], bri_.kpos, bri_.kneg, bri_.lenC);
             }
             const bool wgdone = J.solved[brow] || idle || (J.rec != nullptr && long_r4_done(J, bri_.shape, bri_.kpos, bri_.kneg, bri_.lenC, J.rec[16ull * brow + 1]))
                                 || exec_big_row_wg(J, S, brow, J.bigev, &S.nbig);

@@ -203,6 +203,90 @@ def make_wide(seed, scale=1):
     return dict(n_wires=nv - 1, n_out=base["n_out"], n_pub=0, n_prv=base["n_prv"], rows=[rows[i] for i in order], witness=w)
 
 
+def make_decomp(seed):
+    """Systems made of LONG BINARY DECOMPOSITIONS (the R4 shape, :991-1076, l = 16..120 terms, both orientations -- the reference negates a
+    row of the second one at its first visit, :1001-1011 --, the pivot anywhere in the row) in the states the engine's shortcuts tell apart
+    (fastrow.hip.hpp: long_r4_idle, exec_long_r4, long_r4_done, the watched pair): bits with and without their bit check (bounds [0,1] or
+    not), the lowest bit pinned / unbounded / plain, the pivot pinned at once, pinned late (behind a chain of equalities and products: the
+    row is re-queued while pivot and bits are not unique), never, or shared by a SECOND decomposition of another length (the pivot's bounds
+    then come cut already, or get cut twice); rows in any order. Everything consistent with one witness."""
+    rng = random.Random(7919 * seed + 3)
+    w = {1: 1}
+    rows = []
+    nv = 1
+
+    def fresh(val):
+        nonlocal nv
+        nv += 1
+        w[nv] = val % P
+        return nv
+
+    def fix(v):
+        rows.append(([], [], [(v, 1), (1, (-w[v]) % P)] if w[v] else [(v, 1)]))
+
+    def bitcheck(b):
+        rows.append(([(b, 1), (1, -1)], [(b, 1)], []))
+
+    def late(v, depth):
+        """v becomes unique `depth` pops later: v = u_1, u_1 = u_2, ..., u_depth pinned (x == y rows, or products with a pinned 1)"""
+        cur = v
+        for _ in range(depth):
+            u = fresh(w[cur])
+            if rng.random() < 0.6:
+                rows.append(([], [], [(cur, 1), (u, -1)]))
+            else:
+                one = fresh(1)
+                fix(one)
+                rows.append(([(u, 1)], [(one, 1)], [(cur, 1)]))
+            cur = u
+        fix(cur)
+
+    pivots = []
+    for _ in range(rng.randint(2, 7)):
+        l = rng.choice([rng.randint(16, 40), rng.randint(41, 90), rng.randint(91, 120), rng.randint(3, 15)])
+        nb = l - 1
+        p_check = rng.choice([1.0, 1.0, 1.0, 1.0, 0.97, 0.8, 0.0])
+        bs = [fresh(rng.randint(0, 1)) for _ in range(nb)]
+        for i, b in enumerate(bs):
+            if rng.random() < p_check:
+                bitcheck(b)
+        # (a pinned bit has bounds [v, v], not [0, 1]: R4 stops there for good, :1020-1029 -- one decomposition in five gets one)
+        k0 = rng.random()
+        if k0 < 0.08:
+            fix(bs[0])
+        elif k0 < 0.2:
+            fix(rng.choice(bs))
+        if pivots and rng.random() < 0.3:
+            y = rng.choice(pivots)      # a second decomposition of a pivot: its value has to fit
+            val = w[y]
+            if val >> nb:
+                y = fresh(sum(w[b] << i for i, b in enumerate(bs)))
+            else:
+                for i, b in enumerate(bs):
+                    w[b] = (val >> i) & 1
+        else:
+            y = fresh(sum(w[b] << i for i, b in enumerate(bs)))
+        if y not in pivots:
+            pivots.append(y)
+            k = rng.random()
+            if k < 0.25:
+                fix(y)
+            elif k < 0.7:
+                late(y, rng.randint(1, 6))
+            elif k < 0.8:
+                z = fresh(w[y])                  # an equal variable that is never pinned: bounds travel, nothing becomes unique
+                rows.append(([], [], [(y, 1), (z, -1)]))
+        sgn = rng.choice([1, -1])
+        terms = [(y, sgn)] + [(b, -sgn * (1 << i)) for i, b in enumerate(bs)]
+        if rng.random() < 0.7:
+            rng.shuffle(terms)
+        rows.append(([], [], terms))
+    order = list(range(len(rows)))
+    if rng.random() < 0.6:
+        rng.shuffle(order)
+    return dict(n_wires=nv - 1, n_out=0, n_pub=0, n_prv=0, rows=[rows[i] for i in order], witness=w)
+
+
 def make_oob(seed):
     """A random system in which some rows name variable ids ABOVE num_variables (nWires + 1 .. nWires + 5): the reference sizes
     `variable_states` by num_variables (:681) and raises BoundsError at the first rule that READS such a state -- lazily, since

@@ -108,3 +108,44 @@ def test_fuzz_systems_as_parts(tmp_path):
             g2 = E.solve_batch([s])[0]                 # the resident plan again
             assert_bit_exact("fuzz %d again" % seed, g2, o)
     assert n_split >= 40, n_split
+
+
+def test_default_mode_plans_before_the_first_solve_of_many_medium_groups():
+    """(round 5) ecne_set_split(1), the default: the groups are counted on the device before the first solve (split_screen: union-find over the
+    resident fan-out lists); a file of eight or more groups none of which holds an eighth of its rows -- 12 x Poseidon, 7 320 rows -- is
+    planned right away and its FIRST solve runs as parts; three copies (one group holds a third) wait for the second solve as before"""
+    E.set_split(1)
+    p = multi_copy.cached(POS, 12)
+    s = build_system(None, path=p)
+    assert s.split_info()[0] == 0 and not s.split_info()[3]
+    g = E.solve_batch([s], fetch_states="both")[0]
+    info = s.split_info()
+    assert info[0] == 12 and info[1] == 12 and info[3], info
+    assert_bit_exact("12 x Poseidon, first solve, default mode", g, orc.run(p))
+    E.set_split(0)
+    s1 = build_system(None, path=p)
+    g1 = E.solve_batch([s1], fetch_states="both")[0]
+    assert g.digest == g1.digest and g.summary.pops == g1.summary.pops
+    E.set_split(1)
+    p3 = multi_copy.cached(SPONGE, 3)
+    s3 = build_system(None, path=p3)
+    a = E.solve_batch([s3], fetch_states=False)[0]
+    assert s3.split_info()[0] == 0                                       # one system the first time ...
+    b = E.solve_batch([s3], fetch_states=False)[0]
+    assert s3.split_info()[0] == 3 and a.digest == b.digest              # ... parts from the second solve on (the first took 3 ms or more)
+
+
+def test_plan_does_not_depend_on_the_host_threads(tmp_path):
+    """the parts are copied out, laid out and uploaded side by side on the host's worker threads when the caller asked for any: same parts, same state"""
+    p = multi_copy.cached(POS, 12)
+    digests = []
+    for threads in (1, 5):
+        E.set_host_threads(threads)
+        try:
+            s = build_system(None, path=p)
+            g = E.solve_batch([s], fetch_states="both")[0]
+            assert s.split_info()[0] == 12
+            digests.append((g.digest, g.summary.pops, g.summary.successful_steps, tuple(g.counts())))
+        finally:
+            E.set_host_threads(1)
+    assert digests[0] == digests[1]
