@@ -84,10 +84,10 @@ def schedule_env():
 # grades the model by itself. "ecdsa": one circuit does not shard -- replicas, the time per step stays, the rate grows N-fold.
 DESIGN_PREDICTED_MS = {
     "ecdsa": {1: 5.6, 2: 5.6, 4: 5.6, 8: 5.6},
-    "suite": {1: 10.5, 2: 10.2, 4: 10.2, 8: 10.2},
-    "dag": {1: 8.4, 2: 7.3, 4: 7.3, 8: 7.3},
+    "suite": {1: 10.6, 2: 10.2, 4: 10.2, 8: 10.2},
+    "dag": {1: 7.2, 2: 6.0, 4: 6.0, 8: 6.0},
     "many": {1: 3.0, 2: 1.6, 4: 1.2, 8: 1.2},
-    "secp": {1: 7.3, 2: 7.3, 4: 7.3, 8: 7.3},
+    "secp": {1: 6.0, 2: 6.0, 4: 6.0, 8: 6.0},
     "poseidon": {1: 1.12, 2: 1.12, 4: 1.12, 8: 1.12},
 }
 
