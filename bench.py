@@ -265,13 +265,15 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         inv.append(res)
     torch.cuda.synchronize()
     t_rank = time.perf_counter() - t0
-    gc.enable()
-    inv = [[step_invariants(r) for r in step] for step in inv]           # (after the timed region)
-    if any(step != inv[0] for step in inv):
-        raise SystemExit("bench.py: the timed steps did not reproduce the same result (verdicts / counts / counters differ between steps)")
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    # (after the timed region -- until the end of round 5 this sat in front of `elapsed` and the line's ms_per_step carried it: 0.9 ms per step
+    #  of Python over 504 jobs' counters, `--workload many` 3.0 ms where the steps themselves took 2.1; per_rank.ms_per_step never did)
+    inv = [[step_invariants(r) for r in step] for step in inv]
+    if any(step != inv[0] for step in inv):
+        raise SystemExit("bench.py: the timed steps did not reproduce the same result (verdicts / counts / counters differ between steps)")
     # per-job figures of this rank: rows, device ms, pops, algorithmic bytes (from the solve's own counters -- equal
     # to the oracle's by the parity tests)
     mine = []

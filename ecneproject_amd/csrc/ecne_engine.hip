@@ -1796,11 +1796,15 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                 for (size_t i = 0; i < n; ++i) if (hj[i].nwg == 1) all_descs.push_back({(uint32_t)i, 0u});
             } else
             {
+                // (round 5) a batch of single-workgroup jobs only is ONE launch whatever its size: nothing in it waits for another workgroup,
+                // the dispatcher starts the next job on whichever CU becomes free (the caller hands the jobs over longest first: jobs.Runner) --
+                // 504 mid-depth circuits were three launches of <= 248, each as long as its longest job (1.40 ms of kernel time in all)
+                const size_t launch_cap = any_multi ? cap : (size_t)-1;
                 size_t i = 0;
                 while (i < n) {
                     launch_at.push_back(all_descs.size());
                     size_t in_launch = 0;
-                    while (i < n && in_launch + hj[i].nwg <= cap) {
+                    while (i < n && in_launch + hj[i].nwg <= launch_cap) {
                         for (uint32_t r = 0; r < hj[i].nwg; ++r) all_descs.push_back({(uint32_t)i, r});
                         in_launch += hj[i].nwg;
                         ++i;

@@ -66,9 +66,12 @@ class Runner:
         """one pass over this rank's jobs; returns (results of this rank, all verdicts good on every rank)"""
         E = self.E
         if hasattr(self.systems[0] if self.systems else None, "set_secp_solve"):
-            # one launch for the whole share: every system carries its own secp_solve (:511)
-            for s, f in zip(self.systems, self.secp):
-                s.set_secp_solve(f)
+            # one launch for the whole share: every system carries its own secp_solve (:511) -- set once (504 FFI calls per pass were a
+            # quarter of a millisecond of a 2 ms pass)
+            if not getattr(self, "_secp_set", False):
+                for s, f in zip(self.systems, self.secp):
+                    s.set_secp_solve(f)
+                self._secp_set = True
             res = [None] * len(self.systems)
             if self.systems:
                 out = E.solve_batch([self.systems[k] for k in self.order], device=self.device, stream=stream, fetch_states=fetch_states)
