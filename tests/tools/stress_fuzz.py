@@ -1,6 +1,6 @@
 """Developer aid (GPU box): one-off randomized stress beyond the seeds the test suite pins.
 python tests/tools/stress_fuzz.py [first_seed] [count] [scale]   -- wide systems with long rows (scale > 1: thousands of
-rows, long rows up to 1 100 terms), several workgroup counts."""
+rows, long rows up to 1 100 terms; scale 0: systems of long binary decompositions), several workgroup counts."""
 import os, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.environ.get("AB_PKG", os.path.dirname(os.path.dirname(HERE)))); sys.path.insert(0, os.path.dirname(HERE))      # (AB_PKG: the library of another build of the package)
@@ -14,7 +14,8 @@ d = tempfile.mkdtemp(prefix="ecne_stress_")
 paths = []
 for seed in range(first, first + count):
     p = os.path.join(d, "%d.r1cs" % seed)
-    fuzz_r1cs.write(p, fuzz_r1cs.make_wide(seed, scale) if (seed % 3 or scale > 1) else fuzz_r1cs.make(seed))
+    # (scale 0: the long binary decompositions of make_decomp -- fastrow.hip.hpp's long_r4_idle / exec_long_r4 -- on fresh seeds)
+    fuzz_r1cs.write(p, fuzz_r1cs.make_decomp(seed) if scale == 0 else fuzz_r1cs.make_wide(seed, scale) if (seed % 3 or scale > 1) else fuzz_r1cs.make(seed))
     paths.append(p)
 oracles = [orc.run(p) for p in paths]
 systems = [E.System(E.R1CS(p)) for p in paths]
