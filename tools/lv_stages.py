@@ -10,7 +10,11 @@ from gpu_common import build_system
 names = ["entry", "record + descriptor", "flag bytes", "decisions", "marks + check", "fan-out lists", "commit", "push resolution"]
 for rel in sys.argv[1:]:
     secp = rel == "secp"
-    s = build_system("secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"]) if secp else build_system(rel)
+    if rel.startswith("ecdsa:"):      # ecdsa_like(S) + Secp256k1AddUnequal: the master of a team (state in device memory)
+        import ecdsa_like
+        s = build_system(None, ["secp256k1.r1cs"], ["Secp256k1AddUnequal"], path=ecdsa_like.cached(int(rel.split(":")[1]), 10))
+    else:
+        s = build_system("secp256k1.r1cs", ["bigmultmodp.r1cs", "biglessthan.r1cs"], ["BigMultModP", "BigLessThan"]) if secp else build_system(rel)
     for _ in range(3): r = E.solve_batch([s], secp_solve=secp, fetch_states=False)[0]
     sm = r.summary
     sd = list(sm.sched)
