@@ -43,6 +43,9 @@ int main() {
         printf("%-28s XCC histogram:", m.name);
         for (int i = 0; i < 8; ++i) printf(" %d", xc[i]);
         printf("   distinct (xcc, hw_id[19:8]) places: %d\n", distinct);
+        printf("    XCC of workgroups 0..39:");
+        for (int i = 0; i < 40; ++i) printf(" %u", h[i] >> 28);
+        printf("\n");
         CK(hipStreamDestroy(s));
     }
     return 0;
