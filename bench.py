@@ -86,7 +86,7 @@ DESIGN_PREDICTED_MS = {
     "ecdsa": {1: 5.6, 2: 5.6, 4: 5.6, 8: 5.6},
     "suite": {1: 10.6, 2: 10.2, 4: 10.2, 8: 10.2},
     "dag": {1: 7.2, 2: 6.0, 4: 6.0, 8: 6.0},
-    "many": {1: 3.0, 2: 1.6, 4: 1.2, 8: 1.2},
+    "many": {1: 2.1, 2: 1.5, 4: 1.3, 8: 1.25},
     "secp": {1: 6.0, 2: 6.0, 4: 6.0, 8: 6.0},
     "poseidon": {1: 1.12, 2: 1.12, 4: 1.12, 8: 1.12},
 }

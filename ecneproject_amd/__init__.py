@@ -107,7 +107,8 @@ def set_frontend(mode=-1):
 
 def set_split(mode):
     """One file, several independent parts (include/ecne.h: ecne_set_split): 0 never, 1 from the second solve of a system on when the
-    first took long enough (the default), 2 at the first solve."""
+    first took long enough -- and before the first solve of a file of many medium groups, counted on the device -- (the default), 2 at the
+    first solve."""
     _check(_lib.lib().ecne_set_split(int(mode)))
 
 

@@ -77,8 +77,10 @@ int ecne_set_frontend(int mode);
  * only ever pushes rows of its own group) can be solved as a batch of single-workgroup jobs whose outer loops (:706-1556) run in
  * lockstep, and their states scattered back into the file's own arrays on the device: results, digests and bad rows are those of
  * the file as one system, bit for bit (tests/test_gpu_split.py). 0 = never, 1 = from the second ecne_solve of a system on, when
- * the first took long enough to pay for the plan (the default; ECNE_SPLIT in the environment sets the initial value), 2 = at the
- * first solve. Only ecne_solve / a batch of one, queue_mode 0, no trusted functions; anything unusual in a part (an error, the
+ * the first took long enough to pay for the plan -- and before the FIRST solve of a file of more than 6 144 rows whose groups, counted
+ * on the device (union-find over the resident fan-out lists, ~1.5 ms per million rows), are eight or more with none holding an
+ * eighth of the rows: many medium circuits in one file, what a team is worst at -- (the default; ECNE_SPLIT in the environment sets
+ * the initial value), 2 = at the first solve. The plan's parts are built on the host's worker threads (ecne_set_host_threads). Only ecne_solve / a batch of one, queue_mode 0, no trusted functions; anything unusual in a part (an error, the
  * constant wire's state written) and the file is solved again as one system. Returns ECNE_OK, ECNE_EINVAL for another mode. */
 int ecne_set_split(int mode);
 /* out4 = {parts the system's next solve runs as (0: as one system), groups of rows found, host + upload time of the plan in ms,
