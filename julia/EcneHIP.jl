@@ -9,7 +9,7 @@
 # this shim has not been executed there; it mirrors ecneproject_amd/_lib.py + __init__.py + report.py (ctypes) call for call.
 module EcneHIP
 
-export readR1CS, SolveConstraintsSymbolic, solveWithTrustedFunctions, EcneSystem, EcneR1CS, warmup
+export readR1CS, SolveConstraintsSymbolic, solveWithTrustedFunctions, EcneSystem, EcneR1CS, warmup, device_count, set_host_threads, set_frontend, set_split, split_info
 
 const LIB = get(ENV, "ECNE_HIP_LIB", joinpath(@__DIR__, "..", "ecneproject_amd", "libecne_hip.so"))
 
@@ -153,6 +153,22 @@ function warmup(device::Integer=0)
     ms = Ref{Cdouble}(0.0)
     check(ccall((:ecne_warmup, LIB), Cint, (Cint, Ref{Cdouble}), device, ms))
     ms[]
+end
+
+# run-time knobs of the library (include/ecne.h; no reference counterpart). All optional: the defaults are what the reference's callers get.
+device_count() = Int(ccall((:ecne_device_count, LIB), Cint, ()))
+# worker threads of the host side (reader, abstraction, layout, the parts of a split file): 0 = every core (at most 32); returns the count in effect
+set_host_threads(n::Integer) = Int(ccall((:ecne_set_host_threads, LIB), Cint, (Cint,), n))
+# which front-end turns a file into the solver's arrays: 0 host, 1 device, 2 auto (device from 100 000 constraints on); < 0 only reads
+set_frontend(mode::Integer) = Int(ccall((:ecne_set_frontend, LIB), Cint, (Cint,), mode))
+# one file, several independent parts: 0 never, 1 (default) when it pays -- before the first solve of a file of many medium groups, else from
+# the second solve on --, 2 at the first solve
+set_split(mode::Integer) = check(ccall((:ecne_set_split, LIB), Cint, (Cint,), mode))
+# (parts the next solve runs as -- 0: as one system --, groups of rows found, plan ms, a plan has been looked for)
+function split_info(sys::EcneSystem)
+    a = Ref{NTuple{4,Cdouble}}((0.0, 0.0, 0.0, 0.0))
+    check(ccall((:ecne_system_split_info, LIB), Cint, (Ptr{Cvoid}, Ref{NTuple{4,Cdouble}}), sys.h, a))
+    (Int(a[][1]), Int(a[][2]), a[][3], a[][4] != 0.0)
 end
 
 function readR1CS(filename::String)                  # -> (equations, known, outputs, nVars)
