@@ -32,6 +32,25 @@ def test_exports_match_header(E):
     assert lib.ecne_strerror(-8).decode().startswith("no usable HIP device")
 
 
+def test_julia_binding_names_only_exported_symbols(E):
+    """julia/EcneHIP.jl (the redirect a maintainer of the reference loads; never executed here: no Julia in the image) binds by NAME:
+    every `ccall((:name, LIB), ...)` has to be a symbol include/ecne.h declares and the library exports, and the structs it mirrors have to
+    have the library's sizes"""
+    import ctypes
+    import re
+    from ecneproject_amd import _lib
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "EcneHIP.jl")).read()
+    names = set(re.findall(r"ccall\(\(:(ecne_[a-z_0-9]+), LIB\)", src))
+    assert len(names) >= 20
+    assert names <= set(_lib.EXPORTS), sorted(names - set(_lib.EXPORTS))
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    m = re.search(r"team::NTuple\{4,Int64\}", src)
+    assert m, "EcneSummary in the Julia binding has to end with ecne_summary's team[4]"
+    assert ctypes.sizeof(E.Summary) % 8 == 0
+
+
 def test_reader_matches_oracle_on_every_fixture(E):
     for rel in fixtures.all_r1cs():
         f, kn, out, nv = E.readR1CS(fixtures.path(rel))
