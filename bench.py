@@ -308,7 +308,7 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64x4 (BN254 Fp limbs) + u8/u32 flags", "data": data,
         "config": {"workload": label, "jobs": len(jl), "rows": rows, "verdicts_true": sum(int(j["verdict"]) for j in alljobs),
-                   "all_ran": bool(ok),
+                   "all_ran": bool(runner.all_ran), "all_sound": bool(ok),
                    "scaling_check": scaling_check(args.workload, world, ms_per_step, [pr["ms_per_step"] for pr in per_rank]),
                    "per_rank": [{"rank": pr["rank"], "ms_per_step": round(pr["ms_per_step"], 3), "jobs": [j["job"] for j in pr["jobs"]],
                                  "longest_job_ms": round(max((j["device_ms"] for j in pr["jobs"]), default=0.0), 3)} for pr in per_rank],

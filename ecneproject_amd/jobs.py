@@ -63,15 +63,18 @@ class Runner:
         self._passes = 0
 
     def run(self, stream=None, fetch_states=False, device_for_word="cuda"):
-        """one pass over this rank's jobs; returns (results of this rank, all verdicts good on every rank)"""
+        """one pass over this rank's jobs; returns (results of this rank, verdict word): the word is True iff EVERY job on EVERY rank ran
+        (status 0) AND came back sound (function_good) -- what crosses RCCL for the config-5 DAG must be the AND of the verdicts, not "every
+        job ran" (SURVEY.md 8e). self.all_ran keeps the weaker fact (every job on every rank reached a verdict) from the same all-reduce."""
         E = self.E
         if hasattr(self.systems[0] if self.systems else None, "set_secp_solve"):
             # one launch for the whole share: every system carries its own secp_solve (:511) -- set once (504 FFI calls per pass were a
             # quarter of a millisecond of a 2 ms pass)
-            if not getattr(self, "_secp_set", False):
+            applied = tuple((id(s), bool(f)) for s, f in zip(self.systems, self.secp))
+            if getattr(self, "_secp_applied", None) != applied:          # (re-applied whenever the systems / flags were replaced or extended)
                 for s, f in zip(self.systems, self.secp):
                     s.set_secp_solve(f)
-                self._secp_set = True
+                self._secp_applied = applied
             res = [None] * len(self.systems)
             if self.systems:
                 out = E.solve_batch([self.systems[k] for k in self.order], device=self.device, stream=stream, fetch_states=fetch_states)
@@ -93,10 +96,12 @@ class Runner:
                                         fetch_states=fetch_states)
                     for k, r in zip(idx, out):
                         res[k] = r
-        ok = all(r.status == 0 for r in res)
+        ran = all(r.status == 0 for r in res)
+        sound = all(r.status == 0 and bool(r.function_good) for r in res)
         if self.dist is not None:
-            ok = sharding.allreduce_verdict(ok, self.dist, device=device_for_word)
-        return res, ok
+            ran, sound = sharding.allreduce_words([ran, sound], self.dist, device=device_for_word)
+        self.all_ran = ran
+        return res, sound
 
 
 def main(argv=None):
@@ -121,7 +126,7 @@ def main(argv=None):
                           "unique": int(g.summary.unique_nontrivial), "of": int(g.summary.n_nontrivial),
                           "targets": "%d/%d" % (g.summary.unique_targets, g.summary.n_targets), "device_ms": round(g.summary.device_ms, 3)}))
     if rank == 0:
-        print(json.dumps({"jobs": len(jobs), "n_gpus": world, "all_ran": ok, "wall_s": round(dt, 4)}))
+        print(json.dumps({"jobs": len(jobs), "n_gpus": world, "all_ran": r.all_ran, "all_sound": ok, "wall_s": round(dt, 4)}))
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -24,6 +24,15 @@ def allreduce_verdict(local_all_good, dist, device="cuda"):
     return bool(int(word.item()))
 
 
+def allreduce_words(flags, dist, device="cuda"):
+    """AND of several per-rank booleans in ONE MIN all-reduce (one int32 per flag: [every job ran, every verdict sound])."""
+    import torch
+    word = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(word, op=dist.ReduceOp.MIN)
+    return [bool(int(x)) for x in word.tolist()]
+
+
 def max_over_ranks(x, dist, device="cuda"):
     """MAX all-reduce of one float64 (the timed region of the slowest rank is the job's time)."""
     import torch

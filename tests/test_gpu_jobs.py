@@ -38,7 +38,9 @@ def test_runner_suite_bit_exact():
         assert len(res) == len(jl)
         for j, g, o in zip(jl, res, oracles):
             assert_bit_exact("jobs.Runner suite %s pass %d" % (j.name, rep), g, o)
-        assert ok == all(o.status == 0 for o in oracles)
+        assert runner.all_ran == all(o.status == 0 for o in oracles)
+        assert ok == all(o.status == 0 and o.verdict for o in oracles)           # the word that crosses RCCL: every verdict sound
+        assert ok is False                                                         # (the suite holds unsound circuits)
 
 
 @pytest.mark.gpu
@@ -63,7 +65,7 @@ def test_runner_verification_dag_bit_exact():
         if o.status == 0:
             assert [tuple(x) for x in runner.systems[jl.index(j)].specials()] == [tuple(x) for x in o.specials], j.name
     assert [o.status for o in oracles] == [0, 0, 0, 0, -4]
-    assert ok is False                                   # one job raised
+    assert ok is False and runner.all_ran is False       # one job raised
     assert res[1].function_good is True or res[1].function_good == 1      # test/runtests.jl:35
 
 
@@ -86,7 +88,7 @@ def test_jobs_cli_one_process(tmp_path):
         assert by[s["name"]]["status"] == o.status == 0
         assert by[s["name"]]["sound"] == o.verdict
         assert (by[s["name"]]["unique"], by[s["name"]]["of"]) == (o.summary.unique_nontrivial, o.summary.n_nontrivial)
-    assert [l for l in lines if "jobs" in l][0] == {"jobs": 3, "n_gpus": 1, "all_ran": True, "wall_s": [l for l in lines if "jobs" in l][0]["wall_s"]}
+    assert [l for l in lines if "jobs" in l][0] == {"jobs": 3, "n_gpus": 1, "all_ran": True, "all_sound": all(by[s["name"]]["sound"] for s in spec), "wall_s": [l for l in lines if "jobs" in l][0]["wall_s"]}
 
 
 @pytest.mark.gpu

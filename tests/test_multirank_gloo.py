@@ -91,7 +91,7 @@ names = [jl[i].name for i in runner.mine]
 gathered = [None] * dist.get_world_size()
 dist.all_gather_object(gathered, (names, [bool(r.function_good) for r in res], runner.rows_main))
 if dist.get_rank() == 0:
-    print("RESULT " + json.dumps({"ok": bool(ok), "names": sum([g[0] for g in gathered], []), "verdicts": sum([g[1] for g in gathered], []),
+    print("RESULT " + json.dumps({"ok": bool(ok), "all_ran": bool(runner.all_ran), "names": sum([g[0] for g in gathered], []), "verdicts": sum([g[1] for g in gathered], []),
                                    "rows": [g[2] for g in gathered]}))
 dist.destroy_process_group()
 '''
@@ -111,9 +111,10 @@ def test_two_rank_job_runner(tmp_path):
     import json
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     rels = [r for r in fixtures.circomlib_suite() if "EdDSA" not in r]
-    assert sorted(res["names"]) == sorted(rels) and res["ok"] is True and min(res["rows"]) > 0
+    assert sorted(res["names"]) == sorted(rels) and res["all_ran"] is True and min(res["rows"]) > 0
     want = {r: orc.run(fixtures.path(r), want_states=False).verdict for r in rels}
     assert dict(zip(res["names"], res["verdicts"])) == want
+    assert res["ok"] == all(want.values()) and res["ok"] is False        # the all-reduced word is the AND of the verdicts (the suite holds unsound files)
 
 
 DAG_WORKER = r'''
@@ -159,6 +160,7 @@ main = ecdsa_like.cached(2, 10)
 jl = [J.Job(main, "ecdsa_like(2)", [(fx("secp256k1.r1cs"), "Secp256k1AddUnequal")]),
       J.Job(fx("secp256k1.r1cs"), "secp256k1", [(fx("bigmultmodp.r1cs"), "BigMultModP"), (fx("biglessthan.r1cs"), "BigLessThan")], True),
       J.Job(fx("bigmultmodp.r1cs"), "bigmultmodp"), J.Job(fx("biglessthan.r1cs"), "biglessthan")]
+jl = [j for j in jl if j.name in os.environ["DAG_JOBS"].split(",")]
 runner = J.Runner(jl, dist.get_rank(), dist.get_world_size(), 0, dist, E=OracleEngine)
 res, ok = runner.run(device_for_word="cpu")
 sound = all(bool(r.function_good) for r in res)
@@ -167,30 +169,39 @@ sound_all = sharding.allreduce_verdict(sound, dist, device="cpu")
 gathered = [None] * dist.get_world_size()
 dist.all_gather_object(gathered, ([jl[i].name for i in runner.mine], [bool(r.function_good) for r in res]))
 if dist.get_rank() == 0:
-    print("RESULT " + json.dumps({"ok": bool(ok), "sound_all": bool(sound_all), "names": sum([g[0] for g in gathered], []),
+    print("RESULT " + json.dumps({"ok": bool(ok), "all_ran": bool(runner.all_ran), "sound_all": bool(sound_all), "names": sum([g[0] for g in gathered], []),
                                    "verdicts": sum([g[1] for g in gathered], []), "per_rank": [g[0] for g in gathered]}))
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_verification_dag(tmp_path):
-    """config 5's trusted-subcircuit DAG (SURVEY.md 8e) as four jobs on two gloo ranks: ecdsa_like <- secp256k1,
-    secp256k1 <- bigmultmodp + biglessthan (secp_solve), bigmultmodp, biglessthan; each runs once, the big job sits alone on its
-    rank (LPT), abstraction finds the oracle's special constraints, the verdicts are AND-ed by the all-reduce."""
+def _run_dag(tmp_path, names, port):
     script = tmp_path / "dag_worker.py"
     script.write_text(DAG_WORKER % {"root": ROOT, "tests": HERE})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DAG_JOBS=",".join(names))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
-    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
-    assert sorted(res["names"]) == ["biglessthan", "bigmultmodp", "ecdsa_like(2)", "secp256k1"] and res["ok"] is True
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+
+
+def test_two_rank_verification_dag(tmp_path):
+    """config 5's trusted-subcircuit DAG (SURVEY.md 8e) as four jobs on two gloo ranks: ecdsa_like <- secp256k1,
+    secp256k1 <- bigmultmodp + biglessthan (secp_solve), bigmultmodp, biglessthan; each runs once, the big job sits alone on its
+    rank (LPT), abstraction finds the oracle's special constraints, and the word that crosses the all-reduce is the AND of the VERDICTS
+    (status 0 and function_good), not "every job ran": bigmultmodp alone is unsound, so the full DAG's word is False although every job
+    ran; without that job the word is True."""
+    res = _run_dag(tmp_path, ["ecdsa_like(2)", "secp256k1", "bigmultmodp", "biglessthan"], 29535)
+    assert sorted(res["names"]) == ["biglessthan", "bigmultmodp", "ecdsa_like(2)", "secp256k1"] and res["all_ran"] is True
     assert ["ecdsa_like(2)"] in res["per_rank"]                      # the heavy job alone on one rank
     verdicts = dict(zip(res["names"], res["verdicts"]))
     assert verdicts["secp256k1"] is True                             # test/runtests.jl:35
-    assert res["sound_all"] == all(verdicts.values())
+    assert verdicts["bigmultmodp"] is False                          # the one unsound job of the DAG
+    assert res["sound_all"] == all(verdicts.values()) and res["ok"] is False
+    res = _run_dag(tmp_path, ["ecdsa_like(2)", "secp256k1", "biglessthan"], 29536)
+    assert res["all_ran"] is True and all(res["verdicts"]) and res["ok"] is True
 
 
 MANY_WORKER = r'''
@@ -227,7 +238,7 @@ loads = [sum(runner.weights[i] for i in part) for part in sharding.assign(runner
 gathered = [None] * dist.get_world_size()
 dist.all_gather_object(gathered, ([jl[i].name for i in runner.mine], [bool(r.function_good) for r in res], runner.rows_main))
 if dist.get_rank() == 0:
-    print("RESULT " + json.dumps({"ok": bool(ok), "n_jobs": len(jl), "names": sum([g[0] for g in gathered], []), "rows": [g[2] for g in gathered],
+    print("RESULT " + json.dumps({"ok": bool(ok), "all_ran": bool(runner.all_ran), "n_jobs": len(jl), "names": sum([g[0] for g in gathered], []), "rows": [g[2] for g in gathered],
                                    "verdicts_true": sum(sum(g[1]) for g in gathered), "loads": loads}))
 dist.destroy_process_group()
 '''
@@ -252,7 +263,7 @@ def test_two_rank_many_workload(tmp_path):
     assert res["n_jobs"] == len(jl) == 126 and sorted(res["names"]) == sorted(j.name for j in jl)
     assert not any(k in n for n in res["names"] for k in bench.MANY_EXCLUDES)
     assert min(res["rows"]) > 0 and abs(res["loads"][0] - res["loads"][1]) <= max(res["loads"]) * 0.05      # balanced: no job dominates
-    assert res["ok"] is True and 0 < res["verdicts_true"] < len(jl)
+    assert res["all_ran"] is True and res["ok"] is False and 0 < res["verdicts_true"] < len(jl)       # (every job ran; the word is the AND of the verdicts)
 
 
 REPLICA_WORKER = r'''
