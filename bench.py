@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--stride", type=int, default=10)
     ap.add_argument("--cpu-sample-S", type=int, default=26, help="strides of the CPU-baseline sample (26 = the whole workload: ~13 s solve + ~4 s parse / abstraction on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--job-lines", choices=["auto", "on", "off"], default="auto",
+                    help="default workload: attach the DAG / suite / many lines of the same run (config.job_workloads); auto = when --gpus > 1")
     ap.add_argument("--queue-mode", type=int, default=0)
     ap.add_argument("--copies", type=int, default=8, help="--workload many: copies of every mid-depth circomlib file (8 -> 504 jobs of 63 files)")
     ap.add_argument("--workload", choices=["ecdsa", "suite", "poseidon", "secp", "dag", "many"], default="ecdsa",
@@ -169,6 +171,9 @@ def probe_julia():
     return {"julia": v, "note": "julia found; timing the reference needs an instantiated Ecne checkout (ECNE_REFERENCE_DIR), see julia/dump_unique.jl"}
 
 
+PORT_DETAIL = ("statement-by-statement restatement of the reference (oracle/ecne_oracle.cpp) with Julia's Dict / Set slot order emulated; NOT a tuned CPU solver -- "
+               "it runs 83 k rows/s on config 5 and 0.4-1.2 M rows/s on configs 2 / 3; a GPU/CPU ratio against it says nothing about kernel quality")
+
 MANY_EXCLUDES = ("EdDSAMiMCSpongeVerifier", "EdDSAMiMCVerifier", "EdDSAPoseidonVerifier", "BabyPbk")      # the suite's four long dependency chains (14-24 k rows each)
 
 
@@ -222,7 +227,7 @@ def cpu_baseline_jobs(jobs, label):
     seq = [_oracle_job(t) for t in items]
     wall_seq = time.perf_counter() - t0
     rows, t_solve = sum(r[0] for r in seq), sum(r[1] for r in seq)
-    out = {"value": rows / max(t_solve, 1e-9), "unit": "constraints/s", "cores": 1, "kind": "port",
+    out = {"value": rows / max(t_solve, 1e-9), "unit": "constraints/s", "cores": 1, "kind": "port", "kind_detail": PORT_DETAIL,
            "sample": "%s: the whole workload, %d job(s), %d rows, sequential oracle solve %.3f s in total (parse + abstraction %.3f s excluded, "
                      "as for the GPU); longest single job %.3f s" % (label, len(jobs), rows, t_solve, sum(r[4] for r in seq), max(r[1] for r in seq)),
            "host_cores_available": os.cpu_count(), "reference_probe": probe_julia(), "wall_s_one_core_incl_parse": round(wall_seq, 3),
@@ -240,9 +245,12 @@ def cpu_baseline_jobs(jobs, label):
     return out
 
 
-def run_jobs_workload(args, torch, dist, rank, local_rank, world):
+def run_jobs_workload(args, torch, dist, rank, local_rank, world, workload=None, emit=True):
     """Configs 2, 3, 4 and the config-5 DAG: independent jobs, LPT-packed onto the ranks, one batch launch per rank and step, one
-    all-reduce (MIN) of the verdict word. One step = every job of the workload solved once."""
+    all-reduce (MIN) of the verdict word. One step = every job of the workload solved once. emit=False: rank 0 gets the line back as a
+    dict instead of printing it (the default workload at N > 1 attaches the DAG / suite / many lines of the same run)."""
+    if workload is not None:
+        args = argparse.Namespace(**dict(vars(args), workload=workload))
     import ecneproject_amd as E
     from ecneproject_amd import jobs as J
     from ecneproject_amd import sharding
@@ -292,7 +300,7 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
     if rank != 0:
-        return
+        return None
     alljobs = [j for pr in per_rank for j in pr["jobs"]]
     rows = sum(j["rows_main"] for j in alljobs)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
@@ -331,7 +339,7 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
     }
     out["config"]["python_gc"] = "cyclic collector held off during the timed steps (a full collection with torch loaded: ~40 ms)"
     out["config"]["invariants"] = {"steps_identical": True, "checked": "status, verdict, pops, successful_steps, num_unique, outer_iterations, the four printed counts, rule hits -- every job, every timed step"}
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and emit:
         out["cpu_baseline"] = cpu_baseline_jobs(jl, args.workload)
         # the oracle leg doubles as a check of the timed steps' counters (cpu_baseline_jobs keeps the oracle's per job)
         want = out["cpu_baseline"].pop("_per_job")
@@ -340,7 +348,24 @@ def run_jobs_workload(args, torch, dist, rank, local_rank, world):
         if bad:
             raise SystemExit("bench.py: the solve disagrees with the sequential oracle on %r" % bad[:5])
         out["config"]["invariants"]["matches_oracle"] = "status, verdict, pops of every job equal the sequential oracle's"
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
+
+
+def attached_job_lines(args, torch, dist, rank, local_rank, world):
+    """the workloads that DO shard -- the config-5 verification DAG, the circomlib suite (config 4) and `many` -- measured in
+    the same run as the default line at N > 1 (every rank takes part; rank 0 gets {workload: short line})."""
+    lines = {}
+    for w in ("dag", "suite", "many"):
+        o = run_jobs_workload(args, torch, dist, rank, local_rank, world, workload=w, emit=False)
+        if rank == 0 and o is not None:
+            c = o["config"]
+            lines[w] = {"value": o["value"], "unit": o["unit"], "ms_per_step": round(o["ms_per_step"], 4), "scaling": o["scaling"], "jobs": c["jobs"], "rows": c["rows"],
+                        "all_ran": c["all_ran"], "all_sound": c["all_sound"], "verdicts_true": c["verdicts_true"],
+                        "per_rank": [{"rank": pr["rank"], "ms_per_step": pr["ms_per_step"], "n_jobs": len(pr["jobs"]), "longest_job_ms": pr["longest_job_ms"]} for pr in c["per_rank"]],
+                        "lpt_rank_loads": c["lpt"]["rank_loads"], "lpt_imbalance": c["lpt"]["imbalance"], "scaling_check": c["scaling_check"]}
+    return lines
 
 
 def main():
@@ -371,7 +396,9 @@ def main():
 
     # ---- build the workload (host side, untimed): generate, parse, abstract, lay out, upload, classify
     t0 = time.time()
-    path = ecdsa_like.cached(args.S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid())
+    # One circuit does not shard: at N > 1 every rank solves its OWN instance -- the same template with its own table constants
+    # (tests/ecdsa_like.py seed = rank; rank 0 = the committed workload whose oracle digest is on file) -- N independent jobs, not one job N times.
+    path = ecdsa_like.cached(args.S, args.stride, directory="/tmp/ecne_bench_%d" % os.getuid(), seed=rank)
     t_gen = time.time() - t0
     # The first host-to-device copy of a process sets up the HIP runtime's copy path: ~100 ms with torch's code objects loaded, 27 ms
     # without (tools/fe_first_upload.py) -- whoever copies first pays it. Round 5: the LIBRARY's own warm-up (ecne_warmup: copy path, code
@@ -431,7 +458,7 @@ def main():
     # (vectors, not the oracle: S = 104 costs the oracle minutes)
     state_check = None
     gold_path = os.path.join(HERE, "tests", "golden", "scale_goldens.json")
-    if os.path.exists(gold_path) and args.stride == 10 and args.queue_mode == 0:
+    if os.path.exists(gold_path) and args.stride == 10 and args.queue_mode == 0 and rank == 0:
         with open(gold_path) as f:
             gold = json.load(f).get("ecdsa_like(%d,10)+Secp256k1AddUnequal" % args.S)
         if gold is not None:
@@ -453,8 +480,13 @@ def main():
     rank_ms = [elapsed_rank * 1e3 / max(args.steps, 1)]
     if world > 1:
         gathered = [None] * world
-        dist.all_gather_object(gathered, rank_ms[0])
-        rank_ms = gathered
+        dist.all_gather_object(gathered, (rank_ms[0], inv[0]))
+        rank_ms = [g[0] for g in gathered]
+        if rank == 0 and any(g[1] != inv[0] for g in gathered):      # (the instances differ in their constants only: same counters, same verdict)
+            raise SystemExit("bench.py: the ranks' instances did not reproduce the same counters: %r" % ([g[1] for g in gathered][:3],))
+    job_lines = None
+    if args.job_lines == "on" or (args.job_lines == "auto" and world > 1):
+        job_lines = attached_job_lines(args, torch, dist, rank, local_rank, world)
 
     if rank == 0:
         s = res.summary
@@ -513,7 +545,12 @@ def main():
                                    ("ecdsa_like(S=%d,stride=%d) + trusted secp256k1.r1cs: the SCALE-OUT variant of config 5 (%d strides instead of 26) whose static arrays and state exceed the 256 MiB Infinity Cache -- the HBM-true roofline line, not the headline" % (args.S, args.stride, args.S)),
                        "rows_main": n_main, "rows_reduced": int(info.n_rows), "nnz_reduced": nnz,
                        "specials": int(info.n_specials), "n_vars": int(info.n_vars),
-                       "parallelism": "replicas x%d, RCCL all-reduce of the verdict word" % world if world > 1 else "1 GPU",
+                       "parallelism": ("%d independent instances of the circuit, one per GPU (own table constants each, tests/ecdsa_like.py seed = rank), RCCL all-reduce of the verdict word; "
+                                       "a SINGLE circuit does not shard -- see config.one_circuit" % world) if world > 1 else "1 GPU",
+                       # on ONE circuit more GPUs buy nothing -- the fixed point is one dependency chain. `value` above is the aggregate over N
+                       # independent instances (weak scaling of a job queue); this is the rate of any one of them.
+                       "one_circuit": {"value": n_main * args.steps / elapsed, "unit": "constraints/s", "ms_per_step": ms_per_step, "scaling": "replicated, no speed-up",
+                                       "note": "time to the verdict of one circuit is the same at every N; the workloads that shard are in config.job_workloads"},
                        "scaling_check": scaling_check("ecdsa" if args.S == 26 else "ecdsa_S%d" % args.S, world, ms_per_step, rank_ms,
                                                       {"model": "replicas: value(N) = N x rows / t_step(slowest rank); the all-reduce of one word and the two barriers are the only coupling",
                                                        "all_ranks_agreed_on_the_verdict_word": bool(all(words)) == bool(res.status == 0 and res.function_good)}),
@@ -535,13 +572,24 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_solve_team", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
+                         # the same two fractions under the names a reader looks for: frac = credited (algorithmic) bytes of SURVEY.md 8(d)'s formula / time / 8 TB/s;
+                         # frac_counters = bytes the memory system actually moved (FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s; frac_of_6p3TBps = frac against the
+                         # ~6.3 TB/s a pure streaming kernel reaches on this part (MI355X_MICROARCH.md) instead of the 8 TB/s data-sheet peak
+                         "frac_counters": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
+                         "frac_of_6p3TBps": achieved / 6300.0,
+                         "credited_sweeps": 3 * int(s.outer_iterations) + 1,
                          "latency_model": latency,
                          "alg_bytes_per_launch": b_alg, "kernel_ms": k_ms,
                          "phase_ms": {k: round(v, 3) for k, v in zip(["setup", "queue", "P3", "P4", "P5", "verdict", "P3_rounds"], list(s.phase_ms)[:7])},
                          "queue_ms": {k: round(v, 3) for k, v in zip(["head", "mark", "check", "exec", "flatten", "resolve", "alone_bursts_wave_rounds", "multi_rounds"], list(s.queue_ms)[:8])},
                          "multi_ms": {k: round(v, 3) for k, v in zip(["mark", "check_and_cut", "exec_and_scan", "expand", "count_and_scan", "write"], list(s.multi_ms)[:6])},
-                         "note": "fixed point is dependency-depth bound; see DESIGN.md"},
+                         "note": ("fixed point is dependency-depth bound; see DESIGN.md. `frac` is an accounting of the reference's work, not of this kernel's traffic: the formula credits "
+                                  "%d full sweeps of the system (3 per outer iteration + 1), the engine performs 3 (26 of 28 iterations at S = 26 are finished from the popped rows "
+                                  "alone); the counters say %s of the HBM peak -- the kernel is latency-bound at every size, S = 104 included") %
+                                 (3 * int(s.outer_iterations) + 1, ("%.1f %%" % (100.0 * traffic / (k_ms * 1e-3) / 1e9 / 8000.0)) if traffic else "(no PMC passes on file for this build)")},
         }
+        if job_lines is not None:
+            out["config"]["job_workloads"] = job_lines
         if world == 1 and not args.no_cold:
             # (after the timed region, in fresh subprocesses: the library's own answer to a cold start -- ecne_warmup -- next to no warm-up at all)
             out["config"]["cold_process"] = {"with_ecne_warmup": cold_process(path, local_rank, True), "without": cold_process(path, local_rank, False),
@@ -562,7 +610,7 @@ def main():
                     raise SystemExit("bench.py: the timed solve disagrees with the sequential oracle: %r vs %r" % (inv[0], want))
                 out["config"]["invariants"]["matches_oracle"] = "the same tuple equals the sequential oracle's on this workload"
             out["cpu_baseline"] = {"value": o.summary.n_rows_main / max(o.summary.t_solve, 1e-9), "unit": "constraints/s",
-                                   "cores": 1, "kind": "port",
+                                   "cores": 1, "kind": "port", "kind_detail": PORT_DETAIL,
                                    "sample": "ecdsa_like(S=%d,stride=%d): %d rows, sequential oracle solve %.2f s "
                                              "(parse %.1f s and abstraction %.1f s excluded, as for the GPU)" %
                                              (args.cpu_sample_S, args.stride, o.summary.n_rows_main, o.summary.t_solve,

@@ -67,8 +67,18 @@ class DeviceBusyError(EcneError, TimeoutError):
     status = -11
 
 
+class CapacityError(EcneError, MemoryError):
+    """a device table overflowed or an allocation failed (ECNE_ECAPACITY)"""
+    status = -10
+
+
+class NoConvergenceError(EcneError, RuntimeError):
+    """the propagation queue never drains on this input: the reference would not terminate (include/ecne.h ECNE_ENOCONVERGE)"""
+    status = -12
+
+
 _EXC = {-1: FormatError, -2: BoundsError, -3: DivideError, -4: UndefVarError, -5: AbstractionKeyError,
-        -6: DetSizeError, -7: OSError, -8: NoDeviceError, -9: ValueError, -10: EcneError, -11: DeviceBusyError}
+        -6: DetSizeError, -7: OSError, -8: NoDeviceError, -9: ValueError, -10: CapacityError, -11: DeviceBusyError, -12: NoConvergenceError}
 
 
 def _check(st, what=""):

@@ -2607,6 +2607,7 @@ const char* ecne_strerror(int st) {
         case ECNE_ENODEVICE: return "no usable HIP device (the engine has no CPU fallback)";
         case ECNE_EINVAL: return "invalid argument";
         case ECNE_ECAPACITY: return "internal device table overflow (or out of memory)";
+        case ECNE_ENOCONVERGE: return "the propagation queue does not drain on this input (the reference would not terminate): stopped after 4096 + 64 x nnz pops";
         case ECNE_ETIMEOUT: return "the workgroups of the solve cannot run together (cooperative launch refused, or they did not meet in time): is another process using this device?";
         default: return "unknown status";
     }

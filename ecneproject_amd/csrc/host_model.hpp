@@ -44,6 +44,7 @@ enum Status : int {
     K_EINVAL = -9,
     K_ECAPACITY = -10,  // an internal device table overflowed (never silently truncated)
     K_ETIMEOUT = -11,   // the workgroups of a job did not meet at their barrier in time (the device is shared)
+    K_ENOCONVERGE = -12, // pop_cap reached: the reference's queue never drains on this input (it would not terminate)
 };
 
 // Host-side worker threads (parse, abstraction, layout): opt-in. The library works on the calling thread unless the

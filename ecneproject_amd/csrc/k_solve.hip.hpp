@@ -738,14 +738,14 @@ __device__ __noinline__ void seq_queue_phase(const Job& J, QState& q, unsigned l
     if (J.queue_mode == 2 && chain_ok(J)) {
         // QUEUE, strictly sequential pops on the chain executor (chain.hip.hpp)
         while (q.head != q.tail && !J.ctr->error) {
-            if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+            if (pops > pop_cap) { raise(J, K_ENOCONVERGE); break; }
             chain_pops(J, q, 1u << 16, 0, hits, steps, nuniq, pops, pop_nnz);
         }
         return;
     }
     // QUEUE (:805-1349), strictly sequential pops (debug / parity reference schedule)
     while (q.head != q.tail && !J.ctr->error) {
-        if (pops > pop_cap) { raise(J, K_ECAPACITY); break; }
+        if (pops > pop_cap) { raise(J, K_ENOCONVERGE); break; }
         ECNE_PT(7);
         uint32_t row = J.queue[q.head & J.qmask];
         q.head++;

@@ -908,7 +908,7 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
         unsigned long long rl_t0 = wall_clock64();      // (round log builds: every line's dt runs from here -- the prints themselves stay outside)
 #endif
         if ((round++ & 7u) == 0 && wg_error(J, s_err)) break;
-        if (pops_total > pop_cap) { raise(J, K_ECAPACITY); break; }
+        if (pops_total > pop_cap) { raise(J, K_ENOCONVERGE); break; }
         uint32_t avail = q.tail - q.head;
         // chain executor: a short queue is popped sequentially right away (a round over a handful of rows costs more
         // than their pops, ~0.8 us each), until the queue is empty or a frontier has built up again

@@ -43,8 +43,11 @@ typedef enum ecne_status {
     ECNE_ENODEVICE = -8,  /* no usable HIP device: the engine never falls back to the CPU           */
     ECNE_EINVAL = -9,
     ECNE_ECAPACITY = -10, /* internal device table overflow (reported, never silently truncated)    */
-    ECNE_ETIMEOUT = -11   /* the workgroups of a solve cannot run together: the cooperative launch was refused, or they did not
+    ECNE_ETIMEOUT = -11,  /* the workgroups of a solve cannot run together: the cooperative launch was refused, or they did not
                              meet at their barrier in time -- something else occupies the device (see ecne_solve)        */
+    ECNE_ENOCONVERGE = -12 /* the queue of :805-1349 never drains on this input (rows that re-set each other's bounds / value and
+                             re-queue each other forever, e.g. R3 lb=ub=v against R4's [0, 2^(l-1)-1]): the reference does not
+                             terminate; the solve stops after 4096 + 64 x nnz pops. Not a resource failure (ECNE_ECAPACITY).    */
 } ecne_status;
 
 typedef struct ecne_r1cs ecne_r1cs;     /* a parsed .r1cs file                                   */

@@ -56,7 +56,8 @@ function check(st::Integer)
     st == -4 && throw(UndefVarError(:dsu))           # :762 without secp_solve
     st == -5 && throw(KeyError(msg))                 # abstraction's variable map (:381-382)
     st == -7 && throw(SystemError(msg))
-    st == -10 && throw(OutOfMemoryError())
+    st == -10 && throw(OutOfMemoryError())          # a device table overflowed / allocation failed
+    st == -12 && throw(ErrorException("ecne_hip: $msg (status -12)"))   # the queue never drains: the reference itself would loop forever here -- not a memory error
     error("ecne_hip: $msg (status $st)")           # -6 group of > 10 unknowns, -8 no device, -9 invalid argument, -11 device busy
 end
 

@@ -48,9 +48,9 @@ enum Status {
     ST_EKEY = -5,        // KeyError in abstraction's variable map (:381-382)
     ST_EDETSIZE = -6,    // slow_det on k > 10 unknowns: the reference would need k!*k steps
     ST_EIO = -7,
-    ST_EWATCHDOG = -10,  // the queue never drains (contradictory single-variable rows re-set each other's
+    ST_EWATCHDOG = -12,  // the queue never drains (contradictory single-variable rows re-set each other's
                          // value forever, :966-969): the reference would not terminate; the engine stops
-                         // with ECNE_ECAPACITY after 4096 + 64*nnz pops, and so does this restatement
+                         // with ECNE_ENOCONVERGE after 4096 + 64*nnz pops, and so does this restatement
 };
 struct OracleError {
     int code;

@@ -137,13 +137,14 @@ def _multiplexer(b, w_in, n_in):
     return dict(out=out, inp=inp, sel=sel, emit=emit)
 
 
-def _table_const(i, l, j, idx):
-    x = (i * 7919 + l * 104729 + j * 1299709 + idx * 15485863 + 0x1234567) * 0x9E3779B97F4A7C15
+def _table_const(i, l, j, idx, seed=0):
+    """seed 0 = the committed workload (golden digests); another seed = another table (bench.py --gpus N: one independent job per rank)"""
+    x = (i * 7919 + l * 104729 + j * 1299709 + idx * 15485863 + 0x1234567 + seed * 0x5DEECE66D) * 0x9E3779B97F4A7C15
     x = (x ^ (x >> 31)) % (1 << 86)
     return x | 1
 
 
-def generate(path, S=26, stride=10, nbits=86, k=3, adder_rel="secp256k1.r1cs", adder_path=None):
+def generate(path, S=26, stride=10, nbits=86, k=3, adder_rel="secp256k1.r1cs", adder_path=None, seed=0):
     """Writes ecdsa_like(S) to `path`; returns a dict with its sizes."""
     import fixtures
     adder_path = adder_path or fixtures.path(adder_rel)
@@ -194,7 +195,7 @@ def generate(path, S=26, stride=10, nbits=86, k=3, adder_rel="secp256k1.r1cs", a
             b.wire(m["sel"], sels[i]["out"])
             for idx in range(k):
                 for j in range(n_in):
-                    b.row([], [], [(1, _table_const(i, l, j, idx)), (m["inp"] + j * k + idx, -1)])
+                    b.row([], [], [(1, _table_const(i, l, j, idx, seed)), (m["inp"] + j * k + idx, -1)])
     for i in range(S):
         b.wire(isz[i]["inp"], sels[i]["out"])
     b.row([], [], [(hpn[0]["a"], -1)])
@@ -311,14 +312,14 @@ def generate(path, S=26, stride=10, nbits=86, k=3, adder_rel="secp256k1.r1cs", a
                 n_adders=len(adders), adder_rows=len(a_rows), bytes=os.path.getsize(path))
 
 
-def cached(S=26, stride=10, directory=None):
+def cached(S=26, stride=10, directory=None, seed=0):
     """Path of ecdsa_like(S, stride), generated on first use under the fixture scratch directory."""
     import fixtures
     directory = directory or fixtures._CACHE
     os.makedirs(directory, exist_ok=True)
-    path = os.path.join(directory, "ecdsa_like_S%d_s%d.r1cs" % (S, stride))
+    path = os.path.join(directory, "ecdsa_like_S%d_s%d%s.r1cs" % (S, stride, "" if seed == 0 else "_seed%d" % seed))
     if not os.path.exists(path):
-        generate(path, S=S, stride=stride)
+        generate(path, S=S, stride=stride, seed=seed)
     return path
 
 

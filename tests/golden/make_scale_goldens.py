@@ -23,6 +23,8 @@ from state_digest import numpy_digest  # noqa: E402
 
 CASES = {
     "ecdsa_like(104,10)+Secp256k1AddUnequal": lambda: (ecdsa_like.cached(104, 10), [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"]),
+    # S = 416 (17.6 M rows, 2.3 GB file): the last point of SURVEY.md 8(d)'s scale-out series {26, 104, 416}; ~25 GB of memory for the oracle
+    "ecdsa_like(416,10)+Secp256k1AddUnequal": lambda: (ecdsa_like.cached(416, 10), [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"]),
     "ecdsa_like(26,10)+Secp256k1AddUnequal": lambda: (ecdsa_like.cached(26, 10), [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"]),
     "1400xPoseidon@poseidon": lambda: (multi_copy.cached("ecne_circomlib_tests/Poseidon@poseidon.r1cs", 1400), [], []),
 }

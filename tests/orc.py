@@ -18,7 +18,7 @@ ORDER_JULIA, ORDER_ASCENDING, ORDER_RANDOM = 0, 1, 2
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
 STATUS_NAMES = {0: "OK", -1: "EFORMAT", -2: "EBOUNDS", -3: "EDIVZERO", -4: "EUNDEF_DSU",
-                -5: "EKEY", -6: "EDETSIZE", -7: "EIO", -10: "EWATCHDOG"}
+                -5: "EKEY", -6: "EDETSIZE", -7: "EIO", -10: "ECAPACITY", -12: "EWATCHDOG"}
 
 
 class Summary(C.Structure):

@@ -42,7 +42,7 @@ class JlKeyError(Exception):
 
 
 class Watchdog(Exception):
-    status = -10
+    status = -12
 
 
 # ------------------------------------------------------------------------------------------------ Julia 1.7 Dict / Set

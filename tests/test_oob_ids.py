@@ -37,7 +37,7 @@ def test_oracle_and_second_reading_agree(oob_dir):
             assert differences(r, o) == [], (seed, secp)
             statuses[o.status] = statuses.get(o.status, 0) + 1
     # most runs die with BoundsError; some never read the id (normal end) and a few die earlier with DivideError
-    assert set(statuses) <= {0, -2, -3, -10}
+    assert set(statuses) <= {0, -2, -3, -12}
     assert statuses.get(-2, 0) > 100 and statuses.get(0, 0) >= 10
 
 
