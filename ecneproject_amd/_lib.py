@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libecne_hip.so")
+SO = os.path.join(HERE, os.environ.get("ECNE_LIB", "libecne_hip.so"))      # (ECNE_LIB: a developer build beside the product, e.g. the -DECNE_JITTER soak library)
 
 
 class Info(C.Structure):

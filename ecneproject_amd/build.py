@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(HERE, "libecne_hip.so")
+SO = os.path.join(HERE, os.environ.get("ECNE_BUILD_SO", "libecne_hip.so"))      # (developer builds beside the product: ECNE_BUILD_SO=libecne_hip_jitter.so ECNE_BUILD_FLAGS=-DECNE_JITTER)
 SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))   # every file under csrc/ is a dependency
 
 
@@ -32,7 +32,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return SO
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-fPIC"] + os.environ.get("ECNE_BUILD_FLAGS", "").split()   # e.g. -DECNE_POPPROF (developer builds)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if "ECNE_BUILD_SO" not in os.environ else "build_" + os.path.splitext(os.environ["ECNE_BUILD_SO"])[0])
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for tu in TUS:

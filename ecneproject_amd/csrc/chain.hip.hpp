@@ -21,7 +21,9 @@
 
 namespace ecne {
 
-// the chain executor's preconditions: one workgroup, flags and in_queue tags resident in LDS, row records uploaded
+// the chain executor's preconditions: one workgroup, flags and in_queue tags resident in LDS, row records uploaded.
+// (Also the precondition of every executor that keeps pushes in the LDS queue mirror only -- crew_rounds, level_rounds<true> --; k_solve's
+//  p3p4_incremental relies on their being unreachable for a team's master, see the guard at its call.)
 __device__ __forceinline__ bool chain_ok(const Job& J) {
     return J.nwg == 1 && J.rec != nullptr && J.lds_flags_off != 0xFFFFFFFFu && J.lds_inq_off != 0xFFFFFFFFu;
 }

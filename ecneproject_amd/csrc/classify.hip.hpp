@@ -283,6 +283,10 @@ __device__ __forceinline__ bool neg_div_unit(const fp::u256& num, const fp::u256
 // cfC / clC: where the row's C entries are read from -- the CSR arrays themselves (cbase = 0), or the workgroup's LDS copy of the
 // entries [cbase, ...) of its 256 rows. Returns false when the row has to be deferred (nothing it wrote matters: the general path writes
 // everything again).
+// UNIT = true: the streaming pass (divisors +-1 only, anything else defers the row). UNIT = false: the same lane code with the full
+// field inversion, for the deferred rows (k_classify_wave's second part) -- a circuit with arbitrary linear coefficients (circom --O1 / --O2
+// output, hand-written R1CS) defers a large share of its rows, and one WAVEFRONT per such row was a cliff (round 5's advisor finding).
+template <bool UNIT>
 __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, RowInfo ri, const uint64_t* __restrict__ cfC, const uint32_t* __restrict__ clC, uint32_t cbase) {
     const uint32_t shape_in = ri.shape, kpos_in = ri.kpos, kneg_in = ri.kneg;
     // a product a * b = c (or any row with C empty that is no bit check) needs nothing from this pass
@@ -304,7 +308,8 @@ __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, Ro
                 if (v == ri.x) slope = c;
                 else if (v == 1) icpt = c;
             }
-            if (!neg_div_unit(icpt, slope, val[part])) return false;
+            if (UNIT) { if (!neg_div_unit(icpt, slope, val[part])) return false; }
+            else val[part] = neg_div(icpt, slope);
         }
         st256(J.vals + 4ull * ri.validx, val[0]);
         st256(J.vals + 4ull * (ri.validx + 1), val[1]);
@@ -328,7 +333,8 @@ __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, Ro
                 if (v[e] == 1) c1v = c[e];
                 else if (v[e] == ri.x) cx = c[e];
             }
-            if (!neg_div_unit(c1v, cx, tv)) return false;
+            if (UNIT) { if (!neg_div_unit(c1v, cx, tv)) return false; }
+            else tv = neg_div(c1v, cx);
             st256(J.vals + 4ull * ri.validx, tv);
         }
         if (!(shape & SH_CZERO)) {
@@ -388,7 +394,7 @@ __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, Ro
 // The streaming pass: the short rows, one lane per row (round 5: nothing else in this kernel -- with the long rows' wavefront path in
 // the same kernel, its field inversion and rank sort set the register count for the streaming lanes too, 148 VGPRs = three wavefronts
 // per SIMD; the long rows and the deferred ones get k_classify_wave, launched behind it).
-__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index, uint32_t n_long_blocks) {
+__global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t job_index) {
     __shared__ Job sJ;
     if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
     __syncthreads();
@@ -398,7 +404,6 @@ __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t
         // its own entries alone are more than the buffer) is read from device memory as before.
         __shared__ uint4 s_coef[2 * ECNE_CLS_STAGE];
         __shared__ uint32_t s_col[ECNE_CLS_STAGE];
-        (void)n_long_blocks;
         const uint32_t nb0 = gridDim.x;
         for (uint32_t rb = blockIdx.x * 256; rb < sJ.nC; rb += nb0 * 256) {      // (uniform trip count: barriers inside)
             const uint32_t rend = rb + 256 < sJ.nC ? rb + 256 : sJ.nC;
@@ -417,8 +422,8 @@ __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t
             if (row < sJ.nC) {
                 const RowInfo ri = sJ.rinfo[row];
                 if (ri.lenC <= ECNE_CLS_LANE) {
-                    if (staged) defer = !classify_row_lane(sJ, row, ri, reinterpret_cast<const uint64_t*>(s_coef), s_col, clo);
-                    else defer = !classify_row_lane(sJ, row, ri, sJ.coefC, sJ.colC, 0u);
+                    if (staged) defer = !classify_row_lane<true>(sJ, row, ri, reinterpret_cast<const uint64_t*>(s_coef), s_col, clo);
+                    else defer = !classify_row_lane<true>(sJ, row, ri, sJ.coefC, sJ.colC, 0u);
                 }      // (longer rows are on the layout's list, cls_list: k_classify_wave)
             }
             {   // the deferred rows of a wavefront in one atomic (cls_defer[0] = count, zeroed by the host before the launch)
@@ -435,16 +440,22 @@ __global__ __launch_bounds__(256) void k_classify_rows(const Job* jobs, uint32_t
     }
 }
 
-// One wavefront per row, the general path (classify_row), behind the streaming pass: the rows the layout listed (cls_list: more than
-// ECNE_CLS_LANE entries in C -- latency-bound, each a chain of loads) and the rows k_classify_rows' lanes deferred.
+// Behind the streaming pass: one wavefront per row, the general path (classify_row), for the rows the layout listed (cls_list: more than
+// ECNE_CLS_LANE entries in C -- latency-bound, each a chain of loads); one LANE per row, with the field inversion, for the short rows
+// k_classify_rows deferred (round 6; until then a wavefront each).
 __global__ __launch_bounds__(256) void k_classify_wave(const Job* jobs, uint32_t job_index) {
     __shared__ uint32_t scratch[4][16];
     __shared__ Job sJ;
     if (threadIdx.x < sizeof(Job) / 4) ((uint32_t*)&sJ)[threadIdx.x] = ((const uint32_t*)&jobs[job_index])[threadIdx.x];
     __syncthreads();
-    const uint32_t n0 = sJ.nBigCls, n = n0 + sJ.cls_defer[0];
+    const uint32_t n0 = sJ.nBigCls, nd = sJ.cls_defer[0];
     const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) classify_row(sJ, i < n0 ? sJ.cls_list[i] : sJ.cls_defer[1 + (i - n0)], scratch[wave]);
+    for (uint32_t i = blockIdx.x * 4 + wave; i < n0; i += gridDim.x * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
+    // (the workgroups are dealt the deferred rows from the far end of the grid: the first ones hold the long rows)
+    for (uint32_t i = (gridDim.x - 1u - blockIdx.x) * 256u + threadIdx.x; i < nd; i += gridDim.x * 256u) {
+        const uint32_t row = sJ.cls_defer[1 + i];
+        (void)classify_row_lane<false>(sJ, row, sJ.rinfo[row], sJ.coefC, sJ.colC, 0u);
+    }
 }
 
 }  // namespace ecne

@@ -1363,8 +1363,9 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     // layout listed (cls_list: more entries) and the ones the streaming lanes deferred (a divisor that needs a real inversion: usually none).
     // (Tried: the listed rows on a stream of their own next to the streaming pass -- 0.143 -> 0.140 ms at 2.8 M rows, 0.053 -> 0.054 at 0.7 M:
     //  not worth a second stream, two events and a lock.)
-    hipLaunchKernelGGL(k_classify_rows, dim3(nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u, 0u);
-    hipLaunchKernelGGL(k_classify_wave, dim3(std::max<uint32_t>(nblk1, 64u)), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
+    // (round 6: the deferred short rows get a LANE each in the second launch -- with the inversion --, dealt over at least one workgroup per CU)
+    hipLaunchKernelGGL(k_classify_rows, dim3(nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
+    hipLaunchKernelGGL(k_classify_wave, dim3(std::max<uint32_t>(nblk1, 256u)), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());
@@ -1814,6 +1815,14 @@ static int solve_batch_core(ecne_system** sys, size_t n, const ecne_opts* opts, 
                 launch_at.push_back(all_descs.size());
             }
             bool fail = false;
+#ifdef ECNE_JITTER
+            {   // (developer build: the seed of this launch's pseudo-random delays, job_barrier.hip.hpp)
+                static std::atomic<uint32_t> n_launch{0};
+                const char* je = getenv("ECNE_JITTER_SEED");
+                const uint32_t seed = (je ? (uint32_t)strtoul(je, nullptr, 0) : 1u) * 2654435761u + n_launch.fetch_add(1) * 40503u;
+                if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jitter_seed), &seed, 4, 0, hipMemcpyHostToDevice, stream) != hipSuccess) fail = true;
+            }
+#endif
             if (!all_descs.empty() && hipMemcpyAsync(scratch.d_descs, all_descs.data(), sizeof(WgDesc) * all_descs.size(), hipMemcpyHostToDevice, stream) != hipSuccess) fail = true;
             if (side_launch && !fail && (hipEventRecord(scratch.e_up, stream) != hipSuccess || hipStreamWaitEvent(scratch.side, scratch.e_up, 0) != hipSuccess)) fail = true;
             for (size_t li = 0; li + 1 < launch_at.size() && !fail; ++li) {
@@ -1930,40 +1939,56 @@ static std::atomic<int>& split_setting() {
 static int split_mode() { return split_setting().load(std::memory_order_relaxed); }
 // The device screen of build_split: classification (SH_TOUCH1 comes from there), rows that can write the constant wire's state, the
 // groups of rows (k_cc_*). P.screen = {groups, rows of the largest, SH_TOUCH1 rows, 1 = the long-variable list overflowed: no answer}.
-static int split_screen(ecne_system& P, int device) {
+// (round 6) On the CALLER's stream, under the device's launch lock (shared: the screen's kernels are ordinary launches, but they must not be
+// queued next to another thread's team launch, which holds the lock exclusively), its scratch kept per thread (no hipMalloc / hipFree -- both
+// synchronise the device -- per first solve; buffers above 32 MB are not kept), ONE result copy of five words, launch errors checked.
+struct ScreenScratch {
+    int device = -1; uint32_t* d = nullptr; size_t bytes = 0;
+    uint32_t* get(int dev, size_t need) {
+        if (d && (device != dev || bytes < need)) { (void)hipFree(d); d = nullptr; bytes = 0; }
+        if (!d) { if (hipMalloc((void**)&d, need) != hipSuccess) { (void)hipGetLastError(); d = nullptr; return nullptr; } bytes = need; device = dev; }
+        return d;
+    }
+    void done() { if (d && bytes > (32u << 20)) { (void)hipFree(d); d = nullptr; bytes = 0; } }
+};
+static int split_screen(ecne_system& P, int device, hipStream_t stream) {
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(device));
+    static thread_local ScreenScratch scratch;
     const uint32_t nC = P.dev.job.nC;
-    uint32_t* d = nullptr;      // parent[nC], cnt[nC], long_vars[LONGCAP], out[4], then a Job slot for the classification
-    const size_t words = 2ull * nC + ECNE_CC_LONGCAP + 4;
-    HIP_TRY(hipMalloc((void**)&d, 4 * words + sizeof(Job) + 256));
+    // parent[nC], cnt[nC], long_vars[LONGCAP], out[8] (out[4] = SH_TOUCH1 rows), then a Job slot for the classification
+    const size_t words = 2ull * nC + ECNE_CC_LONGCAP + 8;
+    uint32_t* const d = scratch.get(device, 4 * words + sizeof(Job) + 256);
+    if (!d) return K_ECAPACITY;
     uint32_t* const parent = d, * const cnt = d + nC, * const longv = d + 2ull * nC, * const out = longv + ECNE_CC_LONGCAP;
-    Job* const slot = (Job*)(((uintptr_t)(out + 4) + 255) & ~(uintptr_t)255);
-    int rc = classify_system(P, 0, slot);
-    uint32_t h[4] = {0, 0, 0, 0}, touch = 0;
+    Job* const slot = (Job*)(((uintptr_t)(out + 8) + 255) & ~(uintptr_t)255);
+    std::shared_lock<std::shared_mutex> lock(device_launch_mutex(device));
+    int rc = classify_system(P, stream, slot);
+    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipError_t e = hipSuccess;
     if (rc == K_OK) {
         const uint32_t nb = std::min<uint32_t>(4096u, (std::max(nC, P.dev.job.nV) + 255u) / 256u);
-        e = hipMemsetAsync(out, 0, 16, 0);
-        hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, 0, parent, cnt, nC);
-        hipLaunchKernelGGL(k_cc_hook, dim3(nb), dim3(256), 0, 0, P.dev.job, parent, longv, out);
-        hipLaunchKernelGGL(k_cc_hook_long, dim3(1024), dim3(256), 0, 0, P.dev.job, parent, (const uint32_t*)longv, (const uint32_t*)out);
-        hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, 0, parent, cnt, nC, out);
-        if (e == hipSuccess) e = hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemsetAsync(out, 0, 4, 0);
-        hipLaunchKernelGGL(k_count_shape, dim3(std::min<uint32_t>(1024u, (nC + 255u) / 256u)), dim3(256), 0, 0, P.dev.job, (uint32_t)SH_TOUCH1, out);
-        if (e == hipSuccess) e = hipMemcpy(&touch, out, 4, hipMemcpyDeviceToHost);
+        e = hipMemsetAsync(out, 0, 32, stream);
+        hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, stream, parent, cnt, nC);
+        hipLaunchKernelGGL(k_cc_hook, dim3(nb), dim3(256), 0, stream, P.dev.job, parent, longv, out);
+        hipLaunchKernelGGL(k_cc_hook_long, dim3(1024), dim3(256), 0, stream, P.dev.job, parent, (const uint32_t*)longv, (const uint32_t*)out);
+        hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, stream, parent, cnt, nC, out);
+        hipLaunchKernelGGL(k_count_shape, dim3(std::min<uint32_t>(1024u, (nC + 255u) / 256u)), dim3(256), 0, stream, P.dev.job, (uint32_t)SH_TOUCH1, out + 4);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, out, 32, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
     }
-    (void)hipFree(d);
+    lock.unlock();
+    scratch.done();
     if (rc != K_OK) return rc;
     if (e != hipSuccess) { (void)hipGetLastError(); return ECNE_ENODEVICE; }
-    P.screen[0] = h[0]; P.screen[1] = h[1]; P.screen[2] = touch; P.screen[3] = h[3] ? 1u : 0u;
+    P.screen[0] = h[0]; P.screen[1] = h[1]; P.screen[2] = h[4]; P.screen[3] = h[3] ? 1u : 0u;
     P.screen_done = true;
     P.screen_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return K_OK;
 }
 
-static int build_split(ecne_system& P, int device, uint32_t cap, bool eager, bool first_solve = false) {
+static int build_split(ecne_system& P, int device, uint32_t cap, bool eager, bool first_solve = false, hipStream_t stream = nullptr) {
     static const bool dbg = getenv("ECNE_SPLIT_DEBUG") != nullptr;
 #define SPLIT_NO(why) do { if (dbg) fprintf(stderr, "[ecne split] no plan: %s\n", why); return K_OK; } while (0)
     const auto t0 = std::chrono::steady_clock::now();
@@ -1978,7 +2003,7 @@ static int build_split(ecne_system& P, int device, uint32_t cap, bool eager, boo
     // ~0.1-0.5 ms): a file that is one group -- nearly every file -- is known to be one before its rows are downloaded (18 ms per million)
     // and united on the host (17 ms)
     if (P.dev.arena && P.dev.device == device && P.dev.job.nC) {
-        if (!P.screen_done) { const int rc = split_screen(P, device); if (rc != K_OK) return rc; }
+        if (!P.screen_done) { const int rc = split_screen(P, device, stream); if (rc != K_OK) return rc; }
         if (dbg) fprintf(stderr, "[ecne split] device screen: %u groups, largest %u of %u rows, %u rows can write the constant wire, %.2f ms\n", P.screen[0], P.screen[1], P.dev.job.nC, P.screen[2], P.screen_ms);
         if (P.screen[2]) SPLIT_NO("rows that can write the constant wire's bounds");
         if (!P.screen[3]) {
@@ -2127,7 +2152,7 @@ static int ecne_solve_batch_impl(ecne_system** sys, size_t n, const ecne_opts* o
             if (hipSetDevice(o.device) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, o.device) == hipSuccess && n_cu > 16) {
                 // (the file itself is laid out and uploaded first: its arrays receive the parts' states)
                 int rc = upload_system(P, o.device);
-                if (rc == K_OK) rc = build_split(P, o.device, (uint32_t)(n_cu - 8), mode >= 2, mode < 2 && never_solved);
+                if (rc == K_OK) rc = build_split(P, o.device, (uint32_t)(n_cu - 8), mode >= 2, mode < 2 && never_solved, (hipStream_t)o.stream);
                 if (rc != K_OK) { if (getenv("ECNE_SPLIT_DEBUG")) fprintf(stderr, "[ecne split] plan failed (%d)\n", rc); P.split.reset(); (void)hipGetLastError(); }
             }
         }

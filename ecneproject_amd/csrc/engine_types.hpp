@@ -120,7 +120,7 @@ struct Counters {   // one per job, device memory
     // barrier at the loop top), what the helpers do when the master lets them out of the queue phase, and the state of P3's group table
     unsigned int sync_go;
     unsigned int team_cmd, team_outer;   // team_cmd: TEAM_FULL = P3 and P4 of iteration team_outer with everybody, TEAM_EXIT = the loop has ended
-    unsigned int p3_tbl;                 // 0 = P3's group table is empty; 1 = it holds the counts of the last pass (kept for the incremental passes); 2 = the same, and slots were created that no list records (wiped as a whole)
+    unsigned int p3_tbl;                 // 0 = P3's group table is empty; 1 = it holds the counts of the last pass (kept for the incremental passes)
     unsigned long long q_acc[16];   // helpers' counter deltas: steps, nuniq, hits[0..7], pops, pop_nnz, rounds   // 100 MHz wall clock: 0 setup, 1 P1+P2+queue, 2 P3, 3 P4, 4 P5, 5 verdict; 6 = P3 rounds
 };
 
@@ -170,8 +170,8 @@ struct Job {
     const uint32_t* p4_list;
     const uint32_t* p4_b;      // per P4 row: the B variable
     const uint32_t* p4_s;      // per P4 row: slope variable of A; bit 31 set = none (divexact by zero, :1467)
-    const uint32_t* cls_list;   // rows with lenC > 8, ascending
-    uint32_t* cls_defer;        // k_classify_rows: [0] = how many rows its lanes deferred to a wavefront, then their ids (classify.hip.hpp)
+    const uint32_t* cls_list;   // rows with lenC > ECNE_CLS_LANE (3), ascending: a wavefront each in k_classify_wave
+    uint32_t* cls_defer;        // k_classify_rows: [0] = how many short rows its lanes deferred (a divisor other than +-1: one lane each in k_classify_wave, with the inversion), then their ids (classify.hip.hpp)
     const uint32_t *p5_rows, *p5_y;
     // mutable state
     uint8_t* flags;

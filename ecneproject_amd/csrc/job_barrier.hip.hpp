@@ -22,7 +22,28 @@ __device__ __forceinline__ uint32_t my_xcc_id() {
 // What a workgroup remembers between job barriers (LDS): the generation it waits for next and, once the
 // first barrier of the launch has established them, its XCD's member count and the number of XCDs in use
 // -- so that a barrier costs one atomic per level and one polled word, no other memory round trips.
-struct BarLocal { unsigned gen, members, nxcd, ready, sgen, lazy; };
+struct BarLocal { unsigned gen, members, nxcd, ready, sgen, lazy, jit; };
+
+// -DECNE_JITTER (developer build, tools/gp_soak_jitter.sh): pseudo-random delays in front of every barrier arrival and behind every release,
+// a random start delay per workgroup, the helpers held back past the master's first commands -- to shake out orderings the barrier
+// protocols might depend on by accident. The sequence is a function of (seed, workgroup, call count): g_jitter_seed is set by the host
+// from ECNE_JITTER_SEED before every launch. One call in eight sleeps long (up to ~60 us), the others up to ~7 us.
+#ifdef ECNE_JITTER
+static __device__ uint32_t g_jitter_seed;
+__device__ __forceinline__ BarLocal& bar_local();
+__device__ __forceinline__ void jitter(uint32_t salt) {
+    if (threadIdx.x != 0) return;
+    uint32_t x = (g_jitter_seed + 0x9E3779B9u * (blockIdx.x + 1u)) ^ (salt * 0x85EBCA6Bu) ^ (++bar_local().jit * 0xC2B2AE35u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    uint32_t n = (x & 7u) == 0 ? ((x >> 3) & 15u) : ((x >> 3) & 1u) * ((x >> 4) & 1u);      // units of s_sleep(127) ~ 3.4 us; most calls: none
+    if ((x & 0x3FFu) == 1u) n = 64u + ((x >> 10) & 63u);                                        // one in a thousand: 0.2-0.4 ms
+    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    if (n == 0) for (uint32_t i = 0; i < ((x >> 5) & 3u); ++i) __builtin_amdgcn_s_sleep(8);
+}
+#define ECNE_JIT(salt) jitter(salt)
+#else
+#define ECNE_JIT(salt) do { } while (0)
+#endif
 __device__ __forceinline__ BarLocal& bar_local() {
     __shared__ BarLocal b;
     return b;
@@ -35,7 +56,7 @@ __device__ __forceinline__ void job_heartbeat(const Job& J) {
 }
 __device__ __forceinline__ void job_barrier_init() {   // thread 0, once per launch (the device words are zeroed by the host)
     BarLocal& b = bar_local();
-    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0; b.sgen = 0; b.lazy = 0;
+    b.gen = 0; b.members = 0; b.nxcd = 0; b.ready = 0; b.sgen = 0; b.lazy = 0; b.jit = 0;
 }
 
 // Barrier of a SUB-TEAM: the first J.nwg workgroups of the job (J is a copy of the job with nwg = K and subteam = 1, made by
@@ -43,6 +64,7 @@ __device__ __forceinline__ void job_barrier_init() {   // thread 0, once per lau
 // and acquires, one counter, one generation word -- which costs what the hierarchical one costs up to ~48 workgroups. The local
 // generation is set from the master's command at the start of every chain (different chains have different members).
 __device__ int sub_barrier(const Job& J, int* s_err) {
+    ECNE_JIT(1);
     __syncthreads();
     if (threadIdx.x == 0) {
         Counters* c = J.ctr;
@@ -64,6 +86,7 @@ __device__ int sub_barrier(const Job& J, int* s_err) {
             if ((++spins & 1023u) == 0 && wall_clock64() - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) { raise(J, K_ETIMEOUT); w = 1; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ECNE_JIT(2);
         b.sgen = g + 1;
         *s_err = (w & 1u) ? __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     }
@@ -73,6 +96,7 @@ __device__ int sub_barrier(const Job& J, int* s_err) {
 
 __device__ int job_barrier(const Job& J, int* s_err) {
     if (J.subteam && J.nwg > 1) return sub_barrier(J, s_err);
+    if (J.nwg > 1) ECNE_JIT(3);
     __syncthreads();
     if (threadIdx.x == 0) {
         Counters* c = J.ctr;
@@ -100,6 +124,7 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                 __hip_atomic_fetch_add(&c->xcd_members[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (arrive_top) {
+                ECNE_JIT(4);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned expect = hier ? b.nxcd : J.nwg;
@@ -137,6 +162,7 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ECNE_JIT(5);
             b.gen = g + 1;
             b.lazy = 0;
             if (!hier) {   // the first barrier of the launch just completed: remember the XCD layout
@@ -164,6 +190,7 @@ __device__ __noinline__ uint32_t family_sync(const Job& J, bool progress, uint32
         F->snap_abz = J.abz[1]; F->snap_flags = J.flags[1]; F->snap_nvalues = J.nvalues[1];
     }
     __threadfence();
+    ECNE_JIT(6);
     if (ld_agent(&F->abort)) return 2u;
     const uint32_t g = ld_agent(&F->gen);
     if (atomicAdd(&F->arrived, 1u) == J.fam_size - 1u) {
@@ -180,6 +207,7 @@ __device__ __noinline__ uint32_t family_sync(const Job& J, bool progress, uint32
         }
     }
     __threadfence();
+    ECNE_JIT(7);
     return ld_agent(&F->progress[slot]) ? 1u : 0u;
 }
 

@@ -843,6 +843,11 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     Counters* const ctr = (Counters*)uniptr(J.ctr);
     const uint32_t ht_cap = (nC + uni32(J.nwg) - 1) / uni32(J.nwg) + 2048;   // this workgroup's share of ht_list (its rows + slack)
     if (tid == 0) { s_htn = 0; job_barrier_init(); }
+#ifdef ECNE_JITTER
+    // a random start per workgroup; every other helper of a team is held back well past the master's first commands (0.1-0.3 ms)
+    ECNE_JIT(8);
+    if (tid == 0 && my_rank != 0 && ((blockIdx.x ^ g_jitter_seed) & 1u)) for (uint32_t i = 0; i < 32u + ((g_jitter_seed >> 3) & 63u); ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     // phase clocks (ecne_summary.phase_ms): thread 0 of the master keeps them, in LDS. As eight 64-bit accumulators and a time stamp in
     // the registers of EVERY thread they were live across the whole outer loop: 92 more register spills in this kernel, 0.46 GB of
     // scratch write-backs per ecdsa-scale launch (each job barrier's release writes the dirty scratch lines back) and 0.4 ms.
@@ -957,7 +962,12 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
                 // folded in before the loop test, :708), P3's table kept from a pass without a firing, few pops since, room in this workgroup's
                 // slot list for a new group per popped row
                 const uint32_t h0 = s_inc[1], h1 = q.head;
-                if (!(team_io & 1u) && p3_keep_ok && ld_agent(&ctr->p3_tbl) == 1u && h1 - h0 <= ECNE_INC_MAX && h1 - h0 <= J.qmask && s_htn + (h1 - h0) <= ht_cap) {
+                // INVARIANT the incremental pass rests on: its work list is ring positions [h0, h1), so every row popped since the last pass must
+                // have been STORED in the device ring. The executors that push and pop through the LDS queue mirror without a ring store
+                // (crew_rounds, level_rounds<true>, the chain executor) are only reachable with chain_ok(J) -- one workgroup, LDS-resident state --
+                // which a team's master never has (nwg > 1); level_rounds<false> stores every push (level.hip.hpp). The guard below makes the
+                // dependency explicit: should a mirror-only executor ever be enabled for a team master, the full sweeps run instead of a wrong verdict.
+                if (!chain_ok(J) && !(team_io & 1u) && p3_keep_ok && ld_agent(&ctr->p3_tbl) == 1u && h1 - h0 <= ECNE_INC_MAX && h1 - h0 <= J.qmask && s_htn + (h1 - h0) <= ht_cap) {
                     if (tid == 0) { tk[6]++; s_team[1] += h1 - h0; }
                     solo_done = p3p4_incremental(J, h0, h1, (uint32_t)outer, ht_cap, &s_htn, &s_inc[0], s_longrows) == 0;
                     if (tid == 0 && solo_done) s_team[0]++;
