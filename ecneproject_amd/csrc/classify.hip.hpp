@@ -286,8 +286,15 @@ __device__ __forceinline__ bool neg_div_unit(const fp::u256& num, const fp::u256
 // UNIT = true: the streaming pass (divisors +-1 only, anything else defers the row). UNIT = false: the same lane code with the full
 // field inversion, for the deferred rows (k_classify_wave's second part) -- a circuit with arbitrary linear coefficients (circom --O1 / --O2
 // output, hand-written R1CS) defers a large share of its rows, and one WAVEFRONT per such row was a cliff (round 5's advisor finding).
+// -num / den with 1 / den at hand (UNIT = false: the deferred rows; the inverses come from ONE inversion per wavefront, wave_batch_inv)
+__device__ __forceinline__ fp::u256 neg_div_with(const fp::u256& num, const fp::u256& den, const fp::u256& den_inv) {
+    if (fp::is_one(den)) return fp::neg(num);
+    if (fp::is_one(fp::neg(den))) return num;
+    return fp::mul(fp::neg(num), den_inv);
+}
 template <bool UNIT>
-__device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, RowInfo ri, const uint64_t* __restrict__ cfC, const uint32_t* __restrict__ clC, uint32_t cbase) {
+__device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, RowInfo ri, const uint64_t* __restrict__ cfC, const uint32_t* __restrict__ clC, uint32_t cbase,
+                                                  const fp::u256* inv2 = nullptr) {
     const uint32_t shape_in = ri.shape, kpos_in = ri.kpos, kneg_in = ri.kneg;
     // a product a * b = c (or any row with C empty that is no bit check) needs nothing from this pass
     if ((shape_in & SH_HAS_AB) && !(shape_in & SH_R2) && !((shape_in & SH_C_HAS1) && (shape_in & SH_R5))) return true;
@@ -309,7 +316,7 @@ __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, Ro
                 else if (v == 1) icpt = c;
             }
             if (UNIT) { if (!neg_div_unit(icpt, slope, val[part])) return false; }
-            else val[part] = neg_div(icpt, slope);
+            else val[part] = neg_div_with(icpt, slope, inv2[part]);
         }
         st256(J.vals + 4ull * ri.validx, val[0]);
         st256(J.vals + 4ull * (ri.validx + 1), val[1]);
@@ -334,7 +341,7 @@ __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, Ro
                 else if (v[e] == ri.x) cx = c[e];
             }
             if (UNIT) { if (!neg_div_unit(c1v, cx, tv)) return false; }
-            else tv = neg_div(c1v, cx);
+            else tv = neg_div_with(c1v, cx, inv2[0]);
             st256(J.vals + 4ull * ri.validx, tv);
         }
         if (!(shape & SH_CZERO)) {
@@ -389,6 +396,59 @@ __device__ __forceinline__ bool classify_row_lane(const Job& J, uint32_t row, Ro
         J.rinfo[row] = ri;
     }
     return true;
+}
+
+// ---- the deferred short rows: a divisor that is neither 1 nor -1. The binary EGCD is data-dependent loops inside loops -- 64 lanes each
+// running their own is the worst case of every trip count in lockstep, several hundred microseconds per wavefront -- so the wavefront
+// inverts ONCE: Montgomery's trick over the lanes (prefix and suffix products by shuffles, one EGCD of the total that every lane runs
+// on the same value, i.e. without divergence), each lane's two divisors folded into one factor first.
+__device__ __forceinline__ fp::u256 shfl256_from(const fp::u256& v, int src) { return shfl256(v, src < 0 ? 0 : src > 63 ? 63 : src); }
+// 1 / e for every lane's e (e != 0; a lane that needs nothing passes 1). Montgomery form inside.
+__device__ __forceinline__ fp::u256 wave_batch_inv(const fp::u256& e) {
+    const int lane = lane_id();
+    const fp::u256 m = fp::to_mont(e);
+    fp::u256 pre = m, suf = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const fp::u256 a = shfl256_from(pre, lane - d), b = shfl256_from(suf, lane + d);
+        if (lane >= d) pre = fp::mont_mul(pre, a);
+        if (lane + d < 64) suf = fp::mont_mul(suf, b);
+    }
+    const fp::u256 total = fp::from_mont(shfl256(pre, 63));
+    const fp::u256 tinv = fp::to_mont(fp::inv(total));            // (uniform across the wavefront)
+    const fp::u256 one = fp::to_mont(fp::make(1));
+    const fp::u256 left = shfl256_from(pre, lane - 1), right = shfl256_from(suf, lane + 1);
+    fp::u256 r = fp::mont_mul(lane > 0 ? left : one, lane < 63 ? right : one);
+    r = fp::mont_mul(r, tinv);
+    return fp::from_mont(r);
+}
+// the divisors classify_row_lane will divide by for this row (1 where it divides by nothing): R2's two slopes (:916-927) or R3's c[x] (:961-964)
+__device__ __forceinline__ void deferred_divisors(const Job& J, uint32_t row, const RowInfo& ri, fp::u256& d0, fp::u256& d1) {
+    d0 = fp::make(1); d1 = fp::make(1);
+    const uint32_t shape = ri.shape;
+    if ((shape & SH_HAS_AB) && !(shape & SH_R2) && !((shape & SH_C_HAS1) && (shape & SH_R5))) return;
+    if ((shape & SH_R2) && !(shape & SH_R2_DIV0)) {
+        for (uint32_t k = J.rpA[row]; k < J.rpA[row + 1]; ++k) if (J.colA[k] == ri.x) d0 = ld256(J.coefA + 4ull * k);
+        for (uint32_t k = J.rpB[row]; k < J.rpB[row + 1]; ++k) if (J.colB[k] == ri.x) d1 = ld256(J.coefB + 4ull * k);
+    } else if (!(shape & SH_HAS_AB) && (shape & SH_R3)) {
+        const uint32_t c0 = J.rpC[row], c1 = J.rpC[row + 1];
+        for (uint32_t k = c0; k < c1 && k < c0 + ECNE_CLS_LANE; ++k) if (J.colC[k] != 1u && J.colC[k] == ri.x) d0 = ld256(J.coefC + 4ull * k);
+    }
+}
+// 64 deferred rows, one per lane (all lanes of the wavefront call this; `on` = this lane has a row)
+__device__ __forceinline__ void classify_deferred64(const Job& J, uint32_t row, bool on) {
+    RowInfo ri;
+    fp::u256 d[2];
+    d[0] = fp::make(1); d[1] = fp::make(1);
+    if (on) { ri = J.rinfo[row]; deferred_divisors(J, row, ri, d[0], d[1]); }
+    fp::u256 e[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) e[i] = (fp::is_zero(d[i]) || fp::is_one(d[i]) || fp::is_one(fp::neg(d[i]))) ? fp::make(1) : d[i];
+    const fp::u256 pinv = wave_batch_inv(fp::mul(e[0], e[1]));
+    fp::u256 inv2[2];
+    inv2[0] = fp::mul(pinv, e[1]);
+    inv2[1] = fp::mul(pinv, e[0]);
+    if (on) (void)classify_row_lane<false>(J, row, ri, J.coefC, J.colC, 0u, inv2);
 }
 
 // The streaming pass: the short rows, one lane per row (round 5: nothing else in this kernel -- with the long rows' wavefront path in
@@ -451,10 +511,12 @@ __global__ __launch_bounds__(256) void k_classify_wave(const Job* jobs, uint32_t
     const uint32_t n0 = sJ.nBigCls, nd = sJ.cls_defer[0];
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t i = blockIdx.x * 4 + wave; i < n0; i += gridDim.x * 4) classify_row(sJ, sJ.cls_list[i], scratch[wave]);
-    // (the workgroups are dealt the deferred rows from the far end of the grid: the first ones hold the long rows)
-    for (uint32_t i = (gridDim.x - 1u - blockIdx.x) * 256u + threadIdx.x; i < nd; i += gridDim.x * 256u) {
-        const uint32_t row = sJ.cls_defer[1 + i];
-        (void)classify_row_lane<false>(sJ, row, sJ.rinfo[row], sJ.coefC, sJ.colC, 0u);
+    // (the workgroups are dealt the deferred rows from the far end of the grid: the first ones hold the long rows; uniform trip count per
+    //  wavefront: classify_deferred64 shuffles across its lanes)
+    for (uint32_t i0 = ((gridDim.x - 1u - blockIdx.x) * 4u + wave) * 64u; i0 < nd; i0 += gridDim.x * 256u) {
+        const uint32_t i = i0 + (uint32_t)lane_id();
+        const bool on = i < nd;
+        classify_deferred64(sJ, on ? sJ.cls_defer[1 + i] : 0u, on);
     }
 }
 

@@ -1365,7 +1365,7 @@ static int classify_system(ecne_system& S, hipStream_t stream, Job* d_job_slot) 
     //  not worth a second stream, two events and a lock.)
     // (round 6: the deferred short rows get a LANE each in the second launch -- with the inversion --, dealt over at least one workgroup per CU)
     hipLaunchKernelGGL(k_classify_rows, dim3(nblk0), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
-    hipLaunchKernelGGL(k_classify_wave, dim3(std::max<uint32_t>(nblk1, 256u)), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
+    hipLaunchKernelGGL(k_classify_wave, dim3(std::max<uint32_t>(nblk1, 1024u)), dim3(256), 0, stream, (const Job*)d_job_slot, 0u);
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());

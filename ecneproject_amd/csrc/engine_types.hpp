@@ -110,7 +110,13 @@ struct Counters {   // one per job, device memory
     unsigned int p4_nfired, setup_tail;
     unsigned int p4_live;  // outer iteration in which some P4 candidate still had an untagged, non-unique b (k_solve, P4)
     // multi-workgroup queue rounds: command from the master, shared cut / totals, per-workgroup scan parts
-    unsigned int q_cmd[12];         // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow, mark epoch, team size K, sub-team barrier generation
+    // q_cmd[s]: the master's command to the helpers that wait at the job barrier of GENERATION PARITY s (round 6). A helper reads the words AFTER that
+    // barrier, and one that is not on the commanded team goes straight back to the next job barrier -- nothing made it read them before the master,
+    // done with a short chain, wrote the NEXT command (found by the -DECNE_JITTER soak: a helper held up behind the release read the next command's
+    // team size / its "queue phase over" and ran a chain nobody else ran, or left a barrier early: ECNE_ETIMEOUT). With one block per barrier parity
+    // the words a helper reads behind barrier g are next written for barrier g + 2, which nobody reaches before every helper has arrived at g + 1.
+    unsigned int q_cmd[2][12];      // mode (0 = queue phase over, 1 = run a chain of multi rounds), head, tail, n, window, mwindow, mark epoch, team size K, sub-team barrier generation
+    unsigned int p4_tail;           // the queue tail P4's job-wide REQUEUE starts from (k_solve.hip.hpp)
     unsigned int q_cut, q_c_out, q_tail_out, q_fallback;
     unsigned int q_nhuge, q_huge[8][4];   // REQUEUE events with thousands of rows, expanded by the whole team after the expansion barrier: variable, rank, candidate base
     unsigned int d_cut[2], d_pend2[2], d_flag[2];   // drain rounds (drain.hip.hpp), by level parity: lowest demoted rank, rows left after the level, bit 0 "somebody is unstable" / bit 1 "somebody marked A"

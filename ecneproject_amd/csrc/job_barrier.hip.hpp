@@ -83,7 +83,13 @@ __device__ int sub_barrier(const Job& J, int* s_err) {
         unsigned long long t_wait0 = wall_clock64();
         while (((w = __hip_atomic_load(&c->sub_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) == g) {
             __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 1023u) == 0 && wall_clock64() - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) { raise(J, K_ETIMEOUT); w = 1; break; }
+            if ((++spins & 1023u) == 0 && wall_clock64() - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) {
+#ifdef ECNE_JITTER
+                printf("ECNE TIMEOUT sub_barrier: block %u team %u waits for gen %u, sub_gen %u sub_count %u bar_gen %u bar_count %u team_cmd %u heartbeat %u error %d\n", blockIdx.x, J.nwg, g,
+                       ld_agent(&c->sub_gen), ld_agent(&c->sub_count), ld_agent(&c->bar_gen), ld_agent(&c->bar_count), ld_agent(&c->team_cmd), ld_agent(&c->heartbeat), (int)ld_agent((const uint32_t*)&c->error));
+#endif
+                raise(J, K_ETIMEOUT); w = 1; break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         ECNE_JIT(2);
@@ -158,7 +164,14 @@ __device__ int job_barrier(const Job& J, int* s_err) {
                     const unsigned long long now = wall_clock64();
                     const unsigned hb2 = __hip_atomic_load(&c->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (hb2 != hb) { hb = hb2; t_wait0 = now; }
-                    else if (now - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) { raise(J, K_ETIMEOUT); w = 1; break; }
+                    else if (now - t_wait0 > 100000ull * (unsigned long long)J.bar_timeout_ms) {
+#ifdef ECNE_JITTER
+                        printf("ECNE TIMEOUT job_barrier: block %u of %u xcd %u hier %d members %u nxcd %u lazy %u waits for gen %u, bar_gen %u bar_count %u xcd_count %u sub_gen %u sub_count %u team_cmd %u heartbeat %u error %d\n",
+                               blockIdx.x, J.nwg, x, (int)hier, b.members, b.nxcd, b.lazy, g, ld_agent(&c->bar_gen), ld_agent(&c->bar_count), ld_agent(&c->xcd_count[x][0]), ld_agent(&c->sub_gen), ld_agent(&c->sub_count),
+                               ld_agent(&c->team_cmd), hb2, (int)ld_agent((const uint32_t*)&c->error));
+#endif
+                        raise(J, K_ETIMEOUT); w = 1; break;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

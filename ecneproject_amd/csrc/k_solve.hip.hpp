@@ -52,7 +52,7 @@ __device__ __noinline__ bool p4_phase(const Job& J, ChunkShared& s_chunk, QState
             wg_exclusive_scan(my_fired, s_scan, &wg_fired);
             if (tid == 0 && wg_fired) atomicAdd(&ctr->p4_nfired, wg_fired);
         }
-        if (master && tid == 0) ctr->q_cmd[2] = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
+        if (master && tid == 0) ctr->p4_tail = q.tail;   // (thread 0 holds the queue cursor) for p4's job-wide REQUEUE
         if (job_barrier(J, s_err)) return true;
         const uint32_t p4_fired = ld_agent(&ctr->p4_nfired);   // stable until the master clears it at the end of P4
         // forget the per-variable minima (all workgroups; the next use is a whole queue phase away)
@@ -66,7 +66,7 @@ __device__ __noinline__ bool p4_phase(const Job& J, ChunkShared& s_chunk, QState
             // REQUEUE of their B variables runs on ALL workgroups -- same steps as resolve_pushes, with
             // contiguous blocks per thread and job-wide scans (nothing is being popped: a candidate may
             // push iff its row is not queued; the lowest candidate index per row wins).
-            const uint32_t tail0 = ld_agent(&ctr->q_cmd[2]);
+            const uint32_t tail0 = ld_agent(&ctr->p4_tail);
             const uint32_t T = gstride;
             int err = 0;
             // 1. the event list: B variables of the fired rows, ascending
@@ -888,7 +888,7 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     auto team_leave = [&](uint32_t cmd) {      // master: the queue phase is over for the helpers (they wait at its command barrier)
         if (tid == 0) {
             ctr->team_cmd = cmd; ctr->team_outer = (unsigned)outer;
-            __hip_atomic_store(&ctr->q_cmd[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr->q_cmd[bar_local().gen & 1u][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the block of the barrier about to be arrived at)
         }
         return job_barrier(J, &s_err);
     };

@@ -1352,11 +1352,12 @@ __device__ __noinline__ void queue_phase_chunked(const Job& J, QState& q, ChunkS
             if (tid == 0) {
                 const uint32_t sg = ld_agent(&J.ctr->sub_gen) >> 1;
                 bar_local().sgen = sg;
-                J.ctr->q_cmd[1] = q.head; J.ctr->q_cmd[2] = q.tail; J.ctr->q_cmd[3] = nm;
-                J.ctr->q_cmd[4] = window; J.ctr->q_cmd[5] = mwindow;
-                J.ctr->q_cmd[6] = S.depoch;      // the master's solo drain rounds moved its mark epoch on: everybody continues from there
-                J.ctr->q_cmd[7] = K; J.ctr->q_cmd[8] = sg;
-                __hip_atomic_store(&J.ctr->q_cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned int* const cmd = J.ctr->q_cmd[bar_local().gen & 1u];      // the block of the job barrier about to be arrived at (engine_types.hpp)
+                cmd[1] = q.head; cmd[2] = q.tail; cmd[3] = nm;
+                cmd[4] = window; cmd[5] = mwindow;
+                cmd[6] = S.depoch;      // the master's solo drain rounds moved its mark epoch on: everybody continues from there
+                cmd[7] = K; cmd[8] = sg;
+                __hip_atomic_store(&cmd[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             used_team = true;
             if (job_barrier(J, s_err)) { helpers_released = true; break; }
@@ -1670,12 +1671,17 @@ __device__ __noinline__ void queue_phase_helper(const Job& J, ChunkShared& S, ui
     __syncthreads();
     for (;;) {
         if (job_barrier(J, s_err)) break;
-        if (ld_agent(&J.ctr->q_cmd[0]) == 0) break;
-        uint32_t head = ld_agent(&J.ctr->q_cmd[1]), tail = ld_agent(&J.ctr->q_cmd[2]), n = ld_agent(&J.ctr->q_cmd[3]);
-        uint32_t window = ld_agent(&J.ctr->q_cmd[4]), mwindow = ld_agent(&J.ctr->q_cmd[5]);
-        const uint32_t K = ld_agent(&J.ctr->q_cmd[7]);
+        // the command block of the barrier just passed (its generation's parity; bar_local().gen was moved on by thread 0 in front of the
+        // barrier's closing __syncthreads): the master may be writing the other block -- the next command -- already
+        const unsigned int* const cmd = J.ctr->q_cmd[(bar_local().gen - 1u) & 1u];
+        if (ld_agent(&cmd[0]) == 0) break;
+        uint32_t head = ld_agent(&cmd[1]), tail = ld_agent(&cmd[2]), n = ld_agent(&cmd[3]);
+        uint32_t window = ld_agent(&cmd[4]), mwindow = ld_agent(&cmd[5]);
+        const uint32_t K = ld_agent(&cmd[7]);
+        const uint32_t depoch = ld_agent(&cmd[6]), sgen = ld_agent(&cmd[8]);
+        __syncthreads();      // (every thread has read bar_local().gen before thread 0 can move it again)
         if (wgrank >= K) { if (threadIdx.x == 0) bar_local().lazy = 1; continue; }          // not on this chain's team: back to the job barrier (polling lazily), for the next command
-        if (threadIdx.x == 0) { S.depoch = ld_agent(&J.ctr->q_cmd[6]); bar_local().sgen = ld_agent(&J.ctr->q_cmd[8]); }
+        if (threadIdx.x == 0) { S.depoch = depoch; bar_local().sgen = sgen; }
         __syncthreads();
         ChainState st;
         st.head = head; st.tail = tail; st.window = window; st.mwindow = mwindow; st.streak = 0; st.rounds = 0; st.rows = 0;

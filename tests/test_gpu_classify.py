@@ -75,6 +75,6 @@ def test_non_unit_divisors_lane_fallback(tmp_path):
     E.classify(s)
     ms = sorted(E.classify(s)[1] for _ in range(5))[2]
     print("classify 200 000 rows with non-unit divisors: %.3f ms" % ms)
-    assert ms < 1.0, ms
+    assert ms < 1.5, ms      # (0.51 ms on MI355X: one inversion per wavefront; one divergent EGCD per lane 5.3 ms)
     g = E.solve_batch([s], device=0)[0]
     assert_bit_exact("non-unit divisors, 200 000 rows", g, orc.run(p))
