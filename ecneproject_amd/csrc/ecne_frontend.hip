@@ -1,6 +1,7 @@
 // ecne_frontend.hip — host orchestration of the device front-end (second translation unit of libecne_hip; kernels in
 // frontend.hip.hpp and abstract.hip.hpp, interface in frontend.hpp). Nothing here evaluates a propagation rule.
 #include <cstring>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -33,14 +34,60 @@ struct DeviceGuard {      // the front-end works on the device it is told to and
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+// (round 6) The front-end's SCRATCH blocks -- the parse's word / offset arrays, the layout's temporaries, the sort's workspace -- come from
+// and go back to a small per-process pool instead of hipMalloc / hipFree: a hipFree synchronises the device and unmaps (0.2-0.4 ms each for
+// blocks of hundreds of MB; three of them on the way from a file to its verdict), and the next phase asks for a block of the same order.
+// At most 8 blocks and ECNE_FE_POOL_MB (default 3 072) MB are kept; a block is handed out again only for a request of at least a quarter of
+// its size on the same device. Arrays that stay with a system (rows, layout) are never pooled.
+struct ScratchPool {
+    struct Blk { int dev; char* p; size_t cap; };
+    std::mutex mu;
+    std::vector<Blk> blocks;
+    size_t held = 0;
+    static size_t limit() { static const size_t l = []() { const char* e = std::getenv("ECNE_FE_POOL_MB"); return (size_t)(e ? std::atoll(e) : 3072) << 20; }(); return l; }
+    char* take(size_t bytes, size_t& cap_out) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].dev == dev && blocks[i].cap >= bytes && blocks[i].cap / 4 <= bytes && (best == blocks.size() || blocks[i].cap < blocks[best].cap)) best = i;
+        if (best == blocks.size()) return nullptr;
+        char* p = blocks[best].p;
+        cap_out = blocks[best].cap;
+        held -= blocks[best].cap;
+        blocks.erase(blocks.begin() + (long)best);
+        return p;
+    }
+    bool give(char* p, size_t cap) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        std::lock_guard<std::mutex> g(mu);
+        if (blocks.size() >= 8 || held + cap > limit()) return false;
+        blocks.push_back({dev, p, cap});
+        held += cap;
+        return true;
+    }
+};
+ScratchPool& scratch_pool() { static ScratchPool* p = new ScratchPool(); return *p; }      // (never destroyed: the HIP runtime may be gone at exit)
 struct DevMem {      // one allocation, carved
     char* base = nullptr;
     size_t cap = 0, off = 0;
+    bool pooled = false;
     ~DevMem() { free_now(); }
-    void free_now() { if (base) (void)hipFree(base); base = nullptr; }
-    int alloc(size_t bytes) {
+    void free_now() {
+        if (base && !(pooled && scratch_pool().give(base, cap))) (void)hipFree(base);
+        base = nullptr;
+    }
+    // scratch = true: a temporary of the front-end (pooled); false: memory whose ownership moves to a system
+    int alloc(size_t bytes, bool scratch = false) {
         cap = bytes + 256;
-        if (hipMalloc((void**)&base, cap) != hipSuccess) return K_ENODEVICE;
+        pooled = scratch;
+        if (scratch) {
+            size_t c = 0;
+            if (char* p = scratch_pool().take(cap, c)) { base = p; cap = c; }
+        }
+        if (!base && hipMalloc((void**)&base, cap) != hipSuccess) return K_ENODEVICE;
         if (std::getenv("ECNE_POISON") && hipMemset(base, 0xA5, cap) != hipSuccess) return K_ENODEVICE;      // test hook (see ecne_engine.hip)
         return K_OK;
     }
@@ -160,7 +207,7 @@ int parse_on_device(const uint8_t* file, size_t file_size, size_t cons_off, uint
     {
         size_t b = DevMem::sz((size_t)NW + 16 + head / 4, 4) + 2 * DevMem::sz(NW, 8) + DevMem::sz(ntiles, 8) + DevMem::sz(nchunks, 8) + DevMem::sz(total, 4)
                  + 2 * DevMem::sz(3 * ((size_t)nC + 1), 4) + 3 * DevMem::sz(total, 4) + DevMem::sz((size_t)nC / 1024 + 8, 4) + 4 * 256 + DevMem::sz(3 * ((size_t)nC + 1), 4);
-        const int rc = m.alloc(b);
+        const int rc = m.alloc(b, true);
         if (rc != K_OK) return rc;
     }
     uint32_t* Wbuf = m.take<uint32_t>((size_t)NW + 16 + head / 4);
@@ -256,7 +303,7 @@ int parse_on_device(const uint8_t* file, size_t file_size, size_t cons_off, uint
     if (hm.n_huge) {
         uint32_t gcap, g;
         big_tier_shape(hm.maxn, hm.n_huge, gcap, g);
-        { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
+        { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4, true); if (rc != K_OK) return rc; }
         hipLaunchKernelGGL(k_fe_fill_big<0>, dim3(g), dim3(256), 0, s, (const uint32_t*)W, (const uint32_t*)poff, (const uint32_t*)hugelist, hm.n_huge, nC,
                            (const uint32_t*)cnt, O, lenA, M, (uint32_t*)big.base, gcap, (uint32_t*)nullptr, (uint32_t*)nullptr);
     }
@@ -414,7 +461,7 @@ static int candidates_dev(const AbsRowsDev& Rm, uint64_t nC, const Rows& sub, st
     const uint64_t nb = (nC + 1 + 1023) / 1024;
     size_t bytes = DevMem::sz(nC + 1, 8) * 2 + DevMem::sz(nS, 8) + DevMem::sz(nb, 8) + DevMem::sz(nC, 4) + 256;
     for (int p = 0; p < 3; ++p) bytes += DevMem::sz(nS + 1, 8) + DevMem::sz(std::max<size_t>(sub.coef[p].size(), 1), 32);
-    { const int rc = m.alloc(bytes); if (rc != K_OK) return rc; }
+    { const int rc = m.alloc(bytes, true); if (rc != K_OK) return rc; }
     AbsRows M, S;
     M.n = nC; S.n = nS;
     for (int p = 0; p < 3; ++p) {
@@ -482,7 +529,7 @@ int candidates_for_host_rows(const Rows& rows, const Rows& sub, int device, std:
     DevMem m;
     size_t bytes = 256;
     for (int p = 0; p < 3; ++p) bytes += DevMem::sz(nC + 1, 8) + DevMem::sz(std::max<size_t>(rows.coef[p].size(), 1), 32);
-    { const int rc = m.alloc(bytes); if (rc != K_OK) return rc; }
+    { const int rc = m.alloc(bytes, true); if (rc != K_OK) return rc; }
     AbsRowsDev R;
     const auto t_up = std::chrono::steady_clock::now();
     for (int p = 0; p < 3; ++p) {
@@ -526,7 +573,7 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
         size_t pb = 4096;
         pb += DevMem::sz(PH.nEnt + 1, 4) * 2 + DevMem::sz(4ull * PH.nEnt + 4, 8) + DevMem::sz(3ull * PH.nS + 1, 4) + DevMem::sz(PH.capP, 8) * 2 + DevMem::sz(PH.capP, 4)
             + DevMem::sz(PH.nclass + 2, 4) + DevMem::sz(PH.nvS + 1, 4) + DevMem::sz(PH.nio + 1, 4);
-        { const int rc = pm.alloc(pb); if (rc != K_OK) return rc; }
+        { const int rc = pm.alloc(pb, true); if (rc != K_OK) return rc; }
         AbsPattern P;
         P.nS = PH.nS; P.nvS = PH.nvS; P.nEnt = PH.nEnt; P.nclass = PH.nclass; P.capP = PH.capP; P.nio = PH.nio;
         int rc = K_OK;
@@ -543,7 +590,7 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
         {
             const size_t wb = DevMem::sz(batch, 4) * 4 + DevMem::sz(batch * capW, 8) * 3 + DevMem::sz(batch * std::max<uint32_t>(PH.nclass, 1), 4) + DevMem::sz(batch * std::max<uint32_t>(PH.nvS, 1), 4) +
                               DevMem::sz(batch * std::max<uint32_t>(PH.nio, 1), 4) + 4096;
-            const int rc2 = wm.alloc(wb);
+            const int rc2 = wm.alloc(wb, true);
             if (rc2 != K_OK) return rc2;
         }
         AbsWindows Wn;
@@ -659,7 +706,7 @@ int abstract_on_device(const std::string& name, const std::shared_ptr<DevRows>& 
         const uint32_t nk = (uint32_t)ka.size();
         const uint64_t nrow = row0.back();
         DevMem km;
-        { const int rc = km.alloc(DevMem::sz(nk + 1, 8) * 16 + 4096); if (rc != K_OK) return rc; }
+        { const int rc = km.alloc(DevMem::sz(nk + 1, 8) * 16 + 4096, true); if (rc != K_OK) return rc; }
         KeepRanges K;
         K.n = nk;
         const uint64_t *d_a, *d_b, *d_row0;
@@ -734,7 +781,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         const size_t b = DevMem::sz(3 * ((size_t)nC + 1), 4) + DevMem::sz(3 * (size_t)std::max<uint32_t>(nC, 1), sizeof(PartSum)) + 3 * DevMem::sz(3ull * nC + 1, 4) +
                          5 * DevMem::sz((size_t)nC + 2, 4) + DevMem::sz((size_t)nC + 1, 1) + 2 * DevMem::sz(tall + 1, 8) + DevMem::sz(tall + 2, 4) + 8192 +
                          DevMem::sz((size_t)std::max<uint64_t>(tall, (uint64_t)nC) / 1024 + 16, 4);
-        const int rc = tm.alloc(b);
+        const int rc = tm.alloc(b, true);
         if (rc != K_OK) return rc;
     }
     uint32_t* nzc = tm.take<uint32_t>(3 * ((size_t)nC + 1));
@@ -823,7 +870,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         if (hm.n_huge) {
             uint32_t gcap, g;
             big_tier_shape(hm.maxn, hm.n_huge, gcap, g);
-            { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4); if (rc != K_OK) return rc; }
+            { const int rc = big.alloc((size_t)g * 4 * 4 * gcap * 4, true); if (rc != K_OK) return rc; }
             hipLaunchKernelGGL(k_lay_order_big<0>, dim3(g), dim3(256), 0, s, R, nC, (const uint32_t*)nzc, L, sum, Dst.nontrivial, (const uint32_t*)hugelist, hm.n_huge, M,
                                (uint32_t*)big.base, gcap, (uint32_t*)nullptr, (uint32_t*)nullptr);
         }
@@ -852,7 +899,7 @@ int layout_on_device(const DevRows& D, uint32_t n_vars, uint32_t min_nv, std::un
         while (vbits < 32 && (C.nVall >> vbits)) ++vbits;
         size_t sb = 0;
         FE_TRY(rocprim::radix_sort_keys(nullptr, sb, pairs, pairs2, (size_t)npairs, 0u, 32u + vbits, s));
-        { const int rc = sortm.alloc(sb + 256); if (rc != K_OK) return rc; }
+        { const int rc = sortm.alloc(sb + 256, true); if (rc != K_OK) return rc; }
         FE_TRY(rocprim::radix_sort_keys((void*)sortm.base, sb, pairs, pairs2, (size_t)npairs, 0u, 32u + vbits, s));
         tick("pairs + radix sort");
         FE_TRY(hipMemsetAsync(f_uniq + npairs, 0, 8, s));
@@ -935,7 +982,7 @@ int bad_rows(int device, const Job& J, std::vector<int64_t>& out) {
     DeviceGuard guard(device);
     if (!guard.ok) return K_ENODEVICE;
     DevMem m;
-    { const int rc = m.alloc(DevMem::sz((size_t)J.nC + 2, 4) * 2 + DevMem::sz((size_t)J.nC / 1024 + 16, 4) + 1024); if (rc != K_OK) return rc; }
+    { const int rc = m.alloc(DevMem::sz((size_t)J.nC + 2, 4) * 2 + DevMem::sz((size_t)J.nC / 1024 + 16, 4) + 1024, true); if (rc != K_OK) return rc; }
     uint32_t* f = m.take<uint32_t>((size_t)J.nC + 2);
     uint32_t* list = m.take<uint32_t>((size_t)J.nC + 2);
     uint32_t* tops = m.take<uint32_t>((size_t)J.nC / 1024 + 16);

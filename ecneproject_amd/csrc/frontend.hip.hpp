@@ -52,8 +52,13 @@ template <> struct FeTabPtr<true> { typedef FeLdsPtr type; };
 template <int TIER> struct FeTier {
     static constexpr uint32_t cap = TIER == 1 ? FE_MID_CAP : TIER == 2 ? FE_LARGE_CAP : 0u;
     static constexpr uint32_t waves = TIER == 1 ? FE_MID_WAVES : TIER == 2 ? 1u : 4u;
-    static constexpr uint32_t lds_bytes = waves * 4u * cap * 4u;
+    // (round 6) per wavefront: the four table arrays, then the staged insertions (key, hash, payload) and the list a growth re-inserts from
+    // (key, payload + 1, hash) -- fe_wave_table; `stage` entries each (the most keys a part of the tier holds, rounded up)
+    static constexpr uint32_t stage = TIER == 1 ? 192u : TIER == 2 ? 2752u : 0u;
+    static constexpr uint32_t words = 4u * cap + 6u * stage;
+    static constexpr uint32_t lds_bytes = waves * words * 4u;
 };
+static_assert(FeTier<1>::stage >= FE_MID_MAX + 1 && FeTier<2>::stage >= FE_LARGE_MAX + 1, "staging holds every key of a part of the tier");
 
 __device__ __forceinline__ uint64_t ld64_agent(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -221,6 +226,79 @@ __device__ __forceinline__ fp::u256 fe_ld_coef(const uint32_t* __restrict__ W, u
     return fp::reduce(v);
 }
 
+// ---- the Julia hash table of a long part, built by the whole wavefront (round 6). The slot a key ends up in depends on the insertions before it
+// (linear probing, growth re-inserts in slot order), so the insertions stay one after the other on lane 0 -- but everything around them does not:
+// the keys and their hashes are staged in LDS by all lanes (lane 0's loop was one dependent global load and one 64-bit hash chain per key), a
+// growth zeroes the new table, collects the old slots in order and hashes their keys with all lanes, and lane 0 only walks the probes.
+// 1 025 keys: 0.95 ms -> ~0.2 ms per part (k_fe_fill_big<2> / k_lay_order_big<2>, the 208 long parts of ecdsa_like(26), one wavefront each).
+// t: the table (LDS pointers; the same value in every lane on entry and on return). st_key / st_hash / st_pay: n staged insertions in order
+// (payload = what tab_upsert stores + 1 later). gl_*: scratch for a growth (>= the keys the table holds). Returns nonzero when the table would
+// outgrow t.cap (the caller hands the part to the next tier).
+template <int ADD>
+__device__ __forceinline__ uint32_t fe_wave_table(jlslot::TabT<FeLdsPtr>& t, uint32_t n, FeLdsPtr st_key, FeLdsPtr st_hash, FeLdsPtr st_pay,
+                                                  FeLdsPtr gl_key, FeLdsPtr gl_pay, FeLdsPtr gl_hash) {
+    const int lane = lane_id();
+    for (uint32_t i = lane; i < 16; i += 64) t.pay[i] = 0;
+    t.sz = 16; t.n = 0; t.maxprobe = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    uint32_t k = 0;
+    while (k < n) {
+        // lane 0: insertions from k on, until the table has to grow
+        uint32_t rc = 0, want = 0;
+        if (lane == 0) {
+            uint64_t w64 = 0;
+            while (k < n) {
+                rc = (uint32_t)jlslot::tab_try_upsert(t, st_key[k], st_pay[k], st_hash[k], &w64);
+                if (rc != 1) ++k;
+                if (rc) break;
+            }
+            want = (uint32_t)(w64 > 0x80000000ull ? 0x80000000ull : w64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        k = __shfl(k, 0, 64); rc = __shfl(rc, 0, 64); want = __shfl(want, 0, 64);
+        t.n = __shfl(t.n, 0, 64); t.maxprobe = __shfl(t.maxprobe, 0, 64);
+        if (!rc) break;
+        // ---- growth (tab_grow, by the wavefront): new size, zero the other buffer, the old slots in ascending order with their hashes
+        uint32_t nsz = 16;
+        while (nsz < want) nsz <<= 1;
+        if (nsz > t.cap || want > t.cap) return 1u;
+        for (uint32_t i = lane; i < nsz; i += 64) t.pay2[i] = 0;
+        uint32_t cnt = 0;
+        for (uint32_t s0 = 0; s0 < t.sz; s0 += 64) {
+            const uint32_t sl = s0 + lane;
+            const uint32_t py = sl < t.sz ? t.pay[sl] : 0u;
+            const uint64_t m = __ballot(py != 0);
+            if (py) {
+                const uint32_t o = cnt + (uint32_t)__popcll(m & lanes_below());
+                const uint32_t ky = t.key[sl];
+                gl_key[o] = ky; gl_pay[o] = py; gl_hash[o] = (uint32_t)jlslot::hash64((uint64_t)ky + (uint64_t)ADD);
+            }
+            cnt += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        uint32_t mp = 0;
+        if (lane == 0) {
+            const uint32_t mask = nsz - 1;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t home = gl_hash[i] & mask;
+                uint32_t idx = home;
+                while (t.pay2[idx]) idx = (idx + 1) & mask;
+                const uint32_t probe = (idx - home) & mask;
+                if (probe > mp) mp = probe;
+                t.pay2[idx] = gl_pay[i];
+                t.key2[idx] = gl_key[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        mp = __shfl(mp, 0, 64);
+        FeLdsPtr a = t.key; t.key = t.key2; t.key2 = a;
+        a = t.pay; t.pay = t.pay2; t.pay2 = a;
+        t.sz = nsz;
+        t.maxprobe = mp;
+    }
+    return 0u;
+}
+
 // cnt[p * (nC + 1) + r] = entries part p of row r will hold at most (an empty part becomes {1 => 0}, :113-115)
 __global__ __launch_bounds__(256) void k_fe_terms(const uint32_t* __restrict__ W, const uint32_t* __restrict__ poff, uint32_t total, uint32_t nC,
                                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ midlist, uint32_t* __restrict__ largelist,
@@ -320,7 +398,7 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const 
     uint32_t* const s_tab = reinterpret_cast<uint32_t*>(ecne_dyn_lds);
     const int lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
-    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FeTier<TIER>::cap : gscratch + (size_t)gw * 4 * gcap;
+    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * FeTier<TIER>::words : gscratch + (size_t)gw * 4 * gcap;
     const uint32_t cap = LDS_TABLES ? FeTier<TIER>::cap : gcap;
     for (uint32_t b = gw; b < nlist; b += nw) {
         const uint32_t i = list[b];
@@ -329,6 +407,22 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const 
         const uint32_t r = i / 3u, p = i - 3u * r;
         const uint32_t at = pos[(size_t)p * (nC + 1) + r];
         uint32_t sz = 0, flipped = 0, bad = 0;
+        if constexpr (LDS_TABLES) {
+            // (round 6) keys and hashes staged by all lanes, the table built by fe_wave_table
+            const FeLdsPtr tb = (FeLdsPtr)base;
+            const FeLdsPtr st = tb + 4 * FeTier<TIER>::cap;
+            constexpr uint32_t SG = FeTier<TIER>::stage;
+            for (uint32_t k = lane; k < n; k += 64) {
+                const uint32_t ky = W[j + 1 + 9ull * k];
+                st[k] = ky; st[SG + k] = (uint32_t)jlslot::hash64((uint64_t)ky + 1ull); st[2 * SG + k] = k;
+            }
+            jlslot::TabT<FeLdsPtr> t;
+            t.key = tb; t.pay = tb + cap; t.key2 = tb + 2 * cap; t.pay2 = tb + 3 * cap;
+            t.cap = cap; t.stride = 1;
+            bad = n > SG ? 1u : fe_wave_table<1>(t, n, st, st + SG, st + 2 * SG, st + 3 * SG, st + 4 * SG, st + 5 * SG);
+            sz = t.sz;
+            flipped = t.key != tb;
+        } else {
         if (lane == 0) {
             typedef typename FeTabPtr<LDS_TABLES>::type TP;
             const TP tb = (TP)base;
@@ -342,6 +436,7 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const 
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
+        }
         if (bad) {      // the table outgrew this tier: hand the part to the next one, or give the file back to the host path
             if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(overflow_count, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
             continue;
@@ -605,15 +700,37 @@ __global__ __launch_bounds__(256) void k_lay_count(AbsRowsDev R, uint32_t nC, ui
     if (threadIdx.x == 3) { s_mv = 0; s_mc = 0; s_mn = 0; }
     __syncthreads();
     uint32_t mv = 0, mc = 0, mn = 0, nz3[3] = {0, 0, 0};
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < 3u * nC; i += gridDim.x * 256u) {
-        const uint32_t r = i / 3u, p = i - 3u * r;
+    for (uint32_t i0 = blockIdx.x * 256u + (threadIdx.x & ~63u); i0 < 3u * nC; i0 += gridDim.x * 256u) {      // (uniform per wavefront: shuffles inside)
+        const uint32_t i = i0 + (threadIdx.x & 63u);
+        const bool on = i < 3u * nC;
+        const uint32_t r = on ? i / 3u : 0u, p = on ? i - 3u * r : 0u;
         uint32_t nz = 0;
-        for (uint64_t k = R.ptr[p][r]; k < R.ptr[p][r + 1]; ++k) {
+        const uint64_t ka = on ? R.ptr[p][r] : 0ull, kz = on ? R.ptr[p][r + 1] : 0ull;
+        const bool longp = kz - ka > 48;      // (round 6) a long part is walked by the whole wavefront, not by its lane: 1 025 entries one after the other were 0.5 ms
+        if (!longp)
+        for (uint64_t k = ka; k < kz; ++k) {
             const uint32_t v = R.var[p][k];
             mv = v > mv ? v : mv;
             const uint64_t* c = R.coef[p] + 4 * k;
             nz += (c[0] | c[1] | c[2] | c[3]) != 0;
         }
+        for (uint64_t lm = __ballot(longp); lm; lm &= lm - 1) {      // (the lanes of a wavefront that are in the loop at all reach this together: i advances by the same stride)
+            const int src = __ffsll((long long)lm) - 1;
+            const uint32_t pp = (uint32_t)__shfl((int)p, src, 64);
+            const uint64_t a0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ka >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)ka, src, 64);
+            const uint64_t a1 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kz >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)kz, src, 64);
+            uint32_t z = 0;
+            for (uint64_t k = a0 + (threadIdx.x & 63u); k < a1; k += 64) {
+                const uint32_t v = R.var[pp][k];
+                mv = v > mv ? v : mv;
+                const uint64_t* c = R.coef[pp] + 4 * k;
+                z += (c[0] | c[1] | c[2] | c[3]) != 0;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) z += __shfl_xor(z, d, 64);
+            if ((int)(threadIdx.x & 63u) == src) nz = z;
+        }
+        if (!on) continue;
         nzc[(size_t)p * (nC + 1) + r] = nz;
         if (nz > FE_LARGE_MAX) hugelist[atomicAdd(&M->n_huge, 1u)] = i;
         else if (nz > FE_MID_MAX) largelist[atomicAdd(&M->n_large, 1u)] = i;
@@ -710,7 +827,7 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
     uint32_t* const s_tab = reinterpret_cast<uint32_t*>(ecne_dyn_lds);
     const int lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6, gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
-    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * 4 * FeTier<TIER>::cap : gscratch + (size_t)gw * 4 * gcap;
+    uint32_t* base = LDS_TABLES ? s_tab + (size_t)wave * FeTier<TIER>::words : gscratch + (size_t)gw * 4 * gcap;
     const uint32_t cap = LDS_TABLES ? FeTier<TIER>::cap : gcap;
     for (uint32_t b = gw; b < nlist; b += nw) {
         const uint32_t i = list[b];
@@ -724,6 +841,28 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
         jlslot::TabT<TP> t;
         t.key = tb; t.pay = tb + cap; t.key2 = tb + 2 * cap; t.pay2 = tb + 3 * cap;
         t.cap = cap; t.stride = 1;
+        if constexpr (LDS_TABLES) {
+            // (round 6) the non-zero entries staged in order (variable, hash, position) by all lanes, the table built by fe_wave_table
+            const FeLdsPtr st = (FeLdsPtr)base + 4 * FeTier<TIER>::cap;
+            constexpr uint32_t SG = FeTier<TIER>::stage;
+            uint32_t cnt = 0;
+            for (uint64_t kb = k0; kb < k1; kb += 64) {
+                const uint64_t k = kb + lane;
+                bool nzq = false;
+                uint32_t v = 0;
+                if (k < k1) {
+                    v = R.var[p][k];
+                    const uint64_t* c = R.coef[p] + 4 * k;
+                    nzq = (c[0] | c[1] | c[2] | c[3]) != 0;
+                }
+                if (__ballot(k < k1 && v == 1u)) haskey1 = 1;
+                const uint64_t mask = __ballot(nzq);
+                const uint32_t o = cnt + (uint32_t)__popcll(mask & lanes_below());
+                if (nzq && o < SG) { st[o] = v; st[SG + o] = (uint32_t)jlslot::hash64((uint64_t)v); st[2 * SG + o] = (uint32_t)(k - k0); }
+                cnt += (uint32_t)__popcll(mask);
+            }
+            bad = cnt > SG ? 1u : fe_wave_table<0>(t, cnt, st, st + SG, st + 2 * SG, st + 3 * SG, st + 4 * SG, st + 5 * SG);
+        } else {
         if (lane == 0) jlslot::tab_init(t);
         // all lanes look at 64 dictionary entries at a time (non-zero? key 1?), lane 0 inserts the non-zero ones in order
         for (uint64_t kb = k0; kb < k1; kb += 64) {
@@ -743,6 +882,7 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
                 const uint32_t vv = __shfl(v, src, 64);
                 if (lane == 0 && !bad) bad = jlslot::tab_upsert<0>(t, vv, (uint32_t)(kb + src - k0)) != 0;
             }
+        }
         }
         if (lane == 0) { sz = t.sz; flipped = t.key != tb; }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

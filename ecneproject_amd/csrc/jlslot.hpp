@@ -116,6 +116,37 @@ JLQ int tab_upsert(TabT<P>& t, uint32_t skey, uint32_t payload) {
     }
 }
 
+// tab_upsert with the key's hash at hand (its low 32 bits: a table has at most 2^31 slots) and WITHOUT the growth: 0 = done, 1 = nothing
+// stored, grow to *want slots and call again with the same key, 2 = stored, then grow to *want. The device front-end's long parts grow their
+// tables with the whole wavefront (frontend.hip.hpp, fe_wave_table): same table as tab_upsert's, slot for slot.
+template <class P>
+JLQ int tab_try_upsert(TabT<P>& t, uint32_t skey, uint32_t payload, uint32_t h32, uint64_t* want) {
+    const uint32_t st = t.stride;
+    const uint32_t sz = t.sz, mask = sz - 1;
+    uint32_t idx = h32 & mask, it = 0;
+    bool found_empty = false;
+    for (;;) {
+        if (!t.pay[idx * st]) { found_empty = true; break; }
+        if (t.key[idx * st] == skey) { t.pay[idx * st] = payload + 1; return 0; }
+        idx = (idx + 1) & mask;
+        if (++it > t.maxprobe) break;
+    }
+    if (!found_empty) {
+        const uint32_t lim = (sz >> 6) > 16 ? (sz >> 6) : 16;
+        while (it < lim) {
+            if (!t.pay[idx * st]) { found_empty = true; t.maxprobe = it; break; }
+            idx = (idx + 1) & mask;
+            ++it;
+        }
+    }
+    if (!found_empty) { *want = t.n > 64000 ? (uint64_t)sz * 2 : (uint64_t)sz * 4; return 1; }
+    t.key[idx * st] = skey;
+    t.pay[idx * st] = payload + 1;
+    ++t.n;
+    if ((uint64_t)t.n * 3 > (uint64_t)sz * 2) { *want = t.n > 64000 ? (uint64_t)t.n * 2 : (uint64_t)t.n * 4; return 2; }
+    return 0;
+}
+
 // Which of two DIFFERENT keys comes first when a fresh table that holds just the two is iterated (`for j in Set([k1, k2])`,
 // R1CSConstraintSolver.jl:1130, :1216): 16 slots, k1 inserted first.
 JLQ bool pair_second_first(uint32_t k1, uint32_t k2) {

@@ -789,9 +789,13 @@ __device__ __forceinline__ uint32_t multi_chain_next(const Job& J, uint32_t head
     const uint32_t n = avail < window ? avail : window;
     if (drain_eager(J)) { if (avail < 2) return 0; }
     else if (n <= 64 || avail < multi_min(J) || window < multi_window_min(J)) return 0;
+    // (round 6: from STATIC data only. Every member of the team derives the chain's next step by itself behind the round's last barrier, and
+    //  the master, once it has decided that the chain is over, goes on alone at once -- popping this very row. The test used to read
+    //  J.solved[row0] as well: a member held up behind the barrier could then see the row solved by the master's pop and derive one more
+    //  round that nobody else runs. A solved long row at the head now ends the chain too; the master pops it for nothing and commands the next one.)
     const uint32_t row0 = J.queue[head & J.qmask];
     const uint32_t shape0 = J.rinfo[row0].shape;
-    if ((shape0 & SH_BIG) && !J.solved[row0] && !big_plain(shape0)) return 0;   // a long row that is popped alone
+    if ((shape0 & SH_BIG) && !big_plain(shape0)) return 0;   // a long row that is popped alone
     const uint32_t cap_n = multi_cap(J);
     uint32_t nm = avail < cap_n ? avail : cap_n;
     if (nm > mwindow) nm = mwindow;

@@ -31,6 +31,52 @@ static int one(std::mt19937_64& rng, size_t n, uint64_t keyspace, uint32_t strid
     return 0;
 }
 
+// tab_try_upsert + a growth that re-inserts from a LIST of the old slots (in ascending slot order, hashes precomputed) -- the way the device
+// front-end's wavefront builder does it (frontend.hip.hpp, fe_wave_table) -- against tab_upsert: the same table, slot for slot, buffers and all.
+template <int ADD>
+static int two(std::mt19937_64& rng, size_t n, uint64_t keyspace) {
+    std::vector<uint32_t> keys(n);
+    for (auto& k : keys) k = (uint32_t)(rng() % keyspace);
+    uint32_t cap = 16;
+    while (cap < 8 * n + 64) cap <<= 1;
+    std::vector<uint32_t> a(cap), b(cap), c(cap), d(cap), a2(cap), b2(cap), c2(cap), d2(cap);
+    jlslot::Tab t{a.data(), b.data(), c.data(), d.data(), cap, 1, 0, 0, 0};
+    jlslot::tab_init(t);
+    for (size_t i = 0; i < n; ++i) if (jlslot::tab_upsert<ADD>(t, keys[i], (uint32_t)i)) return 1;
+    jlslot::Tab u{a2.data(), b2.data(), c2.data(), d2.data(), cap, 1, 0, 0, 0};
+    jlslot::tab_init(u);
+    std::vector<uint32_t> lk, lp, lh;
+    size_t k = 0;
+    while (k < n) {
+        uint64_t want = 0;
+        const int rc = jlslot::tab_try_upsert(u, keys[k], (uint32_t)k, (uint32_t)jlslot::hash64((uint64_t)keys[k] + ADD), &want);
+        if (rc != 1) ++k;
+        if (!rc) continue;
+        uint32_t nsz = 16;
+        while (nsz < want) nsz <<= 1;
+        if (nsz > cap) return 1;
+        for (uint32_t i = 0; i < nsz; ++i) u.pay2[i] = 0;
+        lk.clear(); lp.clear(); lh.clear();
+        for (uint32_t sl = 0; sl < u.sz; ++sl) if (u.pay[sl]) { lk.push_back(u.key[sl]); lp.push_back(u.pay[sl]); lh.push_back((uint32_t)jlslot::hash64((uint64_t)u.key[sl] + ADD)); }
+        uint32_t mp = 0;
+        const uint32_t mask = nsz - 1;
+        for (size_t i = 0; i < lk.size(); ++i) {
+            const uint32_t home = lh[i] & mask;
+            uint32_t idx = home;
+            while (u.pay2[idx]) idx = (idx + 1) & mask;
+            const uint32_t probe = (idx - home) & mask;
+            if (probe > mp) mp = probe;
+            u.pay2[idx] = lp[i]; u.key2[idx] = lk[i];
+        }
+        std::swap(u.key, u.key2); std::swap(u.pay, u.pay2);
+        u.sz = nsz; u.maxprobe = mp;
+    }
+    if (t.sz != u.sz || t.n != u.n || t.maxprobe != u.maxprobe) { std::printf("TRY MISMATCH shape n=%zu\n", n); return 1; }
+    for (uint32_t sl = 0; sl < t.sz; ++sl)
+        if (t.pay[sl] != u.pay[sl] || (t.pay[sl] && t.key[sl] != u.key[sl])) { std::printf("TRY MISMATCH slot %u n=%zu\n", sl, n); return 1; }
+    return 0;
+}
+
 int main() {
     std::mt19937_64 rng(12345);
     int bad = 0;
@@ -40,6 +86,13 @@ int main() {
         const uint64_t ks = rep % 3 == 0 ? 16 + rng() % 64 : rep % 3 == 1 ? 1 + rng() % 100000 : 4000000000ull;
         bad += one<0>(rng, n, ks, 1 + rep % 3);
         bad += one<1>(rng, n, ks, 1 + rep % 3);
+        cases += 2;
+    }
+    for (int rep = 0; rep < 3000; ++rep) {
+        const size_t n = 1 + rng() % (rep % 20 == 0 ? 3000 : rep % 5 == 0 ? 200 : 40);
+        const uint64_t ks = rep % 3 == 0 ? 16 + rng() % 64 : rep % 3 == 1 ? 1 + rng() % 100000 : 4000000000ull;
+        bad += two<0>(rng, n, ks);
+        bad += two<1>(rng, n, ks);
         cases += 2;
     }
     for (size_t n : {64001u, 70000u, 130000u}) { bad += one<0>(rng, n, 1u << 30, 1); bad += one<1>(rng, n, 50000, 1); cases += 2; }
