@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 def _repro(args, seed, env=None):
     e = dict(os.environ, ECNE_LIB="libecne_hip_jitter.so", ECNE_JITTER_SEED=str(seed), PYTHONPATH=ROOT)
     e.update(env or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "jitter_repro.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "jitter_repro.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     m = re.search(r"(\d+) tries x (\d+) systems, (\d+) differing", out.stdout)
     assert m, out.stdout[-2000:]

@@ -1,9 +1,9 @@
 """Developer aid (GPU box, -DECNE_JITTER library): one fuzz system solved again and again on a forced team under changing jitter seeds until a
 solve differs from the oracle (an ECNE_ETIMEOUT is a barrier that did not complete: the device prints which one).
-    ECNE_LIB=libecne_hip_jitter.so [ECNE_DRAIN=2] python tools/jitter_repro.py <seed> <scale> <nwg> [tries] [neighbours]"""
+    ECNE_LIB=libecne_hip_jitter.so [ECNE_DRAIN=2] python tests/tools/jitter_repro.py <seed> <scale> <nwg> [tries] [neighbours]"""
 import os, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, os.path.dirname(HERE))
 import ecneproject_amd as E, fuzz_r1cs, orc
 
 seed, scale, nwg = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
