@@ -1071,7 +1071,15 @@ __device__ __forceinline__ void k_solve_body(const Job* jobs, const WgDesc* wgs)
     }
 }
 
+#ifdef ECNE_TEAM_WAVES_PER_EU
+__global__ __launch_bounds__(ECNE_WG) __attribute__((amdgpu_waves_per_eu(ECNE_TEAM_WAVES_PER_EU, ECNE_TEAM_WAVES_PER_EU))) void k_solve(const Job* jobs, const WgDesc* wgs) { k_solve_body<false>(jobs, wgs); }
+#else
 __global__ __launch_bounds__(ECNE_WG) void k_solve(const Job* jobs, const WgDesc* wgs) { k_solve_body<false>(jobs, wgs); }
+#endif
+#ifdef ECNE_TEAM_WAVES_PER_EU      // (experiment, docs/LAB.md round 6: the team kernel at 128 VGPRs = two workgroups per CU)
+__global__ __launch_bounds__(ECNE_WG) __attribute__((amdgpu_waves_per_eu(ECNE_TEAM_WAVES_PER_EU, ECNE_TEAM_WAVES_PER_EU))) void k_solve_team(const Job* jobs, const WgDesc* wgs) { k_solve_body<true>(jobs, wgs); }
+#else
 __global__ __launch_bounds__(ECNE_WG) void k_solve_team(const Job* jobs, const WgDesc* wgs) { k_solve_body<true>(jobs, wgs); }
+#endif
 
 }  // namespace ecne
