@@ -81,17 +81,19 @@ def schedule_env():
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("ECNE_") and k not in skip}
 
 
-# DESIGN.md section 6, the table of predicted ms per step at N = 1, 2, 4, 8 GPUs (LPT packing of the measured single-job times of one MI355X;
-# a batch takes as long as its longest job). `bench.py --gpus N` prints measured next to predicted so that the first run on an 8-GPU node
-# grades the model by itself. "ecdsa": one circuit does not shard -- replicas, the time per step stays, the rate grows N-fold.
-DESIGN_PREDICTED_MS = {
-    "ecdsa": {1: 5.6, 2: 5.6, 4: 5.6, 8: 5.6},
-    "suite": {1: 10.6, 2: 10.2, 4: 10.2, 8: 10.2},
-    "dag": {1: 7.2, 2: 6.0, 4: 6.0, 8: 6.0},
-    "many": {1: 2.1, 2: 1.5, 4: 1.3, 8: 1.25},
-    "secp": {1: 6.0, 2: 6.0, 4: 6.0, 8: 6.0},
-    "poseidon": {1: 1.12, 2: 1.12, 4: 1.12, 8: 1.12},
-}
+# DESIGN.md section 6's prediction of ms per step at N = 1, 2, 4, 8 GPUs (LPT packing of the measured single-job times of one MI355X; a batch takes as
+# long as its longest job) lives in ONE place, profiles/predicted_scaling.json; `bench.py --gpus N` prints measured next to predicted so that the first
+# run on an 8-GPU node grades the model by itself. "ecdsa": one circuit does not shard -- one instance per rank, the time per step stays.
+def _predicted_table():
+    try:
+        with open(os.path.join(HERE, "profiles", "predicted_scaling.json")) as f:
+            t = json.load(f)
+        return {w: {int(n): ms for n, ms in row.items()} for w, row in t["ms_per_step"].items()}, t.get("source", "")
+    except Exception:      # noqa: BLE001  (no table: the check prints measured values only)
+        return {}, "profiles/predicted_scaling.json missing"
+
+
+DESIGN_PREDICTED_MS, DESIGN_PREDICTED_SOURCE = _predicted_table()
 
 
 def scaling_check(workload, world, ms_per_step, rank_ms, extra=None):
@@ -103,7 +105,7 @@ def scaling_check(workload, world, ms_per_step, rank_ms, extra=None):
            "rank_ms_per_step": [round(x, 3) for x in rank_ms],
            "slowest_over_mean_rank": round(max(rank_ms) / max(sum(rank_ms) / len(rank_ms), 1e-9), 3) if rank_ms else None,
            "predicted_table_ms": {str(k): v for k, v in sorted(pred.items())},
-           "source": "DESIGN.md section 6 (single-GPU measurements of round 5 + LPT packing; no multi-GPU run behind it until a SCALE file exists)"}
+           "source": "profiles/predicted_scaling.json = DESIGN.md section 6 (%s; no multi-GPU run behind it until a SCALE file exists)" % DESIGN_PREDICTED_SOURCE}
     if extra:
         out.update(extra)
     return out
