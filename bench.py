@@ -587,7 +587,8 @@ def main():
                          "multi_ms": {k: round(v, 3) for k, v in zip(["mark", "check_and_cut", "exec_and_scan", "expand", "count_and_scan", "write"], list(s.multi_ms)[:6])},
                          "note": ("fixed point is dependency-depth bound; see DESIGN.md. `frac` is an accounting of the reference's work, not of this kernel's traffic: the formula credits "
                                   "%d full sweeps of the system (3 per outer iteration + 1), the engine performs 3 (26 of 28 iterations at S = 26 are finished from the popped rows "
-                                  "alone); the counters say %s of the HBM peak -- the kernel is latency-bound at every size, S = 104 included") %
+                                  "alone); the counters say %s of the HBM peak -- the kernel is latency-bound at every size, S = 104 included. A `frac` above 1 (S = 416: 1 255 credited "
+                                  "sweeps of 17.6 M rows) only says that the engine does not perform the work the formula credits") %
                                  (3 * int(s.outer_iterations) + 1, ("%.1f %%" % (100.0 * traffic / (k_ms * 1e-3) / 1e9 / 8000.0)) if traffic else "(no PMC passes on file for this build)")},
         }
         if job_lines is not None:

@@ -556,23 +556,37 @@ __global__ __launch_bounds__(256) void k_abs_sig(AbsRowsDev R, AbsPattern P, Abs
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     uint64_t one1 = 0, one2 = 0;
     uint32_t one_n = 0;
-    if (q < 3u * P.nS) {
-        const uint32_t jrow = q / 3u, p = q - 3u * jrow;
-        const uint64_t row = (uint64_t)Wn.start[w] + jrow;
-        const uint64_t k0 = R.ptr[p][row], k1 = R.ptr[p][row + 1];
-        uint32_t nz = 0;
-        for (uint64_t k = k0; k < k1; ++k) {
-            const uint64_t* c = R.coef[p] + 4 * k;
-            if ((c[0] | c[1] | c[2] | c[3]) == 0) continue;
-            ++nz;
-            uint64_t h1, h2;
-            sig_hash((uint64_t)q + 1ull, c, h1, h2);
-            const uint32_t v = R.var[p][k];
-            if (v == 1u) { one1 += h1; one2 += h2; ++one_n; }
-            else abs_sig_add(Wn, P, w, (unsigned long long)v + 1ull, h1, h2);
-        }
-        if (nz != P.part_nz[q]) atomicOr(&Wn.status[w], 1u);
+    // (round 6) a long part -- a window of secp256k1 holds 87-term decompositions -- is walked by the whole wavefront (the sums are commutative),
+    // not by its one lane while the other 63 wait
+    const bool on = q < 3u * P.nS;
+    const uint32_t jrow = on ? q / 3u : 0u, p = on ? q - 3u * jrow : 0u;
+    const uint64_t row = (uint64_t)Wn.start[w] + jrow;
+    const uint64_t k0 = on ? R.ptr[p][row] : 0ull, k1 = on ? R.ptr[p][row + 1] : 0ull;
+    const bool longp = k1 - k0 > 32;
+    uint32_t nz = 0;
+    auto entry = [&](uint32_t pp, uint64_t k, uint64_t qq) {
+        const uint64_t* c = R.coef[pp] + 4 * k;
+        if ((c[0] | c[1] | c[2] | c[3]) == 0) return 0u;
+        uint64_t h1, h2;
+        sig_hash(qq + 1ull, c, h1, h2);
+        const uint32_t v = R.var[pp][k];
+        if (v == 1u) { one1 += h1; one2 += h2; ++one_n; }
+        else abs_sig_add(Wn, P, w, (unsigned long long)v + 1ull, h1, h2);
+        return 1u;
+    };
+    if (on && !longp) for (uint64_t k = k0; k < k1; ++k) nz += entry(p, k, (uint64_t)q);
+    for (uint64_t lm = __ballot(longp); lm; lm &= lm - 1) {
+        const int src = __ffsll((long long)lm) - 1;
+        const uint32_t pp = (uint32_t)__shfl((int)p, src, 64), qq = (uint32_t)__shfl((int)q, src, 64);
+        const uint64_t a0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k0 >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)k0, src, 64);
+        const uint64_t a1 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k1 >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)k1, src, 64);
+        uint32_t z = 0;
+        for (uint64_t k = a0 + (uint32_t)lane_id(); k < a1; k += 64) z += entry(pp, k, (uint64_t)qq);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) z += __shfl_xor(z, d, 64);
+        if (lane_id() == src) nz = z;
     }
+    if (on && nz != P.part_nz[q]) atomicOr(&Wn.status[w], 1u);
     const uint64_t any = __ballot(one_n != 0);
     if (any) {
         one1 = wave_sum64(one1); one2 = wave_sum64(one2);

@@ -96,6 +96,19 @@ def _assert_matches_golden(tag, g, gold):
     assert ["%016x" % g.digest[0], "%016x" % g.digest[1]] == gold["digest"], tag      # flags, bounds, tags, values of every variable
 
 
+def test_scale_out_416_full_state_parity():
+    """ecdsa_like(416): 17.6 M rows, a 2.3 GB file -- the last point of SURVEY.md 8(d)'s scale-out series {26, 104, 416} -- through the device
+    front-end: counters (418 outer iterations, 25.6 M pops) and the digest of the WHOLE per-variable state against the oracle's, committed by
+    tests/golden/make_scale_goldens.py (90 minutes and 45 GB of oracle: vectors, not a live oracle run)."""
+    gold = _golden("ecdsa_like(416,10)+Secp256k1AddUnequal")
+    path = ecdsa_like.cached(416, 10)
+    s = build_system(None, *TRUSTED, path=path)
+    g = E.solve_batch([s], fetch_states="digest")[0]
+    _assert_matches_golden("ecdsa_like(416,10)", g, gold)
+    assert int(g.summary.outer_iterations) == 418 and int(g.summary.pops) == 25633135
+    del s, g
+
+
 def test_scale_out_full_state_parity():
     """ecdsa_like(104): 4.4 M rows -- the only case beyond the 256 MiB Infinity Cache -- through the device front-end, and one million-row
     input of a different shape (1 400 Poseidon copies side by side): counters and the WHOLE per-variable state against the oracle's, through
