@@ -10,7 +10,7 @@ with tempfile.TemporaryDirectory() as d:
     asm = os.path.join(d, "e.s")
     subprocess.run(base + ["-S", "--cuda-device-only", src, "-o", asm], capture_output=True, text=True, check=True)
     text = open(asm).read()
-print("# kernel resource usage, round 4 (hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on ecneproject_amd/csrc/ecne_engine.hip;")
+print("# kernel resource usage, round 6 (hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on ecneproject_amd/csrc/ecne_engine.hip;")
 print("# spill stores / loads per function counted in the device assembly: scratch_store_* / scratch_load_* between the function's label and its .size)")
 print()
 for ln in r.stderr.splitlines():
