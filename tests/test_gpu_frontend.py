@@ -366,3 +366,24 @@ def test_paths_the_device_hands_back(tmp_path, monkeypatch):
     assert len(md) == 0 and len(sd) == 0
     from gpu_common import assert_bit_exact
     assert_bit_exact("empty", E.solve_batch([sd])[0], orc.run(empty))
+
+
+def test_scratch_pool_reuse_across_files(tmp_path):
+    """(round 6) the device front-end's scratch blocks are pooled between files (a block is handed out again for any request of a quarter of its
+    size or more): files of very different sizes through the device front-end one after the other, back and forth, each time the same rows in
+    dictionary order and the same static arrays as the host front-end's -- a stale word of somebody else's scratch would show"""
+    import ecneproject_amd as E
+    import ecdsa_like
+    big = ecdsa_like.cached(3, 10)
+    rels = ["ecne_circomlib_tests/EdDSAMiMCSpongeVerifier@eddsamimcsponge.r1cs", "target/division.r1cs", "secp256k1.r1cs",
+            "ecne_circomlib_tests/Poseidon@poseidon.r1cs"]
+    order = [big, rels[1], rels[0], big, rels[3], rels[2], rels[1], big, rels[0]]
+    host = {}
+    for it in order:
+        path = it if os.path.isabs(it) else fixtures.path(it)
+        if path not in host:
+            host[path] = _system(E, 0, path=path)
+        md, sd = _system(E, 1, path=path)
+        assert E.frontend_stats()["parse_device"] == 1.0, path
+        _same_dict_rows("pool " + os.path.basename(path), host[path][0], md)
+        _same_static_arrays("pool " + os.path.basename(path), host[path][1], sd)
