@@ -385,5 +385,5 @@ def test_scratch_pool_reuse_across_files(tmp_path):
             host[path] = _system(E, 0, path=path)
         md, sd = _system(E, 1, path=path)
         assert E.frontend_stats()["parse_device"] == 1.0, path
-        _same_dict_rows("pool " + os.path.basename(path), host[path][0], md)
+        _same_dict_rows("pool " + os.path.basename(path), host[path][1], sd)
         _same_static_arrays("pool " + os.path.basename(path), host[path][1], sd)

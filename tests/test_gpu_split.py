@@ -155,22 +155,28 @@ def test_screen_on_the_callers_stream_from_several_threads():
     """(round 6, the advisor's finding) the first-solve screen runs on the CALLER's stream under the device's launch lock with per-thread
     scratch: four threads, each with a torch stream of its own, solve their own copy of a twelve-part file and of a one-group file at the
     same time -- same plan, same state as a solve on the default stream, nobody's screen in anybody else's way"""
+    import ctypes
     import threading
-    import torch
     E.set_split(1)
     p12 = multi_copy.cached(POS, 12)
     p1 = fixtures.path(SPONGE)
     want12 = E.solve_batch([build_system(None, path=p12)], fetch_states="both")[0]
     want1 = E.solve_batch([build_system(None, path=p1)], fetch_states="both")[0]
     out, errs = {}, []
+    hip = ctypes.CDLL("libamdhip64.so")      # (plain HIP streams: what a C caller of the ABI hands over)
+    streams = []
+    for _ in range(4):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0      # hipStreamNonBlocking
+        streams.append(h)
 
     def work(k):
         try:
-            st = torch.cuda.Stream()
+            st = streams[k]
             for rep in range(3):
                 a, b = build_system(None, path=p12), build_system(None, path=p1)
-                ga = E.solve_batch([a], stream=st.cuda_stream, fetch_states="both")[0]
-                gb = E.solve_batch([b], stream=st.cuda_stream, fetch_states="both")[0]
+                ga = E.solve_batch([a], stream=st.value, fetch_states="both")[0]
+                gb = E.solve_batch([b], stream=st.value, fetch_states="both")[0]
                 out[(k, rep)] = (a.split_info()[0], ga.digest, ga.summary.pops, b.split_info()[0], gb.digest, gb.summary.pops)
         except Exception as e:      # noqa: BLE001
             errs.append(repr(e))
@@ -180,6 +186,8 @@ def test_screen_on_the_callers_stream_from_several_threads():
         t.start()
     for t in ts:
         t.join()
+    for h in streams:
+        hip.hipStreamDestroy(h)
     assert not errs, errs
     assert len(out) == 12
     for key, v in out.items():
