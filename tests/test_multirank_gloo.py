@@ -344,3 +344,21 @@ def test_two_rank_replicas_one_rank_disagrees(tmp_path):
     """the MIN all-reduce: one rank whose replica does not reach the verdict turns the word to False on every rank"""
     res = _run_replicas(tmp_path, 29538, bad_rank=1)
     assert res["ranks"][0]["words"] == res["ranks"][1]["words"] == [False, False, False]
+
+
+def test_per_rank_instances_differ_in_constants_only(tmp_path):
+    """bench.py --gpus N gives rank r its own instance of the circuit, tests/ecdsa_like.py seed = r (a single circuit does not shard: N independent
+    jobs, not one job N times): the files differ, the structure does not -- same rows, same variables, same oracle counters and verdict, so the
+    ranks' invariants can be compared with each other and rank 0 (seed 0) alone carries the committed state digest."""
+    import hashlib
+    import ecdsa_like
+    import orc
+    seen, counters = set(), set()
+    for seed in (0, 1, 5):
+        p = ecdsa_like.cached(2, 10, directory=str(tmp_path), seed=seed)
+        seen.add(hashlib.sha256(open(p, "rb").read()).hexdigest())
+        o = orc.run(p, [fixtures.path("secp256k1.r1cs")], ["Secp256k1AddUnequal"], want_states=False)
+        s = o.summary
+        counters.add((o.status, o.verdict, s.n_rows_main, s.n_vars, s.pops, s.successful_steps, s.num_unique, s.outer_iterations, tuple(s.rule_hits[:13])))
+    assert len(seen) == 3 and len(counters) == 1, counters
+    assert ecdsa_like.cached(2, 10, directory=str(tmp_path), seed=0).endswith("ecdsa_like_S2_s10.r1cs")      # seed 0 = the committed workload's name
