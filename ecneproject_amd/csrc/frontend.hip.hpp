@@ -230,69 +230,71 @@ __device__ __forceinline__ fp::u256 fe_ld_coef(const uint32_t* __restrict__ W, u
 // (linear probing, growth re-inserts in slot order), so the insertions stay one after the other on lane 0 -- but everything around them does not:
 // the keys and their hashes are staged in LDS by all lanes (lane 0's loop was one dependent global load and one 64-bit hash chain per key), a
 // growth zeroes the new table, collects the old slots in order and hashes their keys with all lanes, and lane 0 only walks the probes.
-// 1 025 keys: 0.95 ms -> ~0.2 ms per part (k_fe_fill_big<2> / k_lay_order_big<2>, the 208 long parts of ecdsa_like(26), one wavefront each).
+// 1 025 keys: 0.95 -> 0.58 ms (k_fe_fill_big<2>) / 0.83 -> 0.60 ms (k_lay_order_big<2>) for the 208 long parts of ecdsa_like(26), one wavefront each;
+// the table build is 95 % of that (cycle counters: staging 20 k, table 1.25 M, emission 34 k cycles): two dependent LDS round trips per insertion.
 // t: the table (LDS pointers; the same value in every lane on entry and on return). st_key / st_hash / st_pay: n staged insertions in order
 // (payload = what tab_upsert stores + 1 later). gl_*: scratch for a growth (>= the keys the table holds). Returns nonzero when the table would
 // outgrow t.cap (the caller hands the part to the next tier).
+typedef __attribute__((address_space(3))) uint64_t* FeLdsPtr64;
+// (the table itself: ONE array of 64-bit slots per buffer, payload + 1 in the high word, key in the low one -- jlslot::Tab64T -- so that a probe
+//  is one ds_read_b64 and not two dependent reads; the two buffers are the 4 * cap words the separate arrays took)
 template <int ADD>
-__device__ __forceinline__ uint32_t fe_wave_table(jlslot::TabT<FeLdsPtr>& t, uint32_t n, FeLdsPtr st_key, FeLdsPtr st_hash, FeLdsPtr st_pay,
+__device__ __forceinline__ uint32_t fe_wave_table(jlslot::Tab64T<FeLdsPtr64>& t, uint32_t n, FeLdsPtr st_key, FeLdsPtr st_hash, FeLdsPtr st_pay,
                                                   FeLdsPtr gl_key, FeLdsPtr gl_pay, FeLdsPtr gl_hash) {
     const int lane = lane_id();
-    for (uint32_t i = lane; i < 16; i += 64) t.pay[i] = 0;
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);      // (the same in every lane: say so, the walks below are meant for the scalar unit)
+    for (uint32_t i = lane; i < 16; i += 64) t.cur[i] = 0ull;
     t.sz = 16; t.n = 0; t.maxprobe = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     uint32_t k = 0;
     while (k < n) {
-        // lane 0: insertions from k on, until the table has to grow
+        // insertions from k on, until the table has to grow: EVERY lane walks, on the same values (jlslot.hpp, UNI: the walk runs on the scalar unit)
         uint32_t rc = 0, want = 0;
-        if (lane == 0) {
+        {
             uint64_t w64 = 0;
             while (k < n) {
-                rc = (uint32_t)jlslot::tab_try_upsert(t, st_key[k], st_pay[k], st_hash[k], &w64);
+                const uint32_t ky = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_key[k]), py = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_pay[k]),
+                               hh = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_hash[k]);
+                rc = (uint32_t)jlslot::tab_try_upsert64<true>(t, ky, py, hh, &w64);
                 if (rc != 1) ++k;
                 if (rc) break;
             }
             want = (uint32_t)(w64 > 0x80000000ull ? 0x80000000ull : w64);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        k = __shfl(k, 0, 64); rc = __shfl(rc, 0, 64); want = __shfl(want, 0, 64);
-        t.n = __shfl(t.n, 0, 64); t.maxprobe = __shfl(t.maxprobe, 0, 64);
         if (!rc) break;
         // ---- growth (tab_grow, by the wavefront): new size, zero the other buffer, the old slots in ascending order with their hashes
         uint32_t nsz = 16;
         while (nsz < want) nsz <<= 1;
         if (nsz > t.cap || want > t.cap) return 1u;
-        for (uint32_t i = lane; i < nsz; i += 64) t.pay2[i] = 0;
+        for (uint32_t i = lane; i < nsz; i += 64) t.nxt[i] = 0ull;
         uint32_t cnt = 0;
         for (uint32_t s0 = 0; s0 < t.sz; s0 += 64) {
             const uint32_t sl = s0 + lane;
-            const uint32_t py = sl < t.sz ? t.pay[sl] : 0u;
+            const uint64_t sv = sl < t.sz ? t.cur[sl] : 0ull;
+            const uint32_t py = (uint32_t)(sv >> 32);
             const uint64_t m = __ballot(py != 0);
             if (py) {
                 const uint32_t o = cnt + (uint32_t)__popcll(m & lanes_below());
-                const uint32_t ky = t.key[sl];
+                const uint32_t ky = (uint32_t)sv;
                 gl_key[o] = ky; gl_pay[o] = py; gl_hash[o] = (uint32_t)jlslot::hash64((uint64_t)ky + (uint64_t)ADD);
             }
             cnt += (uint32_t)__popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         uint32_t mp = 0;
-        if (lane == 0) {
+        {
             const uint32_t mask = nsz - 1;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint32_t home = gl_hash[i] & mask;
-                uint32_t idx = home;
-                while (t.pay2[idx]) idx = (idx + 1) & mask;
+            for (uint32_t i = 0; i < cnt; ++i) {      // (every lane, uniformly)
+                const uint32_t home = (uint32_t)__builtin_amdgcn_readfirstlane((int)gl_hash[i]) & mask;
+                const uint32_t idx = jlslot::tab_free_slot64<true>(t.nxt, mask, home);
                 const uint32_t probe = (idx - home) & mask;
                 if (probe > mp) mp = probe;
-                t.pay2[idx] = gl_pay[i];
-                t.key2[idx] = gl_key[i];
+                t.nxt[idx] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)gl_pay[i]) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)gl_key[i]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        mp = __shfl(mp, 0, 64);
-        FeLdsPtr a = t.key; t.key = t.key2; t.key2 = a;
-        a = t.pay; t.pay = t.pay2; t.pay2 = a;
+        const FeLdsPtr64 a = t.cur; t.cur = t.nxt; t.nxt = a;
         t.sz = nsz;
         t.maxprobe = mp;
     }
@@ -416,12 +418,11 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const 
                 const uint32_t ky = W[j + 1 + 9ull * k];
                 st[k] = ky; st[SG + k] = (uint32_t)jlslot::hash64((uint64_t)ky + 1ull); st[2 * SG + k] = k;
             }
-            jlslot::TabT<FeLdsPtr> t;
-            t.key = tb; t.pay = tb + cap; t.key2 = tb + 2 * cap; t.pay2 = tb + 3 * cap;
-            t.cap = cap; t.stride = 1;
+            jlslot::Tab64T<FeLdsPtr64> t;
+            t.cur = (FeLdsPtr64)tb; t.nxt = (FeLdsPtr64)tb + cap; t.cap = cap;
             bad = n > SG ? 1u : fe_wave_table<1>(t, n, st, st + SG, st + 2 * SG, st + 3 * SG, st + 4 * SG, st + 5 * SG);
             sz = t.sz;
-            flipped = t.key != tb;
+            flipped = t.cur != (FeLdsPtr64)tb;
         } else {
         if (lane == 0) {
             typedef typename FeTabPtr<LDS_TABLES>::type TP;
@@ -441,15 +442,35 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_fe_fill_big(const 
             if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(overflow_count, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
             continue;
         }
+        // LDS tiers: the occupied slots (64-bit: key in the low word, payload + 1 in the high one) are first collected in slot order -- LDS work
+        // only -- so that the emission below runs over full wavefronts of entries (a 1 025-entry part sits in 4 096 slots: 64 trips of
+        // dependent global loads with a quarter of the lanes became 17 with all of them). HBM tier: slot by slot from the separate arrays.
         const uint32_t* key = flipped ? base + 2 * cap : base;
         const uint32_t* pay = flipped ? base + 3 * cap : base + cap;
+        uint32_t n_em = sz;
+        const uint32_t* const ckey = base + 4 * FeTier<TIER>::cap + 3 * FeTier<TIER>::stage;      // (the growth's list arrays are free now)
+        const uint32_t* const cpay = ckey + FeTier<TIER>::stage;
+        if constexpr (LDS_TABLES) {
+            const FeLdsPtr64 slots = (FeLdsPtr64)(flipped ? base + 2 * cap : base);
+            const FeLdsPtr lk = (FeLdsPtr)base + 4 * FeTier<TIER>::cap + 3 * FeTier<TIER>::stage, lp = lk + FeTier<TIER>::stage;
+            uint32_t cnt = 0;
+            for (uint32_t s0 = 0; s0 < sz; s0 += 64) {
+                const uint32_t s = s0 + lane;
+                const uint64_t sv = s < sz ? slots[s] : 0ull;
+                const uint64_t mk = __ballot((uint32_t)(sv >> 32) != 0);
+                if ((uint32_t)(sv >> 32)) { const uint32_t o = cnt + (uint32_t)__popcll(mk & lanes_below()); lk[o] = (uint32_t)sv; lp[o] = (uint32_t)(sv >> 32); }
+                cnt += (uint32_t)__popcll(mk);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            n_em = cnt;
+        }
         uint32_t m = 0, nz = 0, mv = 0;
-        for (uint32_t s0 = 0; s0 < sz; s0 += 64) {
+        for (uint32_t s0 = 0; s0 < n_em; s0 += 64) {
             const uint32_t s = s0 + lane;
-            const uint32_t py = s < sz ? (LDS_TABLES ? pay[s] : ld32_agent(&pay[s])) : 0u;
+            const uint32_t py = s < n_em ? (LDS_TABLES ? cpay[s] : ld32_agent(&pay[s])) : 0u;
             const uint64_t mask = __ballot(py != 0);
             if (py) {
-                const uint32_t k = py - 1u, v = (LDS_TABLES ? key[s] : ld32_agent(&key[s])) + 1u;
+                const uint32_t k = py - 1u, v = (LDS_TABLES ? ckey[s] : ld32_agent(&key[s])) + 1u;
                 const uint32_t o = at + m + (uint32_t)__popcll(mask & lanes_below());
                 const fp::u256 c = fe_ld_coef(W, j + 2 + 9ull * k);
                 O.var[p][o] = v;
@@ -875,7 +896,11 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
                 if (nzq && o < SG) { st[o] = v; st[SG + o] = (uint32_t)jlslot::hash64((uint64_t)v); st[2 * SG + o] = (uint32_t)(k - k0); }
                 cnt += (uint32_t)__popcll(mask);
             }
-            bad = cnt > SG ? 1u : fe_wave_table<0>(t, cnt, st, st + SG, st + 2 * SG, st + 3 * SG, st + 4 * SG, st + 5 * SG);
+            jlslot::Tab64T<FeLdsPtr64> t6;
+            t6.cur = (FeLdsPtr64)base; t6.nxt = (FeLdsPtr64)base + cap; t6.cap = cap;
+            bad = cnt > SG ? 1u : fe_wave_table<0>(t6, cnt, st, st + SG, st + 2 * SG, st + 3 * SG, st + 4 * SG, st + 5 * SG);
+            sz = t6.sz;
+            flipped = t6.cur != (FeLdsPtr64)base;
         } else {
         if (lane == 0) jlslot::tab_init(t);
         // all lanes look at 64 dictionary entries at a time (non-zero? key 1?), lane 0 inserts the non-zero ones in order
@@ -898,19 +923,35 @@ __global__ __launch_bounds__(64 * FeTier<TIER>::waves) void k_lay_order_big(AbsR
             }
         }
         }
-        if (lane == 0) { sz = t.sz; flipped = t.key != tb; }
+        if (!LDS_TABLES && lane == 0) { sz = t.sz; flipped = t.key != tb; }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sz = __shfl(sz, 0, 64); flipped = __shfl(flipped, 0, 64); bad = __shfl(bad, 0, 64);
         if (bad) {
             if (lane == 0) { if (LDS_TABLES) overflow_list[atomicAdd(overflow_count, 1u)] = i; else atomicOr(&M->unsupported, 1u); }
             continue;
         }
-        const uint32_t* key = flipped ? base + 2 * cap : base;
+        // (LDS tiers: the occupied 64-bit slots collected in slot order first, the emission over full wavefronts -- as in k_fe_fill_big)
         const uint32_t* pay = flipped ? base + 3 * cap : base + cap;
+        uint32_t n_em = sz;
+        const uint32_t* const cpay = base + 4 * FeTier<TIER>::cap + 4 * FeTier<TIER>::stage;
+        if constexpr (LDS_TABLES) {
+            const FeLdsPtr64 slots = (FeLdsPtr64)(flipped ? base + 2 * cap : base);
+            const FeLdsPtr lp = (FeLdsPtr)base + 4 * FeTier<TIER>::cap + 4 * FeTier<TIER>::stage;
+            uint32_t cnt = 0;
+            for (uint32_t s0 = 0; s0 < sz; s0 += 64) {
+                const uint32_t s = s0 + lane;
+                const uint64_t sv = s < sz ? slots[s] : 0ull;
+                const uint64_t mk = __ballot((uint32_t)(sv >> 32) != 0);
+                if ((uint32_t)(sv >> 32)) lp[cnt + (uint32_t)__popcll(mk & lanes_below())] = (uint32_t)(sv >> 32);
+                cnt += (uint32_t)__popcll(mk);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            n_em = cnt;
+        }
         uint32_t m = 0, first_var = 0, first_non1 = 0, last_non1 = 0, n_non1 = 0, has1 = 0;
-        for (uint32_t s0 = 0; s0 < sz; s0 += 64) {
+        for (uint32_t s0 = 0; s0 < n_em; s0 += 64) {
             const uint32_t s = s0 + lane;
-            const uint32_t py = s < sz ? (LDS_TABLES ? pay[s] : ld32_agent(&pay[s])) : 0u;
+            const uint32_t py = s < n_em ? (LDS_TABLES ? cpay[s] : ld32_agent(&pay[s])) : 0u;
             const uint64_t mask = __ballot(py != 0);
             uint32_t v = 0;
             if (py) {

@@ -147,6 +147,62 @@ JLQ int tab_try_upsert(TabT<P>& t, uint32_t skey, uint32_t payload, uint32_t h32
     return 0;
 }
 
+// The same once more on ONE array of 64-bit slots, payload + 1 in the high word (0 = empty), key in the low word: a probe is one load instead of
+// two dependent ones (frontend.hip.hpp, fe_wave_table: lane 0's probe walk is what is left of a long part's table).
+template <class P64>
+struct Tab64T {
+    P64 cur, nxt;        // the table and the buffer a growth re-inserts into
+    uint32_t cap;        // slots per buffer
+    uint32_t sz, n, maxprobe;
+};
+// UNI = true (device, frontend.hip.hpp): the walk is executed by EVERY lane of the wavefront on the same values -- each LDS read is made
+// wave-uniform (readfirstlane) so that the compiler keeps the walk's arithmetic and branches on the scalar unit. One lane walking by itself
+// is slower still (650 cycles per insertion against 600 this way: what is left is two dependent LDS round trips per insertion -- the staged key,
+// then its slot); the stores are the same value to the same address from all lanes.
+template <bool UNI>
+JLQ uint64_t jl_uni64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (UNI) return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+#endif
+    return x;
+}
+// (Tried, round 6: reading FOUR slots per probe step -- independent loads, one latency -- 0.60 -> 0.83 ms for the 208 long parts of
+//  ecdsa_like(26), lane-0 and wave-uniform versions alike: most insertions find their slot at the first probe, the extra reads only cost.)
+template <bool UNI, class P64>
+JLQ int tab_try_upsert64(Tab64T<P64>& t, uint32_t skey, uint32_t payload, uint32_t h32, uint64_t* want) {
+    const uint32_t sz = t.sz, mask = sz - 1;
+    uint32_t idx = h32 & mask, it = 0;
+    bool found_empty = false;
+    const uint64_t mine = ((uint64_t)(payload + 1u) << 32) | (uint64_t)skey;
+    for (;;) {
+        const uint64_t s = jl_uni64<UNI>(t.cur[idx]);
+        if (!(uint32_t)(s >> 32)) { found_empty = true; break; }
+        if ((uint32_t)s == skey) { t.cur[idx] = mine; return 0; }
+        idx = (idx + 1) & mask;
+        if (++it > t.maxprobe) break;
+    }
+    if (!found_empty) {
+        const uint32_t lim = (sz >> 6) > 16 ? (sz >> 6) : 16;
+        while (it < lim) {
+            if (!(uint32_t)(jl_uni64<UNI>(t.cur[idx]) >> 32)) { found_empty = true; t.maxprobe = it; break; }
+            idx = (idx + 1) & mask;
+            ++it;
+        }
+    }
+    if (!found_empty) { *want = t.n > 64000 ? (uint64_t)sz * 2 : (uint64_t)sz * 4; return 1; }
+    t.cur[idx] = mine;
+    ++t.n;
+    if ((uint64_t)t.n * 3 > (uint64_t)sz * 2) { *want = t.n > 64000 ? (uint64_t)t.n * 2 : (uint64_t)t.n * 4; return 2; }
+    return 0;
+}
+// the first free slot at or behind `home` in the buffer a growth fills (tab_grow's walk)
+template <bool UNI, class P64>
+JLQ uint32_t tab_free_slot64(P64 tab, uint32_t mask, uint32_t home) {
+    uint32_t idx = home;
+    while ((uint32_t)(jl_uni64<UNI>(tab[idx]) >> 32)) idx = (idx + 1) & mask;
+    return idx;
+}
+
 // Which of two DIFFERENT keys comes first when a fresh table that holds just the two is iterated (`for j in Set([k1, k2])`,
 // R1CSConstraintSolver.jl:1130, :1216): 16 slots, k1 inserted first.
 JLQ bool pair_second_first(uint32_t k1, uint32_t k2) {

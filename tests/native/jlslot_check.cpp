@@ -77,6 +77,52 @@ static int two(std::mt19937_64& rng, size_t n, uint64_t keyspace) {
     return 0;
 }
 
+// ... and the 64-bit-slot variant (tab_try_upsert64) the same way
+template <int ADD>
+static int three(std::mt19937_64& rng, size_t n, uint64_t keyspace) {
+    std::vector<uint32_t> keys(n);
+    for (auto& k : keys) k = (uint32_t)(rng() % keyspace);
+    uint32_t cap = 16;
+    while (cap < 8 * n + 64) cap <<= 1;
+    std::vector<uint32_t> a(cap), b(cap), c(cap), d(cap);
+    jlslot::Tab t{a.data(), b.data(), c.data(), d.data(), cap, 1, 0, 0, 0};
+    jlslot::tab_init(t);
+    for (size_t i = 0; i < n; ++i) if (jlslot::tab_upsert<ADD>(t, keys[i], (uint32_t)i)) return 1;
+    std::vector<uint64_t> x(cap, 0), y(cap, 0);
+    jlslot::Tab64T<uint64_t*> u{x.data(), y.data(), cap, 16, 0, 0};
+    std::vector<uint32_t> lk, lp, lh;
+    size_t k = 0;
+    while (k < n) {
+        uint64_t want = 0;
+        const int rc = jlslot::tab_try_upsert64<false>(u, keys[k], (uint32_t)k, (uint32_t)jlslot::hash64((uint64_t)keys[k] + ADD), &want);
+        if (rc != 1) ++k;
+        if (!rc) continue;
+        uint32_t nsz = 16;
+        while (nsz < want) nsz <<= 1;
+        if (nsz > cap) return 1;
+        for (uint32_t i = 0; i < nsz; ++i) u.nxt[i] = 0;
+        lk.clear(); lp.clear(); lh.clear();
+        for (uint32_t sl = 0; sl < u.sz; ++sl) if (u.cur[sl] >> 32) { lk.push_back((uint32_t)u.cur[sl]); lp.push_back((uint32_t)(u.cur[sl] >> 32)); lh.push_back((uint32_t)jlslot::hash64((uint64_t)(uint32_t)u.cur[sl] + ADD)); }
+        uint32_t mp = 0;
+        const uint32_t mask = nsz - 1;
+        for (size_t i = 0; i < lk.size(); ++i) {
+            const uint32_t home = lh[i] & mask;
+            const uint32_t idx = jlslot::tab_free_slot64<false>(u.nxt, mask, home);
+            const uint32_t probe = (idx - home) & mask;
+            if (probe > mp) mp = probe;
+            u.nxt[idx] = ((uint64_t)lp[i] << 32) | lk[i];
+        }
+        std::swap(u.cur, u.nxt);
+        u.sz = nsz; u.maxprobe = mp;
+    }
+    if (t.sz != u.sz || t.n != u.n || t.maxprobe != u.maxprobe) { std::printf("TRY64 MISMATCH shape n=%zu\n", n); return 1; }
+    for (uint32_t sl = 0; sl < t.sz; ++sl) {
+        const uint32_t py = (uint32_t)(u.cur[sl] >> 32), ky = (uint32_t)u.cur[sl];
+        if (t.pay[sl] != py || (py && t.key[sl] != ky)) { std::printf("TRY64 MISMATCH slot %u n=%zu\n", sl, n); return 1; }
+    }
+    return 0;
+}
+
 int main() {
     std::mt19937_64 rng(12345);
     int bad = 0;
@@ -93,7 +139,9 @@ int main() {
         const uint64_t ks = rep % 3 == 0 ? 16 + rng() % 64 : rep % 3 == 1 ? 1 + rng() % 100000 : 4000000000ull;
         bad += two<0>(rng, n, ks);
         bad += two<1>(rng, n, ks);
-        cases += 2;
+        bad += three<0>(rng, n, ks);
+        bad += three<1>(rng, n, ks);
+        cases += 4;
     }
     for (size_t n : {64001u, 70000u, 130000u}) { bad += one<0>(rng, n, 1u << 30, 1); bad += one<1>(rng, n, 50000, 1); cases += 2; }
     // the two-key shortcut
